@@ -1,0 +1,97 @@
+"""The aggregator oracle (oracle/pagg_oracle.py) against the committed golden vectors produced by the
+reference classes, and against the reference classes themselves when /root/reference is mounted."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_files
+from oracle import pagg_oracle as po
+
+PAGG_GOLDENS = golden_files("pagg_*.npz")
+
+
+def load_case(name):
+    g = golden(name)
+    params = {k[len("param/"):]: torch.tensor(v) for k, v in g.items() if k.startswith("param/")}
+    grads = {k[len("grad/"):]: torch.tensor(v) for k, v in g.items() if k.startswith("grad/")}
+    return g, params, grads
+
+
+@pytest.mark.parametrize("name", PAGG_GOLDENS)
+def test_oracle_forward_matches_reference_golden(name):
+    g, params, _ = load_case(name)
+    sel = np.nonzero(g["mask"])[0]
+    out = po.forward(str(g["variant"]), params, torch.tensor(g["X"]), g["ids"], g["codes"], sel,
+                     int(g["W"]), int(g["L"]))
+    assert np.abs(out.numpy() - g["out"]).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", PAGG_GOLDENS)
+def test_oracle_backward_matches_reference_golden(name):
+    g, params, grads = load_case(name)
+    sel = np.nonzero(g["mask"])[0]
+    params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    X = torch.tensor(g["X"]).requires_grad_(True)
+    out = po.forward(str(g["variant"]), params, X, g["ids"], g["codes"], sel, int(g["W"]), int(g["L"]))
+    (out * torch.tensor(g["G"])).sum().backward()
+    for k, ref in grads.items():
+        got = params[k].grad
+        assert got is not None, k
+        tol = 2e-6 * max(1.0, ref.abs().max().item())
+        assert (got - ref).abs().max().item() < tol, k
+    assert (X.grad - torch.tensor(g["grad_X"])).abs().max().item() < 2e-6
+
+
+def test_plan_hetero_quirks():
+    S, W, L = 3, 2, 4
+    P = S * W
+    ids = np.arange(P * L).reshape(P, L)
+    codes = (np.arange(P * L) % L).reshape(P, L)
+    node, code, group, member, ego = po.plan("hetero", ids, codes, S, W, L)
+    # slot 0, step 0 is row r=0: t'=0, p=0 -> last node of path 0
+    assert node[0, 0] == ids[0, L - 1]
+    # slot 1, step 2: r = 6 -> t' = 1, p = 0 -> ids[0, L-2]
+    assert node[1, 2] == ids[0, L - 2]
+    assert (code == codes).all()
+    assert (group == np.arange(P) % S).all() and (member == np.arange(P) // S).all()
+    assert (ego == ids[:, 0]).all()
+    node, code, group, member, ego = po.plan("homo", ids, codes, S, W, L)
+    assert (node == ids).all() and (group == np.arange(P) // W).all()
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("variant,cname", [("hetero", "PathNet"), ("homo", "PathNet_homo"), ("pagg", "PAGG")])
+def test_oracle_matches_live_reference_classes(variant, cname):
+    import warnings
+    warnings.filterwarnings("ignore")
+    from tools.ref_extract import reference_classes
+    cls = reference_classes(0.0)
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    N, F, H, C, W, L, S = 64, 21, 128, 6, 40, 4, 29
+    model = cls[cname](F, H, C, L if variant != "pagg" else N)
+    X = torch.rand(N, F)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.nonzero(mask)[0]
+    ids = rng.integers(0, N, size=(S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = rng.integers(0, L, size=(S, W, L))
+    model.eval()
+    ref = model(X, torch.tensor(ids.reshape(S, W * L)), W, L, torch.tensor(mask), torch.tensor(codes),
+                torch.arange(S * W * L))
+    got = po.forward(variant, dict(model.state_dict()), X, ids, codes, sel, W, L)
+    assert (ref - got).abs().max().item() < 2e-6
+
+
+@pytest.mark.reference
+def test_state_dict_contract_cornell_pth():
+    """saved_models/cornell.pth pins the state_dict keys/shapes of PathNet(1703,128,5,4)."""
+    sd = torch.load("/root/reference/saved_models/cornell.pth", map_location="cpu")
+    want = {"fc0.weight": (128, 1703), "fc0.bias": (128,), "LSTM.weight_ih_l0": (512, 128),
+            "LSTM.weight_hh_l0": (512, 128), "LSTM.bias_ih_l0": (512,), "LSTM.bias_hh_l0": (512,),
+            "fc2.weight": (5, 256), "fc2.bias": (5,), "attw.weight": (1, 256), "attw.bias": (1,)}
+    for d in range(4):
+        want["nets.%d.weight" % d] = (128, 128)
+        want["nets.%d.bias" % d] = (128,)
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want
