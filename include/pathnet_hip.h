@@ -1,0 +1,211 @@
+/*
+ * pathnet_hip.h -- C ABI of libpathnet_hip.so, the MI355X (gfx950) implementation of PathNet's
+ * path-aggregation hot path: the MERW path sampler and the PAGG aggregator forward/backward.
+ *
+ * The reference (Sunefei/PathNet) has no FFI for this path: its two seams are a text file on disk
+ * between the C++ sampler and the Python trainer, and a Python nn.Module surface.
+ * Every entry point below names the reference code it stands in for.  The Python host side in
+ * pathnet_amd/ binds these with ctypes; INTEGRATION.md shows the stubs.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, PODs.  No exceptions cross the boundary.
+ *   - every function returns an int status: PN_OK (0) or a negative PN_ERR_*; pn_last_error()
+ *     returns a thread-local, human readable description of the last failure.
+ *   - the caller owns every buffer (inputs, outputs, workspaces).  The library never frees or
+ *     retains a pointer past the call.  "dev" in a comment = device (HBM) pointer, "host" = host.
+ *   - device work is enqueued on the hipStream_t passed as `stream` (void* here so the header
+ *     needs no HIP include; pass torch.cuda.current_stream().cuda_stream).  Device entry points
+ *     are asynchronous with respect to the host.
+ *   - sizes: n nodes, m edge rows, W walks per node (path_num), L path length, S masked nodes,
+ *     P = S*W paths, H hidden size, F input features, C classes.
+ */
+#ifndef PATHNET_HIP_H_
+#define PATHNET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_ABI_VERSION 1
+
+#define PN_OK 0
+#define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
+#define PN_ERR_IO (-2)           /* file could not be opened / read / written */
+#define PN_ERR_FORMAT (-3)       /* malformed text */
+#define PN_ERR_HIP (-4)          /* a HIP runtime call or kernel launch failed */
+#define PN_ERR_EMPTY_TABLE (-5)  /* a walk reached a node with no outgoing rows (gen_merw.cpp:84-87) */
+#define PN_ERR_NOMEM (-6)
+#define PN_ERR_CAPACITY (-7)     /* caller buffer too small; the required size is reported */
+
+int pn_abi_version(void);
+const char *pn_last_error(void);
+
+/* GPU the library will launch on (current HIP device): name/arch and CU count, for bench reports. */
+typedef struct pn_device_info {
+    char name[128];
+    char arch[64];
+    int32_t compute_units;
+    int32_t lds_bytes_per_block;
+    int64_t hbm_bytes;
+    int32_t clock_khz;
+} pn_device_info;
+int pn_device_query(pn_device_info *out);
+
+/* ================================================================================================
+ * Sampler, host side.  Replaces the set-up half of preprocess/gen_merw.cpp main() (:162-179).
+ * ============================================================================================== */
+
+/* Edge file "<n> <m>\n" then m rows "u v p"  (gen_merw.cpp:162-172, gen_epoch_merw.cpp:145-155).
+ * Call with cap = 0 to read only n and m; then with cap >= m to fill u, v, p (host, file order). */
+int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, double *p, int64_t cap);
+
+/* Alias tables of every node, bit-identical to AliasTable::init (gen_merw.cpp:23-79) run on the
+ * per-node lists that link() (:95-99) builds in file order.  off[n+1] is the per-node prefix of the
+ * triple arrays.  A/B are the two candidate next nodes, S the fp64 split value, and
+ * thr = the smallest 31-bit draw r for which (1.0 * r / RAND_MAX > S), so that roll() (:81-91)
+ * becomes the integer test  r >= thr ? A : B  (thr = 2^31 when no draw qualifies).
+ * Call with cap = 0 to get *total (and off[]); then with cap >= *total.  S may be NULL. */
+int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, const double *p, int64_t *off,
+                   int32_t *A, int32_t *B, double *S, uint32_t *thr, int64_t cap, int64_t *total);
+
+/* Dense hop table dis[n*n] (host, uint8): dis[s*n + x] = 1 + (hops from s to x) for every x within
+ * seq_len-1 hops of s, 0 otherwise -- the values bfs() (gen_merw.cpp:101-123) leaves in dis[][] for
+ * every node a walk of length seq_len can visit.  The emitted distance code is dis - 1. */
+int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t seq_len, uint8_t *dis);
+
+/* The first `count` values rand() returns after srand(seed), starting at stream position `first`
+ * (host, int32).  Uses the same jump algebra as the device generator (glibc TYPE_3 recurrence as
+ * a polynomial over Z/2^32), so any window of the reference's draw stream (gen_merw.cpp:88-89) can
+ * be produced without replaying the stream from the start. */
+int pn_glibc_draws(uint32_t seed, uint64_t first, int64_t count, int32_t *out);
+
+/* ================================================================================================
+ * Sampler, device side.  Replaces the walk loop gen_merw.cpp:182-209 (and the per-epoch variant
+ * gen_epoch_merw.cpp:164-206): one walk per GPU lane.
+ * ============================================================================================== */
+
+#define PN_DRAW_GLIBC_REPLAY 0 /* draws = glibc rand() after srand(seed): bit-exact to the reference binary */
+#define PN_DRAW_PHILOX 1       /* draws = rocRAND Philox4x32-10, subsequence = global walk index (throughput) */
+
+typedef struct pn_sampler_tables {
+    int32_t n;               /* nodes */
+    int64_t total;           /* alias triples */
+    const int64_t *off;      /* dev [n+1]  prefix into the triple array */
+    const int32_t *triples;  /* dev [total*4] packed {A, B, thr, 0} (one 16-byte load per roll) */
+    const uint8_t *dis;      /* dev [n*n]  dense hop table from pn_hops_dense */
+} pn_sampler_tables;
+
+/* Pack host A/B/thr arrays into the 16-byte device layout (host helper, dst is a host buffer of
+ * total*4 int32 that the caller then copies to the device). */
+int pn_alias_pack(int64_t total, const int32_t *A, const int32_t *B, const uint32_t *thr, int32_t *dst);
+
+/* Bytes of device scratch pn_sample_paths needs for this window (0 for PN_DRAW_PHILOX). */
+int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t epoch_count, int32_t node_count,
+                              int64_t *bytes);
+
+/* Sample paths for epochs [epoch_begin, epoch_begin+epoch_count) and source nodes
+ * [node_begin, node_begin+node_count).  ids/codes are dev [epoch_count, node_count, W, L]
+ * (int32 node ids, uint8 distance codes = dis - 1), i.e. exactly the numbers the reference prints,
+ * in the reference's order.  The draw index of (epoch e, node st, walk i, step t) is
+ * 2*(((e*n + st)*W + i)*L + t) (+1 for the probability draw), as in the reference where the last
+ * roll of each walk is drawn and discarded (:195-196).
+ * status_flag (dev int32, may be NULL) is set to PN_ERR_EMPTY_TABLE if any walk reaches a node with
+ * an empty table (the reference exits there). */
+int pn_sample_paths(const pn_sampler_tables *tables, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
+                    int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
+                    uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag, void *stream);
+
+/* ================================================================================================
+ * Path file.  The on-disk interface between sampler and trainer: one line per path,
+ * "[v0, v1, ..., v_{L-1}, d0, ..., d_{L-1}]\n"  (writer gen_merw.cpp:189-206; reader
+ * PathNet_run.py:418-423 and :325-334, which requires the trailing "]\n").
+ * ============================================================================================== */
+int pn_paths_write_text(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L,
+                        int32_t append);
+/* cap = 0: count lines only (ids/codes may be NULL).  Otherwise fills up to cap paths. */
+int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths);
+
+/* ================================================================================================
+ * Aggregator ("PAGG"): the forward() of PathNet (PathNet_run.py:172-211), PathNet_homo (:239-278)
+ * and PAGG (baseline/GPRGNN/src/copy.py:327-359), and its backward (autograd in the reference,
+ * PathNet_run.py:351).
+ * ============================================================================================== */
+#define PN_VARIANT_HETERO 0 /* class PathNet      : LSTM, flip/time-major quirk, softmax(LeakyReLU) attention */
+#define PN_VARIANT_HOMO 1   /* class PathNet_homo : LSTM, ReLU after fc0 and after the bank, (1+att) attention */
+#define PN_VARIANT_PAGG 2   /* class PAGG         : tanh RNN, plain mean over paths */
+
+typedef struct pn_pagg_shape {
+    int32_t variant;
+    int32_t N, F, H, C; /* nodes, input features, hidden, classes */
+    int32_t S, W, L;    /* masked nodes, paths per node, path length */
+} pn_pagg_shape;
+
+/* All pointers are device pointers.  Weights use the reference state_dict layout
+ * (nn.Linear weight [out, in]; LSTM/RNN weight_ih/hh [G*H, H] with torch gate order i,f,g,o).
+ * Gradient pointers (g_*) may be NULL in forward; in backward a NULL gradient is skipped. */
+typedef struct pn_pagg_args {
+    pn_pagg_shape shape;
+    /* inputs */
+    const float *X;       /* [N, F] */
+    const int32_t *ids;   /* [S, W, L] path node ids, path-major as in the path file */
+    const uint8_t *codes; /* [S, W, L] distance codes */
+    const int32_t *sel;   /* [S] node index of each masked node (nonzero(indices)) */
+    /* parameters */
+    const float *fc0_w, *fc0_b;   /* [H, F], [H] */
+    const float *bank_w, *bank_b; /* [L, H, H], [L, H]   nets.<d> / nei<d> stacked by d */
+    const float *w_ih, *w_hh;     /* [G*H, H]            G = 4 (LSTM) or 1 (RNN) */
+    const float *b_ih, *b_hh;     /* [G*H] */
+    const float *att_w, *att_b;   /* [2H], [1]           unused for PN_VARIANT_PAGG */
+    const float *fc2_w, *fc2_b;   /* [C, 2H], [C] */
+    /* dropout (F.dropout(training=True) on the recurrent input [L,P,H] and on the classifier input
+     * [S,2H]): p = 0 disables.  With mask pointers set, those multiplicative masks (already scaled by
+     * 1/(1-p)) are used instead of the built-in Philox masks -- this is how parity tests inject the
+     * reference's mask. */
+    float p_seq, p_cls;
+    uint64_t seed;
+    const float *mask_seq; /* [L, P, H] or NULL */
+    const float *mask_cls; /* [S, 2H]  or NULL */
+    /* outputs */
+    float *out; /* [S, C] logits */
+    /* saved-for-backward + scratch, sized by pn_pagg_workspace_bytes */
+    void *workspace;
+    int64_t workspace_bytes;
+    /* backward only */
+    const float *g_out; /* [S, C] upstream gradient */
+    float *g_X;         /* [N, F] or NULL */
+    float *g_fc0_w, *g_fc0_b, *g_bank_w, *g_bank_b, *g_w_ih, *g_w_hh, *g_b_ih, *g_b_hh, *g_att_w, *g_att_b,
+        *g_fc2_w, *g_fc2_b;
+} pn_pagg_args;
+
+int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes);
+/* out = forward(...).  Leaves what backward needs in the workspace. */
+int pn_pagg_forward(const pn_pagg_args *args, void *stream);
+/* Gradients of sum(out * g_out) w.r.t. every parameter (overwritten, not accumulated) and X.
+ * Must follow a pn_pagg_forward on the same args/workspace. */
+int pn_pagg_backward(const pn_pagg_args *args, void *stream);
+
+/* Stand-alone stages of the same path, exposed for measurement and tests. */
+/* rows[q, t, :] = table[(node(q,t) * L + code(q,t)), :] for the variant's index plan: the
+ * [P, L, H] path-feature gather with the distance code fused in (PathNet_run.py:179 / :246). */
+int pn_pagg_gather(const pn_pagg_shape *shape, const float *table /* [N, L, H] */, const int32_t *ids,
+                   const uint8_t *codes, float *rows /* [P, L, H] */, void *stream);
+
+/* C[m*ldc + n] = act( sum_k A[m*sAm + k*sAk] * B[n*sBn + k*sBk] + bias[n] ): the fp32 MFMA GEMM
+ * every dense layer of the path uses (nn.Linear: sAk = sBk = 1).  One stride of each operand must
+ * be 1.  bias may be NULL; relu != 0 applies max(0, .). */
+int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C,
+                int64_t ldc, const float *bias, int32_t M, int32_t N, int32_t K, int32_t relu, void *stream);
+
+/* Byte offsets inside the aggregator workspace of the intermediates tests look at:
+ * out[0] Xh [N,H], out[1] Z [N,L,H], out[2] hn [P,H] (pooling-group order), out[3] layer1 [S,2H]. */
+int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]);
+
+/* Timing of the kernels launched by the last forward/backward on this thread is not kept here;
+ * use HIP events on `stream` (bench.py does). */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PATHNET_HIP_H_ */

@@ -1,0 +1,123 @@
+"""ctypes binding of libpathnet_hip.so (include/pathnet_hip.h).
+
+There is no fallback: if the HIP library has not been built, importing the product path fails
+loudly -- results must never silently come from a CPU path.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libpathnet_hip.so")
+
+PN_OK = 0
+PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (
+    -1, -2, -3, -4, -5, -6, -7)
+DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
+VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+
+class PnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libpathnet_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class DeviceInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 128), ("arch", ctypes.c_char * 64), ("compute_units", ctypes.c_int32),
+                ("lds_bytes_per_block", ctypes.c_int32), ("hbm_bytes", ctypes.c_int64), ("clock_khz", ctypes.c_int32)]
+
+
+class SamplerTables(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("total", ctypes.c_int64), ("off", vp), ("triples", vp), ("dis", vp)]
+
+
+class PaggShape(ctypes.Structure):
+    _fields_ = [("variant", ctypes.c_int32), ("N", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("C", ctypes.c_int32), ("S", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32)]
+
+
+class PaggArgs(ctypes.Structure):
+    _fields_ = ([("shape", PaggShape), ("X", vp), ("ids", vp), ("codes", vp), ("sel", vp)] +
+                [(k, vp) for k in ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w",
+                                   "att_b", "fc2_w", "fc2_b")] +
+                [("p_seq", ctypes.c_float), ("p_cls", ctypes.c_float), ("seed", ctypes.c_uint64), ("mask_seq", vp),
+                 ("mask_cls", vp), ("out", vp), ("workspace", vp), ("workspace_bytes", ctypes.c_int64),
+                 ("g_out", vp), ("g_X", vp)] +
+                [("g_" + k, vp) for k in ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w",
+                                          "att_b", "fc2_w", "fc2_b")])
+
+
+# name -> (restype, argtypes): every symbol include/pathnet_hip.h declares
+SIGNATURES = {
+    "pn_abi_version": (ctypes.c_int, []),
+    "pn_last_error": (ctypes.c_char_p, []),
+    "pn_device_query": (ctypes.c_int, [ctypes.POINTER(DeviceInfo)]),
+    "pn_edges_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, c_f64p, ctypes.c_int64]),
+    "pn_alias_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, c_f64p, c_i64p, c_i32p, c_i32p,
+                                      c_f64p, c_u32p, ctypes.c_int64, c_i64p]),
+    "pn_alias_pack": (ctypes.c_int, [ctypes.c_int64, c_i32p, c_i32p, c_u32p, c_i32p]),
+    "pn_hops_dense": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, ctypes.c_int32, c_u8p]),
+    "pn_glibc_draws": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64, c_i32p]),
+    "pn_sample_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                                 ctypes.c_int32, c_i64p]),
+    "pn_sample_paths": (ctypes.c_int, [ctypes.POINTER(SamplerTables), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                       vp, vp, vp, ctypes.c_int64, vp, vp]),
+    "pn_paths_write_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32,
+                                           ctypes.c_int32]),
+    "pn_paths_read_text": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, c_i32p, c_u8p, ctypes.c_int64, c_i64p]),
+    "pn_pagg_workspace_bytes": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
+    "pn_pagg_forward": (ctypes.c_int, [ctypes.POINTER(PaggArgs), vp]),
+    "pn_pagg_backward": (ctypes.c_int, [ctypes.POINTER(PaggArgs), vp]),
+    "pn_pagg_gather": (ctypes.c_int, [ctypes.POINTER(PaggShape), vp, vp, vp, vp, vp]),
+    "pn_gemm_f32": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp,
+                                   ctypes.c_int64, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                   vp]),
+    "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library (once).  Raises ImportError if it was not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("pathnet_amd: %s is missing -- build the HIP extension first "
+                              "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+                              % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        if lib.pn_abi_version() != 1:
+            raise ImportError("libpathnet_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != PN_OK:
+        raise PnError(rc, load().pn_last_error().decode(errors="replace"))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)
+
+
+def np_ptr(a, ctype):
+    return a.ctypes.data_as(ctypes.POINTER(ctype))

@@ -1,0 +1,417 @@
+// pn_host.cpp -- host half of libpathnet_hip.so: everything the sampler needs before the GPU walks
+// (edge file, alias tables, hop table, glibc stream algebra) and the text path-file reader/writer.
+//
+// Reference behaviour reproduced (file:line in /root/reference):
+//   preprocess/gen_merw.cpp:162-172, :95-99   edge rows -> per-node lists in file order
+//   preprocess/gen_merw.cpp:23-79            AliasTable::init
+//   preprocess/gen_merw.cpp:81-91            AliasTable::roll  (here: its fp64 compare turned into
+//                                            an exact integer threshold per triple)
+//   preprocess/gen_merw.cpp:101-123          bfs() / dis[][]
+//   preprocess/gen_merw.cpp:189-206          text line format;  PathNet_run.py:418-423 reader
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "pn_internal.h"
+
+namespace pn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// glibc TYPE_3 generator algebra
+// ------------------------------------------------------------------------------------------------
+GlibcPoly glibc_poly_one() {
+    GlibcPoly p{};
+    p.c[0] = 1;
+    return p;
+}
+
+GlibcPoly glibc_poly_mul(const GlibcPoly &a, const GlibcPoly &b) {
+    uint32_t t[61] = {0};
+    for (int i = 0; i < 31; i++)
+        for (int j = 0; j < 31; j++) t[i + j] += a.c[i] * b.c[j];
+    // x^k = x^(k-3) + x^(k-31) for k >= 31
+    for (int k = 60; k >= 31; k--) {
+        t[k - 3] += t[k];
+        t[k - 31] += t[k];
+    }
+    GlibcPoly r;
+    std::memcpy(r.c, t, sizeof r.c);
+    return r;
+}
+
+GlibcPoly glibc_poly_xpow(uint64_t d) {
+    GlibcPoly result = glibc_poly_one();
+    GlibcPoly base{};
+    base.c[1] = 1;
+    while (d) {
+        if (d & 1) result = glibc_poly_mul(result, base);
+        base = glibc_poly_mul(base, base);
+        d >>= 1;
+    }
+    return result;
+}
+
+GlibcState glibc_apply(const GlibcPoly &p, const GlibcState &st) {
+    uint32_t w[61];
+    std::memcpy(w, st.s, sizeof st.s);
+    for (int j = 31; j < 61; j++) w[j] = w[j - 31] + w[j - 3];
+    GlibcState out;
+    for (int m = 0; m < 31; m++) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 31; k++) acc += p.c[k] * w[m + k];
+        out.s[m] = acc;
+    }
+    return out;
+}
+
+GlibcState glibc_seed_state(uint32_t seed) {
+    // srandom_r: r[0] = seed (0 -> 1), r[i] = 16807 * r[i-1] mod (2^31 - 1) via Schrage, i < 31;
+    // r[31..33] = r[0..2]; from i = 34 on r[i] = r[i-31] + r[i-3].  rand() number k is r[344+k] >> 1.
+    uint32_t r[34];
+    if (seed == 0) seed = 1;
+    r[0] = seed;
+    int32_t word = (int32_t)seed;
+    for (int i = 1; i < 31; i++) {
+        long hi = word / 127773, lo = word % 127773;
+        long w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        word = (int32_t)w;
+        r[i] = (uint32_t)word;
+    }
+    for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+    GlibcState base;  // window r[3..33]: its successor is r[34] = r[3] + r[31] = s[0] + s[28]
+    for (int i = 0; i < 31; i++) base.s[i] = r[3 + i];
+    // advance the window so that s[0] = r[344]
+    return glibc_apply(glibc_poly_xpow(341), base);
+}
+
+}  // namespace pn
+
+using namespace pn;
+
+extern "C" {
+
+int pn_abi_version(void) { return PN_ABI_VERSION; }
+const char *pn_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// edge file
+// ------------------------------------------------------------------------------------------------
+static bool slurp(const char *path, std::string &out) {
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long sz = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    out.resize(sz > 0 ? (size_t)sz : 0);
+    size_t got = sz > 0 ? std::fread(&out[0], 1, (size_t)sz, f) : 0;
+    std::fclose(f);
+    return got == out.size();
+}
+
+int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, double *p, int64_t cap) {
+    if (!path || !n || !m) PN_FAIL(PN_ERR_ARG, "pn_edges_read_text: null argument");
+    std::string txt;
+    if (!slurp(path, txt)) PN_FAIL(PN_ERR_IO, "cannot read edge file %s: %s", path, std::strerror(errno));
+    const char *s = txt.c_str();
+    char *end = nullptr;
+    long nn = std::strtol(s, &end, 10);
+    if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: missing node count", path);
+    s = end;
+    long long mm = std::strtoll(s, &end, 10);
+    if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: missing row count", path);
+    s = end;
+    if (nn < 0 || mm < 0) PN_FAIL(PN_ERR_FORMAT, "%s: negative header", path);
+    *n = (int32_t)nn;
+    *m = (int64_t)mm;
+    if (cap == 0) return PN_OK;
+    if (cap < mm) PN_FAIL(PN_ERR_CAPACITY, "edge buffers hold %lld rows, file has %lld", (long long)cap, mm);
+    if (!u || !v || !p) PN_FAIL(PN_ERR_ARG, "pn_edges_read_text: null output with cap > 0");
+    for (long long i = 0; i < mm; i++) {
+        long a = std::strtol(s, &end, 10);
+        if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: row %lld truncated", path, i);
+        s = end;
+        long b = std::strtol(s, &end, 10);
+        if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: row %lld truncated", path, i);
+        s = end;
+        double pr = std::strtod(s, &end);  // same conversion scanf("%lf") performs
+        if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: row %lld truncated", path, i);
+        s = end;
+        u[i] = (int32_t)a;
+        v[i] = (int32_t)b;
+        p[i] = pr;
+    }
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// alias tables
+// ------------------------------------------------------------------------------------------------
+// smallest draw r in [0, 2^31) with (1.0 * r / RAND_MAX) > s, or 2^31 if there is none.  The quotient
+// is monotone in r, so a bisection over the exact fp64 expression of roll() is exact.
+static uint32_t draw_threshold(double s) {
+    const double rmax = 2147483647.0;
+    if (!(1.0 * 2147483647 / rmax > s)) return 2147483648u;  // also catches NaN
+    uint32_t lo = 0, hi = 2147483647u;                        // pred(hi) is true
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (1.0 * (double)mid / rmax > s)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+namespace {
+struct Pending {
+    int32_t id;
+    double mass;
+};
+}  // namespace
+
+int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, const double *p, int64_t *off,
+                   int32_t *A, int32_t *B, double *S, uint32_t *thr, int64_t cap, int64_t *total) {
+    if (n < 0 || m < 0 || !off || !total || (m > 0 && (!u || !v || !p)))
+        PN_FAIL(PN_ERR_ARG, "pn_alias_build: bad argument");
+    // bucket the rows per source node, keeping file order (link(), gen_merw.cpp:95-99)
+    std::vector<int64_t> start((size_t)n + 1, 0);
+    for (int64_t e = 0; e < m; e++) {
+        if (u[e] < 0 || u[e] >= n) PN_FAIL(PN_ERR_ARG, "edge row %lld: source %d out of range", (long long)e, u[e]);
+        start[(size_t)u[e] + 1]++;
+    }
+    for (int32_t i = 0; i < n; i++) start[(size_t)i + 1] += start[i];
+    std::vector<int64_t> cursor(start.begin(), start.end() - 1);
+    std::vector<int32_t> nbr((size_t)m);
+    std::vector<double> prob((size_t)m);
+    for (int64_t e = 0; e < m; e++) {
+        int64_t at = cursor[u[e]]++;
+        nbr[(size_t)at] = v[e];
+        prob[(size_t)at] = p[e];
+    }
+    int64_t count = 0;
+    auto emit = [&](int32_t a, int32_t b, double s) {
+        if (count < cap) {
+            if (A) A[count] = a;
+            if (B) B[count] = b;
+            if (S) S[count] = s;
+            if (thr) thr[count] = draw_threshold(s);
+        }
+        count++;
+    };
+    std::deque<Pending> heavy, light;
+    for (int32_t node = 0; node < n; node++) {
+        off[node] = count;
+        const int64_t k = start[(size_t)node + 1] - start[node];
+        heavy.clear();
+        light.clear();
+        for (int64_t j = 0; j < k; j++) {
+            Pending e{nbr[(size_t)(start[node] + j)], prob[(size_t)(start[node] + j)] * (double)k};
+            (e.mass > 1.0 ? heavy : light).push_back(e);
+        }
+        while (!heavy.empty() && !light.empty()) {
+            Pending hv = heavy.front();
+            heavy.pop_front();
+            Pending lt = light.front();
+            light.pop_front();
+            emit(hv.id, lt.id, lt.mass);
+            const double rest = hv.mass - (1.0 - lt.mass);
+            if (std::fabs(rest - 1.0) < 1e-5) {  // eps, gen_merw.cpp:5 and :48
+                emit(hv.id, hv.id, rest);
+                continue;
+            }
+            (rest > 1.0 ? heavy : light).push_back(Pending{hv.id, rest});
+        }
+        for (; !heavy.empty(); heavy.pop_front()) emit(heavy.front().id, heavy.front().id, 1.0);
+        for (; !light.empty(); light.pop_front()) emit(light.front().id, light.front().id, 1.0);
+    }
+    off[n] = count;
+    *total = count;
+    if (cap != 0 && cap < count)
+        PN_FAIL(PN_ERR_CAPACITY, "alias buffers hold %lld triples, need %lld", (long long)cap, (long long)count);
+    return PN_OK;
+}
+
+int pn_alias_pack(int64_t total, const int32_t *A, const int32_t *B, const uint32_t *thr, int32_t *dst) {
+    if (total < 0 || (total > 0 && (!A || !B || !thr || !dst))) PN_FAIL(PN_ERR_ARG, "pn_alias_pack: bad argument");
+    for (int64_t i = 0; i < total; i++) {
+        dst[4 * i + 0] = A[i];
+        dst[4 * i + 1] = B[i];
+        dst[4 * i + 2] = (int32_t)thr[i];
+        dst[4 * i + 3] = 0;
+    }
+    return PN_OK;
+}
+
+int pn_glibc_draws(uint32_t seed, uint64_t first, int64_t count, int32_t *out) {
+    if (count < 0 || (count > 0 && !out)) PN_FAIL(PN_ERR_ARG, "pn_glibc_draws: bad argument");
+    GlibcState st = glibc_apply(glibc_poly_xpow(first), glibc_seed_state(seed));
+    uint32_t ring[31];
+    std::memcpy(ring, st.s, sizeof ring);
+    // ring[j] holds word (pos + j); the word after the window is w[0] + w[28]
+    for (int64_t k = 0; k < count; k++) {
+        const int at = (int)(k % 31);
+        out[k] = (int32_t)(ring[at] >> 1);
+        ring[at] = ring[at] + ring[(at + 28) % 31];
+    }
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hop table
+// ------------------------------------------------------------------------------------------------
+int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t seq_len, uint8_t *dis) {
+    if (n < 0 || m < 0 || seq_len < 1 || seq_len > 254 || !dis || (m > 0 && (!u || !v)))
+        PN_FAIL(PN_ERR_ARG, "pn_hops_dense: bad argument");
+    std::vector<int64_t> start((size_t)n + 1, 0);
+    for (int64_t e = 0; e < m; e++) {
+        if (u[e] < 0 || u[e] >= n || v[e] < 0 || v[e] >= n)
+            PN_FAIL(PN_ERR_ARG, "edge row %lld out of range", (long long)e);
+        start[(size_t)u[e] + 1]++;
+    }
+    for (int32_t i = 0; i < n; i++) start[(size_t)i + 1] += start[i];
+    std::vector<int64_t> cursor(start.begin(), start.end() - 1);
+    std::vector<int32_t> nbr((size_t)m);
+    for (int64_t e = 0; e < m; e++) nbr[(size_t)cursor[u[e]]++] = v[e];
+    std::memset(dis, 0, (size_t)n * (size_t)n);
+    std::vector<int32_t> frontier, next;
+    for (int32_t src = 0; src < n; src++) {
+        uint8_t *row = dis + (size_t)src * (size_t)n;
+        row[src] = 1;
+        frontier.assign(1, src);
+        // a walk of seq_len nodes reaches at most seq_len-1 hops: label levels 1..seq_len
+        for (int32_t level = 1; level < seq_len && !frontier.empty(); level++) {
+            next.clear();
+            for (int32_t x : frontier)
+                for (int64_t j = start[x]; j < start[(size_t)x + 1]; j++) {
+                    int32_t y = nbr[(size_t)j];
+                    if (row[y] == 0) {
+                        row[y] = (uint8_t)(level + 1);
+                        next.push_back(y);
+                    }
+                }
+            frontier.swap(next);
+        }
+    }
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// path file
+// ------------------------------------------------------------------------------------------------
+static inline char *put_uint(char *w, uint32_t x) {
+    char tmp[12];
+    int k = 0;
+    do {
+        tmp[k++] = (char)('0' + x % 10);
+        x /= 10;
+    } while (x);
+    while (k) *w++ = tmp[--k];
+    return w;
+}
+
+int pn_paths_write_text(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L,
+                        int32_t append) {
+    if (!path || npaths < 0 || L < 1 || (npaths > 0 && (!ids || !codes)))
+        PN_FAIL(PN_ERR_ARG, "pn_paths_write_text: bad argument");
+    FILE *f = std::fopen(path, append ? "ab" : "wb");
+    if (!f) PN_FAIL(PN_ERR_IO, "cannot open %s for writing: %s", path, std::strerror(errno));
+    const size_t line_max = (size_t)L * (12 + 5) + 4;
+    const int64_t chunk = 1 << 16;
+    std::vector<char> buf(line_max * (size_t)chunk);
+    for (int64_t p0 = 0; p0 < npaths; p0 += chunk) {
+        int64_t p1 = std::min(npaths, p0 + chunk);
+        char *w = buf.data();
+        for (int64_t q = p0; q < p1; q++) {
+            *w++ = '[';
+            for (int32_t t = 0; t < L; t++) {
+                int32_t id = ids[q * L + t];
+                if (id < 0) {
+                    *w++ = '-';
+                    w = put_uint(w, (uint32_t)(-(int64_t)id));
+                } else
+                    w = put_uint(w, (uint32_t)id);
+                *w++ = ',';
+                *w++ = ' ';
+            }
+            for (int32_t t = 0; t < L; t++) {
+                w = put_uint(w, codes[q * L + t]);
+                if (t + 1 < L) {
+                    *w++ = ',';
+                    *w++ = ' ';
+                }
+            }
+            *w++ = ']';
+            *w++ = '\n';
+        }
+        size_t nbytes = (size_t)(w - buf.data());
+        if (std::fwrite(buf.data(), 1, nbytes, f) != nbytes) {
+            std::fclose(f);
+            PN_FAIL(PN_ERR_IO, "short write to %s", path);
+        }
+    }
+    if (std::fclose(f) != 0) PN_FAIL(PN_ERR_IO, "close failed on %s", path);
+    return PN_OK;
+}
+
+int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) {
+    if (!path || L < 1 || !npaths) PN_FAIL(PN_ERR_ARG, "pn_paths_read_text: bad argument");
+    std::string txt;
+    if (!slurp(path, txt)) PN_FAIL(PN_ERR_IO, "cannot read path file %s: %s", path, std::strerror(errno));
+    const char *s = txt.data(), *e = s + txt.size();
+    int64_t count = 0;
+    while (s < e) {
+        // the reader slices line[1:-2] (PathNet_run.py:327): first char '[' and the last two "]\n"
+        if (*s != '[') PN_FAIL(PN_ERR_FORMAT, "%s: line %lld does not start with '['", path, (long long)count);
+        s++;
+        for (int32_t k = 0; k < 2 * L; k++) {
+            while (s < e && *s == ' ') s++;
+            bool neg = false;
+            if (s < e && *s == '-') {
+                neg = true;
+                s++;
+            }
+            if (s >= e || *s < '0' || *s > '9')
+                PN_FAIL(PN_ERR_FORMAT, "%s: line %lld field %d is not an integer", path, (long long)count, k);
+            int64_t val = 0;
+            while (s < e && *s >= '0' && *s <= '9') val = val * 10 + (*s++ - '0');
+            if (neg) val = -val;
+            if (cap > 0 && count < cap) {
+                if (k < L)
+                    ids[count * L + k] = (int32_t)val;
+                else
+                    codes[count * L + (k - L)] = (uint8_t)val;
+            }
+            if (k + 1 < 2 * L) {
+                if (s >= e || *s != ',')
+                    PN_FAIL(PN_ERR_FORMAT, "%s: line %lld has fewer than %d fields", path, (long long)count, 2 * L);
+                s++;
+            }
+        }
+        if (s >= e || *s != ']' || s + 1 >= e || s[1] != '\n')
+            PN_FAIL(PN_ERR_FORMAT, "%s: line %lld does not end with \"]\\n\" after %d fields", path, (long long)count,
+                    2 * L);
+        s += 2;
+        count++;
+    }
+    *npaths = count;
+    if (cap > 0 && count > cap)
+        PN_FAIL(PN_ERR_CAPACITY, "path buffers hold %lld paths, file has %lld", (long long)cap, (long long)count);
+    return PN_OK;
+}
+
+}  // extern "C"

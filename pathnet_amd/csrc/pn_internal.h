@@ -1,0 +1,42 @@
+// pn_internal.h -- shared by the translation units of libpathnet_hip.so (not part of the ABI).
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/pathnet_hip.h"
+
+namespace pn {
+
+// thread-local error text behind pn_last_error()
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define PN_FAIL(code, ...)          \
+    do {                            \
+        ::pn::set_error(__VA_ARGS__); \
+        return (code);              \
+    } while (0)
+
+#define PN_CHECK_HIP(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) PN_FAIL(PN_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---- glibc rand() (TYPE_3 additive feedback) as polynomial algebra over Z/2^32 -------------------
+// The word sequence obeys r[j+31] = r[j] + r[j+28]; a "state" is 31 consecutive words and
+// x^d mod (x^31 - x^28 - 1) maps the state at position 0 to the state at position d.
+struct GlibcPoly {
+    uint32_t c[31];
+};
+struct GlibcState {
+    uint32_t s[31];
+};
+GlibcPoly glibc_poly_one();
+GlibcPoly glibc_poly_mul(const GlibcPoly &a, const GlibcPoly &b);
+GlibcPoly glibc_poly_xpow(uint64_t d);
+GlibcState glibc_apply(const GlibcPoly &p, const GlibcState &st);
+// state whose s[0] >> 1 is the first rand() after srand(seed)
+GlibcState glibc_seed_state(uint32_t seed);
+
+}  // namespace pn

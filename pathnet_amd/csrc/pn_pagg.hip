@@ -1,0 +1,719 @@
+// pn_pagg.hip -- the path aggregator ("PAGG") forward and backward on gfx950.
+//
+// Replaces the forward() bodies of
+//   PathNet       /root/reference/PathNet_run.py:172-211   (variant HETERO)
+//   PathNet_homo  /root/reference/PathNet_run.py:239-278   (variant HOMO)
+//   PAGG          /root/reference/baseline/GPRGNN/src/copy.py:327-359   (variant PAGG)
+// and the autograd backward the reference gets from loss.backward() (PathNet_run.py:351).
+//
+// How the reference's op sequence maps onto kernels here
+//   fc0 (+ReLU)                      :175 / :242-243      -> gemm_kernel            Xh[N,H]
+//   L Linear layers on P*L gathered rows, stack, select by distance code
+//                                    :185-191 / :249-255  -> ONE gemm over the N nodes:
+//        Z[v, d, :] = nets[d](Xh[v])  for every node v and code d  (N*L rows instead of P*L*L),
+//        after which "gather + select" is a single row gather  Z[node(q,t)*L + code(q,t)].
+//        Same dot products per emitted row, ~S*W*L/N times fewer FLOPs, no [P*L, L, H] temporary.
+//   X[neis] gather, flip / view quirks :179-184 / :246     -> plan_kernel (index plan only)
+//   dropout, nn.LSTM / nn.RNN          :194-195 / :264-265 -> seq_fwd_kernel: coalesced 4*H-byte row
+//        gather into an LDS path tile, fp32 MFMA (v_mfma_f32_32x32x2_f32) for [x_t ; h_{t-1}] x
+//        [W_ih ; W_hh]^T, cell math in registers, h_t back to LDS, L steps without leaving the CU.
+//   attention over the W paths, mean, concat ego, dropout, fc2
+//                                    :196-210 / :266-277  -> pool_fwd_kernel: one wavefront per
+//        node, wave shuffles for the per-path dot products and the reduction over W.
+//
+// Precision: everything is fp32 with fp32 accumulation (the f32-input MFMA is an exact FMA chain),
+// because the contract is 1e-5 on fp32 logits against the reference CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "pn_internal.h"
+#include "pn_kernels.h"
+
+using namespace pn;
+
+namespace {
+
+// ================================================================================================
+// generic fp32 GEMM on MFMA:  C[m][n] (op)= act( sum_k A(m,k) * B(n,k) + bias[n] )
+//   A(m,k) = A[m*sAm + k*sAk] (optionally multiplied by [gateA(m,k) > 0]), B(n,k) = B[n*sBn + k*sBk];
+//   exactly one stride of each operand is 1.  64x64 block tile, 4 waves of 32x32, K tile 32, both
+//   operand tiles K-major in LDS (pitch 65) so every MFMA operand fetch is a conflict-free
+//   ds_read_b32 of 32 consecutive floats per half-wave.
+// ================================================================================================
+constexpr int GEMM_BM = 64, GEMM_BN = 64, GEMM_KT = 32, GEMM_PITCH = 65;
+enum { GEMM_STORE = 0, GEMM_ADD = 1, GEMM_ATOMIC = 2 };
+
+struct GemmParams {
+    const float *A;
+    int64_t sAm, sAk;
+    const float *gateA;
+    const float *B;
+    int64_t sBn, sBk;
+    float *C;
+    int64_t ldc;
+    const float *bias;
+    int M, N, K;
+    int relu, mode;
+    int kchunk;  // K range per blockIdx.z
+};
+
+template <bool A_KCONTIG, bool B_KCONTIG>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    __shared__ float As[GEMM_KT * GEMM_PITCH];
+    __shared__ float Bs[GEMM_KT * GEMM_PITCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+
+    for (int k0 = kbeg; k0 < kend; k0 += GEMM_KT) {
+#pragma unroll
+        for (int i = 0; i < (GEMM_BM * GEMM_KT) / 256; i++) {
+            const int idx = tid + 256 * i;
+            const int m = A_KCONTIG ? (idx >> 5) : (idx & 63);
+            const int k = A_KCONTIG ? (idx & 31) : (idx >> 6);
+            const int gm = m0 + m, gk = k0 + k;
+            float v = 0.0f;
+            if (gm < p.M && gk < kend) {
+                const int64_t at = (int64_t)gm * p.sAm + (int64_t)gk * p.sAk;
+                v = p.A[at];
+                if (p.gateA && !(p.gateA[at] > 0.0f)) v = 0.0f;
+            }
+            As[k * GEMM_PITCH + m] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < (GEMM_BN * GEMM_KT) / 256; i++) {
+            const int idx = tid + 256 * i;
+            const int n = B_KCONTIG ? (idx >> 5) : (idx & 63);
+            const int k = B_KCONTIG ? (idx & 31) : (idx >> 6);
+            const int gn = n0 + n, gk = k0 + k;
+            float v = 0.0f;
+            if (gn < p.N && gk < kend) v = p.B[(int64_t)gn * p.sBn + (int64_t)gk * p.sBk];
+            Bs[k * GEMM_PITCH + n] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KT / 2; kk++) {
+            const float a = As[(2 * kk + hk) * GEMM_PITCH + wm * 32 + li];
+            const float b = Bs[(2 * kk + hk) * GEMM_PITCH + wn * 32 + li];
+            acc = mfma32(a, b, acc);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + li;
+    if (col >= p.N) return;
+    const float bias = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 32 + acc_row(r, lane);
+        if (row >= p.M) continue;
+        float v = acc[r] + bias;
+        if (p.relu) v = fmaxf(v, 0.0f);
+        float *dst = p.C + (int64_t)row * p.ldc + col;
+        if (p.mode == GEMM_STORE)
+            *dst = v;
+        else if (p.mode == GEMM_ADD)
+            *dst += v;
+        else
+            atomicAdd(dst, v);
+    }
+}
+
+int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
+                int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
+                int mode, int ksplit) {
+    if (M <= 0 || N <= 0) return PN_OK;
+    GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0};
+    if (ksplit < 1) ksplit = 1;
+    if (mode != GEMM_ATOMIC) ksplit = 1;
+    int kchunk = (K + ksplit - 1) / ksplit;
+    kchunk = ((kchunk + GEMM_KT - 1) / GEMM_KT) * GEMM_KT;
+    if (kchunk < GEMM_KT) kchunk = GEMM_KT;
+    p.kchunk = kchunk;
+    const int nz = K > 0 ? (K + kchunk - 1) / kchunk : 1;
+    dim3 grid((N + GEMM_BN - 1) / GEMM_BN, (M + GEMM_BM - 1) / GEMM_BM, nz);
+    const bool ak = (sAk == 1), bk = (sBk == 1);
+    if (ak && bk)
+        hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, p);
+    else if (ak && !bk)
+        hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, stream, p);
+    else if (!ak && bk)
+        hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, p);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+// out[n] (+)= sum_m A[m*ld + n] * [gate[m*ld+n] > 0]      (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, const float *__restrict__ gate,
+                                                     int64_t ld, int M, int N, int rows_per_block,
+                                                     float *__restrict__ out) {
+    __shared__ float part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.0f;
+    if (n < N)
+        for (int m = r0 + wave; m < r1; m += 4) {
+            const int64_t at = (int64_t)m * ld + n;
+            float v = A[at];
+            if (gate && !(gate[at] > 0.0f)) v = 0.0f;
+            s += v;
+        }
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) atomicAdd(out + n, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+
+// ================================================================================================
+// index plan (the reference's view/flip/transposes collapsed into index arithmetic)
+//   slot' = group * W + member is the order every later kernel uses (pooling groups contiguous).
+//   original sequence slot q:  HOMO/PAGG q = slot'            (group = q / W)
+//                              HETERO    q = member * S + group  (h_n.view(W, S, H), PathNet_run.py:196-197)
+//   step t of slot q reads   HOMO/PAGG node ids[q, t]
+//                            HETERO    r = q*L + t, node ids[r % P, L-1 - r / P]  (flip + reshape, :182-183)
+//   and always the code codes[q, t] (:184 / :248).
+// ================================================================================================
+__device__ __forceinline__ void plan_entry(int variant, const int32_t *ids, const uint8_t *codes, int S, int W, int L,
+                                           int slot, int t, int &q, int &node, int &code) {
+    const int P = S * W;
+    if (variant == PN_VARIANT_HETERO) {
+        const int g = slot / W, mem = slot - g * W;
+        q = mem * S + g;
+        const int64_t r = (int64_t)q * L + t;
+        node = ids[(r % P) * L + (L - 1 - (int)(r / P))];
+    } else {
+        q = slot;
+        node = ids[(int64_t)q * L + t];
+    }
+    code = codes[(int64_t)q * L + t];
+}
+
+__global__ void plan_kernel(int variant, const int32_t *__restrict__ ids, const uint8_t *__restrict__ codes, int S,
+                            int W, int L, int N, int32_t *__restrict__ rowidx, int32_t *__restrict__ egoidx,
+                            int32_t *__restrict__ slotof) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t P = (int64_t)S * W;
+    if (i >= P * L) return;
+    const int slot = (int)(i / L), t = (int)(i - (int64_t)slot * L);
+    int q, node, code;
+    plan_entry(variant, ids, codes, S, W, L, slot, t, q, node, code);
+    node = min(max(node, 0), N - 1);
+    code = min(code, L - 1);
+    rowidx[i] = node * L + code;
+    if (t == 0) {
+        slotof[slot] = q;
+        // attention ego: HOMO uses the transformed row of (q, step 0) (ego_full, :259-260);
+        // HETERO uses the untransformed Xh row of path q's first node (neis[0], :199)
+        egoidx[slot] = variant == PN_VARIANT_HETERO ? min(max(ids[(int64_t)q * L], 0), N - 1) : node * L + code;
+    }
+}
+
+// rows[slot', t, :] = table[rowidx, :]   (stand-alone gather, also the HBM-roofline microbenchmark)
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_kernel(int variant, const float *__restrict__ table,
+                                                     const int32_t *__restrict__ ids,
+                                                     const uint8_t *__restrict__ codes, int S, int W, int L, int N,
+                                                     int H, float *__restrict__ rows) {
+    const int hv = H / VEC;
+    const int64_t total = (int64_t)S * W * L * hv;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / hv;
+        const int c = (int)(i - row * hv);
+        const int slot = (int)(row / L), t = (int)(row - (int64_t)slot * L);
+        int q, node, code;
+        plan_entry(variant, ids, codes, S, W, L, slot, t, q, node, code);
+        node = min(max(node, 0), N - 1);
+        code = min(code, L - 1);
+        const int64_t src = ((int64_t)node * L + code) * hv + c;
+        if (VEC == 4)
+            reinterpret_cast<float4 *>(rows)[i] = reinterpret_cast<const float4 *>(table)[src];
+        else
+            rows[i] = table[src];
+    }
+}
+
+// ================================================================================================
+// recurrent weights repacked into MFMA B-fragment order so that every fragment load is one fully
+// coalesced 1 KB global_load_dwordx4 per wave:
+//   Wp[((w*G + g)*(H/4) + s4)*64 + lane][e] = Wcat[g*H + 32*w + (lane&31)][(lane>>5)*H + 4*s4 + e]
+// with Wcat = [W_ih | W_hh] ([G*H, 2H]).  The lane half (lane>>5) selects the x or the h part, so one
+// MFMA step multiplies x_t by W_ih in lanes 0-31 and h_{t-1} by W_hh in lanes 32-63 and sums both.
+// ================================================================================================
+__global__ void pack_fwd_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G,
+                                float *__restrict__ Wp, float *__restrict__ biasc) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)G * H * 2 * H;
+    if (idx < (int64_t)G * H) biasc[idx] = b_ih[idx] + b_hh[idx];
+    if (idx >= total) return;
+    const int e = idx & 3, lane = (idx >> 2) & 63;
+    int64_t rest = idx >> 8;
+    const int s4 = rest % (H / 4);
+    rest /= (H / 4);
+    const int g = rest % G, w = rest / G;
+    const int row = g * H + 32 * w + (lane & 31), k = 4 * s4 + e;
+    Wp[idx] = (lane >> 5) == 0 ? w_ih[(int64_t)row * H + k] : w_hh[(int64_t)row * H + k];
+}
+
+// ================================================================================================
+// seq_fwd_kernel: gather + dropout + LSTM/RNN over the L steps of MT sequence slots.
+//   block = H/32 waves; wave w owns hidden units [32w, 32w+32) of every gate; LDS holds the
+//   A tile [MT][x_t (H) | h_{t-1} (H)] (+4 floats of row padding: conflict-free ds_read_b128).
+// ================================================================================================
+struct SeqFwdParams {
+    const float *Z;         // [N*L, H] bank output (post activation)
+    const int32_t *rowidx;  // [P, L]
+    const int32_t *slotof;  // [P]
+    const float *Wp;        // packed recurrent weights
+    const float *biasc;     // [G*H]
+    float *hn;              // [P, H] final hidden state per slot'
+    float *saved;           // [P, L, SV, H]  SV = 5 (i,f,g,o,c) for LSTM, 1 (h_t) for RNN; may be null
+    int P, L;
+    float p_drop;
+    uint64_t seed;
+    const float *mask;      // [L, P, H] explicit mask (reference order: original slot q) or null
+};
+
+template <int H, int G, int MT>
+__global__ __launch_bounds__(H / 32 * 64) void seq_fwd_kernel(SeqFwdParams p) {
+    constexpr int NW = H / 32, NT = NW * 64, MTILES = MT / 32, PITCH = 2 * H + 4, SV = (G == 4 ? 5 : 1);
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int q0 = blockIdx.x * MT;
+    const int col = 32 * wave + li;
+
+    for (int idx = tid; idx < MT * H; idx += NT) lds[(idx / H) * PITCH + H + (idx % H)] = 0.0f;
+
+    f32x16 cst[MTILES];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) cst[mt][r] = 0.0f;
+    float bias[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) bias[g] = p.biasc[g * H + col];
+
+    const float4 *Z4 = reinterpret_cast<const float4 *>(p.Z);
+    const float4 *Wp4 = reinterpret_cast<const float4 *>(p.Wp);
+
+    for (int t = 0; t < p.L; t++) {
+        // ---- coalesced row gather of x_t (H*4 bytes per row) with the dropout mask fused in -------
+        for (int idx = tid; idx < MT * (H / 4); idx += NT) {
+            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+            const int q = q0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < p.P) {
+                const int ri = p.rowidx[(int64_t)q * p.L + t];
+                v = Z4[(int64_t)ri * (H / 4) + c4];
+                if (p.mask) {
+                    const float4 m = reinterpret_cast<const float4 *>(
+                        p.mask)[((int64_t)t * p.P + p.slotof[q]) * (H / 4) + c4];
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                } else if (p.p_drop > 0.0f) {
+                    const float4 m = dropout4(p.seed, ((uint64_t)t * p.P + p.slotof[q]) * (H / 4) + c4, 1u, p.p_drop);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
+            *reinterpret_cast<float4 *>(&lds[row * PITCH + 4 * c4]) = v;
+        }
+        __syncthreads();
+
+        f32x16 acc[MTILES][G];
+#pragma unroll
+        for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mt][g][r] = bias[g];
+
+        // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T : lanes 0-31 walk the x half of K, lanes 32-63 the h half
+        float4 bcur[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) bcur[g] = Wp4[((int64_t)(wave * G + g) * (H / 4)) * 64 + lane];
+#pragma unroll 2
+        for (int s4 = 0; s4 < H / 4; s4++) {
+            float4 bnext[G];
+            const int sn = (s4 + 1 < H / 4) ? s4 + 1 : s4;
+#pragma unroll
+            for (int g = 0; g < G; g++) bnext[g] = Wp4[((int64_t)(wave * G + g) * (H / 4) + sn) * 64 + lane];
+            float4 a[MTILES];
+#pragma unroll
+            for (int mt = 0; mt < MTILES; mt++)
+                a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * H + 4 * s4]);
+#pragma unroll
+            for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    acc[mt][g] = mfma32(a[mt].x, bcur[g].x, acc[mt][g]);
+                    acc[mt][g] = mfma32(a[mt].y, bcur[g].y, acc[mt][g]);
+                    acc[mt][g] = mfma32(a[mt].z, bcur[g].z, acc[mt][g]);
+                    acc[mt][g] = mfma32(a[mt].w, bcur[g].w, acc[mt][g]);
+                }
+#pragma unroll
+            for (int g = 0; g < G; g++) bcur[g] = bnext[g];
+        }
+        __syncthreads();  // every wave is done reading x_t / h_{t-1}
+
+        // ---- cell update in registers; h_t goes back to LDS for the next step ----------------------
+#pragma unroll
+        for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = mt * 32 + acc_row(r, lane);
+                const int q = q0 + row;
+                float h;
+                if (G == 4) {
+                    const float ig = sigmoidf_(acc[mt][0][r]);
+                    const float fg = sigmoidf_(acc[mt][G > 1 ? 1 : 0][r]);
+                    const float gg = tanhf(acc[mt][G > 2 ? 2 : 0][r]);
+                    const float og = sigmoidf_(acc[mt][G > 3 ? 3 : 0][r]);
+                    const float c = fg * cst[mt][r] + ig * gg;
+                    cst[mt][r] = c;
+                    h = og * tanhf(c);
+                    if (p.saved && q < p.P) {
+                        float *sv = p.saved + (((int64_t)q * p.L + t) * SV) * H + col;
+                        sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+                    }
+                } else {
+                    h = tanhf(acc[mt][0][r]);
+                    if (p.saved && q < p.P) p.saved[((int64_t)q * p.L + t) * H + col] = h;
+                }
+                lds[row * PITCH + H + col] = h;
+                if (t == p.L - 1 && q < p.P) p.hn[(int64_t)q * H + col] = h;
+            }
+    }
+}
+
+// ================================================================================================
+// pool_fwd_kernel: one wavefront per pooling group (= output node).
+// ================================================================================================
+struct PoolParams {
+    int variant, S, W, H, C;
+    const float *hn;        // [P, H] in slot' order
+    const float *ego_tab;   // Z (HOMO) or Xh (HETERO)
+    const int32_t *egoidx;  // [P] row of ego_tab
+    const float *Xh;        // [N, H]
+    const int32_t *sel;     // [S]
+    const float *att_w, *att_b, *fc2_w, *fc2_b;
+    float p_drop;
+    uint64_t seed;
+    const float *mask;      // [S, 2H] or null
+    float *coef;            // [P] pooling coefficient per slot' (1+att | softmax | 1)
+    float *rawsc;           // [P] raw attention score (pre LeakyReLU) per slot'
+    float *layer1;          // [S, 2H] classifier input after dropout
+    float *out;             // [S, C]
+};
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
+    extern __shared__ float lds[];  // [4][W]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= p.S) return;
+    float *sc = lds + wave * p.W;
+    const int H = p.H;
+    const float inv_w = 1.0f / (float)p.W;
+
+    if (p.variant != PN_VARIANT_PAGG) {
+        const float ab = p.att_b[0];
+        for (int mem = 0; mem < p.W; mem++) {
+            const int64_t s = (int64_t)g * p.W + mem;
+            const float *h = p.hn + s * H;
+            const float *e = p.ego_tab + (int64_t)p.egoidx[s] * H;
+            float part = 0.0f;
+            for (int j = lane; j < H; j += 64) part += h[j] * p.att_w[j] + e[j] * p.att_w[H + j];
+            const float score = wave_sum(part) + ab;
+            if (lane == 0) {
+                sc[mem] = score;
+                p.rawsc[s] = score;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (p.variant == PN_VARIANT_HETERO) {
+        // softmax over the W members of LeakyReLU(score) (F.softmax implicit dim 0 of [W,S,1])
+        float mx = -3.4e38f;
+        for (int mem = lane; mem < p.W; mem += 64) {
+            float v = sc[mem];
+            v = v > 0.0f ? v : 0.01f * v;
+            mx = fmaxf(mx, v);
+        }
+        mx = wave_max(mx);
+        float sum = 0.0f;
+        for (int mem = lane; mem < p.W; mem += 64) {
+            float v = sc[mem];
+            v = v > 0.0f ? v : 0.01f * v;
+            sum += expf(v - mx);
+        }
+        sum = wave_sum(sum);
+        for (int mem = lane; mem < p.W; mem += 64) {
+            float v = sc[mem];
+            v = v > 0.0f ? v : 0.01f * v;
+            sc[mem] = expf(v - mx) / sum;
+        }
+    } else if (p.variant == PN_VARIANT_HOMO) {
+        for (int mem = lane; mem < p.W; mem += 64) sc[mem] = 1.0f + sc[mem];
+    } else {
+        for (int mem = lane; mem < p.W; mem += 64) sc[mem] = 1.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int mem = lane; mem < p.W; mem += 64) p.coef[(int64_t)g * p.W + mem] = sc[mem];
+
+    // pooled = mean_w coef_w * h_w ; layer1 = dropout([Xh[sel[g]] ; pooled])
+    float *l1 = p.layer1 + (int64_t)g * 2 * H;
+    const float *ego = p.Xh + (int64_t)p.sel[g] * H;
+    for (int j = lane; j < H; j += 64) {
+        float acc = 0.0f;
+        for (int mem = 0; mem < p.W; mem++) acc += sc[mem] * p.hn[((int64_t)g * p.W + mem) * H + j];
+        float a = ego[j], b = acc * inv_w;
+        if (p.mask) {
+            a *= p.mask[(int64_t)g * 2 * H + j];
+            b *= p.mask[(int64_t)g * 2 * H + H + j];
+        } else if (p.p_drop > 0.0f) {
+            const float4 m0 = dropout4(p.seed, ((uint64_t)g * 2 * H + j) >> 2, 2u, p.p_drop);
+            const float4 m1 = dropout4(p.seed, ((uint64_t)g * 2 * H + H + j) >> 2, 2u, p.p_drop);
+            const int e0 = j & 3;
+            a *= e0 == 0 ? m0.x : e0 == 1 ? m0.y : e0 == 2 ? m0.z : m0.w;
+            b *= e0 == 0 ? m1.x : e0 == 1 ? m1.y : e0 == 2 ? m1.z : m1.w;
+        }
+        l1[j] = a;
+        l1[H + j] = b;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    for (int c = 0; c < p.C; c++) {
+        float part = 0.0f;
+        for (int j = lane; j < 2 * H; j += 64) part += l1[j] * p.fc2_w[(int64_t)c * 2 * H + j];
+        part = wave_sum(part);
+        if (lane == 0) p.out[(int64_t)g * p.C + c] = part + p.fc2_b[c];
+    }
+}
+
+// ================================================================================================
+// workspace layout
+// ================================================================================================
+struct WsLayout {
+    size_t Xh, Z, rowidx, egoidx, slotof, Wp, biasc, hn, saved, coef, rawsc, layer1;  // forward
+    size_t WpT, dG, dZ, dXh, dhn, dl1;                                                // backward
+    size_t total;
+};
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+WsLayout ws_layout(const pn_pagg_shape &s) {
+    WsLayout w{};
+    const size_t N = s.N, H = s.H, L = s.L, P = (size_t)s.S * s.W, S = s.S;
+    const size_t G = s.variant == PN_VARIANT_PAGG ? 1 : 4, SV = G == 4 ? 5 : 1;
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = at;
+        at = align256(at + bytes);
+        return o;
+    };
+    w.Xh = take(N * H * 4);
+    w.Z = take(N * L * H * 4);
+    w.rowidx = take(P * L * 4);
+    w.egoidx = take(P * 4);
+    w.slotof = take(P * 4);
+    w.Wp = take(G * H * 2 * H * 4);
+    w.biasc = take(G * H * 4);
+    w.hn = take(P * H * 4);
+    w.saved = take(P * L * SV * H * 4);
+    w.coef = take(P * 4);
+    w.rawsc = take(P * 4);
+    w.layer1 = take(S * 2 * H * 4);
+    w.WpT = take(G * H * 2 * H * 4);
+    w.dG = take(P * L * G * H * 4);
+    w.dZ = take(N * L * H * 4);
+    w.dXh = take(N * H * 4);
+    w.dhn = take(P * H * 4);
+    w.dl1 = take(S * 2 * H * 4);
+    w.total = at;
+    return w;
+}
+
+int check_shape(const pn_pagg_shape &s) {
+    if (s.variant < 0 || s.variant > 2) PN_FAIL(PN_ERR_ARG, "unknown variant %d", s.variant);
+    if (s.H != 32 && s.H != 64 && s.H != 128 && s.H != 256)
+        PN_FAIL(PN_ERR_ARG, "hidden size %d not supported (32, 64, 128, 256)", s.H);
+    if (s.N < 1 || s.F < 1 || s.C < 1 || s.S < 0 || s.W < 1 || s.L < 1 || s.L > 64)
+        PN_FAIL(PN_ERR_ARG, "bad aggregator shape N=%d F=%d C=%d S=%d W=%d L=%d", s.N, s.F, s.C, s.S, s.W, s.L);
+    if (s.variant == PN_VARIANT_PAGG && s.L != 4)
+        PN_FAIL(PN_ERR_ARG, "PAGG has exactly four distance layers nei0..nei3 (copy.py:310-313); L=%d", s.L);
+    if ((int64_t)s.S * s.W * s.L > 2000000000LL || (int64_t)s.N * s.L > 2000000000LL)
+        PN_FAIL(PN_ERR_ARG, "index space exceeds int32; split the node set");
+    return PN_OK;
+}
+
+template <int H, int G>
+int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
+    constexpr int MT = (H >= 256 && G == 4) ? 32 : 64;  // 8 waves x 2 per SIMD: keep the accumulators in 256 regs
+    constexpr size_t lds_bytes = (size_t)MT * (2 * H + 4) * 4;
+    auto kern = seq_fwd_kernel<H, G, MT>;
+    PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes));
+    const int blocks = (sp.P + MT - 1) / MT;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64), lds_bytes, stream, sp);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+template <int G>
+int dispatch_seq_fwd(hipStream_t stream, int H, const SeqFwdParams &sp) {
+    switch (H) {
+        case 32: return launch_seq_fwd<32, G>(stream, sp);
+        case 64: return launch_seq_fwd<64, G>(stream, sp);
+        case 128: return launch_seq_fwd<128, G>(stream, sp);
+        case 256: return launch_seq_fwd<256, G>(stream, sp);
+    }
+    PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes) {
+    if (!shape || !bytes) PN_FAIL(PN_ERR_ARG, "pn_pagg_workspace_bytes: null");
+    if (int rc = check_shape(*shape)) return rc;
+    *bytes = (int64_t)ws_layout(*shape).total;
+    return PN_OK;
+}
+
+int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C,
+                int64_t ldc, const float *bias, int32_t M, int32_t N, int32_t K, int32_t relu, void *stream_) {
+    if (!A || !B || !C || M < 0 || N < 0 || K < 0) PN_FAIL(PN_ERR_ARG, "pn_gemm_f32: bad argument");
+    if ((sAm != 1 && sAk != 1) || (sBn != 1 && sBk != 1)) PN_FAIL(PN_ERR_ARG, "pn_gemm_f32: one stride per operand must be 1");
+    return launch_gemm((hipStream_t)stream_, A, sAm, sAk, nullptr, B, sBn, sBk, C, ldc, bias, M, N, K, relu,
+                       GEMM_STORE, 1);
+}
+
+int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
+    if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_debug_offsets: null");
+    if (int rc = check_shape(*shape)) return rc;
+    const WsLayout w = ws_layout(*shape);
+    out[0] = (int64_t)w.Xh;
+    out[1] = (int64_t)w.Z;
+    out[2] = (int64_t)w.hn;
+    out[3] = (int64_t)w.layer1;
+    return PN_OK;
+}
+
+int pn_pagg_gather(const pn_pagg_shape *shape, const float *table, const int32_t *ids, const uint8_t *codes,
+                   float *rows, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!shape || !table || !ids || !codes || !rows) PN_FAIL(PN_ERR_ARG, "pn_pagg_gather: null");
+    const pn_pagg_shape &s = *shape;
+    if (s.S < 0 || s.W < 1 || s.L < 1 || s.H < 1 || s.N < 1) PN_FAIL(PN_ERR_ARG, "pn_pagg_gather: bad shape");
+    const int64_t rowsn = (int64_t)s.S * s.W * s.L;
+    if (rowsn == 0) return PN_OK;
+    const bool vec = (s.H % 4 == 0) && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(rows)) % 16 == 0);
+    const int64_t work = rowsn * (vec ? s.H / 4 : s.H);
+    const int blocks = (int)std::min<int64_t>((work + 255) / 256, 256 * 32);
+    if (vec)
+        hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, stream, s.variant, table, ids, codes, s.S, s.W,
+                           s.L, s.N, s.H, rows);
+    else
+        hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, s.variant, table, ids, codes, s.S, s.W,
+                           s.L, s.N, s.H, rows);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a) PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null args");
+    const pn_pagg_shape &s = a->shape;
+    if (int rc = check_shape(s)) return rc;
+    if (!a->X || !a->ids || !a->codes || !a->sel || !a->fc0_w || !a->fc0_b || !a->bank_w || !a->bank_b || !a->w_ih ||
+        !a->w_hh || !a->b_ih || !a->b_hh || !a->fc2_w || !a->fc2_b || !a->out || !a->workspace)
+        PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null tensor");
+    if (s.variant != PN_VARIANT_PAGG && (!a->att_w || !a->att_b)) PN_FAIL(PN_ERR_ARG, "attention weights missing");
+    const WsLayout w = ws_layout(s);
+    if (a->workspace_bytes < (int64_t)w.total)
+        PN_FAIL(PN_ERR_CAPACITY, "aggregator workspace holds %lld bytes, need %lld", (long long)a->workspace_bytes,
+                (long long)w.total);
+    if (s.S == 0) return PN_OK;
+    char *ws = reinterpret_cast<char *>(a->workspace);
+    float *Xh = reinterpret_cast<float *>(ws + w.Xh), *Z = reinterpret_cast<float *>(ws + w.Z);
+    int32_t *rowidx = reinterpret_cast<int32_t *>(ws + w.rowidx), *egoidx = reinterpret_cast<int32_t *>(ws + w.egoidx),
+            *slotof = reinterpret_cast<int32_t *>(ws + w.slotof);
+    float *Wp = reinterpret_cast<float *>(ws + w.Wp), *biasc = reinterpret_cast<float *>(ws + w.biasc);
+    float *hn = reinterpret_cast<float *>(ws + w.hn), *saved = reinterpret_cast<float *>(ws + w.saved);
+    const int H = s.H, L = s.L, G = s.variant == PN_VARIANT_PAGG ? 1 : 4;
+    const int P = s.S * s.W;
+    const int homo = s.variant == PN_VARIANT_HOMO;
+
+    // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
+    if (int rc = launch_gemm(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1, Xh, H, a->fc0_b, s.N, H, s.F, homo,
+                             GEMM_STORE, 1))
+        return rc;
+    // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
+    if (int rc = launch_gemm(stream, Xh, H, 1, nullptr, a->bank_w, H, 1, Z, (int64_t)L * H, a->bank_b, s.N, L * H, H,
+                             homo, GEMM_STORE, 1))
+        return rc;
+    {
+        const int64_t n = (int64_t)P * L;
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s.variant, a->ids,
+                           a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
+        PN_CHECK_HIP(hipGetLastError());
+        const int64_t nw = (int64_t)G * H * 2 * H;
+        hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
+                           a->b_ih, a->b_hh, H, G, Wp, biasc);
+        PN_CHECK_HIP(hipGetLastError());
+    }
+    SeqFwdParams sp{};
+    sp.Z = Z;
+    sp.rowidx = rowidx;
+    sp.slotof = slotof;
+    sp.Wp = Wp;
+    sp.biasc = biasc;
+    sp.hn = hn;
+    sp.saved = saved;
+    sp.P = P;
+    sp.L = L;
+    sp.p_drop = a->p_seq;
+    sp.seed = a->seed;
+    sp.mask = a->mask_seq;
+    if (int rc = (G == 4 ? dispatch_seq_fwd<4>(stream, H, sp) : dispatch_seq_fwd<1>(stream, H, sp))) return rc;
+
+    PoolParams pp{};
+    pp.variant = s.variant;
+    pp.S = s.S;
+    pp.W = s.W;
+    pp.H = H;
+    pp.C = s.C;
+    pp.hn = hn;
+    pp.ego_tab = homo ? Z : Xh;
+    pp.egoidx = egoidx;
+    pp.Xh = Xh;
+    pp.sel = a->sel;
+    pp.att_w = a->att_w;
+    pp.att_b = a->att_b;
+    pp.fc2_w = a->fc2_w;
+    pp.fc2_b = a->fc2_b;
+    pp.p_drop = a->p_cls;
+    pp.seed = a->seed;
+    pp.mask = a->mask_cls;
+    pp.coef = reinterpret_cast<float *>(ws + w.coef);
+    pp.rawsc = reinterpret_cast<float *>(ws + w.rawsc);
+    pp.layer1 = reinterpret_cast<float *>(ws + w.layer1);
+    pp.out = a->out;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((s.S + 3) / 4), dim3(256), (size_t)4 * s.W * sizeof(float), stream, pp);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
+    (void)a;
+    (void)stream_;
+    PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: not built yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,303 @@
+// pn_sampler.hip -- the MERW walker on gfx950: one walk per lane.
+//
+// Replaces the hot loop of /root/reference/preprocess/gen_merw.cpp:182-209 (and the per-epoch file
+// variant gen_epoch_merw.cpp:164-206).  Per step a lane does what AliasTable::roll() (:81-91) does:
+//   slot = r0 % table_len;  next = (r1 >= thr[slot]) ? A[slot] : B[slot]
+// where thr is the exact integer form of `1.0*r1/RAND_MAX > S[slot]` computed on the host
+// (pn_alias_build), and emits the node id and the distance code dis[st][u]-1 (:192-193, :201).
+//
+// Draw sources
+//   PN_DRAW_GLIBC_REPLAY: the sequential glibc rand() stream after srand(seed), regenerated ON THE
+//     DEVICE.  The TYPE_3 generator is a linear recurrence over Z/2^32 (r[j+31] = r[j] + r[j+28]),
+//     so the state at any stream position is a polynomial jump x^d mod (x^31 - x^28 - 1) applied to
+//     the seed state.  The host prepares three tiny tables (one state per epoch of the window, one
+//     jump per block, one jump per thread); each thread then jumps to its own position and emits
+//     248 consecutive draws.  The walker reads draw 2*(walk*L + t) (+1) from that buffer, which
+//     reproduces the reference binary's output bit for bit.
+//   PN_DRAW_PHILOX: rocRAND's Philox4x32-10 device generator, subsequence = global walk index;
+//     no stream buffer, any window of any epoch is independent (throughput mode).
+//
+// Memory: alias triples are packed {A, B, thr, 0} = one 16-byte load per roll; the dense hop table
+// is n*n bytes in HBM (Pubmed-size 389 MB, the reference's cap n = 100050 is 10 GB of 288 GB).
+// The first hop of every walk starts at its source node, so each workgroup stages the alias tables
+// of the few source nodes it covers in LDS; later hops hit L2.
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+
+#include <cstring>
+#include <vector>
+
+#include "pn_internal.h"
+
+namespace {
+
+constexpr int kFillThreads = 256;               // threads per block of the stream generator
+constexpr int kFillBatches = 8;                 // 31-draw batches per thread
+constexpr int kDrawsPerThread = 31 * kFillBatches;          // 248
+constexpr int kDrawsPerBlock = kDrawsPerThread * kFillThreads;  // 63488
+constexpr int kWalkThreads = 256;
+constexpr int kStageTriples = 1024;             // 16 KB of LDS for first-hop tables
+
+// new_state[m] = sum_k c[k] * w[m + k], w = the 31-word state extended by 30 recurrence steps
+__device__ __forceinline__ void glibc_jump(const uint32_t *__restrict__ c, uint32_t (&s)[31]) {
+    uint32_t w[61];
+#pragma unroll
+    for (int j = 0; j < 31; j++) w[j] = s[j];
+#pragma unroll
+    for (int j = 31; j < 61; j++) w[j] = w[j - 31] + w[j - 3];
+    uint32_t coef[31];
+#pragma unroll
+    for (int k = 0; k < 31; k++) coef[k] = c[k];
+#pragma unroll
+    for (int m = 0; m < 31; m++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 31; k++) acc += coef[k] * w[m + k];
+        s[m] = acc;
+    }
+}
+
+// grid = (blocks_per_epoch, epoch_count).  Segment e holds seg_len draws that start at the stream
+// position encoded in epoch_state[e].
+__global__ __launch_bounds__(kFillThreads) void glibc_fill_kernel(const uint32_t *__restrict__ epoch_state,
+                                                                   const uint32_t *__restrict__ block_jump,
+                                                                   const uint32_t *__restrict__ thread_jump,
+                                                                   int64_t seg_len, int32_t *__restrict__ draws) {
+    const int e = blockIdx.y;
+    const int64_t first = (int64_t)blockIdx.x * kDrawsPerBlock + (int64_t)threadIdx.x * kDrawsPerThread;
+    if (first >= seg_len) return;
+    uint32_t s[31];
+#pragma unroll
+    for (int j = 0; j < 31; j++) s[j] = epoch_state[e * 31 + j];
+    glibc_jump(block_jump + (size_t)blockIdx.x * 31, s);
+    glibc_jump(thread_jump + (size_t)threadIdx.x * 31, s);
+    int32_t *out = draws + (int64_t)e * seg_len;
+#pragma unroll 1
+    for (int b = 0; b < kFillBatches; b++) {
+        const int64_t at = first + 31 * b;
+#pragma unroll
+        for (int j = 0; j < 31; j++)
+            if (at + j < seg_len) out[at + j] = (int32_t)(s[j] >> 1);
+        // next 31 words: n[j] = s[j] + s[j+28] (j < 3), n[j] = s[j] + n[j-3] (j >= 3)
+        uint32_t nx[31];
+#pragma unroll
+        for (int j = 0; j < 31; j++) nx[j] = s[j] + (j < 3 ? s[j + 28] : nx[j - 3]);
+#pragma unroll
+        for (int j = 0; j < 31; j++) s[j] = nx[j];
+    }
+}
+
+struct WalkParams {
+    int32_t n;
+    const int64_t *off;
+    const int4 *triples;
+    const uint8_t *dis;
+    int32_t W, L;
+    uint64_t seed;
+    int64_t epoch_begin, epoch_count;
+    int32_t node_begin, node_count;
+    int32_t *ids;
+    uint8_t *codes;
+    const int32_t *draws;  // GLIBC only: [epoch_count][node_count*W*2L]
+    int32_t *status;
+};
+
+template <int DRAW>
+__global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
+    __shared__ int4 s_tab[kStageTriples];
+    const int64_t per_epoch = (int64_t)p.node_count * p.W;
+    const int64_t total = per_epoch * p.epoch_count;
+    const int64_t g0 = (int64_t)blockIdx.x * kWalkThreads;
+    const int64_t g = g0 + threadIdx.x;
+
+    // ---- stage the first-hop tables of the source nodes this block covers (block-uniform) --------
+    const int64_t g_last = (g0 + kWalkThreads - 1 < total ? g0 + kWalkThreads - 1 : total - 1);
+    const int64_t e_first = g0 / per_epoch, e_last = g_last / per_epoch;
+    int64_t stage_base = 0, stage_cnt = 0;
+    int32_t st_lo = 0, st_hi = -1;
+    if (e_first == e_last) {
+        st_lo = p.node_begin + (int32_t)((g0 % per_epoch) / p.W);
+        st_hi = p.node_begin + (int32_t)((g_last % per_epoch) / p.W);
+        stage_base = p.off[st_lo];
+        stage_cnt = p.off[st_hi + 1] - stage_base;
+        if (stage_cnt > kStageTriples) {
+            stage_cnt = 0;
+            st_hi = st_lo - 1;
+        }
+    }
+    for (int64_t i = threadIdx.x; i < stage_cnt; i += kWalkThreads) s_tab[i] = p.triples[stage_base + i];
+    __syncthreads();
+    if (g >= total) return;
+
+    const int64_t e_l = g / per_epoch;
+    const int64_t rem = g - e_l * per_epoch;
+    const int32_t st = p.node_begin + (int32_t)(rem / p.W);
+    const int32_t wi = (int32_t)(rem % p.W);
+    const uint64_t walk = ((uint64_t)(p.epoch_begin + e_l) * (uint64_t)p.n + (uint64_t)st) * (uint64_t)p.W + wi;
+
+    rocrand_state_philox4x32_10 rng;
+    uint4 word = {0, 0, 0, 0};
+    if (DRAW == PN_DRAW_PHILOX) rocrand_init(p.seed, walk, 0, &rng);
+    const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * 2 * (int64_t)p.L : nullptr;
+
+    const uint8_t *dis_row = p.dis + (size_t)st * (size_t)p.n;
+    int32_t *out_ids = p.ids + g * p.L;
+    uint8_t *out_codes = p.codes + g * p.L;
+    int32_t x = st;
+    for (int32_t t = 0; t < p.L; t++) {
+        out_ids[t] = x;
+        out_codes[t] = (uint8_t)(dis_row[x] - 1);
+        const int64_t o0 = p.off[x];
+        const int32_t len = (int32_t)(p.off[x + 1] - o0);
+        uint32_t r0, r1;
+        if (DRAW == PN_DRAW_GLIBC_REPLAY) {
+            r0 = (uint32_t)my_draws[2 * t];
+            r1 = (uint32_t)my_draws[2 * t + 1];
+        } else {
+            if ((t & 1) == 0) word = rocrand4(&rng);   // draws 2t, 2t+1 = words (2t)&3, (2t+1)&3 of block t>>1
+            r0 = ((t & 1) ? word.z : word.x) >> 1;
+            r1 = ((t & 1) ? word.w : word.y) >> 1;
+        }
+        if (len <= 0) {
+            if (p.status) atomicExch(p.status, PN_ERR_EMPTY_TABLE);
+            for (int32_t k = t + 1; k < p.L; k++) {
+                out_ids[k] = x;
+                out_codes[k] = out_codes[t];
+            }
+            return;
+        }
+        const int64_t slot = o0 + (int64_t)(r0 % (uint32_t)len);
+        int4 tr;
+        if (t == 0 && st >= st_lo && st <= st_hi)
+            tr = s_tab[slot - stage_base];
+        else
+            tr = p.triples[slot];
+        x = (r1 >= (uint32_t)tr.z) ? tr.x : tr.y;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pn_device_query(pn_device_info *out) {
+    if (!out) PN_FAIL(PN_ERR_ARG, "pn_device_query: null");
+    int dev = 0;
+    PN_CHECK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    std::snprintf(out->name, sizeof out->name, "%s", prop.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", prop.gcnArchName);
+    out->compute_units = prop.multiProcessorCount;
+    out->lds_bytes_per_block = (int32_t)prop.sharedMemPerBlock;
+    out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    out->clock_khz = prop.clockRate;
+    return PN_OK;
+}
+
+static int64_t fill_blocks(int64_t seg_len) { return (seg_len + kDrawsPerBlock - 1) / kDrawsPerBlock; }
+
+int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t epoch_count, int32_t node_count,
+                              int64_t *bytes) {
+    if (!bytes || W < 1 || L < 1 || epoch_count < 0 || node_count < 0) PN_FAIL(PN_ERR_ARG, "bad sampler window");
+    if (draw_source == PN_DRAW_PHILOX) {
+        *bytes = 0;
+        return PN_OK;
+    }
+    if (draw_source != PN_DRAW_GLIBC_REPLAY) PN_FAIL(PN_ERR_ARG, "unknown draw source %d", draw_source);
+    const int64_t seg_len = (int64_t)node_count * W * 2 * L;
+    const int64_t tables = (epoch_count + fill_blocks(seg_len) + kFillThreads) * 31 * 4;
+    *bytes = ((tables + 255) / 256) * 256 + epoch_count * seg_len * 4;
+    return PN_OK;
+}
+
+int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
+                    int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
+                    uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!tb || !tb->off || !tb->triples || !tb->dis || !ids || !codes)
+        PN_FAIL(PN_ERR_ARG, "pn_sample_paths: null table or output");
+    if (W < 1 || L < 1 || epoch_begin < 0 || epoch_count < 0 || node_begin < 0 || node_count < 0 ||
+        (int64_t)node_begin + node_count > tb->n)
+        PN_FAIL(PN_ERR_ARG, "pn_sample_paths: bad window (n=%d W=%d L=%d nodes [%d,+%d))", tb->n, W, L, node_begin,
+                node_count);
+    const int64_t total = epoch_count * node_count * W;
+    if (total == 0) return PN_OK;
+    if (total / kWalkThreads + 1 > 2147483647LL) PN_FAIL(PN_ERR_ARG, "window too large for one launch");
+
+    WalkParams wp{};
+    wp.n = tb->n;
+    wp.off = tb->off;
+    wp.triples = reinterpret_cast<const int4 *>(tb->triples);
+    wp.dis = tb->dis;
+    wp.W = W;
+    wp.L = L;
+    wp.seed = seed;
+    wp.epoch_begin = epoch_begin;
+    wp.epoch_count = epoch_count;
+    wp.node_begin = node_begin;
+    wp.node_count = node_count;
+    wp.ids = ids;
+    wp.codes = codes;
+    wp.status = status_flag;
+
+    if (draw_source == PN_DRAW_GLIBC_REPLAY) {
+        int64_t need = 0;
+        pn_sample_workspace_bytes(W, L, draw_source, epoch_count, node_count, &need);
+        if (!workspace || workspace_bytes < need)
+            PN_FAIL(PN_ERR_CAPACITY, "sampler workspace holds %lld bytes, need %lld", (long long)workspace_bytes,
+                    (long long)need);
+        const int64_t seg_len = (int64_t)node_count * W * 2 * L;
+        const int64_t nblk = fill_blocks(seg_len);
+        // host: one state per epoch of the window + the block / thread jump polynomials
+        std::vector<uint32_t> host((size_t)(epoch_count + nblk + kFillThreads) * 31);
+        const uint64_t stride = 2ull * L * W * (uint64_t)tb->n;            // draws per epoch
+        const uint64_t first = stride * (uint64_t)epoch_begin + 2ull * L * W * (uint64_t)node_begin;
+        pn::GlibcState base = pn::glibc_seed_state((uint32_t)seed);
+        pn::GlibcPoly pos = pn::glibc_poly_xpow(first);
+        const pn::GlibcPoly step = pn::glibc_poly_xpow(stride);
+        for (int64_t e = 0; e < epoch_count; e++) {
+            pn::GlibcState st = pn::glibc_apply(pos, base);
+            memcpy(&host[(size_t)e * 31], st.s, sizeof st.s);
+            pos = pn::glibc_poly_mul(pos, step);
+        }
+        {
+            pn::GlibcPoly acc = pn::glibc_poly_one();
+            const pn::GlibcPoly jb = pn::glibc_poly_xpow(kDrawsPerBlock);
+            for (int64_t b = 0; b < nblk; b++) {
+                memcpy(&host[(size_t)(epoch_count + b) * 31], acc.c, sizeof acc.c);
+                acc = pn::glibc_poly_mul(acc, jb);
+            }
+            acc = pn::glibc_poly_one();
+            const pn::GlibcPoly jt = pn::glibc_poly_xpow(kDrawsPerThread);
+            for (int t = 0; t < kFillThreads; t++) {
+                memcpy(&host[(size_t)(epoch_count + nblk + t) * 31], acc.c, sizeof acc.c);
+                acc = pn::glibc_poly_mul(acc, jt);
+            }
+        }
+        uint32_t *d_tables = reinterpret_cast<uint32_t *>(workspace);
+        const int64_t table_bytes = (int64_t)host.size() * 4;
+        int32_t *d_draws = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) +
+                                                       ((table_bytes + 255) / 256) * 256);
+        PN_CHECK_HIP(hipMemcpyAsync(d_tables, host.data(), (size_t)table_bytes, hipMemcpyHostToDevice, stream));
+        PN_CHECK_HIP(hipStreamSynchronize(stream));  // `host` dies at scope exit (parity mode, not the fast path)
+        dim3 grid((unsigned)nblk, (unsigned)epoch_count);
+        hipLaunchKernelGGL(glibc_fill_kernel, grid, dim3(kFillThreads), 0, stream, d_tables,
+                           d_tables + (size_t)epoch_count * 31, d_tables + (size_t)(epoch_count + nblk) * 31, seg_len,
+                           d_draws);
+        PN_CHECK_HIP(hipGetLastError());
+        wp.draws = d_draws;
+        const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
+        hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_GLIBC_REPLAY>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+        PN_CHECK_HIP(hipGetLastError());
+    } else if (draw_source == PN_DRAW_PHILOX) {
+        const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
+        hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_PHILOX>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+        PN_CHECK_HIP(hipGetLastError());
+    } else {
+        PN_FAIL(PN_ERR_ARG, "unknown draw source %d", draw_source);
+    }
+    return PN_OK;
+}
+
+}  // extern "C"

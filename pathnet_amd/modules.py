@@ -1,0 +1,241 @@
+"""Drop-in aggregator modules with the reference's constructor / forward surface and state_dict keys.
+
+  PathNet       <- /root/reference/PathNet_run.py:150-211   (heterophilous datasets)
+  PathNet_homo  <- /root/reference/PathNet_run.py:214-278   (cora / citeseer / pubmed)
+  PAGG          <- /root/reference/baseline/GPRGNN/src/copy.py:299-359
+
+``forward(X, neis, num_w, walk_len, indices, layer_type, indxx)`` keeps the reference's argument
+meaning (PathNet_run.py:172): X fp32 [N, F] on the GPU, neis [S, W*L] node ids, indices a bool mask
+[N] (numpy or torch), layer_type [S, W, L] distance codes, indxx ignored (it is arange(S*W*L)).
+All arithmetic runs in hand-written HIP kernels through libpathnet_hip.so; there is no PyTorch
+fallback -- if the library is missing, construction fails.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+# The reference reads the module-level global `dropout` inside forward (PathNet_run.py:71, :194).
+# A training script can set pathnet_amd.modules.dropout the same way, or pass dropout= to the ctor.
+dropout = 0.7
+
+_VARIANT = {"hetero": _lib.VARIANT_HETERO, "homo": _lib.VARIANT_HOMO, "pagg": _lib.VARIANT_PAGG}
+_PARAM_ORDER = ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w",
+                "fc2_b")
+
+
+def _shape(variant, N, F, H, C, S, W, L):
+    return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L)
+
+
+def workspace_bytes(variant, N, F, H, C, S, W, L):
+    n = ctypes.c_int64(0)
+    sh = _shape(variant, N, F, H, C, S, W, L)
+    _lib.check(_lib.load().pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(n)))
+    return n.value
+
+
+class _PaggFunction(torch.autograd.Function):
+    """forward/backward through pn_pagg_forward / pn_pagg_backward."""
+
+    @staticmethod
+    def forward(ctx, cfg, X, ids, codes, sel, *params):
+        lib = _lib.load()
+        p = dict(zip(_PARAM_ORDER, params))
+        dev = X.device
+        out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
+        sh = _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
+        nbytes = ctypes.c_int64(0)
+        _lib.check(lib.pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(nbytes)))
+        ws = cfg.get("workspace")
+        if ws is None or ws.numel() < nbytes.value or ws.device != dev:
+            ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+        a = _lib.PaggArgs()
+        a.shape = sh
+        a.X, a.ids, a.codes, a.sel = X.data_ptr(), ids.data_ptr(), codes.data_ptr(), sel.data_ptr()
+        for k in _PARAM_ORDER:
+            setattr(a, k, p[k].data_ptr() if p[k] is not None else None)
+        a.p_seq, a.p_cls, a.seed = cfg["p_seq"], cfg["p_cls"], cfg["seed"]
+        ms, mc = cfg.get("mask_seq"), cfg.get("mask_cls")
+        a.mask_seq = ms.data_ptr() if ms is not None else None
+        a.mask_cls = mc.data_ptr() if mc is not None else None
+        a.out = out.data_ptr()
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        if cfg["S"] > 0:
+            _lib.check(lib.pn_pagg_forward(ctypes.byref(a), stream))
+        ctx.cfg, ctx.ws, ctx.masks = cfg, ws, (ms, mc)
+        ctx.save_for_backward(X, ids, codes, sel, *[t for t in params if t is not None])
+        ctx.present = [t is not None for t in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load()
+        cfg = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        X, ids, codes, sel = saved[:4]
+        it = iter(saved[4:])
+        params = [next(it) if pres else None for pres in ctx.present]
+        p = dict(zip(_PARAM_ORDER, params))
+        g_out = g_out.contiguous().float()
+        sh = _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
+        a = _lib.PaggArgs()
+        a.shape = sh
+        a.X, a.ids, a.codes, a.sel = X.data_ptr(), ids.data_ptr(), codes.data_ptr(), sel.data_ptr()
+        grads = {}
+        for k in _PARAM_ORDER:
+            setattr(a, k, p[k].data_ptr() if p[k] is not None else None)
+            if p[k] is not None:
+                grads[k] = torch.empty_like(p[k])
+                setattr(a, "g_" + k, grads[k].data_ptr())
+        gX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
+        a.g_X = gX.data_ptr() if gX is not None else None
+        a.p_seq, a.p_cls, a.seed = cfg["p_seq"], cfg["p_cls"], cfg["seed"]
+        ms, mc = ctx.masks
+        a.mask_seq = ms.data_ptr() if ms is not None else None
+        a.mask_cls = mc.data_ptr() if mc is not None else None
+        a.workspace, a.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
+        a.g_out = g_out.data_ptr()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+        if cfg["S"] > 0:
+            _lib.check(lib.pn_pagg_backward(ctypes.byref(a), stream))
+        else:
+            for g in grads.values():
+                g.zero_()
+            if gX is not None:
+                gX.zero_()
+        return (None, gX, None, None, None) + tuple(grads.get(k) for k in _PARAM_ORDER)
+
+
+def _as_index_tensors(neis, layer_type, indices, num_w, walk_len, device):
+    """Reference argument conventions -> device int32 ids [S,W,L], uint8 codes, int32 sel [S]."""
+    if isinstance(indices, np.ndarray):
+        sel = torch.from_numpy(np.flatnonzero(indices).astype(np.int32))
+    else:
+        idx = torch.as_tensor(indices)
+        sel = (torch.nonzero(idx, as_tuple=False).flatten() if idx.dtype == torch.bool else idx.flatten()).to(
+            torch.int32)
+    S = int(sel.numel())
+    ids = torch.as_tensor(neis)
+    codes = torch.as_tensor(layer_type)
+    if ids.dtype != torch.int32:
+        ids = ids.to(torch.int32)
+    if codes.dtype != torch.uint8:
+        codes = codes.to(torch.uint8)
+    ids = ids.reshape(S, num_w, walk_len).to(device, non_blocking=True).contiguous()
+    codes = codes.reshape(S, num_w, walk_len).to(device, non_blocking=True).contiguous()
+    return ids, codes, sel.to(device, non_blocking=True).contiguous(), S
+
+
+class _Aggregator(nn.Module):
+    variant = None
+
+    def _common_init(self, feature_length, hidden_size, out_size, dropout_p):
+        _lib.load()     # fail at construction if the HIP library is missing
+        self.feature_length, self.hidden_size, self.out_size = feature_length, hidden_size, out_size
+        self._dropout = dropout_p
+        self._ws_eval = None
+        self._mask_seq = None     # test hook: explicit dropout masks (reference order)
+        self._mask_cls = None
+
+    # ---- dropout probability: ctor argument, else the module-level global like the reference -------
+    def dropout_p(self):
+        return float(dropout if self._dropout is None else self._dropout)
+
+    def set_dropout(self, p):
+        self._dropout = p
+
+    def _bank(self):
+        raise NotImplementedError
+
+    def _cell(self):
+        raise NotImplementedError
+
+    def forward(self, X, neis, num_w, walk_len, indices, layer_type, indxx=None):
+        dev = X.device
+        if dev.type != "cuda":
+            raise RuntimeError("pathnet_amd aggregators run on the GPU only (X is on %s); no CPU fallback" % dev)
+        X = X.contiguous().float()
+        ids, codes, sel, S = _as_index_tensors(neis, layer_type, indices, num_w, walk_len, dev)
+        bank_w, bank_b = self._bank()
+        cell = self._cell()
+        att = getattr(self, "attw", None)
+        training = self.training
+        p = self.dropout_p() if training else 0.0
+        cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=self.hidden_size, C=self.out_size, S=S,
+                   W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None,
+                   seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
+        if training and (self._mask_seq is not None or self._mask_cls is not None):
+            cfg["mask_seq"], cfg["mask_cls"] = self._mask_seq, self._mask_cls
+            cfg["p_seq"] = cfg["p_cls"] = 0.0
+        if not torch.is_grad_enabled():
+            need = workspace_bytes(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"], cfg["L"])
+            if self._ws_eval is None or self._ws_eval.numel() < need or self._ws_eval.device != dev:
+                self._ws_eval = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+            cfg["workspace"] = self._ws_eval
+        params = (self.fc0.weight, self.fc0.bias, bank_w, bank_b, cell.weight_ih_l0, cell.weight_hh_l0,
+                  cell.bias_ih_l0, cell.bias_hh_l0,
+                  att.weight.reshape(-1) if att is not None else None, att.bias if att is not None else None,
+                  self.fc2.weight, self.fc2.bias)
+        return _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
+
+
+class PathNet(_Aggregator):
+    """PathNet_run.py:150-211.  state_dict: fc0, LSTM, fc2, nets.<d>, attw."""
+    variant = "hetero"
+
+    def __init__(self, feature_length, hidden_size, out_size, wl, dropout=None, **kwargs):
+        super().__init__()
+        self._common_init(feature_length, hidden_size, out_size, dropout)
+        self.fc0 = nn.Linear(feature_length, hidden_size)
+        self.LSTM = nn.LSTM(hidden_size, hidden_size)
+        self.fc2 = nn.Linear(2 * hidden_size, out_size)
+        self.nets = nn.ModuleList([nn.Linear(hidden_size, hidden_size) for _ in range(wl)])
+        self.attw = nn.Linear(2 * hidden_size, 1)
+        self.Lrelu = nn.LeakyReLU()
+
+    def _bank(self):
+        return torch.stack([l.weight for l in self.nets]), torch.stack([l.bias for l in self.nets])
+
+    def _cell(self):
+        return self.LSTM
+
+
+class PathNet_homo(PathNet):
+    """PathNet_run.py:214-278 (xavier_uniform on fc0/fc2, :236-237)."""
+    variant = "homo"
+
+    def __init__(self, feature_length, hidden_size, out_size, wl, dropout=None, **kwargs):
+        super().__init__(feature_length, hidden_size, out_size, wl, dropout=dropout, **kwargs)
+        nn.init.xavier_uniform_(self.fc0.weight)
+        nn.init.xavier_uniform_(self.fc2.weight)
+
+
+class PAGG(_Aggregator):
+    """baseline/GPRGNN/src/copy.py:299-359.  state_dict: fc0, RNN, fc2, nei0..nei3.  dropout is 0.9 there."""
+    variant = "pagg"
+
+    def __init__(self, feature_length, hidden_size, out_size, node_num, dropout=0.9, **kwargs):
+        super().__init__()
+        self._common_init(feature_length, hidden_size, out_size, dropout)
+        self.node_num = node_num
+        self.fc0 = nn.Linear(feature_length, hidden_size)
+        self.RNN = nn.RNN(hidden_size, hidden_size)
+        self.fc2 = nn.Linear(2 * hidden_size, out_size)
+        self.nei0 = nn.Linear(hidden_size, hidden_size)
+        self.nei1 = nn.Linear(hidden_size, hidden_size)
+        self.nei2 = nn.Linear(hidden_size, hidden_size)
+        self.nei3 = nn.Linear(hidden_size, hidden_size)
+        for lin in (self.fc0, self.fc2, self.nei0, self.nei1, self.nei2, self.nei3):
+            nn.init.xavier_uniform_(lin.weight)
+
+    def _bank(self):
+        ls = (self.nei0, self.nei1, self.nei2, self.nei3)
+        return torch.stack([l.weight for l in ls]), torch.stack([l.bias for l in ls])
+
+    def _cell(self):
+        return self.RNN

@@ -1,0 +1,173 @@
+"""MERW path sampler: host set-up + GPU walker, and the gen_merw / gen_epoch_merw command line.
+
+Mirrors /root/reference/preprocess/gen_merw.cpp: ``main`` (:125-213) becomes
+``MerwSampler.from_edge_file(...)`` (parse :162-172, alias tables :174-176, hop table :178-179) and
+``MerwSampler.sample(...)`` (walk loop :182-209) which runs on the GPU through libpathnet_hip.so.
+``python -m pathnet_amd.sampler <data_name> <path_num> <path_length>`` keeps the reference CLI: reads
+``../edge_input/<name>.in`` and writes ``./<name>_<W>_<L>_merw.txt`` (or one file per epoch with
+``--per-epoch``, gen_epoch_merw.cpp:166-178), 1000 epochs.
+"""
+import ctypes
+import sys
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, pathfile
+
+DRAW_GLIBC_REPLAY = _lib.DRAW_GLIBC_REPLAY
+DRAW_PHILOX = _lib.DRAW_PHILOX
+
+
+def read_edge_file(path):
+    """-> (n, u int32[m], v int32[m], p float64[m]) in file order (gen_merw.cpp:162-172)."""
+    lib = _lib.load()
+    n, m = ctypes.c_int32(0), ctypes.c_int64(0)
+    _lib.check(lib.pn_edges_read_text(str(path).encode(), ctypes.byref(n), ctypes.byref(m), None, None, None, 0))
+    u = np.empty(m.value, np.int32)
+    v = np.empty(m.value, np.int32)
+    p = np.empty(m.value, np.float64)
+    if m.value:
+        _lib.check(lib.pn_edges_read_text(str(path).encode(), ctypes.byref(n), ctypes.byref(m),
+                                          _lib.np_ptr(u, ctypes.c_int32), _lib.np_ptr(v, ctypes.c_int32),
+                                          _lib.np_ptr(p, ctypes.c_double), m.value))
+    return n.value, u, v, p
+
+
+def build_alias(n, u, v, p):
+    """AliasTable::init for every node (gen_merw.cpp:23-79) -> off[int64 n+1], A, B, S(float64), thr(uint32)."""
+    lib = _lib.load()
+    u = np.ascontiguousarray(u, np.int32)
+    v = np.ascontiguousarray(v, np.int32)
+    p = np.ascontiguousarray(p, np.float64)
+    off = np.zeros(n + 1, np.int64)
+    total = ctypes.c_int64(0)
+    args = (n, len(u), _lib.np_ptr(u, ctypes.c_int32), _lib.np_ptr(v, ctypes.c_int32), _lib.np_ptr(p, ctypes.c_double),
+            _lib.np_ptr(off, ctypes.c_int64))
+    _lib.check(lib.pn_alias_build(*args, None, None, None, None, 0, ctypes.byref(total)))
+    t = max(total.value, 1)
+    A, B = np.empty(t, np.int32), np.empty(t, np.int32)
+    S, thr = np.empty(t, np.float64), np.empty(t, np.uint32)
+    _lib.check(lib.pn_alias_build(*args, _lib.np_ptr(A, ctypes.c_int32), _lib.np_ptr(B, ctypes.c_int32),
+                                  _lib.np_ptr(S, ctypes.c_double), _lib.np_ptr(thr, ctypes.c_uint32), total.value,
+                                  ctypes.byref(total)))
+    k = total.value
+    return off, A[:k], B[:k], S[:k], thr[:k]
+
+
+def hops_dense(n, u, v, seq_len):
+    """dis[n, n] uint8 = 1 + hops for nodes within seq_len-1 hops (bfs, gen_merw.cpp:101-123)."""
+    u = np.ascontiguousarray(u, np.int32)
+    v = np.ascontiguousarray(v, np.int32)
+    dis = np.empty((n, n), np.uint8)
+    _lib.check(_lib.load().pn_hops_dense(n, len(u), _lib.np_ptr(u, ctypes.c_int32), _lib.np_ptr(v, ctypes.c_int32),
+                                         seq_len, _lib.np_ptr(dis, ctypes.c_uint8)))
+    return dis
+
+
+def glibc_draws(seed, first, count):
+    out = np.empty(count, np.int32)
+    _lib.check(_lib.load().pn_glibc_draws(seed & 0xFFFFFFFF, first, count, _lib.np_ptr(out, ctypes.c_int32)))
+    return out
+
+
+class MerwSampler:
+    """Device-resident sampler tables for one graph and one path length."""
+
+    def __init__(self, n, u, v, p, seq_len, device="cuda"):
+        self.n, self.L = int(n), int(seq_len)
+        self.device = torch.device(device)
+        off, A, B, S, thr = build_alias(n, u, v, p)
+        self.host = dict(off=off, A=A, B=B, S=S, thr=thr)
+        packed = np.empty(max(len(A), 1) * 4, np.int32)
+        _lib.check(_lib.load().pn_alias_pack(len(A), _lib.np_ptr(A, ctypes.c_int32), _lib.np_ptr(B, ctypes.c_int32),
+                                             _lib.np_ptr(thr, ctypes.c_uint32), _lib.np_ptr(packed, ctypes.c_int32)))
+        dis = hops_dense(n, u, v, seq_len)
+        self.d_off = torch.from_numpy(off).to(self.device)
+        self.d_triples = torch.from_numpy(packed).to(self.device)
+        self.d_dis = torch.from_numpy(dis).to(self.device)
+        self.total = len(A)
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._ws = None
+
+    @classmethod
+    def from_edge_file(cls, path, seq_len, device="cuda"):
+        n, u, v, p = read_edge_file(path)
+        return cls(n, u, v, p, seq_len, device=device)
+
+    def sample(self, W, seed, epoch_begin=0, epoch_count=1, node_begin=0, node_count=None,
+               draw_source=DRAW_PHILOX, check=True, out=None):
+        """-> ids int32 [epoch_count, node_count, W, L], codes uint8 [...] on the GPU."""
+        lib = _lib.load()
+        if node_count is None:
+            node_count = self.n - node_begin
+        L = self.L
+        if out is None:
+            ids = torch.empty((epoch_count, node_count, W, L), dtype=torch.int32, device=self.device)
+            codes = torch.empty((epoch_count, node_count, W, L), dtype=torch.uint8, device=self.device)
+        else:
+            ids, codes = out
+        need = ctypes.c_int64(0)
+        _lib.check(lib.pn_sample_workspace_bytes(W, L, draw_source, epoch_count, node_count, ctypes.byref(need)))
+        if need.value and (self._ws is None or self._ws.numel() < need.value):
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        tb = _lib.SamplerTables(self.n, self.total, self.d_off.data_ptr(), self.d_triples.data_ptr(),
+                                self.d_dis.data_ptr())
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if check:
+            self._status.zero_()
+        _lib.check(lib.pn_sample_paths(ctypes.byref(tb), W, L, draw_source, seed & 0xFFFFFFFFFFFFFFFF, epoch_begin,
+                                       epoch_count, node_begin, node_count, _lib.ptr(ids), _lib.ptr(codes),
+                                       _lib.ptr(self._ws) if need.value else None, need.value,
+                                       _lib.ptr(self._status), ctypes.c_void_p(stream)))
+        if check and int(self._status.item()) != 0:
+            # the reference prints this and exits (gen_merw.cpp:84-87)
+            raise _lib.PnError(int(self._status.item()), "ERROR:: A.size() == 0 in Alias Table")
+        return ids, codes
+
+
+def main(argv=None):
+    """Drop-in for ./gen_merw and ./gen_epoch_merw (argv: <data_name> <path_num> <path_length>)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    per_epoch = "--per-epoch" in argv
+    opts = {"--seed": None, "--epochs": "1000", "--draw": "glibc", "--in": None, "--out-root": "./"}
+    pos = []
+    i = 0
+    while i < len(argv):
+        a = argv[i]
+        if a == "--per-epoch":
+            i += 1
+        elif a in opts:
+            opts[a] = argv[i + 1]
+            i += 2
+        else:
+            pos.append(a)
+            i += 1
+    if len(pos) != 3:
+        print("ERROR: Incorrect number of parameters. ", file=sys.stderr)   # gen_merw.cpp:128-132
+        return 0
+    name, W, L = pos[0], int(pos[1]), int(pos[2])
+    edge = opts["--in"] or "../edge_input/%s.in" % name
+    seed = int(opts["--seed"]) if opts["--seed"] is not None else int(time.time())  # srand(time(0)), :161
+    epochs = int(opts["--epochs"])
+    draw = DRAW_GLIBC_REPLAY if opts["--draw"] == "glibc" else DRAW_PHILOX
+    smp = MerwSampler.from_edge_file(edge, L)
+    print(name + ": " + str(smp.n), file=sys.stderr)                        # :164
+    root = opts["--out-root"]
+    whole = pathfile.whole_run_name(root, name, W, L)
+    chunk = max(1, min(epochs, (64 << 20) // max(1, smp.n * W * L * 5)))
+    for e0 in range(0, epochs, chunk):
+        ec = min(chunk, epochs - e0)
+        ids, codes = smp.sample(W, seed, epoch_begin=e0, epoch_count=ec, draw_source=draw)
+        ids, codes = ids.cpu().numpy(), codes.cpu().numpy()
+        for k in range(ec):
+            if per_epoch:
+                pathfile.write_paths(pathfile.per_epoch_name(root, name, W, L, e0 + k), ids[k], codes[k])
+            else:
+                pathfile.write_paths(whole, ids[k], codes[k], append=(e0 + k) > 0)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

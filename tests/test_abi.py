@@ -1,0 +1,110 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/pathnet_hip.h declares,
+and its host-only entry points (no GPU needed) agree with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden, golden_files
+from oracle import merw
+from pathnet_amd import _lib, pathfile, sampler
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "pathnet_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 15
+    for name in names:
+        assert hasattr(lib, name), name
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.pn_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", golden_files("sampler_*.npz"))
+def test_host_alias_tables_and_thresholds_match_oracle(name):
+    g = golden(name)
+    n = int(g["n"])
+    off, A, B, S, thr = sampler.build_alias(n, g["u"], g["v"], g["p"])
+    o2, A2, B2, S2 = merw.alias_build(n, g["u"], g["v"], g["p"])
+    assert (off == o2).all() and (A == A2).all() and (B == B2).all()
+    assert (S == S2).all()          # fp64 bit-identical
+    # integer threshold == the reference's fp64 compare, on random draws and at the boundaries
+    rng = np.random.default_rng(0)
+    for r in (rng.integers(0, 2 ** 31 - 1, len(S)), np.minimum(thr.astype(np.int64), 2 ** 31 - 1),
+              np.maximum(thr.astype(np.int64) - 1, 0), np.full(len(S), 2 ** 31 - 1), np.zeros(len(S), np.int64)):
+        assert ((1.0 * r / 2147483647 > S) == (r >= thr.astype(np.int64))).all()
+
+
+def test_host_hop_table_matches_reference_bfs_on_reachable_nodes():
+    g = golden("sampler_synthetic97_12_5.npz")
+    n, L = int(g["n"]), int(g["L"])
+    d = sampler.hops_dense(n, g["u"], g["v"], L)
+    d2 = merw.bfs_dense(n, g["u"], g["v"], L)
+    within = (d2 >= 1) & (d2 <= L)          # what a walk of L nodes can reach
+    assert (d[within] == d2[within]).all() and (d[~within] == 0).all()
+
+
+def test_host_glibc_jump_algebra():
+    for seed, first in ((1, 0), (7, 1), (123, 30), (99, 31), (5, 1 << 20), (2 ** 32 - 1, 987654321)):
+        assert (sampler.glibc_draws(seed, first, 200) == merw.glibc_stream(seed, 200, skip=first)).all()
+
+
+def test_path_file_round_trip_and_format(tmp_path):
+    g = golden("sampler_cornell_7_6.npz")
+    ids, codes = g["ids"][0], g["codes"][0]
+    f = os.path.join(tmp_path, "p.txt")
+    pathfile.write_paths(f, ids, codes)
+    assert open(f, "rb").read() == merw.format_text(ids, codes)
+    i2, c2 = pathfile.read_paths(f, int(g["L"]))
+    assert (i2 == ids.reshape(-1, ids.shape[-1])).all() and (c2 == codes.reshape(-1, ids.shape[-1])).all()
+    # the reference reader: list(map(int, line[1:-2].split(",")))  (PathNet_run.py:327)
+    line = open(f).readline()
+    info = list(map(int, line[1:-2].split(",")))
+    assert info[:6] == ids.reshape(-1, 6)[0].tolist() and info[6:] == codes.reshape(-1, 6)[0].tolist()
+    pathfile.write_paths(f, ids, codes, append=True)
+    assert pathfile.read_paths(f, 6)[0].shape[0] == 2 * ids.size // 6
+
+
+def test_path_file_errors(tmp_path):
+    f = os.path.join(tmp_path, "bad.txt")
+    open(f, "w").write("[1, 2, 3, 0, 1\n")
+    with pytest.raises(_lib.PnError) as e:
+        pathfile.read_paths(f, 2)
+    assert e.value.code == _lib.PN_ERR_FORMAT
+    with pytest.raises(_lib.PnError) as e:
+        pathfile.read_paths(os.path.join(tmp_path, "missing.txt"), 2)
+    assert e.value.code == _lib.PN_ERR_IO
+    open(f, "w").write("")
+    assert pathfile.read_paths(f, 4)[0].shape == (0, 4)
+
+
+def test_edge_file_reader(tmp_path):
+    g = golden("sampler_synthetic97_12_5.npz")
+    f = os.path.join(tmp_path, "g.in")
+    merw.write_edge_file(f, int(g["n"]), g["u"], g["v"], g["p"])
+    n, u, v, p = sampler.read_edge_file(f)
+    assert n == int(g["n"]) and (u == g["u"]).all() and (v == g["v"]).all() and (p == g["p"]).all()
+    with pytest.raises(_lib.PnError):
+        sampler.read_edge_file(os.path.join(tmp_path, "nope.in"))
+
+
+def test_workspace_query_and_shape_validation():
+    from pathnet_amd import modules
+    assert modules.workspace_bytes("homo", 100, 16, 128, 3, 10, 40, 4) > 0
+    with pytest.raises(_lib.PnError):
+        modules.workspace_bytes("homo", 100, 16, 100, 3, 10, 40, 4)      # H not supported
+    with pytest.raises(_lib.PnError):
+        modules.workspace_bytes("pagg", 100, 16, 64, 3, 10, 40, 5)        # PAGG has 4 distance layers
+
+
+def test_sampler_cli_wrong_argc(capsys):
+    assert sampler.main(["only", "two"]) == 0      # reference prints to stderr and returns 0 (gen_merw.cpp:128-132)
+    assert "Incorrect number of parameters" in capsys.readouterr().err

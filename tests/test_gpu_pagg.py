@@ -1,0 +1,187 @@
+"""Aggregator HIP path (through the C ABI) against the reference goldens and the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, golden_files
+from oracle import pagg_oracle as po
+
+pytestmark = pytest.mark.gpu
+TOL_OUT = 1e-5          # north_star: within 1e-5 on PAGG fp32 outputs
+
+
+def build_module(variant, F, H, C, L, N, params):
+    import pathnet_amd
+    cls = {"hetero": pathnet_amd.PathNet, "homo": pathnet_amd.PathNet_homo, "pagg": pathnet_amd.PAGG}[variant]
+    m = cls(F, H, C, L if variant != "pagg" else N)
+    if params is not None:
+        missing = m.load_state_dict({k: torch.as_tensor(v) for k, v in params.items()}, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+    return m.cuda()
+
+
+def run_module(m, X, ids, codes, mask, W, L):
+    S = int(mask.sum())
+    neis = torch.as_tensor(ids.reshape(S, W * L).astype(np.int64))           # CPU int64 like the reference
+    lt = torch.as_tensor(codes.reshape(S, W, L).astype(np.int64))
+    return m(X, neis, W, L, mask, lt, None)
+
+
+def test_gemm_f32_matches_torch():
+    from pathnet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    for (M, N, K) in [(64, 64, 32), (70, 33, 45), (2708, 128, 1433), (5, 512, 128), (257, 130, 7)]:
+        A = torch.randn(M, K, device="cuda")
+        B = torch.randn(N, K, device="cuda")
+        bias = torch.randn(N, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        _lib.check(lib.pn_gemm_f32(A.data_ptr(), K, 1, B.data_ptr(), K, 1, C.data_ptr(), N, bias.data_ptr(), M, N, K, 0,
+                                   None))
+        ref = (A.double() @ B.double().t() + bias.double()).float()
+        err = (C - ref).abs().max().item()
+        assert err < 1e-4 * max(1.0, K ** 0.5 / 8), (M, N, K, err)
+        # transposed operands (m-contiguous A, n-contiguous B) + relu
+        At, Bt = A.t().contiguous(), B.t().contiguous()
+        _lib.check(lib.pn_gemm_f32(At.data_ptr(), 1, M, Bt.data_ptr(), 1, N, C.data_ptr(), N, None, M, N, K, 1, None))
+        ref = torch.relu(A.double() @ B.double().t()).float()
+        assert (C - ref).abs().max().item() < 1e-4 * max(1.0, K ** 0.5 / 8), (M, N, K, "T")
+
+
+def test_gemm_detects_transposes():
+    from pathnet_amd import _lib
+    lib = _lib.load()
+    M, N, K = 64, 64, 64
+    A = torch.eye(M, K, device="cuda")
+    B = torch.arange(N * K, device="cuda", dtype=torch.float32).reshape(N, K)      # asymmetric
+    C = torch.empty(M, N, device="cuda")
+    _lib.check(lib.pn_gemm_f32(A.data_ptr(), K, 1, B.data_ptr(), K, 1, C.data_ptr(), N, None, M, N, K, 0, None))
+    assert torch.equal(C, B.t().contiguous())
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+def test_gather_stage_matches_plan(variant):
+    from pathnet_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    N, H, S, W, L = 300, 128, 37, 40, 4
+    table = torch.randn(N, L, H, device="cuda")
+    ids = rng.integers(0, N, (S, W, L)).astype(np.int32)
+    codes = rng.integers(0, L, (S, W, L)).astype(np.uint8)
+    rows = torch.empty(S * W, L, H, device="cuda")
+    sh = _lib.PaggShape({"hetero": 0, "homo": 1, "pagg": 2}[variant], N, 1, H, 1, S, W, L)
+    _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), torch.as_tensor(ids).cuda().data_ptr(),
+                                  torch.as_tensor(codes).cuda().data_ptr(), rows.data_ptr(), None))
+    node, code, group, member, ego = po.plan(variant, ids, codes, S, W, L)
+    order = np.argsort(group * W + member, kind="stable")               # rows come out in pooling-group order
+    want = table.cpu()[torch.as_tensor(node[order]), torch.as_tensor(code[order])]
+    assert torch.equal(rows.cpu(), want)
+
+
+@pytest.mark.parametrize("name", golden_files("pagg_*.npz"))
+def test_forward_matches_reference_golden(name):
+    g = golden(name)
+    variant = str(g["variant"])
+    N, F, H, C, W, L = (int(g[k]) for k in "NFHCWL")
+    params = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    m = build_module(variant, F, H, C, L, N, params).eval()
+    with torch.no_grad():
+        out = run_module(m, torch.as_tensor(g["X"]).cuda(), g["ids"], g["codes"], g["mask"], W, L)
+    err = np.abs(out.cpu().numpy() - g["out"]).max()
+    assert err < TOL_OUT, err
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+@pytest.mark.parametrize("H,W,L,S,N,F,C", [(128, 40, 4, 87, 183, 1703, 5), (64, 7, 4, 33, 90, 50, 3),
+                                           (32, 40, 4, 130, 200, 30, 7), (256, 10, 4, 21, 64, 40, 4)])
+def test_forward_matches_oracle_random(variant, H, W, L, S, N, F, C):
+    torch.manual_seed(1)
+    rng = np.random.default_rng(2)
+    m = build_module(variant, F, H, C, L, N, None)
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith("bias"):
+                v.uniform_(-0.3, 0.3)
+    X = torch.rand(N, F)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    m.eval()
+    with torch.no_grad():
+        out = run_module(m, X.cuda(), ids, codes, mask, W, L).cpu()
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want, inter = po.forward(variant, params, X, ids, codes, sel, W, L, return_intermediates=True)
+    err = (out - want).abs().max().item()
+    assert err < TOL_OUT, (err, want.abs().max().item())
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo"])
+def test_l6_paths(variant):
+    torch.manual_seed(4)
+    rng = np.random.default_rng(4)
+    N, F, H, C, W, L, S = 120, 24, 128, 3, 40, 6, 50
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    X = torch.rand(N, F)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    with torch.no_grad():
+        out = run_module(m, X.cuda(), ids, codes, mask, W, L).cpu()
+    want = po.forward(variant, {k: v.cpu() for k, v in m.state_dict().items()}, X, ids, codes, sel, W, L)
+    assert (out - want).abs().max().item() < TOL_OUT
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+def test_training_mode_with_injected_dropout_masks(variant):
+    """F.dropout cannot be matched bit for bit across RNGs; with the reference's mask injected the
+    training-mode forward must still agree (SURVEY.md §7 'hard parts')."""
+    torch.manual_seed(7)
+    rng = np.random.default_rng(7)
+    N, F, H, C, W, L, S = 80, 20, 64, 4, 12, 4, 31
+    m = build_module(variant, F, H, C, L, N, None).train()
+    pdrop = 0.7
+    P = S * W
+    mask_seq = (torch.rand(L, P, H) >= pdrop).float() / (1 - pdrop)
+    mask_cls = (torch.rand(S, 2 * H) >= pdrop).float() / (1 - pdrop)
+    m._mask_seq, m._mask_cls = mask_seq.cuda(), mask_cls.cuda()
+    X = torch.rand(N, F)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    with torch.no_grad():
+        out = run_module(m, X.cuda(), ids, codes, mask, W, L).cpu()
+    want = po.forward(variant, {k: v.cpu() for k, v in m.state_dict().items()}, X, ids, codes, sel, W, L,
+                      drop_seq=mask_seq, drop_cls=mask_cls)
+    assert (out - want).abs().max().item() < TOL_OUT
+
+
+def test_builtin_dropout_statistics_and_determinism():
+    torch.manual_seed(9)
+    rng = np.random.default_rng(9)
+    N, F, H, C, W, L, S = 60, 16, 64, 3, 40, 4, 40
+    import pathnet_amd
+    m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.5).cuda().train()
+    X = torch.rand(N, F).cuda()
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    ids = rng.integers(0, N, (S, W, L))
+    codes = np.zeros((S, W, L), np.int64)
+    with torch.no_grad():
+        torch.manual_seed(1)
+        a = run_module(m, X, ids, codes, mask, W, L)
+        torch.manual_seed(1)
+        b = run_module(m, X, ids, codes, mask, W, L)
+        c = run_module(m, X, ids, codes, mask, W, L)
+        m.eval()
+        e = run_module(m, X, ids, codes, mask, W, L)
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, e)
+    assert torch.isfinite(a).all()

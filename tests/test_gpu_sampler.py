@@ -1,0 +1,136 @@
+"""GPU sampler (pn_sample_paths) against the reference-binary goldens and the C oracle.  Bit-exact."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden, golden_files
+from oracle import merw
+
+pytestmark = pytest.mark.gpu
+
+
+def make_sampler(g, L=None):
+    from pathnet_amd import MerwSampler
+    return MerwSampler(int(g["n"]), g["u"], g["v"], g["p"], int(g["L"]) if L is None else L)
+
+
+@pytest.mark.parametrize("name", golden_files("sampler_*.npz"))
+def test_glibc_replay_bit_exact_vs_reference_golden(name):
+    from pathnet_amd import DRAW_GLIBC_REPLAY
+    g = golden(name)
+    smp = make_sampler(g)
+    ids, codes = smp.sample(int(g["W"]), int(g["seed"]), epoch_count=int(g["epochs"]), draw_source=DRAW_GLIBC_REPLAY)
+    ids, codes = ids.cpu().numpy(), codes.cpu().numpy()
+    assert ids.shape == g["ids"].shape
+    bad = np.argwhere(ids != g["ids"])
+    assert bad.size == 0, "first mismatch at %s: got %s want %s" % (bad[0], ids[tuple(bad[0])], g["ids"][tuple(bad[0])])
+    assert (codes == g["codes"]).all()
+
+
+def test_glibc_replay_windows_match_full_stream():
+    from pathnet_amd import DRAW_GLIBC_REPLAY
+    g = golden("sampler_cornell_7_6.npz")
+    smp = make_sampler(g)
+    ids, codes = smp.sample(int(g["W"]), int(g["seed"]), epoch_begin=1, epoch_count=2, node_begin=17, node_count=50,
+                            draw_source=DRAW_GLIBC_REPLAY)
+    assert (ids.cpu().numpy() == g["ids"][1:3, 17:67]).all()
+    assert (codes.cpu().numpy() == g["codes"][1:3, 17:67]).all()
+
+
+def test_glibc_replay_deep_in_the_stream_matches_oracle():
+    from pathnet_amd import DRAW_GLIBC_REPLAY
+    g = golden("sampler_cornell_40_4.npz")
+    n, W, L = int(g["n"]), 40, 4
+    smp = make_sampler(g)
+    ids, codes = smp.sample(W, 20220722, epoch_begin=997, epoch_count=3, draw_source=DRAW_GLIBC_REPLAY)
+    oi, oc = merw.sample_full(n, g["u"], g["v"], g["p"], W, L, merw.DRAW_GLIBC, 20220722, epoch_begin=997,
+                              epoch_count=3)
+    assert (ids.cpu().numpy() == oi).all() and (codes.cpu().numpy() == oc).all()
+
+
+@pytest.mark.parametrize("name", ["sampler_synthetic97_12_5.npz", "sampler_nba_5_4.npz"])
+def test_philox_bit_exact_vs_oracle(name):
+    from pathnet_amd import DRAW_PHILOX
+    g = golden(name)
+    n, W, L = int(g["n"]), int(g["W"]), int(g["L"])
+    smp = make_sampler(g)
+    ids, codes = smp.sample(W, 0xC0FFEE1234, epoch_begin=3, epoch_count=2, draw_source=DRAW_PHILOX)
+    oi, oc = merw.sample_full(n, g["u"], g["v"], g["p"], W, L, merw.DRAW_PHILOX, 0xC0FFEE1234, epoch_begin=3,
+                              epoch_count=2)
+    assert (ids.cpu().numpy() == oi).all() and (codes.cpu().numpy() == oc).all()
+
+
+def synthetic_graph(n, deg, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, n, n * deg // 2)
+    b = rng.integers(0, n, n * deg // 2)
+    und = np.unique(np.stack([np.minimum(a, b), np.maximum(a, b)], 1)[a != b], axis=0)
+    src = np.concatenate([und[:, 0], und[:, 1], np.arange(n)])
+    dst = np.concatenate([und[:, 1], und[:, 0], np.arange(n)])
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    w = rng.random(len(src)) + 0.1
+    tot = np.zeros(n)
+    np.add.at(tot, src, w)
+    p = w / tot[src]
+    u = np.repeat(src, 2).astype(np.int32)        # every row twice, like the shipped files
+    v = np.repeat(dst, 2).astype(np.int32)
+    return n, u, v, np.repeat(p, 2)
+
+
+def test_structural_invariants_at_cora_scale_philox():
+    from pathnet_amd import DRAW_PHILOX, MerwSampler
+    n, u, v, p = synthetic_graph(2708, 4, 0)
+    W, L = 40, 4
+    smp = MerwSampler(n, u, v, p, L)
+    ids, codes = smp.sample(W, 11, epoch_count=4, draw_source=DRAW_PHILOX)
+    ids, codes = ids.cpu().numpy(), codes.cpu().numpy()
+    assert (ids[:, :, :, 0] == np.arange(n)[None, :, None]).all() and (codes[..., 0] == 0).all()
+    key = set((u.astype(np.int64) * n + v).tolist())
+    flat = ids.reshape(-1, L).astype(np.int64)
+    for t in range(L - 1):
+        assert set((flat[:, t] * n + flat[:, t + 1]).tolist()) <= key          # every hop is an edge row
+    dis = merw.bfs_dense(n, u, v, L)
+    want = dis[np.repeat(np.arange(n), W)[None, :].repeat(4, 0).reshape(-1)[:, None], flat] - 1
+    assert (codes.reshape(-1, L) == want).all()                                 # code = BFS hops
+    oi, oc = merw.sample_full(n, u, v, p, W, L, merw.DRAW_PHILOX, 11, epoch_count=4)
+    assert (ids == oi).all() and (codes == oc).all()
+
+
+def test_empty_table_is_reported():
+    from pathnet_amd import DRAW_PHILOX, MerwSampler, _lib
+    # node 2 has no outgoing rows; walks from 0 reach it
+    u = np.array([0, 0, 1, 1], np.int32)
+    v = np.array([2, 2, 0, 0], np.int32)
+    p = np.array([0.5, 0.5, 0.5, 0.5])
+    smp = MerwSampler(3, u, v, p, 3)
+    with pytest.raises(_lib.PnError) as e:
+        smp.sample(4, 1, draw_source=DRAW_PHILOX)
+    assert e.value.code == _lib.PN_ERR_EMPTY_TABLE
+
+
+@pytest.mark.skipif(not merw.have_ref(), reason="oracle/_ref not built")
+def test_cli_output_is_byte_identical_to_reference_program(tmp_path):
+    """python -m pathnet_amd.sampler <name> <W> <L> vs ./gen_merw <name> <W> <L> (same srand seed)."""
+    g = golden("sampler_synthetic97_12_5.npz")
+    W, L, seed, epochs = 6, 4, 31337, 5
+    os.makedirs(os.path.join(tmp_path, "preprocess"))
+    os.makedirs(os.path.join(tmp_path, "edge_input"))
+    edge = os.path.join(tmp_path, "edge_input", "syn.in")
+    merw.write_edge_file(edge, int(g["n"]), g["u"], g["v"], g["p"])
+    cwd = os.path.join(tmp_path, "preprocess")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.run([sys.executable, "-m", "pathnet_amd.sampler", "syn", str(W), str(L), "--seed", str(seed),
+                    "--epochs", str(epochs)], cwd=cwd, env=env, check=True)
+    mine = open(os.path.join(cwd, "syn_%d_%d_merw.txt" % (W, L)), "rb").read()
+    ref = merw.run_ref(edge, W, L, seed, max_bytes=len(mine))
+    assert len(mine) == epochs * int(g["n"]) * W * (len(mine) // (epochs * int(g["n"]) * W)) and mine == ref
+    # per-epoch variant (gen_epoch_merw.cpp): same stream, one file per epoch
+    subprocess.run([sys.executable, "-m", "pathnet_amd.sampler", "syn", str(W), str(L), "--seed", str(seed),
+                    "--epochs", "3", "--per-epoch"], cwd=cwd, env=env, check=True)
+    cat = b"".join(open(os.path.join(cwd, "syn_%d_%d_%d_merw.txt" % (W, L, e)), "rb").read() for e in range(3))
+    assert cat == ref[:len(cat)]
