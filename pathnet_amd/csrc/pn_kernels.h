@@ -56,4 +56,11 @@ __device__ __forceinline__ float4 dropout4(uint64_t seed, uint64_t vec, uint32_t
                        r.w >= cut ? scale : 0.0f);
 }
 
+// the same mask, one element at a time (element index e of the [.., H] tensor the mask covers)
+__device__ __forceinline__ float dropout1(uint64_t seed, uint64_t e, uint32_t stream, float p) {
+    const float4 m = dropout4(seed, e >> 2, stream, p);
+    const int k = (int)(e & 3);
+    return k == 0 ? m.x : k == 1 ? m.y : k == 2 ? m.z : m.w;
+}
+
 }  // namespace pn

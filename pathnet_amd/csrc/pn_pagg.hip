@@ -25,6 +25,7 @@
 // because the contract is 1e-5 on fp32 logits against the reference CPU path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "pn_internal.h"
@@ -495,6 +496,362 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
     }
 }
 
+
+// ================================================================================================
+// BACKWARD
+// ================================================================================================
+// recurrent weights in B-fragment order for  [dx_t ; dh_{t-1}] = dG_t . [W_ih | W_hh]   (K = G*H):
+//   WpT[((w*2 + nt)*(GH/8) + s4)*64 + lane][e] = Wcat[k = (lane>>5)*GH/2 + 4*s4 + e][n = nt*H + 32*w + (lane&31)]
+__global__ void pack_bwd_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int H, int G,
+                                float *__restrict__ WpT) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int GH = G * H;
+    if (idx >= (int64_t)GH * 2 * H) return;
+    const int e = idx & 3, lane = (idx >> 2) & 63;
+    int64_t rest = idx >> 8;
+    const int s4 = rest % (GH / 8);
+    rest /= (GH / 8);
+    const int nt = rest % 2, w = rest / 2;
+    const int k = (lane >> 5) * (GH / 2) + 4 * s4 + e, n = 32 * w + (lane & 31);
+    WpT[idx] = nt == 0 ? w_ih[(int64_t)k * H + n] : w_hh[(int64_t)k * H + n];
+}
+
+// ---- pooling / attention / classifier backward: one wavefront per group -------------------------
+struct PoolBwdParams {
+    int variant, S, W, H, C;
+    const float *hn, *ego_tab;
+    const int32_t *egoidx, *sel;
+    const float *att_w, *fc2_w, *g_out, *coef, *rawsc;
+    float p_drop;
+    uint64_t seed;
+    const float *mask;
+    float *dhn;        // [P, H]
+    float *dXh;        // [N, H]  (+= ego of the classifier input; HETERO: += attention ego)
+    float *dego;       // table the attention-ego gradient goes to: dZ (HOMO) or dXh (HETERO)
+    float *g_att_w, *g_att_b;
+};
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int H = p.H, W = p.W;
+    float *dco = lds + wave * (2 * W + H);   // [W] d coef, then [W] d score, then [H] d pooled / W
+    float *dsc = dco + W;
+    float *dp = dsc + W;
+    float *red = lds + 4 * (2 * W + H);      // [4][2H] per-wave attention-weight partials
+    const int g = blockIdx.x * 4 + wave;
+    const bool active = g < p.S;
+    const float inv_w = 1.0f / (float)W;
+    float gaw_h[4] = {0.f, 0.f, 0.f, 0.f}, gaw_e[4] = {0.f, 0.f, 0.f, 0.f}, gab = 0.0f;
+
+    if (active) {
+        for (int j = lane; j < H; j += 64) {
+            float a = 0.0f, b = 0.0f;
+            for (int c = 0; c < p.C; c++) {
+                const float go = p.g_out[(int64_t)g * p.C + c];
+                a += go * p.fc2_w[(int64_t)c * 2 * H + j];
+                b += go * p.fc2_w[(int64_t)c * 2 * H + H + j];
+            }
+            if (p.mask) {
+                a *= p.mask[(int64_t)g * 2 * H + j];
+                b *= p.mask[(int64_t)g * 2 * H + H + j];
+            } else if (p.p_drop > 0.0f) {
+                a *= dropout1(p.seed, (uint64_t)g * 2 * H + j, 2u, p.p_drop);
+                b *= dropout1(p.seed, (uint64_t)g * 2 * H + H + j, 2u, p.p_drop);
+            }
+            atomicAdd(&p.dXh[(int64_t)p.sel[g] * H + j], a);
+            dp[j] = b * inv_w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int mem = 0; mem < W; mem++) {
+            const float *h = p.hn + ((int64_t)g * W + mem) * H;
+            float part = 0.0f;
+            for (int j = lane; j < H; j += 64) part += dp[j] * h[j];
+            part = wave_sum(part);
+            if (lane == 0) dco[mem] = part;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (p.variant == PN_VARIANT_HETERO) {
+            float tot = 0.0f;
+            for (int mem = lane; mem < W; mem += 64) tot += p.coef[(int64_t)g * W + mem] * dco[mem];
+            tot = wave_sum(tot);
+            for (int mem = lane; mem < W; mem += 64) {
+                const int64_t s = (int64_t)g * W + mem;
+                dsc[mem] = p.coef[s] * (dco[mem] - tot) * (p.rawsc[s] > 0.0f ? 1.0f : 0.01f);
+            }
+        } else {
+            for (int mem = lane; mem < W; mem += 64) dsc[mem] = p.variant == PN_VARIANT_HOMO ? dco[mem] : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int mem = 0; mem < W; mem++) {
+            const int64_t s = (int64_t)g * W + mem;
+            const float ds = dsc[mem], cf = p.coef[s];
+            const int64_t erow = p.variant == PN_VARIANT_PAGG ? 0 : (int64_t)p.egoidx[s] * H;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = lane + 64 * i;
+                if (j < H) {
+                    float dh = cf * dp[j];
+                    if (p.variant != PN_VARIANT_PAGG) {
+                        dh += ds * p.att_w[j];
+                        gaw_h[i] += ds * p.hn[s * H + j];
+                        gaw_e[i] += ds * p.ego_tab[erow + j];
+                        atomicAdd(&p.dego[erow + j], ds * p.att_w[H + j]);
+                    }
+                    p.dhn[s * H + j] = dh;
+                }
+            }
+            gab += ds;
+        }
+    }
+    if (p.variant == PN_VARIANT_PAGG) return;   // block-uniform
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = lane + 64 * i;
+        if (j < H) {
+            red[wave * 2 * H + j] = gaw_h[i];
+            red[wave * 2 * H + H + j] = gaw_e[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * H; j += 256)
+        atomicAdd(&p.g_att_w[j], red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j]);
+    if (lane == 0 && active) atomicAdd(p.g_att_b, gab);
+}
+
+// ---- BPTT through the recurrent cell, fused with the gather-backward scatter ---------------------
+struct SeqBwdParams {
+    const float *saved;     // [P, L, SV, H]
+    const float *dhn;       // [P, H]
+    const int32_t *rowidx, *slotof;
+    const float *WpT;
+    float *dG;              // [P, L, G*H] pre-activation gate gradients (input of the weight-gradient GEMM)
+    float *dZ;              // [N*L, H]    += d x_t   (atomic scatter: the backward of the row gather)
+    int P, L;
+    float p_drop;
+    uint64_t seed;
+    const float *mask;
+};
+
+template <int H, int G, int MT>
+__global__ __launch_bounds__(H / 32 * 64) void seq_bwd_kernel(SeqBwdParams p) {
+    constexpr int MTILES = MT / 32, GH = G * H, PITCH = GH + 4, SV = (G == 4 ? 5 : 1);
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int q0 = blockIdx.x * MT;
+    const int col = 32 * wave + li;
+    const float4 *W4 = reinterpret_cast<const float4 *>(p.WpT);
+
+    f32x16 dh[MTILES], dc[MTILES];
+#pragma unroll
+    for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int q = q0 + mt * 32 + acc_row(r, lane);
+            dh[mt][r] = q < p.P ? p.dhn[(int64_t)q * H + col] : 0.0f;
+            dc[mt][r] = 0.0f;
+        }
+
+    for (int t = p.L - 1; t >= 0; t--) {
+#pragma unroll
+        for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = mt * 32 + acc_row(r, lane);
+                const int q = q0 + row;
+                const bool ok = q < p.P;
+                if (G == 4) {
+                    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f;
+                    if (ok) {
+                        const float *sv = p.saved + (((int64_t)q * p.L + t) * SV) * H + col;
+                        ig = sv[0]; fg = sv[H]; gg = sv[2 * H]; og = sv[3 * H]; c = sv[4 * H];
+                        if (t > 0) cprev = sv[4 * H - (int64_t)SV * H];
+                    }
+                    const float tc = tanhf(c);
+                    const float dhv = dh[mt][r];
+                    const float d_o = dhv * tc;
+                    const float dct = dc[mt][r] + dhv * og * (1.0f - tc * tc);
+                    const float a_i = dct * gg * ig * (1.0f - ig);
+                    const float a_f = dct * cprev * fg * (1.0f - fg);
+                    const float a_g = dct * ig * (1.0f - gg * gg);
+                    const float a_o = d_o * og * (1.0f - og);
+                    dc[mt][r] = dct * fg;
+                    float *l = &lds[row * PITCH + col];
+                    l[0] = a_i; l[H] = a_f; l[2 * (G > 1 ? H : 0)] = a_g; l[3 * (G > 1 ? H : 0)] = a_o;
+                    if (ok) {
+                        float *d = p.dG + ((int64_t)q * p.L + t) * GH + col;
+                        d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
+                    }
+                } else {
+                    const float h = ok ? p.saved[((int64_t)q * p.L + t) * H + col] : 0.0f;
+                    const float a = dh[mt][r] * (1.0f - h * h);
+                    lds[row * PITCH + col] = a;
+                    if (ok) p.dG[((int64_t)q * p.L + t) * GH + col] = a;
+                }
+            }
+        __syncthreads();
+
+        f32x16 acc[MTILES][2];
+#pragma unroll
+        for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.0f;
+#pragma unroll 2
+        for (int s4 = 0; s4 < GH / 8; s4++) {
+            float4 b[2], a[MTILES];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) b[nt] = W4[((int64_t)(wave * 2 + nt) * (GH / 8) + s4) * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < MTILES; mt++)
+                a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * (GH / 2) + 4 * s4]);
+#pragma unroll
+            for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    acc[mt][nt] = mfma32(a[mt].x, b[nt].x, acc[mt][nt]);
+                    acc[mt][nt] = mfma32(a[mt].y, b[nt].y, acc[mt][nt]);
+                    acc[mt][nt] = mfma32(a[mt].z, b[nt].z, acc[mt][nt]);
+                    acc[mt][nt] = mfma32(a[mt].w, b[nt].w, acc[mt][nt]);
+                }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int mt = 0; mt < MTILES; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int q = q0 + mt * 32 + acc_row(r, lane);
+                if (q < p.P) {
+                    float dx = acc[mt][0][r];
+                    const uint64_t e = ((uint64_t)t * p.P + p.slotof[q]) * H + col;
+                    if (p.mask)
+                        dx *= p.mask[e];
+                    else if (p.p_drop > 0.0f)
+                        dx *= dropout1(p.seed, e, 1u, p.p_drop);
+                    atomicAdd(&p.dZ[(int64_t)p.rowidx[(int64_t)q * p.L + t] * H + col], dx);
+                }
+                dh[mt][r] = acc[mt][1][r];
+            }
+    }
+}
+
+// ---- recurrent weight gradients:  g_W_ih | g_W_hh  [G*H, 2H] = sum over the P*L rows of
+//      dG[row, :]^T (x) [x_row ; h_prev_row]   (x re-gathered with its dropout mask, h_prev rebuilt
+//      from the saved gates) -- split over row ranges, accumulated with atomics -----------------------
+struct WgradParams {
+    const float *dG, *Z, *saved;
+    const int32_t *rowidx, *slotof;
+    int P, L, H, G;
+    float p_drop;
+    uint64_t seed;
+    const float *mask;
+    float *g_w_ih, *g_w_hh;
+    int64_t rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+    __shared__ float As[GEMM_KT * GEMM_PITCH];
+    __shared__ float Bs[GEMM_KT * GEMM_PITCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = p.H, GH = p.G * H, SV = p.G == 4 ? 5 : 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int64_t rows = (int64_t)p.P * p.L;
+    const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
+    const int64_t rend = min(rows, rbeg + p.rows_per_split);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    for (int64_t k0 = rbeg; k0 < rend; k0 += GEMM_KT) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + 256 * i;
+            const int k = idx >> 6, c = idx & 63;
+            const int64_t row = k0 + k;
+            float a = 0.0f, b = 0.0f;
+            if (row < rend) {
+                if (m0 + c < GH) a = p.dG[row * GH + m0 + c];
+                const int n = n0 + c;
+                const int q = (int)(row / p.L), t = (int)(row - (int64_t)q * p.L);
+                if (n < H) {
+                    b = p.Z[(int64_t)p.rowidx[row] * H + n];
+                    const uint64_t e = ((uint64_t)t * p.P + p.slotof[q]) * H + n;
+                    if (p.mask)
+                        b *= p.mask[e];
+                    else if (p.p_drop > 0.0f)
+                        b *= dropout1(p.seed, e, 1u, p.p_drop);
+                } else if (n < 2 * H && t > 0) {
+                    const float *sv = p.saved + ((row - 1) * SV) * H + (n - H);
+                    b = p.G == 4 ? sv[3 * H] * tanhf(sv[4 * H]) : sv[0];
+                }
+            }
+            As[k * GEMM_PITCH + c] = a;
+            Bs[k * GEMM_PITCH + c] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KT / 2; kk++) {
+            const float a = As[(2 * kk + hk) * GEMM_PITCH + wm * 32 + li];
+            const float b = Bs[(2 * kk + hk) * GEMM_PITCH + wn * 32 + li];
+            acc = mfma32(a, b, acc);
+        }
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + li;
+    if (n >= 2 * H) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm * 32 + acc_row(r, lane);
+        if (m >= GH) continue;
+        if (n < H)
+            atomicAdd(&p.g_w_ih[(int64_t)m * H + n], acc[r]);
+        else
+            atomicAdd(&p.g_w_hh[(int64_t)m * H + (n - H)], acc[r]);
+    }
+}
+
+__global__ void copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t ld, int M, int N, float *out) {
+    if (M <= 0 || N <= 0) return PN_OK;
+    int ysplit = (M + 511) / 512;
+    if (ysplit > 1024) ysplit = 1024;
+    const int rows_per_block = (M + ysplit - 1) / ysplit;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, ysplit), dim3(256), 0, stream, A, gate, ld, M, N,
+                       rows_per_block, out);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+template <int H, int G>
+int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
+    constexpr int MT = 32;
+    constexpr size_t lds_bytes = (size_t)MT * (G * H + 4) * 4;
+    auto kern = seq_bwd_kernel<H, G, MT>;
+    PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds_bytes));
+    const int blocks = (sp.P + MT - 1) / MT;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64), lds_bytes, stream, sp);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+template <int G>
+int dispatch_seq_bwd(hipStream_t stream, int H, const SeqBwdParams &sp) {
+    switch (H) {
+        case 32: return launch_seq_bwd<32, G>(stream, sp);
+        case 64: return launch_seq_bwd<64, G>(stream, sp);
+        case 128: return launch_seq_bwd<128, G>(stream, sp);
+        case 256: return launch_seq_bwd<256, G>(stream, sp);
+    }
+    PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
+}
+
 // ================================================================================================
 // workspace layout
 // ================================================================================================
@@ -711,9 +1068,187 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
 }
 
 int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
-    (void)a;
-    (void)stream_;
-    PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: not built yet");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!a) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null args");
+    const pn_pagg_shape &s = a->shape;
+    if (int rc = check_shape(s)) return rc;
+    if (!a->X || !a->ids || !a->codes || !a->sel || !a->fc0_w || !a->bank_w || !a->w_ih || !a->w_hh || !a->fc2_w ||
+        !a->g_out || !a->workspace)
+        PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null tensor");
+    const WsLayout w = ws_layout(s);
+    if (a->workspace_bytes < (int64_t)w.total)
+        PN_FAIL(PN_ERR_CAPACITY, "aggregator workspace holds %lld bytes, need %lld", (long long)a->workspace_bytes,
+                (long long)w.total);
+    const int H = s.H, L = s.L, G = s.variant == PN_VARIANT_PAGG ? 1 : 4, GH = G * H;
+    const int P = s.S * s.W;
+    const int homo = s.variant == PN_VARIANT_HOMO;
+    const bool has_att = s.variant != PN_VARIANT_PAGG;
+    char *ws = reinterpret_cast<char *>(a->workspace);
+    float *Xh = reinterpret_cast<float *>(ws + w.Xh), *Z = reinterpret_cast<float *>(ws + w.Z);
+    int32_t *rowidx = reinterpret_cast<int32_t *>(ws + w.rowidx), *egoidx = reinterpret_cast<int32_t *>(ws + w.egoidx),
+            *slotof = reinterpret_cast<int32_t *>(ws + w.slotof);
+    float *hn = reinterpret_cast<float *>(ws + w.hn), *saved = reinterpret_cast<float *>(ws + w.saved);
+    float *coef = reinterpret_cast<float *>(ws + w.coef), *rawsc = reinterpret_cast<float *>(ws + w.rawsc);
+    float *layer1 = reinterpret_cast<float *>(ws + w.layer1), *WpT = reinterpret_cast<float *>(ws + w.WpT);
+    float *dG = reinterpret_cast<float *>(ws + w.dG), *dZ = reinterpret_cast<float *>(ws + w.dZ);
+    float *dXh = reinterpret_cast<float *>(ws + w.dXh), *dhn = reinterpret_cast<float *>(ws + w.dhn);
+    // gradient buffers that are accumulated into: a NULL output is redirected to scratch (dl1 region)
+    float *scratch = reinterpret_cast<float *>(ws + w.dl1);
+    (void)scratch;
+
+    auto zero = [&](float *ptr, size_t count) -> int {
+        if (ptr && count) PN_CHECK_HIP(hipMemsetAsync(ptr, 0, count * sizeof(float), stream));
+        return PN_OK;
+    };
+    if (int rc = zero(dZ, (size_t)s.N * L * H)) return rc;
+    if (int rc = zero(dXh, (size_t)s.N * H)) return rc;
+    if (int rc = zero(a->g_att_w, has_att ? (size_t)2 * H : 0)) return rc;
+    if (int rc = zero(a->g_att_b, has_att ? 1 : 0)) return rc;
+    if (int rc = zero(a->g_w_ih, (size_t)GH * H)) return rc;
+    if (int rc = zero(a->g_w_hh, (size_t)GH * H)) return rc;
+    if (int rc = zero(a->g_b_ih, (size_t)GH)) return rc;
+    if (int rc = zero(a->g_fc2_b, (size_t)s.C)) return rc;
+    if (int rc = zero(a->g_bank_w, (size_t)L * H * H)) return rc;
+    if (int rc = zero(a->g_bank_b, (size_t)L * H)) return rc;
+    if (int rc = zero(a->g_fc0_w, (size_t)H * s.F)) return rc;
+    if (int rc = zero(a->g_fc0_b, (size_t)H)) return rc;
+    if (s.S == 0) {
+        if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
+        if (int rc = zero(a->g_b_hh, (size_t)GH)) return rc;
+        if (int rc = zero(a->g_X, (size_t)s.N * s.F)) return rc;
+        return PN_OK;
+    }
+
+    // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out)
+    if (a->g_fc2_w)
+        if (int rc = launch_gemm(stream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
+                                 2 * H, s.S, 0, GEMM_STORE, 1))
+            return rc;
+    if (a->g_fc2_b)
+        if (int rc = launch_colsum(stream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
+
+    // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
+    {
+        PoolBwdParams pp{};
+        pp.variant = s.variant;
+        pp.S = s.S;
+        pp.W = s.W;
+        pp.H = H;
+        pp.C = s.C;
+        pp.hn = hn;
+        pp.ego_tab = homo ? Z : Xh;
+        pp.egoidx = egoidx;
+        pp.sel = a->sel;
+        pp.att_w = a->att_w;
+        pp.fc2_w = a->fc2_w;
+        pp.g_out = a->g_out;
+        pp.coef = coef;
+        pp.rawsc = rawsc;
+        pp.p_drop = a->p_cls;
+        pp.seed = a->seed;
+        pp.mask = a->mask_cls;
+        pp.dhn = dhn;
+        pp.dXh = dXh;
+        pp.dego = homo ? dZ : dXh;
+        // attention gradients are optional outputs: fall back to scratch so the kernel needs no branches
+        pp.g_att_w = a->g_att_w ? a->g_att_w : scratch;
+        pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
+        if (has_att && (!a->g_att_w || !a->g_att_b))
+            if (int rc = zero(scratch, (size_t)2 * H + 1)) return rc;
+        const size_t lds_bytes = (size_t)(4 * (2 * s.W + H) + 8 * H) * sizeof(float);
+        hipLaunchKernelGGL(pool_bwd_kernel, dim3((s.S + 3) / 4), dim3(256), lds_bytes, stream, pp);
+        PN_CHECK_HIP(hipGetLastError());
+    }
+
+    // BPTT + gather-backward scatter
+    {
+        const int64_t nw = (int64_t)GH * 2 * H;
+        hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
+                           H, G, WpT);
+        PN_CHECK_HIP(hipGetLastError());
+        SeqBwdParams sp{};
+        sp.saved = saved;
+        sp.dhn = dhn;
+        sp.rowidx = rowidx;
+        sp.slotof = slotof;
+        sp.WpT = WpT;
+        sp.dG = dG;
+        sp.dZ = dZ;
+        sp.P = P;
+        sp.L = L;
+        sp.p_drop = a->p_seq;
+        sp.seed = a->seed;
+        sp.mask = a->mask_seq;
+        if (int rc = (G == 4 ? dispatch_seq_bwd<4>(stream, H, sp) : dispatch_seq_bwd<1>(stream, H, sp))) return rc;
+    }
+
+    // recurrent weight / bias gradients
+    if (a->g_w_ih && a->g_w_hh) {
+        WgradParams wp{};
+        wp.dG = dG;
+        wp.Z = Z;
+        wp.saved = saved;
+        wp.rowidx = rowidx;
+        wp.slotof = slotof;
+        wp.P = P;
+        wp.L = L;
+        wp.H = H;
+        wp.G = G;
+        wp.p_drop = a->p_seq;
+        wp.seed = a->seed;
+        wp.mask = a->mask_seq;
+        wp.g_w_ih = a->g_w_ih;
+        wp.g_w_hh = a->g_w_hh;
+        const int64_t rows = (int64_t)P * L;
+        const int tiles = ((GH + 63) / 64) * ((2 * H + 63) / 64);
+        int64_t nz = std::max<int64_t>(1, std::min<int64_t>((2048 + tiles - 1) / tiles, (rows + 255) / 256));
+        int64_t rps = (rows + nz - 1) / nz;
+        rps = (rps + GEMM_KT - 1) / GEMM_KT * GEMM_KT;
+        nz = (rows + rps - 1) / rps;
+        wp.rows_per_split = rps;
+        hipLaunchKernelGGL(wgrad_kernel, dim3((2 * H + 63) / 64, (GH + 63) / 64, (unsigned)nz), dim3(256), 0, stream,
+                           wp);
+        PN_CHECK_HIP(hipGetLastError());
+    } else if (a->g_w_ih || a->g_w_hh) {
+        PN_FAIL(PN_ERR_ARG, "g_w_ih and g_w_hh must be requested together");
+    }
+    if (a->g_b_ih) {
+        if (int rc = launch_colsum(stream, dG, nullptr, GH, P * L, GH, a->g_b_ih)) return rc;
+        if (a->g_b_hh) {
+            hipLaunchKernelGGL(copy_kernel, dim3((GH + 255) / 256), dim3(256), 0, stream, a->g_b_ih, a->g_b_hh,
+                               (int64_t)GH);
+            PN_CHECK_HIP(hipGetLastError());
+        }
+    } else if (a->g_b_hh) {
+        if (int rc = zero(a->g_b_hh, (size_t)GH)) return rc;
+        if (int rc = launch_colsum(stream, dG, nullptr, GH, P * L, GH, a->g_b_hh)) return rc;
+    }
+
+    // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh
+    const float *zgate = homo ? Z : nullptr;
+    if (int rc = launch_gemm(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, s.N, H, L * H, 0,
+                             GEMM_ADD, 1))
+        return rc;
+    if (a->g_bank_w)
+        if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, s.N,
+                                 0, GEMM_ATOMIC, (s.N + 511) / 512))
+            return rc;
+    if (a->g_bank_b)
+        if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, s.N, L * H, a->g_bank_b)) return rc;
+
+    // fc0 backward (ReLU gate for HOMO)
+    const float *xgate = homo ? Xh : nullptr;
+    if (a->g_fc0_w)
+        if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, s.F, a->g_fc0_w, s.F, nullptr, H, s.F, s.N, 0,
+                                 GEMM_ATOMIC, (s.N + 511) / 512))
+            return rc;
+    if (a->g_fc0_b)
+        if (int rc = launch_colsum(stream, dXh, xgate, H, s.N, H, a->g_fc0_b)) return rc;
+    if (a->g_X)
+        if (int rc = launch_gemm(stream, dXh, H, 1, xgate, a->fc0_w, 1, s.F, a->g_X, s.F, nullptr, s.N, s.F, H, 0,
+                                 GEMM_STORE, 1))
+            return rc;
+    return PN_OK;
 }
 
 }  // extern "C"

@@ -72,8 +72,10 @@ def test_gather_stage_matches_plan(variant):
     codes = rng.integers(0, L, (S, W, L)).astype(np.uint8)
     rows = torch.empty(S * W, L, H, device="cuda")
     sh = _lib.PaggShape({"hetero": 0, "homo": 1, "pagg": 2}[variant], N, 1, H, 1, S, W, L)
-    _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), torch.as_tensor(ids).cuda().data_ptr(),
-                                  torch.as_tensor(codes).cuda().data_ptr(), rows.data_ptr(), None))
+    d_ids, d_codes = torch.as_tensor(ids).cuda(), torch.as_tensor(codes).cuda()      # keep alive across the call
+    _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), d_ids.data_ptr(), d_codes.data_ptr(),
+                                  rows.data_ptr(), None))
+    torch.cuda.synchronize()
     node, code, group, member, ego = po.plan(variant, ids, codes, S, W, L)
     order = np.argsort(group * W + member, kind="stable")               # rows come out in pooling-group order
     want = table.cpu()[torch.as_tensor(node[order]), torch.as_tensor(code[order])]
@@ -185,3 +187,145 @@ def test_builtin_dropout_statistics_and_determinism():
         e = run_module(m, X, ids, codes, mask, W, L)
     assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, e)
     assert torch.isfinite(a).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# backward
+# ------------------------------------------------------------------------------------------------
+def grad_tol(ref):
+    return 3e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("name", golden_files("pagg_*.npz"))
+def test_backward_matches_reference_golden(name):
+    g = golden(name)
+    variant = str(g["variant"])
+    N, F, H, C, W, L = (int(g[k]) for k in "NFHCWL")
+    params = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    m = build_module(variant, F, H, C, L, N, params).eval()
+    X = torch.as_tensor(g["X"]).cuda().requires_grad_(True)
+    out = run_module(m, X, g["ids"], g["codes"], g["mask"], W, L)
+    (out * torch.as_tensor(g["G"]).cuda()).sum().backward()
+    worst = {}
+    for k, v in m.named_parameters():
+        ref = g["grad/" + k]
+        assert v.grad is not None, k
+        err = np.abs(v.grad.cpu().numpy() - ref).max()
+        worst[k] = (err, grad_tol(ref))
+    ref = g["grad_X"]
+    worst["X"] = (np.abs(X.grad.cpu().numpy() - ref).max(), grad_tol(ref))
+    bad = {k: v for k, v in worst.items() if not v[0] < v[1]}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+@pytest.mark.parametrize("H,W,S,N,F,C,train", [(128, 40, 87, 183, 300, 5, False), (128, 40, 50, 100, 64, 3, True),
+                                                (64, 9, 33, 70, 20, 4, True), (256, 6, 20, 40, 16, 2, False)])
+def test_backward_matches_oracle_random(variant, H, W, S, N, F, C, train):
+    torch.manual_seed(21)
+    rng = np.random.default_rng(22)
+    L = 4
+    m = build_module(variant, F, H, C, L, N, None)
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith("bias"):
+                v.uniform_(-0.3, 0.3)
+    X = torch.rand(N, F)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    G = torch.randn(S, C)
+    drop_seq = drop_cls = None
+    if train:
+        pdrop = 0.5
+        drop_seq = (torch.rand(L, S * W, H) >= pdrop).float() / (1 - pdrop)
+        drop_cls = (torch.rand(S, 2 * H) >= pdrop).float() / (1 - pdrop)
+        m.train()
+        m._mask_seq, m._mask_cls = drop_seq.cuda(), drop_cls.cuda()
+    else:
+        m.eval()
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    (out * G.cuda()).sum().backward()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Xo = X.clone().requires_grad_(True)
+    want = po.forward(variant, pr, Xo, ids, codes, sel, W, L, drop_seq=drop_seq, drop_cls=drop_cls)
+    (want * G).sum().backward()
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT
+    bad = {}
+    for k, v in m.named_parameters():
+        ref = pr[k].grad.numpy()
+        err = np.abs(v.grad.cpu().numpy() - ref).max()
+        if not err < grad_tol(ref):
+            bad[k] = (err, grad_tol(ref))
+    err = (Xd.grad.cpu() - Xo.grad).abs().max().item()
+    if not err < grad_tol(Xo.grad.numpy()):
+        bad["X"] = err
+    assert not bad, bad
+
+
+def test_builtin_dropout_backward_is_consistent_with_forward():
+    """With the built-in Philox masks the backward must regenerate exactly the forward's mask:
+    check d(out)/d(params) by finite differences along one random direction, same seed."""
+    torch.manual_seed(5)
+    rng = np.random.default_rng(5)
+    import pathnet_amd
+    N, F, H, C, W, L, S = 50, 12, 64, 3, 10, 4, 20
+    m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.4).cuda().train()
+    X = torch.rand(N, F).cuda()
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    ids = rng.integers(0, N, (S, W, L))
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    G = torch.randn(S, C).cuda()
+
+    def loss():
+        torch.manual_seed(77)           # same dropout seed every call
+        return (run_module(m, X, ids, codes, mask, W, L) * G).sum()
+
+    l0 = loss()
+    l0.backward()
+    direction = {k: torch.randn_like(v) for k, v in m.named_parameters()}
+    analytic = sum((v.grad * direction[k]).sum().item() for k, v in m.named_parameters())
+    eps = 1e-3
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            v.add_(eps * direction[k])
+        lp = loss().item()
+        for k, v in m.named_parameters():
+            v.sub_(2 * eps * direction[k])
+        lm = loss().item()
+    numeric = (lp - lm) / (2 * eps)
+    assert abs(numeric - analytic) < 2e-2 * max(1.0, abs(analytic)), (numeric, analytic)
+
+
+def test_training_loop_reduces_loss():
+    """The unchanged reference recipe: Adam(lr=0.005, wd=5e-4) + CrossEntropyLoss (PathNet_run.py:295-297)."""
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    import pathnet_amd
+    N, F, H, C, W, L, S = 120, 32, 64, 4, 20, 4, 60
+    m = pathnet_amd.PathNet(F, H, C, L, dropout=0.3).cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=0.005, weight_decay=0.0005)
+    lossf = torch.nn.CrossEntropyLoss()
+    Y = torch.as_tensor(rng.integers(0, C, N))
+    X = (torch.rand(N, F) + torch.nn.functional.one_hot(Y, F).float() * 2).cuda()
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = np.flatnonzero(mask)[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    first = last = None
+    for step in range(60):
+        m.train()
+        out = run_module(m, X, ids, codes, mask, W, L)
+        loss = lossf(out, Y[mask].cuda())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < 0.5 * first, (first, last)
