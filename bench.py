@@ -1,0 +1,362 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the path-aggregation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch, i.e. one training step of the reference loop
+(/root/reference/PathNet_run.py:336-352) on the workload BASELINE.json's metric is quoted on
+(configs[1]: Cora, path_num=40, path_len=4, hid=128):
+    sample this epoch's W paths for every node on the GPU (MERW walker, Philox draws)
+ -> select the paths of the masked (train) nodes
+ -> PAGG forward (PathNet_homo) -> cross-entropy -> PAGG backward -> Adam step (lr 0.005, wd 5e-4)
+Inputs are synthetic (no dataset ships with the reference mount) but Cora-shaped: N=2708 nodes,
+F=1433 bag-of-words-like features, C=7, 48% of the nodes masked, MERW-like transition rows with every
+row duplicated and self loops, as in the shipped edge_input files.
+Everything is resident in HBM before the timed region.  value = paths aggregated per second
+(S*W per step, whole job).  With N > 1 each rank owns an N-th of a graph that is N times larger
+(weak scaling): node-sharded fc0, one all-gather of the projected feature matrix per step, one
+reduce-scatter of its gradient and one flat all-reduce of the parameter gradients (RCCL).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak, same guide
+
+
+def synthetic_graph(n, seed, avg_und_deg=3.9):
+    """Symmetric sparse graph + self loops, MERW-like probabilities (p ~ psi_v / psi_u-normalised from a few
+    power iterations), every row written twice like init_rw.py:83-86 does."""
+    rng = np.random.default_rng(seed)
+    m_und = int(n * avg_und_deg / 2)
+    a = rng.integers(0, n, m_und * 2)
+    b = rng.integers(0, n, m_und * 2)
+    keep = a != b
+    und = np.unique(np.stack([np.minimum(a, b)[keep], np.maximum(a, b)[keep]], 1), axis=0)[:m_und]
+    src = np.concatenate([und[:, 0], und[:, 1], np.arange(n)])
+    dst = np.concatenate([und[:, 1], und[:, 0], np.arange(n)])
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    psi = np.ones(n)
+    for _ in range(20):
+        nxt = np.zeros(n)
+        np.add.at(nxt, src, psi[dst])
+        psi = nxt / np.linalg.norm(nxt)
+    w = psi[dst]
+    tot = np.zeros(n)
+    np.add.at(tot, src, w)
+    p = w / tot[src]
+    return n, np.repeat(src, 2).astype(np.int32), np.repeat(dst, 2).astype(np.int32), np.repeat(p, 2)
+
+
+def workload(rank, world, seed=0):
+    """Cora-shaped workload; with world > 1 every rank owns a 2708-node block of a world*2708-node graph."""
+    n_loc, F, C, H, W, L = 2708, 1433, 7, 128, 40, 4
+    n = n_loc * world
+    g = synthetic_graph(n, seed)
+    rng = np.random.default_rng(seed + 1)
+    X = (rng.random((n, F)) < 0.0127).astype(np.float32)          # Cora's bag-of-words density
+    X /= np.maximum(X.sum(1, keepdims=True), 1.0)                 # row-normalised like dataset.py's preprocess
+    Y = rng.integers(0, C, n)
+    perm = rng.permutation(n)
+    mask = np.zeros(n, bool)
+    mask[perm[: int(0.48 * n)]] = True
+    return dict(n=n, n_loc=n_loc, F=F, C=C, H=H, W=W, L=L, graph=g, X=X, Y=Y, mask=mask)
+
+
+def stage_names(lib):
+    return [lib.pn_profile_stage_name(i).decode() for i in range(lib.pn_profile_stage_count())]
+
+
+def read_profile(lib, names):
+    ms = (ctypes.c_double * len(names))()
+    cnt = (ctypes.c_int64 * len(names))()
+    from pathnet_amd import _lib
+    _lib.check(lib.pn_profile_read(ms, cnt))
+    return {names[i]: (ms[i], cnt[i]) for i in range(len(names)) if cnt[i]}
+
+
+def cpu_baseline(wl, seconds_budget=20.0):
+    """The oracle's port of the reference PAGG step (oracle/pagg_oracle.py: same torch CPU arithmetic as
+    the reference classes) timed on this host: forward + CE + backward + Adam on a bounded node sample."""
+    from oracle import pagg_oracle as po
+    from oracle import merw
+    n, F, C, H, W, L = wl["n"], wl["F"], wl["C"], wl["H"], wl["W"], wl["L"]
+    torch.manual_seed(0)
+    sel_all = np.flatnonzero(wl["mask"])
+    S = len(sel_all)            # the same batch the GPU step aggregates
+    sel = sel_all[:S]
+    gn, u, v, p = wl["graph"]
+    ids, codes = merw.sample_full(gn, u, v, p, W, L, merw.DRAW_PHILOX, 1, epoch_count=1)
+    ids, codes = ids[0][sel], codes[0][sel]
+    lin = torch.nn.Linear
+    mods = {"fc0": lin(F, H), "fc2": lin(2 * H, C), "attw": lin(2 * H, 1), "LSTM": torch.nn.LSTM(H, H)}
+    params = {}
+    for k, m in mods.items():
+        for pn_, t in m.named_parameters():
+            params["%s.%s" % (k, pn_)] = t.detach().clone().requires_grad_(True)
+    for d in range(L):
+        m = lin(H, H)
+        params["nets.%d.weight" % d] = m.weight.detach().clone().requires_grad_(True)
+        params["nets.%d.bias" % d] = m.bias.detach().clone().requires_grad_(True)
+    opt = torch.optim.Adam(list(params.values()), lr=0.005, weight_decay=0.0005)
+    X = torch.from_numpy(wl["X"])
+    Y = torch.from_numpy(wl["Y"][sel])
+    lossf = torch.nn.CrossEntropyLoss()
+    times = []
+    t_begin = time.time()
+    for it in range(12):
+        t0 = time.time()
+        out = po.forward("homo", params, X, ids, codes, sel, W, L)
+        loss = lossf(out, Y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+        if it >= 3 and time.time() - t_begin > seconds_budget:
+            break
+    med = float(np.median(times[1:]))
+    return {"value": S * W / med, "unit": "paths/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/pagg_oracle.py (torch CPU, reference arithmetic) fwd+CE+bwd+Adam on %d of the %d "
+                      "masked nodes (%d paths), all %d nodes projected by fc0 as in the reference; median of %d "
+                      "steps" % (S, len(sel_all), S * W, n, len(times) - 1), "ms_per_step": med * 1e3}
+
+
+def cpu_baseline_sampler(seconds_budget=20.0):
+    """The unmodified reference sampler (oracle/_ref/gen_merw, compiled from gen_merw.cpp) on a graph sized
+    so that its fixed 1000 epochs take ~10 s; single-threaded like the reference; output -> /dev/null."""
+    from oracle import merw
+    if not merw.have_ref():
+        return None
+    n = 280
+    g = synthetic_graph(n, 7)
+    path = "/tmp/pn_bench_edges_%d.in" % os.getpid()
+    merw.write_edge_file(path, *g)
+    t0 = time.time()
+    merw.run_ref(path, 40, 4, 1, to_devnull=True, timeout=600)
+    dt = time.time() - t0
+    os.remove(path)
+    return {"value": 1000 * n * 40 / dt, "unit": "sampled paths/s", "cores": 1, "kind": "reference",
+            "sample": "oracle/_ref/gen_merw (unmodified gen_merw.cpp, -O2 -mcmodel=medium) on a %d-node synthetic graph, "
+                      "W=40 L=4, its fixed 1000 epochs = %d paths, output to /dev/null, whole-process wall %.1f s"
+                      % (n, 1000 * n * 40, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import pathnet_amd
+    from pathnet_amd import _lib
+    lib = _lib.load()
+    names = stage_names(lib)
+
+    wl = workload(rank, world)
+    n, F, C, H, W, L = wl["n"], wl["F"], wl["C"], wl["H"], wl["W"], wl["L"]
+    gn, u, v, p = wl["graph"]
+    smp = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev)
+    torch.manual_seed(0)
+    model = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.7).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.005, weight_decay=0.0005)
+    lossf = torch.nn.CrossEntropyLoss()
+    Y = torch.from_numpy(wl["Y"]).to(dev)
+
+    if world == 1:
+        X = torch.from_numpy(wl["X"]).to(dev)
+        sel = torch.from_numpy(np.flatnonzero(wl["mask"]).astype(np.int64)).to(dev)
+        sel32 = sel.to(torch.int32)
+        node_begin, node_count = 0, n
+        runner = None
+    else:
+        from pathnet_amd import dist as pdist
+        n_loc = wl["n_loc"]
+        node_begin, node_count = rank * n_loc, n_loc
+        X = torch.from_numpy(wl["X"][node_begin:node_begin + n_loc]).to(dev)      # this rank's rows only
+        loc_mask = wl["mask"][node_begin:node_begin + n_loc]
+        sel = torch.from_numpy(np.flatnonzero(loc_mask).astype(np.int64)).to(dev)          # local row ids
+        sel32 = (sel + node_begin).to(torch.int32)                                         # global node ids
+        runner = pdist.ShardedAggregator(model, n_total=n, row_begin=node_begin, row_count=n_loc)
+    S = int(sel.numel())
+    Ysel = Y[sel + (node_begin if world > 1 else 0)]
+    ids_buf = torch.empty((1, node_count, W, L), dtype=torch.int32, device=dev)
+    codes_buf = torch.empty((1, node_count, W, L), dtype=torch.uint8, device=dev)
+
+    def step(epoch):
+        smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, node_begin=node_begin, node_count=node_count,
+                   draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(ids_buf, codes_buf))
+        ids = ids_buf[0].index_select(0, sel)
+        codes = codes_buf[0].index_select(0, sel)
+        model.train()
+        if runner is None:
+            out = model(X, ids, W, L, sel32, codes, None)
+        else:
+            out = runner(X, ids, W, L, sel32, codes)
+        loss = lossf(out, Ysel)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if runner is not None:
+            runner.allreduce_grads()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up, with every stage bracketed by HIP events to find the dominant kernel ----------------
+    _lib.check(lib.pn_profile_configure(1, -1))
+    for e in range(max(1, args.warmup)):
+        step(e)
+    torch.cuda.synchronize()
+    prof = read_profile(lib, names)
+    kernel_stages = {k: v[0] / v[1] for k, v in prof.items()}
+    dominant = max(kernel_stages, key=kernel_stages.get)
+    # ---- timed region: exactly K steps; only the dominant kernel carries an event pair ----------------
+    _lib.check(lib.pn_profile_configure(2, names.index(dominant)))
+    barrier()
+    t0 = time.perf_counter()
+    for e in range(args.steps):
+        step(1000 + e)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom = read_profile(lib, names)[dominant]
+    dom_ms = dom[0] / dom[1]
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s_tot = torch.tensor([S], dtype=torch.int64, device=dev)
+        dist.all_reduce(s_tot)
+        S_total = int(s_tot.item())
+    else:
+        S_total = S
+    ms_per_step = elapsed / args.steps * 1e3
+    value = S_total * W / (elapsed / args.steps)
+
+    # ---- untimed extras on rank 0: per-stage breakdown, sampler-only rate, gather microbenchmark ------
+    _lib.check(lib.pn_profile_configure(1, -1))
+    for e in range(min(10, args.steps)):
+        step(5000 + e)
+    torch.cuda.synchronize()
+    prof = read_profile(lib, names)
+    stages_ms = {k: round(v[0] / v[1], 4) for k, v in prof.items()}
+    _lib.check(lib.pn_profile_configure(0, -1))
+
+    P = S * W
+    G4 = 4
+    flops_seq = 2.0 * P * L * (2 * H) * (G4 * H)              # [x;h] (2H) x 4H gate columns, per step and path
+    algo = {"seq_fwd": flops_seq, "seq_bwd": flops_seq, "wgrad": flops_seq}
+    if dominant in algo:
+        achieved = algo[dominant] / (dom_ms * 1e-3) / 1e12
+        roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(dom[1]),
+                    "algorithmic_flops_per_launch": flops_seq,
+                    "note": "fp32-input MFMA (1e-5 parity forces fp32); flops = L*16*H^2 per path (SURVEY.md §8d)"}
+    else:
+        roofline = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None, "traffic": None, "avg_launch_ms": round(dom_ms, 4)}
+
+    extras = {}
+    if rank == 0:
+        # sampler alone: one epoch of all local nodes per launch
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        big_e = 16
+        ids_big = torch.empty((big_e, node_count, W, L), dtype=torch.int32, device=dev)
+        codes_big = torch.empty((big_e, node_count, W, L), dtype=torch.uint8, device=dev)
+        smp.sample(W, 99, epoch_count=big_e, node_begin=node_begin, node_count=node_count, out=(ids_big, codes_big))
+        ev0.record()
+        for r in range(reps):
+            smp.sample(W, 99, epoch_begin=r * big_e, epoch_count=big_e, node_begin=node_begin, node_count=node_count,
+                       check=False, out=(ids_big, codes_big))
+        ev1.record()
+        torch.cuda.synchronize()
+        dt = ev0.elapsed_time(ev1) * 1e-3 / reps
+        paths = big_e * node_count * W
+        extras["sampler"] = {"value": paths / dt, "unit": "sampled paths/s", "draws": "philox",
+                             "paths_per_launch": paths, "ms_per_launch": dt * 1e3,
+                             "algorithmic_bytes_per_path": L * (16 + 1) + L * 5,
+                             "achieved_GBs": paths * (L * 17 + L * 5) / dt / 1e9}
+        # the [P, L, H] path-feature gather alone, at Pubmed scale (north_star's HBM-roofline target)
+        Ng, Sg = 19717, 9464
+        table = torch.randn(Ng, L, H, device=dev)
+        gi = torch.randint(0, Ng, (Sg, W, L), dtype=torch.int32, device=dev)
+        gc = torch.randint(0, L, (Sg, W, L), dtype=torch.uint8, device=dev)
+        rows = torch.empty((Sg * W, L, H), device=dev)
+        sh = _lib.PaggShape(_lib.VARIANT_HOMO, Ng, 1, H, 1, Sg, W, L)
+        for _ in range(3):
+            _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), gi.data_ptr(), gc.data_ptr(),
+                                          rows.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ev0.record()
+        for _ in range(20):
+            _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), gi.data_ptr(), gc.data_ptr(),
+                                          rows.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ev1.record()
+        torch.cuda.synchronize()
+        dt = ev0.elapsed_time(ev1) * 1e-3 / 20
+        read_b = Sg * W * (L * H * 4 + L * 5)                  # 2068 B/path at L=4, H=128
+        extras["gather_pubmed_scale"] = {"paths": Sg * W, "ms": dt * 1e3, "read_GBs": read_b / dt / 1e9,
+                                         "read_frac_of_hbm_peak": read_b / dt / 1e9 / HBM_PEAK_GBS,
+                                         "read_plus_write_GBs": (read_b + Sg * W * L * H * 4) / dt / 1e9,
+                                         "algorithmic_read_bytes_per_path": L * H * 4 + L * 5,
+                                         "note": "table (40 MB) is cache resident; rows (775 MB) are written to HBM"}
+
+    result = {
+        "metric": "paths aggregated/sec (PAGG fwd+bwd, one training step incl. on-GPU MERW sampling + Adam)",
+        "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Cora-shaped synthetic (configs[1]): N=%d F=%d C=%d hid=%d path_num=%d path_len=%d, "
+                               "%d masked nodes = %d paths/step, PathNet_homo, dropout 0.7, Adam" %
+                               (n, F, C, H, W, L, S_total, S_total * W),
+                   "nodes": n, "paths_per_step": S_total * W, "parallelism": "node-shard x%d" % world},
+        "roofline": roofline,
+        "stages_ms": stages_ms,
+    }
+    result.update(extras)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl)
+        sb = cpu_baseline_sampler()
+        if sb:
+            result["cpu_baseline_sampler"] = sb
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

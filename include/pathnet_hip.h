@@ -202,8 +202,16 @@ int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_
  * out[0] Xh [N,H], out[1] Z [N,L,H], out[2] hn [P,H] (pooling-group order), out[3] layer1 [S,2H]. */
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]);
 
-/* Timing of the kernels launched by the last forward/backward on this thread is not kept here;
- * use HIP events on `stream` (bench.py does). */
+/* ================================================================================================
+ * Per-stage timing with HIP events recorded on the caller's stream (measurement only).
+ * mode 0: off (default).  mode 1: bracket every stage.  mode 2: bracket only stage `stage`.
+ * pn_profile_read waits for the recorded events, adds the elapsed times into ms_sum[i] / count[i]
+ * (arrays of pn_profile_stage_count() entries) and clears the recording.
+ * ============================================================================================== */
+int pn_profile_configure(int32_t mode, int32_t stage);
+int pn_profile_stage_count(void);
+const char *pn_profile_stage_name(int32_t stage);
+int pn_profile_read(double *ms_sum, int64_t *count);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,10 @@ SIGNATURES = {
     "pn_gemm_f32": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp,
                                    ctypes.c_int64, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                    vp]),
+    "pn_profile_configure": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
+    "pn_profile_stage_count": (ctypes.c_int, []),
+    "pn_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int32]),
+    "pn_profile_read": (ctypes.c_int, [c_f64p, c_i64p]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
 }
 

@@ -39,4 +39,17 @@ GlibcState glibc_apply(const GlibcPoly &p, const GlibcState &st);
 // state whose s[0] >> 1 is the first rand() after srand(seed)
 GlibcState glibc_seed_state(uint32_t seed);
 
+// ---- per-stage HIP-event timing (pn_profile_*) -------------------------------------------------------
+enum Stage {
+    ST_SAMPLER_FILL = 0, ST_SAMPLER_WALK, ST_GATHER, ST_FC0, ST_BANK, ST_PLAN_PACK, ST_SEQ_FWD, ST_POOL_FWD,
+    ST_FC2_GRAD, ST_POOL_BWD, ST_SEQ_BWD, ST_WGRAD, ST_BIAS_GRAD, ST_BANK_BWD, ST_FC0_BWD, ST_COUNT
+};
+// RAII bracket: records a start event now and a stop event at scope exit when profiling selects `stage`
+struct StageTimer {
+    StageTimer(int stage, void *stream);
+    ~StageTimer();
+    int slot;
+    void *stream;
+};
+
 }  // namespace pn

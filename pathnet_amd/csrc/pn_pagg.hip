@@ -973,6 +973,7 @@ int pn_pagg_gather(const pn_pagg_shape *shape, const float *table, const int32_t
     const bool vec = (s.H % 4 == 0) && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(rows)) % 16 == 0);
     const int64_t work = rowsn * (vec ? s.H / 4 : s.H);
     const int blocks = (int)std::min<int64_t>((work + 255) / 256, 256 * 32);
+    StageTimer tm(ST_GATHER, stream);
     if (vec)
         hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, stream, s.variant, table, ids, codes, s.S, s.W,
                            s.L, s.N, s.H, rows);
@@ -1008,14 +1009,21 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     const int homo = s.variant == PN_VARIANT_HOMO;
 
     // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
-    if (int rc = launch_gemm(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1, Xh, H, a->fc0_b, s.N, H, s.F, homo,
-                             GEMM_STORE, 1))
-        return rc;
-    // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
-    if (int rc = launch_gemm(stream, Xh, H, 1, nullptr, a->bank_w, H, 1, Z, (int64_t)L * H, a->bank_b, s.N, L * H, H,
-                             homo, GEMM_STORE, 1))
-        return rc;
     {
+        StageTimer tm(ST_FC0, stream);
+        if (int rc = launch_gemm(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1, Xh, H, a->fc0_b, s.N, H, s.F, homo,
+                                 GEMM_STORE, 1))
+            return rc;
+    }
+    // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
+    {
+        StageTimer tm(ST_BANK, stream);
+        if (int rc = launch_gemm(stream, Xh, H, 1, nullptr, a->bank_w, H, 1, Z, (int64_t)L * H, a->bank_b, s.N, L * H,
+                                 H, homo, GEMM_STORE, 1))
+            return rc;
+    }
+    {
+        StageTimer tm(ST_PLAN_PACK, stream);
         const int64_t n = (int64_t)P * L;
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s.variant, a->ids,
                            a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
@@ -1038,7 +1046,10 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     sp.p_drop = a->p_seq;
     sp.seed = a->seed;
     sp.mask = a->mask_seq;
-    if (int rc = (G == 4 ? dispatch_seq_fwd<4>(stream, H, sp) : dispatch_seq_fwd<1>(stream, H, sp))) return rc;
+    {
+        StageTimer tm(ST_SEQ_FWD, stream);
+        if (int rc = (G == 4 ? dispatch_seq_fwd<4>(stream, H, sp) : dispatch_seq_fwd<1>(stream, H, sp))) return rc;
+    }
 
     PoolParams pp{};
     pp.variant = s.variant;
@@ -1062,7 +1073,11 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     pp.rawsc = reinterpret_cast<float *>(ws + w.rawsc);
     pp.layer1 = reinterpret_cast<float *>(ws + w.layer1);
     pp.out = a->out;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((s.S + 3) / 4), dim3(256), (size_t)4 * s.W * sizeof(float), stream, pp);
+    {
+        StageTimer tm(ST_POOL_FWD, stream);
+        hipLaunchKernelGGL(pool_fwd_kernel, dim3((s.S + 3) / 4), dim3(256), (size_t)4 * s.W * sizeof(float), stream,
+                           pp);
+    }
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -1120,12 +1135,14 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     }
 
     // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out)
+    StageTimer *tm_fc2 = new StageTimer(ST_FC2_GRAD, stream);
     if (a->g_fc2_w)
         if (int rc = launch_gemm(stream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
                                  2 * H, s.S, 0, GEMM_STORE, 1))
             return rc;
     if (a->g_fc2_b)
         if (int rc = launch_colsum(stream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
+    delete tm_fc2;
 
     // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
     {
@@ -1156,12 +1173,14 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         if (has_att && (!a->g_att_w || !a->g_att_b))
             if (int rc = zero(scratch, (size_t)2 * H + 1)) return rc;
         const size_t lds_bytes = (size_t)(4 * (2 * s.W + H) + 8 * H) * sizeof(float);
+        StageTimer tm(ST_POOL_BWD, stream);
         hipLaunchKernelGGL(pool_bwd_kernel, dim3((s.S + 3) / 4), dim3(256), lds_bytes, stream, pp);
         PN_CHECK_HIP(hipGetLastError());
     }
 
     // BPTT + gather-backward scatter
     {
+        StageTimer tm(ST_SEQ_BWD, stream);
         const int64_t nw = (int64_t)GH * 2 * H;
         hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
                            H, G, WpT);
@@ -1206,12 +1225,14 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         rps = (rps + GEMM_KT - 1) / GEMM_KT * GEMM_KT;
         nz = (rows + rps - 1) / rps;
         wp.rows_per_split = rps;
+        StageTimer tm(ST_WGRAD, stream);
         hipLaunchKernelGGL(wgrad_kernel, dim3((2 * H + 63) / 64, (GH + 63) / 64, (unsigned)nz), dim3(256), 0, stream,
                            wp);
         PN_CHECK_HIP(hipGetLastError());
     } else if (a->g_w_ih || a->g_w_hh) {
         PN_FAIL(PN_ERR_ARG, "g_w_ih and g_w_hh must be requested together");
     }
+    StageTimer *tm_bias = new StageTimer(ST_BIAS_GRAD, stream);
     if (a->g_b_ih) {
         if (int rc = launch_colsum(stream, dG, nullptr, GH, P * L, GH, a->g_b_ih)) return rc;
         if (a->g_b_hh) {
@@ -1224,8 +1245,10 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         if (int rc = launch_colsum(stream, dG, nullptr, GH, P * L, GH, a->g_b_hh)) return rc;
     }
 
+    delete tm_bias;
     // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh
     const float *zgate = homo ? Z : nullptr;
+    StageTimer *tm_bank = new StageTimer(ST_BANK_BWD, stream);
     if (int rc = launch_gemm(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, s.N, H, L * H, 0,
                              GEMM_ADD, 1))
         return rc;
@@ -1236,8 +1259,10 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     if (a->g_bank_b)
         if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, s.N, L * H, a->g_bank_b)) return rc;
 
+    delete tm_bank;
     // fc0 backward (ReLU gate for HOMO)
     const float *xgate = homo ? Xh : nullptr;
+    StageTimer tm_fc0(ST_FC0_BWD, stream);
     if (a->g_fc0_w)
         if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, s.F, a->g_fc0_w, s.F, nullptr, H, s.F, s.N, 0,
                                  GEMM_ATOMIC, (s.N + 511) / 512))

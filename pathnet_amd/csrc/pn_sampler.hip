@@ -178,7 +178,68 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
 
 }  // namespace
 
+namespace pn {
+// ---- per-stage HIP-event timing -------------------------------------------------------------------
+static int g_prof_mode = 0, g_prof_stage = -1;
+struct ProfRec {
+    int stage;
+    hipEvent_t a, b;
+};
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_free;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_free.empty()) {
+        hipEvent_t e = g_prof_free.back();
+        g_prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+StageTimer::StageTimer(int stage, void *stream_) : slot(-1), stream(stream_) {
+    if (g_prof_mode == 0 || (g_prof_mode == 2 && stage != g_prof_stage)) return;
+    ProfRec r{stage, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, (hipStream_t)stream);
+    slot = (int)g_prof_recs.size();
+    g_prof_recs.push_back(r);
+}
+StageTimer::~StageTimer() {
+    if (slot >= 0) (void)hipEventRecord(g_prof_recs[(size_t)slot].b, (hipStream_t)stream);
+}
+}  // namespace pn
+
 extern "C" {
+
+int pn_profile_configure(int32_t mode, int32_t stage) {
+    if (mode < 0 || mode > 2) PN_FAIL(PN_ERR_ARG, "profile mode %d", mode);
+    pn::g_prof_mode = mode;
+    pn::g_prof_stage = stage;
+    return PN_OK;
+}
+int pn_profile_stage_count(void) { return pn::ST_COUNT; }
+const char *pn_profile_stage_name(int32_t stage) {
+    static const char *names[pn::ST_COUNT] = {"sampler_glibc_fill", "sampler_walk", "gather",   "fc0",      "bank",
+                                              "plan_pack",          "seq_fwd",      "pool_fwd", "fc2_grad", "pool_bwd",
+                                              "seq_bwd",            "wgrad",        "bias_grad", "bank_bwd", "fc0_bwd"};
+    return (stage >= 0 && stage < pn::ST_COUNT) ? names[stage] : "?";
+}
+int pn_profile_read(double *ms_sum, int64_t *count) {
+    if (!ms_sum || !count) PN_FAIL(PN_ERR_ARG, "pn_profile_read: null");
+    for (auto &r : pn::g_prof_recs) {
+        PN_CHECK_HIP(hipEventSynchronize(r.b));
+        float ms = 0.0f;
+        PN_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_sum[r.stage] += ms;
+        count[r.stage] += 1;
+        pn::g_prof_free.push_back(r.a);
+        pn::g_prof_free.push_back(r.b);
+    }
+    pn::g_prof_recs.clear();
+    return PN_OK;
+}
 
 int pn_device_query(pn_device_info *out) {
     if (!out) PN_FAIL(PN_ERR_ARG, "pn_device_query: null");
@@ -282,15 +343,20 @@ int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t d
         PN_CHECK_HIP(hipMemcpyAsync(d_tables, host.data(), (size_t)table_bytes, hipMemcpyHostToDevice, stream));
         PN_CHECK_HIP(hipStreamSynchronize(stream));  // `host` dies at scope exit (parity mode, not the fast path)
         dim3 grid((unsigned)nblk, (unsigned)epoch_count);
+        {
+        pn::StageTimer tm(pn::ST_SAMPLER_FILL, stream);
         hipLaunchKernelGGL(glibc_fill_kernel, grid, dim3(kFillThreads), 0, stream, d_tables,
                            d_tables + (size_t)epoch_count * 31, d_tables + (size_t)(epoch_count + nblk) * 31, seg_len,
                            d_draws);
+        }
         PN_CHECK_HIP(hipGetLastError());
         wp.draws = d_draws;
+        pn::StageTimer tm(pn::ST_SAMPLER_WALK, stream);
         const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
         hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_GLIBC_REPLAY>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
         PN_CHECK_HIP(hipGetLastError());
     } else if (draw_source == PN_DRAW_PHILOX) {
+        pn::StageTimer tm(pn::ST_SAMPLER_WALK, stream);
         const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
         hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_PHILOX>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
         PN_CHECK_HIP(hipGetLastError());
