@@ -177,6 +177,13 @@ typedef struct pn_pagg_args {
     float *g_X;         /* [N, F] or NULL */
     float *g_fc0_w, *g_fc0_b, *g_bank_w, *g_bank_b, *g_w_ih, *g_w_hh, *g_b_ih, *g_b_hh, *g_att_w, *g_att_b,
         *g_fc2_w, *g_fc2_b;
+    /* node-sharded multi-GPU use (pathnet_amd/dist.py): when Xh_in is set the projected feature matrix
+     * Xh [N, H] (fc0 output, after ReLU for HOMO) is taken from the caller -- every rank projects its
+     * own rows with pn_gemm_f32 and the rows are all-gathered over RCCL -- and X / fc0_* are ignored.
+     * In backward g_Xh [N, H] then receives d loss / d Xh (to be reduce-scattered to the row owners and
+     * finished with pn_linear_backward) instead of g_fc0_* / g_X. */
+    const float *Xh_in;
+    float *g_Xh;
 } pn_pagg_args;
 
 int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes);
@@ -197,6 +204,12 @@ int pn_pagg_gather(const pn_pagg_shape *shape, const float *table /* [N, L, H] *
  * be 1.  bias may be NULL; relu != 0 applies max(0, .). */
 int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C,
                 int64_t ldc, const float *bias, int32_t M, int32_t N, int32_t K, int32_t relu, void *stream);
+
+/* Backward of Y = act(X . W^T + b) for `rows` rows (nn.Linear, fc0 of the path: PathNet_run.py:175 / :242):
+ * dY [rows, out_f] is gated by [gate > 0] when gate != NULL (ReLU backward, gate = Y), then
+ * g_W [out_f, in_f] = dY^T . X,  g_b [out_f] = colsum(dY),  g_X [rows, in_f] = dY . W.  Any output may be NULL. */
+int pn_linear_backward(const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
+                       int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream);
 
 /* Byte offsets inside the aggregator workspace of the intermediates tests look at:
  * out[0] Xh [N,H], out[1] Z [N,L,H], out[2] hn [P,H] (pooling-group order), out[3] layer1 [S,2H]. */

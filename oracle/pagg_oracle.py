@@ -60,8 +60,14 @@ def _lin(x, w, b):
     return x @ w.t() + b
 
 
+def project(variant, fc0_w, fc0_b, X):
+    """fc0 (+ ReLU for the homo class): PathNet_run.py:175 / :242-243 / copy.py:330."""
+    Xh = _lin(X, fc0_w, fc0_b)
+    return torch.relu(Xh) if variant == "homo" else Xh
+
+
 def forward(variant, params, X, ids, codes, sel, W, L, drop_seq=None, drop_cls=None, dtype=torch.float32,
-            return_intermediates=False):
+            return_intermediates=False, Xh=None):
     """Reference forward, restated.
 
     params : dict name -> tensor with the reference state_dict keys (fc0.*, nets.<d>.* or nei<d>.*,
@@ -72,15 +78,15 @@ def forward(variant, params, X, ids, codes, sel, W, L, drop_seq=None, drop_cls=N
     drop_cls : None or mask [S, 2H] (F.dropout on the classifier input, :209 / :276 / copy.py:357)
     """
     g = {k: (v.detach() if not v.requires_grad else v).to(dtype) for k, v in params.items()}
-    X = X.to(dtype)
     S = len(sel)
     P = S * W
     node, code, group, member, ego = plan(variant, np.asarray(ids), np.asarray(codes), S, W, L)
-    H = g["fc0.weight"].shape[0]
+    H = g["fc2.weight"].shape[1] // 2
 
-    Xh = _lin(X, g["fc0.weight"], g["fc0.bias"])
-    if variant == "homo":
-        Xh = torch.relu(Xh)                                             # PathNet_run.py:243
+    if Xh is None:
+        Xh = project(variant, g["fc0.weight"], g["fc0.bias"], X.to(dtype))
+    else:
+        Xh = Xh.to(dtype)       # already projected (node-sharded runs project row blocks separately)
 
     # distance-indexed Linear bank: row (q, t) goes through nets[code[q, t]] only (:249-255)
     nd = torch.from_numpy(node.reshape(-1))

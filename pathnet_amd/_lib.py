@@ -51,7 +51,8 @@ class PaggArgs(ctypes.Structure):
                  ("mask_cls", vp), ("out", vp), ("workspace", vp), ("workspace_bytes", ctypes.c_int64),
                  ("g_out", vp), ("g_X", vp)] +
                 [("g_" + k, vp) for k in ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w",
-                                          "att_b", "fc2_w", "fc2_b")])
+                                          "att_b", "fc2_w", "fc2_b")] +
+                [("Xh_in", vp), ("g_Xh", vp)])
 
 
 # name -> (restype, argtypes): every symbol include/pathnet_hip.h declares
@@ -84,6 +85,8 @@ SIGNATURES = {
     "pn_profile_stage_count": (ctypes.c_int, []),
     "pn_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int32]),
     "pn_profile_read": (ctypes.c_int, [c_f64p, c_i64p]),
+    "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp,
+                                          vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
 }
 

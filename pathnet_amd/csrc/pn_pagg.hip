@@ -72,32 +72,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
+    // software pipeline: the next K tile's global loads are issued before the MFMAs of the current one
+    float ra[8], rb[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + 256 * i;
+            {
+                const int m = A_KCONTIG ? (idx >> 5) : (idx & 63);
+                const int k = A_KCONTIG ? (idx & 31) : (idx >> 6);
+                const int gm = m0 + m, gk = k0 + k;
+                float v = 0.0f;
+                if (gm < p.M && gk < kend) {
+                    const int64_t at = (int64_t)gm * p.sAm + (int64_t)gk * p.sAk;
+                    v = p.A[at];
+                    if (p.gateA && !(p.gateA[at] > 0.0f)) v = 0.0f;
+                }
+                ra[i] = v;
+            }
+            {
+                const int n = B_KCONTIG ? (idx >> 5) : (idx & 63);
+                const int k = B_KCONTIG ? (idx & 31) : (idx >> 6);
+                const int gn = n0 + n, gk = k0 + k;
+                rb[i] = (gn < p.N && gk < kend) ? p.B[(int64_t)gn * p.sBn + (int64_t)gk * p.sBk] : 0.0f;
+            }
+        }
+    };
+    if (kbeg < kend) gload(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_KT) {
 #pragma unroll
-        for (int i = 0; i < (GEMM_BM * GEMM_KT) / 256; i++) {
+        for (int i = 0; i < 8; i++) {
             const int idx = tid + 256 * i;
-            const int m = A_KCONTIG ? (idx >> 5) : (idx & 63);
-            const int k = A_KCONTIG ? (idx & 31) : (idx >> 6);
-            const int gm = m0 + m, gk = k0 + k;
-            float v = 0.0f;
-            if (gm < p.M && gk < kend) {
-                const int64_t at = (int64_t)gm * p.sAm + (int64_t)gk * p.sAk;
-                v = p.A[at];
-                if (p.gateA && !(p.gateA[at] > 0.0f)) v = 0.0f;
-            }
-            As[k * GEMM_PITCH + m] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < (GEMM_BN * GEMM_KT) / 256; i++) {
-            const int idx = tid + 256 * i;
-            const int n = B_KCONTIG ? (idx >> 5) : (idx & 63);
-            const int k = B_KCONTIG ? (idx & 31) : (idx >> 6);
-            const int gn = n0 + n, gk = k0 + k;
-            float v = 0.0f;
-            if (gn < p.N && gk < kend) v = p.B[(int64_t)gn * p.sBn + (int64_t)gk * p.sBk];
-            Bs[k * GEMM_PITCH + n] = v;
+            As[(A_KCONTIG ? (idx & 31) : (idx >> 6)) * GEMM_PITCH + (A_KCONTIG ? (idx >> 5) : (idx & 63))] = ra[i];
+            Bs[(B_KCONTIG ? (idx & 31) : (idx >> 6)) * GEMM_PITCH + (B_KCONTIG ? (idx >> 5) : (idx & 63))] = rb[i];
         }
         __syncthreads();
+        if (k0 + GEMM_KT < kend) gload(k0 + GEMM_KT);
 #pragma unroll
         for (int kk = 0; kk < GEMM_KT / 2; kk++) {
             const float a = As[(2 * kk + hk) * GEMM_PITCH + wm * 32 + li];
@@ -276,6 +286,8 @@ struct SeqFwdParams {
     const float *biasc;     // [G*H]
     float *hn;              // [P, H] final hidden state per slot'
     float *saved;           // [P, L, SV, H]  SV = 5 (i,f,g,o,c) for LSTM, 1 (h_t) for RNN; may be null
+    float *xh;              // [P, L, 2H]     the recurrent GEMM's input rows [x_t (after dropout) | h_{t-1}]:
+                            //                the weight-gradient GEMM of the backward reads them back; may be null
     int P, L;
     float p_drop;
     uint64_t seed;
@@ -283,7 +295,7 @@ struct SeqFwdParams {
 };
 
 template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64) void seq_fwd_kernel(SeqFwdParams p) {
+__global__ __launch_bounds__(H / 32 * 64, 2) void seq_fwd_kernel(SeqFwdParams p) {
     constexpr int NW = H / 32, NT = NW * 64, MTILES = MT / 32, PITCH = 2 * H + 4, SV = (G == 4 ? 5 : 1);
     extern __shared__ float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
@@ -323,6 +335,11 @@ __global__ __launch_bounds__(H / 32 * 64) void seq_fwd_kernel(SeqFwdParams p) {
                 }
             }
             *reinterpret_cast<float4 *>(&lds[row * PITCH + 4 * c4]) = v;
+            if (p.xh && q < p.P) {
+                float4 *xr = reinterpret_cast<float4 *>(p.xh + ((int64_t)q * p.L + t) * 2 * H);
+                xr[c4] = v;
+                if (t == 0) xr[H / 4 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         __syncthreads();
 
@@ -335,30 +352,41 @@ __global__ __launch_bounds__(H / 32 * 64) void seq_fwd_kernel(SeqFwdParams p) {
                 for (int r = 0; r < 16; r++) acc[mt][g][r] = bias[g];
 
         // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T : lanes 0-31 walk the x half of K, lanes 32-63 the h half
-        float4 bcur[G];
+        // B fragments stream from L2 through a DEPTH-deep register ring (fully unrolled, static indices):
+        // DEPTH k-steps of weight loads are always in flight under the MFMAs.
+        constexpr int KSTEPS = H / 4, DEPTH = 1;   // one k-step (G KB per wave) of weights in flight under 4*G*MTILES MFMAs
+        const float4 *wbase = Wp4 + ((int64_t)wave * G * KSTEPS) * 64 + lane;
+        float4 ring[DEPTH][G];
 #pragma unroll
-        for (int g = 0; g < G; g++) bcur[g] = Wp4[((int64_t)(wave * G + g) * (H / 4)) * 64 + lane];
-#pragma unroll 2
-        for (int s4 = 0; s4 < H / 4; s4++) {
-            float4 bnext[G];
-            const int sn = (s4 + 1 < H / 4) ? s4 + 1 : s4;
+        for (int d = 0; d < DEPTH; d++)
 #pragma unroll
-            for (int g = 0; g < G; g++) bnext[g] = Wp4[((int64_t)(wave * G + g) * (H / 4) + sn) * 64 + lane];
-            float4 a[MTILES];
+            for (int g = 0; g < G; g++) ring[d][g] = wbase[((int64_t)g * KSTEPS + d) * 64];
+#pragma unroll 1
+        for (int s4o = 0; s4o < KSTEPS; s4o += DEPTH)
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int s4 = s4o + d;
+            const int sn = min(s4 + DEPTH, KSTEPS - 1);   // tail re-loads the last step (harmless, branch-free)
+            float4 a[MTILES], b[G];
 #pragma unroll
             for (int mt = 0; mt < MTILES; mt++)
                 a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * H + 4 * s4]);
 #pragma unroll
-            for (int mt = 0; mt < MTILES; mt++)
+            for (int g = 0; g < G; g++) {
+                b[g] = ring[d][g];
+                ring[d][g] = wbase[((int64_t)g * KSTEPS + sn) * 64];
+            }
 #pragma unroll
-                for (int g = 0; g < G; g++) {
-                    acc[mt][g] = mfma32(a[mt].x, bcur[g].x, acc[mt][g]);
-                    acc[mt][g] = mfma32(a[mt].y, bcur[g].y, acc[mt][g]);
-                    acc[mt][g] = mfma32(a[mt].z, bcur[g].z, acc[mt][g]);
-                    acc[mt][g] = mfma32(a[mt].w, bcur[g].w, acc[mt][g]);
-                }
+            for (int mt = 0; mt < MTILES; mt++) {
 #pragma unroll
-            for (int g = 0; g < G; g++) bcur[g] = bnext[g];
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].x, b[g].x, acc[mt][g]);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].y, b[g].y, acc[mt][g]);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].z, b[g].z, acc[mt][g]);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].w, b[g].w, acc[mt][g]);
+            }
         }
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
 
@@ -387,7 +415,12 @@ __global__ __launch_bounds__(H / 32 * 64) void seq_fwd_kernel(SeqFwdParams p) {
                     if (p.saved && q < p.P) p.saved[((int64_t)q * p.L + t) * H + col] = h;
                 }
                 lds[row * PITCH + H + col] = h;
-                if (t == p.L - 1 && q < p.P) p.hn[(int64_t)q * H + col] = h;
+                if (q < p.P) {
+                    if (t == p.L - 1)
+                        p.hn[(int64_t)q * H + col] = h;
+                    else if (p.xh)
+                        p.xh[((int64_t)q * p.L + t + 1) * 2 * H + H + col] = h;
+                }
             }
     }
 }
@@ -634,7 +667,7 @@ struct SeqBwdParams {
 };
 
 template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64) void seq_bwd_kernel(SeqBwdParams p) {
+__global__ __launch_bounds__(H / 32 * 64, 2) void seq_bwd_kernel(SeqBwdParams p) {
     constexpr int MTILES = MT / 32, GH = G * H, PITCH = GH + 4, SV = (G == 4 ? 5 : 1);
     extern __shared__ float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
@@ -698,23 +731,39 @@ __global__ __launch_bounds__(H / 32 * 64) void seq_bwd_kernel(SeqBwdParams p) {
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.0f;
-#pragma unroll 2
-        for (int s4 = 0; s4 < GH / 8; s4++) {
-            float4 b[2], a[MTILES];
+        constexpr int KSTEPS = GH / 8, DEPTH = (KSTEPS < 4 ? KSTEPS : 4);
+        const float4 *wbase = W4 + ((int64_t)wave * 2 * KSTEPS) * 64 + lane;
+        float4 ring[DEPTH][2];
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) b[nt] = W4[((int64_t)(wave * 2 + nt) * (GH / 8) + s4) * 64 + lane];
+        for (int d = 0; d < DEPTH; d++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) ring[d][nt] = wbase[((int64_t)nt * KSTEPS + d) * 64];
+#pragma unroll 1
+        for (int s4o = 0; s4o < KSTEPS; s4o += DEPTH)
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            const int s4 = s4o + d;
+            const int sn = min(s4 + DEPTH, KSTEPS - 1);
+            float4 b[2], a[MTILES];
 #pragma unroll
             for (int mt = 0; mt < MTILES; mt++)
                 a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * (GH / 2) + 4 * s4]);
 #pragma unroll
-            for (int mt = 0; mt < MTILES; mt++)
+            for (int nt = 0; nt < 2; nt++) {
+                b[nt] = ring[d][nt];
+                ring[d][nt] = wbase[((int64_t)nt * KSTEPS + sn) * 64];
+            }
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) {
-                    acc[mt][nt] = mfma32(a[mt].x, b[nt].x, acc[mt][nt]);
-                    acc[mt][nt] = mfma32(a[mt].y, b[nt].y, acc[mt][nt]);
-                    acc[mt][nt] = mfma32(a[mt].z, b[nt].z, acc[mt][nt]);
-                    acc[mt][nt] = mfma32(a[mt].w, b[nt].w, acc[mt][nt]);
-                }
+            for (int mt = 0; mt < MTILES; mt++) {
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].x, b[nt].x, acc[mt][nt]);
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].y, b[nt].y, acc[mt][nt]);
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].z, b[nt].z, acc[mt][nt]);
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].w, b[nt].w, acc[mt][nt]);
+            }
         }
         __syncthreads();
 
@@ -737,78 +786,120 @@ __global__ __launch_bounds__(H / 32 * 64) void seq_bwd_kernel(SeqBwdParams p) {
     }
 }
 
-// ---- recurrent weight gradients:  g_W_ih | g_W_hh  [G*H, 2H] = sum over the P*L rows of
-//      dG[row, :]^T (x) [x_row ; h_prev_row]   (x re-gathered with its dropout mask, h_prev rebuilt
-//      from the saved gates) -- split over row ranges, accumulated with atomics -----------------------
+// ---- recurrent weight gradients:  [g_W_ih | g_W_hh]  [G*H, 2H] = dG^T [G*H, R] . XH [R, 2H],  R = P*L rows,
+//      plus the bias gradient colsum(dG).  Both operands are row-major with the reduction dimension
+//      outermost, i.e. already "K-major": tiles go global -> LDS with coalesced 16-byte loads and no
+//      transposition.  128x128 output tile per workgroup (4 waves x (2x2) 32x32 MFMA tiles), the R rows
+//      are split over blockIdx.z; partial tiles go to a [split][G*H][2H] buffer and are summed by
+//      wgrad_reduce_kernel (deterministic, no atomics). -----------------------------------------------
+constexpr int WG_BM = 128, WG_BN = 128, WG_KT = 32, WG_PITCH = 132;
+
 struct WgradParams {
-    const float *dG, *Z, *saved;
-    const int32_t *rowidx, *slotof;
-    int P, L, H, G;
-    float p_drop;
-    uint64_t seed;
-    const float *mask;
-    float *g_w_ih, *g_w_hh;
+    const float *dG;   // [R, GH]
+    const float *xh;   // [R, 2H]
+    int64_t R;
+    int GH, H2;
     int64_t rows_per_split;
+    float *part_w;     // [nsplit, GH, 2H]
+    float *part_b;     // [nsplit, GH]
 };
 
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
-    __shared__ float As[GEMM_KT * GEMM_PITCH];
-    __shared__ float Bs[GEMM_KT * GEMM_PITCH];
+    __shared__ float As[WG_KT * WG_PITCH];
+    __shared__ float Bs[WG_KT * WG_PITCH];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int H = p.H, GH = p.G * H, SV = p.G == 4 ? 5 : 1;
-    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int64_t rows = (int64_t)p.P * p.L;
+    const int m0 = blockIdx.y * WG_BM, n0 = blockIdx.x * WG_BN;
     const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
-    const int64_t rend = min(rows, rbeg + p.rows_per_split);
-    f32x16 acc;
+    const int64_t rend = min(p.R, rbeg + p.rows_per_split);
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-    for (int64_t k0 = rbeg; k0 < rend; k0 += GEMM_KT) {
+    for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int idx = tid + 256 * i;
-            const int k = idx >> 6, c = idx & 63;
-            const int64_t row = k0 + k;
-            float a = 0.0f, b = 0.0f;
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    float bsum = 0.0f;
+
+    // each thread moves 4 float4 of each operand per K tile: row k = i*8 + tid/32, columns 4*(tid%32)..+3
+    const int lk = tid >> 5, lc = (tid & 31) * 4;
+    float4 ra[4], rb[4];
+    auto load_tiles = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int64_t row = k0 + i * 8 + lk;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = ra[i];
             if (row < rend) {
-                if (m0 + c < GH) a = p.dG[row * GH + m0 + c];
-                const int n = n0 + c;
-                const int q = (int)(row / p.L), t = (int)(row - (int64_t)q * p.L);
-                if (n < H) {
-                    b = p.Z[(int64_t)p.rowidx[row] * H + n];
-                    const uint64_t e = ((uint64_t)t * p.P + p.slotof[q]) * H + n;
-                    if (p.mask)
-                        b *= p.mask[e];
-                    else if (p.p_drop > 0.0f)
-                        b *= dropout1(p.seed, e, 1u, p.p_drop);
-                } else if (n < 2 * H && t > 0) {
-                    const float *sv = p.saved + ((row - 1) * SV) * H + (n - H);
-                    b = p.G == 4 ? sv[3 * H] * tanhf(sv[4 * H]) : sv[0];
-                }
+                if (m0 + lc < p.GH) ra[i] = *reinterpret_cast<const float4 *>(p.dG + row * p.GH + m0 + lc);
+                if (n0 + lc < p.H2) rb[i] = *reinterpret_cast<const float4 *>(p.xh + row * p.H2 + n0 + lc);
             }
-            As[k * GEMM_PITCH + c] = a;
-            Bs[k * GEMM_PITCH + c] = b;
+        }
+    };
+    load_tiles(rbeg);
+    for (int64_t k0 = rbeg; k0 < rend; k0 += WG_KT) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<float4 *>(&As[(i * 8 + lk) * WG_PITCH + lc]) = ra[i];
+            *reinterpret_cast<float4 *>(&Bs[(i * 8 + lk) * WG_PITCH + lc]) = rb[i];
         }
         __syncthreads();
+        if (k0 + WG_KT < rend) load_tiles(k0 + WG_KT);   // in flight while the MFMAs below run
+        if (blockIdx.x == 0 && tid < WG_BM) {
 #pragma unroll
-        for (int kk = 0; kk < GEMM_KT / 2; kk++) {
-            const float a = As[(2 * kk + hk) * GEMM_PITCH + wm * 32 + li];
-            const float b = Bs[(2 * kk + hk) * GEMM_PITCH + wn * 32 + li];
-            acc = mfma32(a, b, acc);
+            for (int k = 0; k < WG_KT; k++) bsum += As[k * WG_PITCH + tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < WG_KT / 2; kk++) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = As[(2 * kk + hk) * WG_PITCH + wm * 64 + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < 2; j++) b[j] = Bs[(2 * kk + hk) * WG_PITCH + wn * 64 + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
-    const int n = n0 + wn * 32 + li;
-    if (n >= 2 * H) return;
+    float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm * 32 + acc_row(r, lane);
-        if (m >= GH) continue;
-        if (n < H)
-            atomicAdd(&p.g_w_ih[(int64_t)m * H + n], acc[r]);
-        else
-            atomicAdd(&p.g_w_hh[(int64_t)m * H + (n - H)], acc[r]);
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+            if (n >= p.H2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (m < p.GH) pw[(int64_t)m * p.H2 + n] = acc[i][j][r];
+            }
+        }
+    if (blockIdx.x == 0 && tid < WG_BM && m0 + tid < p.GH) p.part_b[(int64_t)blockIdx.z * p.GH + m0 + tid] = bsum;
+}
+
+// sums the split partials and scatters them into the reference layouts g_W_ih [GH,H], g_W_hh [GH,H], g_b_*
+__global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const float *__restrict__ part_b, int nsplit,
+                                    int GH, int H, float *__restrict__ g_w_ih, float *__restrict__ g_w_hh,
+                                    float *__restrict__ g_b_ih, float *__restrict__ g_b_hh) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nw = (int64_t)GH * 2 * H;
+    if (i < nw) {
+        float s = 0.0f;
+        for (int z = 0; z < nsplit; z++) s += part_w[(int64_t)z * nw + i];
+        const int m = (int)(i / (2 * H)), n = (int)(i - (int64_t)m * 2 * H);
+        if (n < H) {
+            if (g_w_ih) g_w_ih[(int64_t)m * H + n] = s;
+        } else if (g_w_hh) {
+            g_w_hh[(int64_t)m * H + (n - H)] = s;
+        }
+    } else if (i < nw + GH) {
+        const int m = (int)(i - nw);
+        float s = 0.0f;
+        for (int z = 0; z < nsplit; z++) s += part_b[(int64_t)z * GH + m];
+        if (g_b_ih) g_b_ih[m] = s;
+        if (g_b_hh) g_b_hh[m] = s;
     }
 }
 
@@ -857,7 +948,9 @@ int dispatch_seq_bwd(hipStream_t stream, int H, const SeqBwdParams &sp) {
 // ================================================================================================
 struct WsLayout {
     size_t Xh, Z, rowidx, egoidx, slotof, Wp, biasc, hn, saved, coef, rawsc, layer1;  // forward
-    size_t WpT, dG, dZ, dXh, dhn, dl1;                                                // backward
+    size_t xh;                                                                        // forward (saved)
+    size_t WpT, dG, dZ, dXh, dhn, dl1, wpart;                                         // backward
+    int wgrad_split;
     size_t total;
 };
 
@@ -891,6 +984,17 @@ WsLayout ws_layout(const pn_pagg_shape &s) {
     w.dXh = take(N * H * 4);
     w.dhn = take(P * H * 4);
     w.dl1 = take(S * 2 * H * 4);
+    w.xh = take(P * L * 2 * H * 4);
+    {
+        // split of the P*L rows of the weight-gradient GEMM: enough workgroups to fill 256 CUs ~3x
+        const size_t rows = P * L, tiles = ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN);
+        size_t nz = (768 + tiles - 1) / tiles;
+        const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
+        if (nz > max_nz) nz = max_nz;
+        if (nz < 1) nz = 1;
+        w.wgrad_split = (int)nz;
+        w.wpart = take(nz * (G * H * 2 * H + G * H) * 4);
+    }
     w.total = at;
     return w;
 }
@@ -910,7 +1014,8 @@ int check_shape(const pn_pagg_shape &s) {
 
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
-    constexpr int MT = (H >= 256 && G == 4) ? 32 : 64;  // 8 waves x 2 per SIMD: keep the accumulators in 256 regs
+    constexpr int MT = 32;  // 64 accumulator registers per wave -> several workgroups per CU hide each other's
+                            // gather / cell / barrier phases behind MFMA work
     constexpr size_t lds_bytes = (size_t)MT * (2 * H + 4) * 4;
     auto kern = seq_fwd_kernel<H, G, MT>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -951,6 +1056,31 @@ int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_
                        GEMM_STORE, 1);
 }
 
+int pn_linear_backward(const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
+                       int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dY || rows < 0 || in_f < 1 || out_f < 1) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: bad argument");
+    StageTimer tm(ST_FC0_BWD, stream);
+    if (g_W) {
+        if (!X) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: g_W needs X");
+        PN_CHECK_HIP(hipMemsetAsync(g_W, 0, (size_t)out_f * in_f * sizeof(float), stream));
+        if (int rc = launch_gemm(stream, dY, 1, out_f, gate, X, 1, in_f, g_W, in_f, nullptr, out_f, in_f, rows, 0,
+                                 GEMM_ATOMIC, (rows + 255) / 256))
+            return rc;
+    }
+    if (g_b) {
+        PN_CHECK_HIP(hipMemsetAsync(g_b, 0, (size_t)out_f * sizeof(float), stream));
+        if (int rc = launch_colsum(stream, dY, gate, out_f, rows, out_f, g_b)) return rc;
+    }
+    if (g_X) {
+        if (!W) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: g_X needs W");
+        if (int rc = launch_gemm(stream, dY, out_f, 1, gate, W, 1, in_f, g_X, in_f, nullptr, rows, in_f, out_f, 0,
+                                 GEMM_STORE, 1))
+            return rc;
+    }
+    return PN_OK;
+}
+
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
     if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_debug_offsets: null");
     if (int rc = check_shape(*shape)) return rc;
@@ -989,9 +1119,10 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     if (!a) PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null args");
     const pn_pagg_shape &s = a->shape;
     if (int rc = check_shape(s)) return rc;
-    if (!a->X || !a->ids || !a->codes || !a->sel || !a->fc0_w || !a->fc0_b || !a->bank_w || !a->bank_b || !a->w_ih ||
-        !a->w_hh || !a->b_ih || !a->b_hh || !a->fc2_w || !a->fc2_b || !a->out || !a->workspace)
+    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->bank_b || !a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh ||
+        !a->fc2_w || !a->fc2_b || !a->out || !a->workspace)
         PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null tensor");
+    if (!a->Xh_in && (!a->X || !a->fc0_w || !a->fc0_b)) PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: X / fc0 missing");
     if (s.variant != PN_VARIANT_PAGG && (!a->att_w || !a->att_b)) PN_FAIL(PN_ERR_ARG, "attention weights missing");
     const WsLayout w = ws_layout(s);
     if (a->workspace_bytes < (int64_t)w.total)
@@ -999,7 +1130,8 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
                 (long long)w.total);
     if (s.S == 0) return PN_OK;
     char *ws = reinterpret_cast<char *>(a->workspace);
-    float *Xh = reinterpret_cast<float *>(ws + w.Xh), *Z = reinterpret_cast<float *>(ws + w.Z);
+    const float *Xh = a->Xh_in ? a->Xh_in : reinterpret_cast<const float *>(ws + w.Xh);
+    float *Z = reinterpret_cast<float *>(ws + w.Z);
     int32_t *rowidx = reinterpret_cast<int32_t *>(ws + w.rowidx), *egoidx = reinterpret_cast<int32_t *>(ws + w.egoidx),
             *slotof = reinterpret_cast<int32_t *>(ws + w.slotof);
     float *Wp = reinterpret_cast<float *>(ws + w.Wp), *biasc = reinterpret_cast<float *>(ws + w.biasc);
@@ -1009,10 +1141,10 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     const int homo = s.variant == PN_VARIANT_HOMO;
 
     // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
-    {
+    if (!a->Xh_in) {
         StageTimer tm(ST_FC0, stream);
-        if (int rc = launch_gemm(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1, Xh, H, a->fc0_b, s.N, H, s.F, homo,
-                                 GEMM_STORE, 1))
+        if (int rc = launch_gemm(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1, reinterpret_cast<float *>(ws + w.Xh),
+                                 H, a->fc0_b, s.N, H, s.F, homo, GEMM_STORE, 1))
             return rc;
     }
     // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
@@ -1041,6 +1173,7 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     sp.biasc = biasc;
     sp.hn = hn;
     sp.saved = saved;
+    sp.xh = reinterpret_cast<float *>(ws + w.xh);
     sp.P = P;
     sp.L = L;
     sp.p_drop = a->p_seq;
@@ -1087,9 +1220,10 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     if (!a) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null args");
     const pn_pagg_shape &s = a->shape;
     if (int rc = check_shape(s)) return rc;
-    if (!a->X || !a->ids || !a->codes || !a->sel || !a->fc0_w || !a->bank_w || !a->w_ih || !a->w_hh || !a->fc2_w ||
-        !a->g_out || !a->workspace)
+    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->w_ih || !a->w_hh || !a->fc2_w || !a->g_out || !a->workspace)
         PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null tensor");
+    if (!a->Xh_in && (!a->X || !a->fc0_w)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: X / fc0 missing");
+    if (a->Xh_in && !a->g_Xh) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: g_Xh is required with Xh_in");
     const WsLayout w = ws_layout(s);
     if (a->workspace_bytes < (int64_t)w.total)
         PN_FAIL(PN_ERR_CAPACITY, "aggregator workspace holds %lld bytes, need %lld", (long long)a->workspace_bytes,
@@ -1099,14 +1233,16 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     const int homo = s.variant == PN_VARIANT_HOMO;
     const bool has_att = s.variant != PN_VARIANT_PAGG;
     char *ws = reinterpret_cast<char *>(a->workspace);
-    float *Xh = reinterpret_cast<float *>(ws + w.Xh), *Z = reinterpret_cast<float *>(ws + w.Z);
+    const float *Xh = a->Xh_in ? a->Xh_in : reinterpret_cast<const float *>(ws + w.Xh);
+    float *Z = reinterpret_cast<float *>(ws + w.Z);
     int32_t *rowidx = reinterpret_cast<int32_t *>(ws + w.rowidx), *egoidx = reinterpret_cast<int32_t *>(ws + w.egoidx),
             *slotof = reinterpret_cast<int32_t *>(ws + w.slotof);
     float *hn = reinterpret_cast<float *>(ws + w.hn), *saved = reinterpret_cast<float *>(ws + w.saved);
     float *coef = reinterpret_cast<float *>(ws + w.coef), *rawsc = reinterpret_cast<float *>(ws + w.rawsc);
     float *layer1 = reinterpret_cast<float *>(ws + w.layer1), *WpT = reinterpret_cast<float *>(ws + w.WpT);
     float *dG = reinterpret_cast<float *>(ws + w.dG), *dZ = reinterpret_cast<float *>(ws + w.dZ);
-    float *dXh = reinterpret_cast<float *>(ws + w.dXh), *dhn = reinterpret_cast<float *>(ws + w.dhn);
+    float *dXh = a->Xh_in ? a->g_Xh : reinterpret_cast<float *>(ws + w.dXh);
+    float *dhn = reinterpret_cast<float *>(ws + w.dhn);
     // gradient buffers that are accumulated into: a NULL output is redirected to scratch (dl1 region)
     float *scratch = reinterpret_cast<float *>(ws + w.dl1);
     (void)scratch;
@@ -1119,15 +1255,17 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     if (int rc = zero(dXh, (size_t)s.N * H)) return rc;
     if (int rc = zero(a->g_att_w, has_att ? (size_t)2 * H : 0)) return rc;
     if (int rc = zero(a->g_att_b, has_att ? 1 : 0)) return rc;
-    if (int rc = zero(a->g_w_ih, (size_t)GH * H)) return rc;
-    if (int rc = zero(a->g_w_hh, (size_t)GH * H)) return rc;
-    if (int rc = zero(a->g_b_ih, (size_t)GH)) return rc;
     if (int rc = zero(a->g_fc2_b, (size_t)s.C)) return rc;
     if (int rc = zero(a->g_bank_w, (size_t)L * H * H)) return rc;
     if (int rc = zero(a->g_bank_b, (size_t)L * H)) return rc;
-    if (int rc = zero(a->g_fc0_w, (size_t)H * s.F)) return rc;
-    if (int rc = zero(a->g_fc0_b, (size_t)H)) return rc;
+    if (!a->Xh_in) {
+        if (int rc = zero(a->g_fc0_w, (size_t)H * s.F)) return rc;
+        if (int rc = zero(a->g_fc0_b, (size_t)H)) return rc;
+    }
     if (s.S == 0) {
+        if (int rc = zero(a->g_w_ih, (size_t)GH * H)) return rc;
+        if (int rc = zero(a->g_w_hh, (size_t)GH * H)) return rc;
+        if (int rc = zero(a->g_b_ih, (size_t)GH)) return rc;
         if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
         if (int rc = zero(a->g_b_hh, (size_t)GH)) return rc;
         if (int rc = zero(a->g_X, (size_t)s.N * s.F)) return rc;
@@ -1136,10 +1274,12 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
 
     // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out)
     StageTimer *tm_fc2 = new StageTimer(ST_FC2_GRAD, stream);
-    if (a->g_fc2_w)
+    if (a->g_fc2_w) {
+        if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
         if (int rc = launch_gemm(stream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
-                                 2 * H, s.S, 0, GEMM_STORE, 1))
+                                 2 * H, s.S, 0, GEMM_ATOMIC, (s.S + 127) / 128))
             return rc;
+    }
     if (a->g_fc2_b)
         if (int rc = launch_colsum(stream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
     delete tm_fc2;
@@ -1201,50 +1341,33 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         if (int rc = (G == 4 ? dispatch_seq_bwd<4>(stream, H, sp) : dispatch_seq_bwd<1>(stream, H, sp))) return rc;
     }
 
-    // recurrent weight / bias gradients
-    if (a->g_w_ih && a->g_w_hh) {
+    // recurrent weight / bias gradients: [g_W_ih | g_W_hh] = dG^T . XH, g_b = colsum(dG)
+    StageTimer *tm_bias = nullptr;
+    if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
         WgradParams wp{};
         wp.dG = dG;
-        wp.Z = Z;
-        wp.saved = saved;
-        wp.rowidx = rowidx;
-        wp.slotof = slotof;
-        wp.P = P;
-        wp.L = L;
-        wp.H = H;
-        wp.G = G;
-        wp.p_drop = a->p_seq;
-        wp.seed = a->seed;
-        wp.mask = a->mask_seq;
-        wp.g_w_ih = a->g_w_ih;
-        wp.g_w_hh = a->g_w_hh;
-        const int64_t rows = (int64_t)P * L;
-        const int tiles = ((GH + 63) / 64) * ((2 * H + 63) / 64);
-        int64_t nz = std::max<int64_t>(1, std::min<int64_t>((2048 + tiles - 1) / tiles, (rows + 255) / 256));
-        int64_t rps = (rows + nz - 1) / nz;
-        rps = (rps + GEMM_KT - 1) / GEMM_KT * GEMM_KT;
-        nz = (rows + rps - 1) / rps;
+        wp.xh = reinterpret_cast<const float *>(ws + w.xh);
+        wp.R = (int64_t)P * L;
+        wp.GH = GH;
+        wp.H2 = 2 * H;
+        const int nz = w.wgrad_split;
+        int64_t rps = (wp.R + nz - 1) / nz;
+        rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
         wp.rows_per_split = rps;
-        StageTimer tm(ST_WGRAD, stream);
-        hipLaunchKernelGGL(wgrad_kernel, dim3((2 * H + 63) / 64, (GH + 63) / 64, (unsigned)nz), dim3(256), 0, stream,
-                           wp);
-        PN_CHECK_HIP(hipGetLastError());
-    } else if (a->g_w_ih || a->g_w_hh) {
-        PN_FAIL(PN_ERR_ARG, "g_w_ih and g_w_hh must be requested together");
-    }
-    StageTimer *tm_bias = new StageTimer(ST_BIAS_GRAD, stream);
-    if (a->g_b_ih) {
-        if (int rc = launch_colsum(stream, dG, nullptr, GH, P * L, GH, a->g_b_ih)) return rc;
-        if (a->g_b_hh) {
-            hipLaunchKernelGGL(copy_kernel, dim3((GH + 255) / 256), dim3(256), 0, stream, a->g_b_ih, a->g_b_hh,
-                               (int64_t)GH);
+        const int nz_used = (int)((wp.R + rps - 1) / rps);
+        wp.part_w = reinterpret_cast<float *>(ws + w.wpart);
+        wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
+        {
+            StageTimer tm(ST_WGRAD, stream);
+            hipLaunchKernelGGL(wgrad_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
+                               dim3(256), 0, stream, wp);
+            PN_CHECK_HIP(hipGetLastError());
+            const int64_t nred = (int64_t)GH * 2 * H + GH;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, stream,
+                               wp.part_w, wp.part_b, nz_used, GH, H, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
             PN_CHECK_HIP(hipGetLastError());
         }
-    } else if (a->g_b_hh) {
-        if (int rc = zero(a->g_b_hh, (size_t)GH)) return rc;
-        if (int rc = launch_colsum(stream, dG, nullptr, GH, P * L, GH, a->g_b_hh)) return rc;
     }
-
     delete tm_bias;
     // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh
     const float *zgate = homo ? Z : nullptr;
@@ -1254,12 +1377,13 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         return rc;
     if (a->g_bank_w)
         if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, s.N,
-                                 0, GEMM_ATOMIC, (s.N + 511) / 512))
+                                 0, GEMM_ATOMIC, (s.N + 255) / 256))
             return rc;
     if (a->g_bank_b)
         if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, s.N, L * H, a->g_bank_b)) return rc;
 
     delete tm_bank;
+    if (a->Xh_in) return PN_OK;   // the caller finishes fc0 after the reduce-scatter of g_Xh
     // fc0 backward (ReLU gate for HOMO)
     const float *xgate = homo ? Xh : nullptr;
     StageTimer tm_fc0(ST_FC0_BWD, stream);
