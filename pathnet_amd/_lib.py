@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libpathnet_hip.so")
+LIB_PATH = os.environ.get("PN_LIB_PATH", os.path.join(HERE, "csrc", "libpathnet_hip.so"))   # PN_LIB_PATH: tuning builds
 
 PN_OK = 0
 PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (

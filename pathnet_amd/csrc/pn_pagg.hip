@@ -33,6 +33,29 @@
 
 using namespace pn;
 
+// tuning knobs of the two recurrent kernels (tools/tune_seq.sh builds variants with -D...)
+#ifndef PN_FWD_MT
+#define PN_FWD_MT 32        // sequence slots per workgroup, forward
+#endif
+#ifndef PN_FWD_DEPTH
+#define PN_FWD_DEPTH 1      // k-steps of weight fragments in flight, forward
+#endif
+#ifndef PN_FWD_WAVES
+#define PN_FWD_WAVES 2      // __launch_bounds__ min waves per SIMD, forward
+#endif
+#ifndef PN_FWD_PREFETCH_X
+#define PN_FWD_PREFETCH_X 1 // fetch the x_{t+1} rows under the MFMAs of step t
+#endif
+#ifndef PN_BWD_MT
+#define PN_BWD_MT 32
+#endif
+#ifndef PN_BWD_DEPTH
+#define PN_BWD_DEPTH 4
+#endif
+#ifndef PN_BWD_WAVES
+#define PN_BWD_WAVES 2
+#endif
+
 namespace {
 
 // ================================================================================================
@@ -295,9 +318,9 @@ struct SeqFwdParams {
 };
 
 template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64, 2) void seq_fwd_kernel(SeqFwdParams p) {
+__global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqFwdParams p) {
     constexpr int NW = H / 32, NT = NW * 64, MTILES = MT / 32, PITCH = 2 * H + 4, SV = (G == 4 ? 5 : 1);
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int q0 = blockIdx.x * MT;
     const int col = 32 * wave + li;
@@ -314,11 +337,15 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void seq_fwd_kernel(SeqFwdParams p)
     for (int g = 0; g < G; g++) bias[g] = p.biasc[g * H + col];
 
     const float4 *Z4 = reinterpret_cast<const float4 *>(p.Z);
-    const float4 *Wp4 = reinterpret_cast<const float4 *>(p.Wp);
 
-    for (int t = 0; t < p.L; t++) {
-        // ---- coalesced row gather of x_t (H*4 bytes per row) with the dropout mask fused in -------
-        for (int idx = tid; idx < MT * (H / 4); idx += NT) {
+    // ---- coalesced row gather of x_t (H*4 bytes per row) with the dropout mask fused in.  The rows of step
+    //      t+1 are fetched into registers while the MFMAs of step t run (PN_FWD_PREFETCH_X) -----------------
+    constexpr int NLD = MT / 8;   // float4 per thread = MT * (H/4) / NT
+    float4 xr[NLD];
+    auto gather_issue = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
             const int q = q0 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -334,14 +361,35 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void seq_fwd_kernel(SeqFwdParams p)
                     v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
                 }
             }
-            *reinterpret_cast<float4 *>(&lds[row * PITCH + 4 * c4]) = v;
+            xr[i] = v;
+        }
+    };
+    auto gather_commit = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + NT * i;
+            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+            const int q = q0 + row;
+            *reinterpret_cast<float4 *>(&lds[row * PITCH + 4 * c4]) = xr[i];
             if (p.xh && q < p.P) {
-                float4 *xr = reinterpret_cast<float4 *>(p.xh + ((int64_t)q * p.L + t) * 2 * H);
-                xr[c4] = v;
-                if (t == 0) xr[H / 4 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 *xo = reinterpret_cast<float4 *>(p.xh + ((int64_t)q * p.L + t) * 2 * H);
+                xo[c4] = xr[i];
+                if (t == 0) xo[H / 4 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+    };
+#if PN_FWD_PREFETCH_X
+    gather_issue(0);
+#endif
+    for (int t = 0; t < p.L; t++) {
+#if !PN_FWD_PREFETCH_X
+        gather_issue(t);
+#endif
+        gather_commit(t);
         __syncthreads();
+#if PN_FWD_PREFETCH_X
+        if (t + 1 < p.L) gather_issue(t + 1);
+#endif
 
         f32x16 acc[MTILES][G];
 #pragma unroll
@@ -352,42 +400,45 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void seq_fwd_kernel(SeqFwdParams p)
                 for (int r = 0; r < 16; r++) acc[mt][g][r] = bias[g];
 
         // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T : lanes 0-31 walk the x half of K, lanes 32-63 the h half
-        // B fragments stream from L2 through a DEPTH-deep register ring (fully unrolled, static indices):
-        // DEPTH k-steps of weight loads are always in flight under the MFMAs.
-        constexpr int KSTEPS = H / 4, DEPTH = 1;   // one k-step (G KB per wave) of weights in flight under 4*G*MTILES MFMAs
-        const float4 *wbase = Wp4 + ((int64_t)wave * G * KSTEPS) * 64 + lane;
-        float4 ring[DEPTH][G];
+        // B fragments stream L2 -> VGPR one k-step (G KB per wave) ahead of the MFMAs that use them: two
+        // register sets, the loads of step s+1 are issued before the MFMAs of step s (async_load_b128 keeps
+        // hipcc from sinking them to their use).
+        constexpr int KSTEPS = H / 4;
+        static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
+        const f32x4 *wb = reinterpret_cast<const f32x4 *>(p.Wp) + ((int64_t)wave * G * KSTEPS) * 64 + lane;
+        f32x4 b0[G], b1[G];
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-            for (int g = 0; g < G; g++) ring[d][g] = wbase[((int64_t)g * KSTEPS + d) * 64];
-#pragma unroll 1
-        for (int s4o = 0; s4o < KSTEPS; s4o += DEPTH)
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            const int s4 = s4o + d;
-            const int sn = min(s4 + DEPTH, KSTEPS - 1);   // tail re-loads the last step (harmless, branch-free)
-            float4 a[MTILES], b[G];
+        for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS) * 64);
+        auto mfma_step = [&](int s4, const f32x4 (&b)[G]) {
+            float4 a[MTILES];
 #pragma unroll
             for (int mt = 0; mt < MTILES; mt++)
                 a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * H + 4 * s4]);
 #pragma unroll
-            for (int g = 0; g < G; g++) {
-                b[g] = ring[d][g];
-                ring[d][g] = wbase[((int64_t)g * KSTEPS + sn) * 64];
-            }
-#pragma unroll
             for (int mt = 0; mt < MTILES; mt++) {
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].x, b[g].x, acc[mt][g]);
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].x, b[g][0], acc[mt][g]);
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].y, b[g].y, acc[mt][g]);
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].y, b[g][1], acc[mt][g]);
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].z, b[g].z, acc[mt][g]);
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].z, b[g][2], acc[mt][g]);
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].w, b[g].w, acc[mt][g]);
+                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].w, b[g][3], acc[mt][g]);
             }
+        };
+#pragma unroll 1
+        for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
+#pragma unroll
+            for (int g = 0; g < G; g++) async_load_b128(b1[g], wb + ((int64_t)g * KSTEPS + s4 + 1) * 64);
+            wait_frag<G, G>(b0);                      // b0 landed; b1's G loads may stay in flight
+            mfma_step(s4, b0);
+            const int sn = min(s4 + 2, KSTEPS - 2);   // last trip re-loads a fragment nobody reads (keeps counts uniform)
+#pragma unroll
+            for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS + sn) * 64);
+            wait_frag<G, G>(b1);
+            mfma_step(s4 + 1, b1);
         }
+        wait_frag<0, G>(b0);                          // drain before the registers are reused
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
 
         // ---- cell update in registers; h_t goes back to LDS for the next step ----------------------
@@ -401,17 +452,17 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void seq_fwd_kernel(SeqFwdParams p)
                 if (G == 4) {
                     const float ig = sigmoidf_(acc[mt][0][r]);
                     const float fg = sigmoidf_(acc[mt][G > 1 ? 1 : 0][r]);
-                    const float gg = tanhf(acc[mt][G > 2 ? 2 : 0][r]);
+                    const float gg = tanhf_(acc[mt][G > 2 ? 2 : 0][r]);
                     const float og = sigmoidf_(acc[mt][G > 3 ? 3 : 0][r]);
                     const float c = fg * cst[mt][r] + ig * gg;
                     cst[mt][r] = c;
-                    h = og * tanhf(c);
+                    h = og * tanhf_(c);
                     if (p.saved && q < p.P) {
                         float *sv = p.saved + (((int64_t)q * p.L + t) * SV) * H + col;
                         sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
                     }
                 } else {
-                    h = tanhf(acc[mt][0][r]);
+                    h = tanhf_(acc[mt][0][r]);
                     if (p.saved && q < p.P) p.saved[((int64_t)q * p.L + t) * H + col] = h;
                 }
                 lds[row * PITCH + H + col] = h;
@@ -667,13 +718,12 @@ struct SeqBwdParams {
 };
 
 template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64, 2) void seq_bwd_kernel(SeqBwdParams p) {
+__global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqBwdParams p) {
     constexpr int MTILES = MT / 32, GH = G * H, PITCH = GH + 4, SV = (G == 4 ? 5 : 1);
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int q0 = blockIdx.x * MT;
     const int col = 32 * wave + li;
-    const float4 *W4 = reinterpret_cast<const float4 *>(p.WpT);
 
     f32x16 dh[MTILES], dc[MTILES];
 #pragma unroll
@@ -700,7 +750,7 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void seq_bwd_kernel(SeqBwdParams p)
                         ig = sv[0]; fg = sv[H]; gg = sv[2 * H]; og = sv[3 * H]; c = sv[4 * H];
                         if (t > 0) cprev = sv[4 * H - (int64_t)SV * H];
                     }
-                    const float tc = tanhf(c);
+                    const float tc = tanhf_(c);
                     const float dhv = dh[mt][r];
                     const float d_o = dhv * tc;
                     const float dct = dc[mt][r] + dhv * og * (1.0f - tc * tc);
@@ -731,40 +781,42 @@ __global__ __launch_bounds__(H / 32 * 64, 2) void seq_bwd_kernel(SeqBwdParams p)
             for (int nt = 0; nt < 2; nt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.0f;
-        constexpr int KSTEPS = GH / 8, DEPTH = (KSTEPS < 4 ? KSTEPS : 4);
-        const float4 *wbase = W4 + ((int64_t)wave * 2 * KSTEPS) * 64 + lane;
-        float4 ring[DEPTH][2];
+        constexpr int KSTEPS = GH / 8;
+        static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
+        const f32x4 *wb = reinterpret_cast<const f32x4 *>(p.WpT) + ((int64_t)wave * 2 * KSTEPS) * 64 + lane;
+        f32x4 b0[2], b1[2];
 #pragma unroll
-        for (int d = 0; d < DEPTH; d++)
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) ring[d][nt] = wbase[((int64_t)nt * KSTEPS + d) * 64];
-#pragma unroll 1
-        for (int s4o = 0; s4o < KSTEPS; s4o += DEPTH)
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            const int s4 = s4o + d;
-            const int sn = min(s4 + DEPTH, KSTEPS - 1);
-            float4 b[2], a[MTILES];
+        for (int nt = 0; nt < 2; nt++) async_load_b128(b0[nt], wb + ((int64_t)nt * KSTEPS) * 64);
+        auto mfma_step = [&](int s4, const f32x4 (&b)[2]) {
+            float4 a[MTILES];
 #pragma unroll
             for (int mt = 0; mt < MTILES; mt++)
                 a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * (GH / 2) + 4 * s4]);
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                b[nt] = ring[d][nt];
-                ring[d][nt] = wbase[((int64_t)nt * KSTEPS + sn) * 64];
-            }
-#pragma unroll
             for (int mt = 0; mt < MTILES; mt++) {
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].x, b[nt].x, acc[mt][nt]);
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].x, b[nt][0], acc[mt][nt]);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].y, b[nt].y, acc[mt][nt]);
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].y, b[nt][1], acc[mt][nt]);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].z, b[nt].z, acc[mt][nt]);
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].z, b[nt][2], acc[mt][nt]);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].w, b[nt].w, acc[mt][nt]);
+                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].w, b[nt][3], acc[mt][nt]);
             }
+        };
+#pragma unroll 1
+        for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) async_load_b128(b1[nt], wb + ((int64_t)nt * KSTEPS + s4 + 1) * 64);
+            wait_frag<2, 2>(b0);
+            mfma_step(s4, b0);
+            const int sn = min(s4 + 2, KSTEPS - 2);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) async_load_b128(b0[nt], wb + ((int64_t)nt * KSTEPS + sn) * 64);
+            wait_frag<2, 2>(b1);
+            mfma_step(s4 + 1, b1);
         }
+        wait_frag<0, 2>(b0);
         __syncthreads();
 
 #pragma unroll
@@ -921,7 +973,7 @@ int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t
 
 template <int H, int G>
 int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
-    constexpr int MT = 32;
+    constexpr int MT = PN_BWD_MT;
     constexpr size_t lds_bytes = (size_t)MT * (G * H + 4) * 4;
     auto kern = seq_bwd_kernel<H, G, MT>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1014,8 +1066,7 @@ int check_shape(const pn_pagg_shape &s) {
 
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
-    constexpr int MT = 32;  // 64 accumulator registers per wave -> several workgroups per CU hide each other's
-                            // gather / cell / barrier phases behind MFMA work
+    constexpr int MT = PN_FWD_MT;
     constexpr size_t lds_bytes = (size_t)MT * (2 * H + 4) * 4;
     auto kern = seq_fwd_kernel<H, G, MT>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
