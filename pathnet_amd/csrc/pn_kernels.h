@@ -39,6 +39,13 @@ template <int N>
 __device__ __forceinline__ void wait_vm(f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x4 &r3) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "i"(N));
 }
+template <int N>
+__device__ __forceinline__ void wait_vm(f32x4 &r0, f32x4 &r1, f32x4 &r2, f32x4 &r3, f32x4 &r4, f32x4 &r5, f32x4 &r6,
+                                        f32x4 &r7) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+                 : "i"(N));
+}
 template <int N, int G>
 __device__ __forceinline__ void wait_frag(f32x4 (&b)[G]) {
     if constexpr (G == 1) wait_vm<N>(b[0]);

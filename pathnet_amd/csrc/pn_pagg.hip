@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "pn_internal.h"
 #include "pn_kernels.h"
@@ -44,7 +45,7 @@ using namespace pn;
 #define PN_FWD_WAVES 2      // __launch_bounds__ min waves per SIMD, forward
 #endif
 #ifndef PN_FWD_PREFETCH_X
-#define PN_FWD_PREFETCH_X 1 // fetch the x_{t+1} rows under the MFMAs of step t
+#define PN_FWD_PREFETCH_X 0 // 1: fetch the x_{t+1} rows under the MFMAs of step t (measured slower: r01 tune3)
 #endif
 #ifndef PN_BWD_MT
 #define PN_BWD_MT 32
@@ -719,61 +720,89 @@ struct SeqBwdParams {
 
 template <int H, int G, int MT>
 __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqBwdParams p) {
-    constexpr int MTILES = MT / 32, GH = G * H, PITCH = GH + 4, SV = (G == 4 ? 5 : 1);
+    constexpr int NT = H / 32 * 64, MTILES = MT / 32, GH = G * H, PITCH = GH + 4, SV = (G == 4 ? 5 : 1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    int *s_rowidx = reinterpret_cast<int *>(lds + MT * PITCH);   // [MT][L] gather rows of this tile
+    int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int q0 = blockIdx.x * MT;
     const int col = 32 * wave + li;
 
-    f32x16 dh[MTILES], dc[MTILES];
+    for (int i = tid; i < MT * p.L; i += NT) {
+        const int q = q0 + i / p.L;
+        s_rowidx[i] = q < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
+    }
+    for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
+
+    f32x16 dh[MTILES], dc[MTILES], cnext[MTILES];   // cnext: c_t of the step processed next (= c_{t-1} now)
 #pragma unroll
     for (int mt = 0; mt < MTILES; mt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int q = q0 + mt * 32 + acc_row(r, lane);
-            dh[mt][r] = q < p.P ? p.dhn[(int64_t)q * H + col] : 0.0f;
+            const int qc = min(q, p.P - 1);
+            const float dh0 = p.dhn[(int64_t)qc * H + col];     // unconditional load, select afterwards
+            dh[mt][r] = q < p.P ? dh0 : 0.0f;
             dc[mt][r] = 0.0f;
+            cnext[mt][r] = G == 4 ? p.saved[(((int64_t)qc * p.L + (p.L - 1)) * SV + 4) * H + col] : 0.0f;
         }
 
     for (int t = p.L - 1; t >= 0; t--) {
+        // ---- cell backward.  All loads of a half tile are issued together (unconditionally, padded rows read a
+        //      clamped row and are zeroed afterwards) so the wave pays one memory round trip, not one per element.
 #pragma unroll
         for (int mt = 0; mt < MTILES; mt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = mt * 32 + acc_row(r, lane);
-                const int q = q0 + row;
-                const bool ok = q < p.P;
-                if (G == 4) {
-                    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, c = 0.f, cprev = 0.f;
-                    if (ok) {
-                        const float *sv = p.saved + (((int64_t)q * p.L + t) * SV) * H + col;
-                        ig = sv[0]; fg = sv[H]; gg = sv[2 * H]; og = sv[3 * H]; c = sv[4 * H];
-                        if (t > 0) cprev = sv[4 * H - (int64_t)SV * H];
+            for (int half = 0; half < 2; half++) {
+                float vi[8], vf[8], vg[8], vo[8], vc[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int r = half * 8 + e;
+                    const int qc = min(q0 + mt * 32 + acc_row(r, lane), p.P - 1);
+                    const float *sv = p.saved + (((int64_t)qc * p.L + t) * SV) * H + col;
+                    if (G == 4) {
+                        vi[e] = sv[0]; vf[e] = sv[H]; vg[e] = sv[2 * H]; vo[e] = sv[3 * H];
+                        vc[e] = t > 0 ? sv[4 * H - (int64_t)SV * H] : 0.0f;     // c_{t-1}
+                    } else {
+                        vi[e] = sv[0];                                            // h_t
                     }
-                    const float tc = tanhf_(c);
-                    const float dhv = dh[mt][r];
-                    const float d_o = dhv * tc;
-                    const float dct = dc[mt][r] + dhv * og * (1.0f - tc * tc);
-                    const float a_i = dct * gg * ig * (1.0f - ig);
-                    const float a_f = dct * cprev * fg * (1.0f - fg);
-                    const float a_g = dct * ig * (1.0f - gg * gg);
-                    const float a_o = d_o * og * (1.0f - og);
-                    dc[mt][r] = dct * fg;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int r = half * 8 + e;
+                    const int row = mt * 32 + acc_row(r, lane);
+                    const int q = q0 + row;
+                    const bool ok = q < p.P;
                     float *l = &lds[row * PITCH + col];
-                    l[0] = a_i; l[H] = a_f; l[2 * (G > 1 ? H : 0)] = a_g; l[3 * (G > 1 ? H : 0)] = a_o;
-                    if (ok) {
-                        float *d = p.dG + ((int64_t)q * p.L + t) * GH + col;
-                        d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
+                    float *d = p.dG + ((int64_t)min(q, p.P - 1) * p.L + t) * GH + col;
+                    if (G == 4) {
+                        const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
+                        const float tc = tanhf_(cnext[mt][r]);
+                        const float dhv = dh[mt][r];
+                        const float d_o = dhv * tc;
+                        const float dct = dc[mt][r] + dhv * og * (1.0f - tc * tc);
+                        float a_i = dct * gg * ig * (1.0f - ig);
+                        float a_f = dct * cprev * fg * (1.0f - fg);
+                        float a_g = dct * ig * (1.0f - gg * gg);
+                        float a_o = d_o * og * (1.0f - og);
+                        if (!ok) a_i = a_f = a_g = a_o = 0.0f;
+                        dc[mt][r] = dct * fg;
+                        cnext[mt][r] = cprev;
+                        l[0] = a_i; l[H] = a_f; l[2 * (G > 1 ? H : 0)] = a_g; l[3 * (G > 1 ? H : 0)] = a_o;
+                        if (ok) {
+                            d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
+                        }
+                    } else {
+                        const float h = vi[e];
+                        const float a = ok ? dh[mt][r] * (1.0f - h * h) : 0.0f;
+                        l[0] = a;
+                        if (ok) d[0] = a;
                     }
-                } else {
-                    const float h = ok ? p.saved[((int64_t)q * p.L + t) * H + col] : 0.0f;
-                    const float a = dh[mt][r] * (1.0f - h * h);
-                    lds[row * PITCH + col] = a;
-                    if (ok) p.dG[((int64_t)q * p.L + t) * GH + col] = a;
                 }
             }
         __syncthreads();
 
+        // ---- [dx_t ; dh_{t-1}] = dG_t . [W_ih | W_hh]; the dh half is not needed at t = 0 ------------------------
         f32x16 acc[MTILES][2];
 #pragma unroll
         for (int mt = 0; mt < MTILES; mt++)
@@ -784,54 +813,63 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
         constexpr int KSTEPS = GH / 8;
         static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
         const f32x4 *wb = reinterpret_cast<const f32x4 *>(p.WpT) + ((int64_t)wave * 2 * KSTEPS) * 64 + lane;
-        f32x4 b0[2], b1[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; nt++) async_load_b128(b0[nt], wb + ((int64_t)nt * KSTEPS) * 64);
-        auto mfma_step = [&](int s4, const f32x4 (&b)[2]) {
+        auto mfma_step = [&](int s4, const f32x4 (&b)[2], const int ntn) {
             float4 a[MTILES];
 #pragma unroll
             for (int mt = 0; mt < MTILES; mt++)
                 a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * (GH / 2) + 4 * s4]);
 #pragma unroll
             for (int mt = 0; mt < MTILES; mt++) {
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].x, b[nt][0], acc[mt][nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].y, b[nt][1], acc[mt][nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].z, b[nt][2], acc[mt][nt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma32(a[mt].w, b[nt][3], acc[mt][nt]);
+                acc[mt][0] = mfma32(a[mt].x, b[0][0], acc[mt][0]);
+                if (ntn > 1) acc[mt][1] = mfma32(a[mt].x, b[1][0], acc[mt][1]);
+                acc[mt][0] = mfma32(a[mt].y, b[0][1], acc[mt][0]);
+                if (ntn > 1) acc[mt][1] = mfma32(a[mt].y, b[1][1], acc[mt][1]);
+                acc[mt][0] = mfma32(a[mt].z, b[0][2], acc[mt][0]);
+                if (ntn > 1) acc[mt][1] = mfma32(a[mt].z, b[1][2], acc[mt][1]);
+                acc[mt][0] = mfma32(a[mt].w, b[0][3], acc[mt][0]);
+                if (ntn > 1) acc[mt][1] = mfma32(a[mt].w, b[1][3], acc[mt][1]);
             }
         };
+        auto k_loop = [&](auto ntn_tag) {
+            constexpr int NTN = decltype(ntn_tag)::value;
+            f32x4 b0[2], b1[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) async_load_b128(b0[nt], wb + ((int64_t)(nt < NTN ? nt : 0) * KSTEPS) * 64);
 #pragma unroll 1
-        for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
+            for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) async_load_b128(b1[nt], wb + ((int64_t)nt * KSTEPS + s4 + 1) * 64);
-            wait_frag<2, 2>(b0);
-            mfma_step(s4, b0);
-            const int sn = min(s4 + 2, KSTEPS - 2);
+                for (int nt = 0; nt < 2; nt++)
+                    async_load_b128(b1[nt], wb + ((int64_t)(nt < NTN ? nt : 0) * KSTEPS + s4 + 1) * 64);
+                wait_frag<2, 2>(b0);
+                mfma_step(s4, b0, NTN);
+                const int sn = min(s4 + 2, KSTEPS - 2);
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) async_load_b128(b0[nt], wb + ((int64_t)nt * KSTEPS + sn) * 64);
-            wait_frag<2, 2>(b1);
-            mfma_step(s4 + 1, b1);
-        }
-        wait_frag<0, 2>(b0);
+                for (int nt = 0; nt < 2; nt++)
+                    async_load_b128(b0[nt], wb + ((int64_t)(nt < NTN ? nt : 0) * KSTEPS + sn) * 64);
+                wait_frag<2, 2>(b1);
+                mfma_step(s4 + 1, b1, NTN);
+            }
+            wait_frag<0, 2>(b0);
+        };
+        if (t > 0)
+            k_loop(std::integral_constant<int, 2>{});
+        else
+            k_loop(std::integral_constant<int, 1>{});
         __syncthreads();
 
 #pragma unroll
         for (int mt = 0; mt < MTILES; mt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int q = q0 + mt * 32 + acc_row(r, lane);
-                if (q < p.P) {
+                const int row = mt * 32 + acc_row(r, lane);
+                if (q0 + row < p.P) {
                     float dx = acc[mt][0][r];
-                    const uint64_t e = ((uint64_t)t * p.P + p.slotof[q]) * H + col;
+                    const uint64_t e = ((uint64_t)t * p.P + s_slotof[row]) * H + col;
                     if (p.mask)
                         dx *= p.mask[e];
                     else if (p.p_drop > 0.0f)
                         dx *= dropout1(p.seed, e, 1u, p.p_drop);
-                    atomicAdd(&p.dZ[(int64_t)p.rowidx[(int64_t)q * p.L + t] * H + col], dx);
+                    atomicAdd(&p.dZ[(int64_t)s_rowidx[row * p.L + t] * H + col], dx);
                 }
                 dh[mt][r] = acc[mt][1][r];
             }
@@ -844,7 +882,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
 //      transposition.  128x128 output tile per workgroup (4 waves x (2x2) 32x32 MFMA tiles), the R rows
 //      are split over blockIdx.z; partial tiles go to a [split][G*H][2H] buffer and are summed by
 //      wgrad_reduce_kernel (deterministic, no atomics). -----------------------------------------------
-constexpr int WG_BM = 128, WG_BN = 128, WG_KT = 32, WG_PITCH = 132;
+constexpr int WG_BM = 256, WG_BN = 256, WG_KT = 32, WG_PITCH = 260, WG_THREADS = 512;
 
 struct WgradParams {
     const float *dG;   // [R, GH]
@@ -856,71 +894,79 @@ struct WgradParams {
     float *part_b;     // [nsplit, GH]
 };
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
-    __shared__ float As[WG_KT * WG_PITCH];
-    __shared__ float Bs[WG_KT * WG_PITCH];
+// 256 x 256 output tile per workgroup: with 2H <= 256 the dG rows are read from HBM exactly once and the
+// [x|h] rows once per 256 gate columns.  8 waves as 4 (m) x 2 (n), each 64 x 128 = 2 x 4 MFMA tiles.
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float As[WG_KT * WG_PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[WG_KT * WG_PITCH];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * WG_BM, n0 = blockIdx.x * WG_BN;
     const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
     const int64_t rend = min(p.R, rbeg + p.rows_per_split);
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
     float bsum = 0.0f;
 
-    // each thread moves 4 float4 of each operand per K tile: row k = i*8 + tid/32, columns 4*(tid%32)..+3
-    const int lk = tid >> 5, lc = (tid & 31) * 4;
-    float4 ra[4], rb[4];
-    auto load_tiles = [&](int64_t k0) {
+    // a thread moves 4 x 16 bytes of each operand per K tile: row k = i*8 + tid/64, columns 4*(tid%64)..+3.
+    // Out-of-range rows/columns load a clamped (valid) address and are zeroed when written to LDS.
+    const int lk = tid >> 6, lc = (tid & 63) * 4;
+    const bool a_ok = m0 + lc < p.GH, b_ok = n0 + lc < p.H2;
+    const int a_col = a_ok ? m0 + lc : 0, b_col = b_ok ? n0 + lc : 0;
+    f32x4 ra[4], rb[4];
+    auto issue = [&](int64_t k0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int64_t row = k0 + i * 8 + lk;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[i] = ra[i];
-            if (row < rend) {
-                if (m0 + lc < p.GH) ra[i] = *reinterpret_cast<const float4 *>(p.dG + row * p.GH + m0 + lc);
-                if (n0 + lc < p.H2) rb[i] = *reinterpret_cast<const float4 *>(p.xh + row * p.H2 + n0 + lc);
-            }
+            const int64_t row = min(k0 + i * 8 + lk, rend - 1);
+            async_load_b128(ra[i], p.dG + row * p.GH + a_col);
+            async_load_b128(rb[i], p.xh + row * p.H2 + b_col);
         }
     };
-    load_tiles(rbeg);
+    if (rbeg >= rend) return;   // block-uniform
+    issue(rbeg);
     for (int64_t k0 = rbeg; k0 < rend; k0 += WG_KT) {
+        wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            *reinterpret_cast<float4 *>(&As[(i * 8 + lk) * WG_PITCH + lc]) = ra[i];
-            *reinterpret_cast<float4 *>(&Bs[(i * 8 + lk) * WG_PITCH + lc]) = rb[i];
+            const bool row_ok = k0 + i * 8 + lk < rend;
+            f32x4 va = ra[i], vb = rb[i];
+            if (!(row_ok && a_ok)) va = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(row_ok && b_ok)) vb = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4 *>(&As[(i * 8 + lk) * WG_PITCH + lc]) = va;
+            *reinterpret_cast<f32x4 *>(&Bs[(i * 8 + lk) * WG_PITCH + lc]) = vb;
         }
         __syncthreads();
-        if (k0 + WG_KT < rend) load_tiles(k0 + WG_KT);   // in flight while the MFMAs below run
-        if (blockIdx.x == 0 && tid < WG_BM) {
+        issue(min(k0 + WG_KT, rend - 1));   // next tile in flight under the MFMAs (last trip: harmless re-load)
+        if (tid < WG_BM) {
 #pragma unroll
             for (int k = 0; k < WG_KT; k++) bsum += As[k * WG_PITCH + tid];
         }
 #pragma unroll
         for (int kk = 0; kk < WG_KT / 2; kk++) {
-            float a[2], b[2];
+            float a[2], b[4];
 #pragma unroll
             for (int i = 0; i < 2; i++) a[i] = As[(2 * kk + hk) * WG_PITCH + wm * 64 + i * 32 + li];
 #pragma unroll
-            for (int j = 0; j < 2; j++) b[j] = Bs[(2 * kk + hk) * WG_PITCH + wn * 64 + j * 32 + li];
+            for (int j = 0; j < 4; j++) b[j] = Bs[(2 * kk + hk) * WG_PITCH + wn * 128 + j * 32 + li];
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
         }
         __syncthreads();
     }
+    wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);   // drain the trailing prefetch
     float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int n = n0 + wn * 64 + j * 32 + li;
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wn * 128 + j * 32 + li;
             if (n >= p.H2) continue;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -974,7 +1020,7 @@ int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t
 template <int H, int G>
 int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int MT = PN_BWD_MT;
-    constexpr size_t lds_bytes = (size_t)MT * (G * H + 4) * 4;
+    const size_t lds_bytes = (size_t)MT * (G * H + 4) * 4 + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_bwd_kernel<H, G, MT>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
@@ -1040,7 +1086,7 @@ WsLayout ws_layout(const pn_pagg_shape &s) {
     {
         // split of the P*L rows of the weight-gradient GEMM: enough workgroups to fill 256 CUs ~3x
         const size_t rows = P * L, tiles = ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN);
-        size_t nz = (768 + tiles - 1) / tiles;
+        size_t nz = (256 + tiles - 1) / tiles;     // one 8-wave workgroup per CU
         const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
         if (nz > max_nz) nz = max_nz;
         if (nz < 1) nz = 1;
@@ -1411,7 +1457,7 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         {
             StageTimer tm(ST_WGRAD, stream);
             hipLaunchKernelGGL(wgrad_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
-                               dim3(256), 0, stream, wp);
+                               dim3(WG_THREADS), 0, stream, wp);
             PN_CHECK_HIP(hipGetLastError());
             const int64_t nred = (int64_t)GH * 2 * H + GH;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, stream,
