@@ -274,14 +274,18 @@ def main():
 
     P = S * W
     G4 = 4
-    flops_seq = 2.0 * P * L * (2 * H) * (G4 * H)              # [x;h] (2H) x 4H gate columns, per step and path
-    algo = {"seq_fwd": flops_seq, "seq_bwd": flops_seq, "wgrad": flops_seq}
+    # LSTM = L*16*H^2 flops per path ([x;h] (2H) x 4H gate columns per step).  The backward
+    # kernels are charged only what the math requires: h_{-1} = 0, so the dh_{-1} product (seq_bwd) and the
+    # W_hh gradient of the t = 0 rows (wgrad) are not algorithmic work: (2L-1)/(2L) of the forward figure.
+    flops_seq = 2.0 * P * L * (2 * H) * (G4 * H)
+    algo = {"seq_fwd": flops_seq, "seq_bwd": flops_seq * (2 * L - 1) / (2 * L),
+            "wgrad": flops_seq * (2 * L - 1) / (2 * L)}
     if dominant in algo:
         achieved = algo[dominant] / (dom_ms * 1e-3) / 1e12
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(dom[1]),
-                    "algorithmic_flops_per_launch": flops_seq,
+                    "algorithmic_flops_per_launch": algo[dominant],
                     "note": "fp32-input MFMA (1e-5 parity forces fp32); flops = L*16*H^2 per path (SURVEY.md §8d)"}
     else:
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",

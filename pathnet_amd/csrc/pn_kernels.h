@@ -27,6 +27,16 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 __device__ __forceinline__ void async_load_b128(f32x4 &dst, const void *ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
 }
+__device__ __forceinline__ void async_load_b32(float &dst, const void *ptr) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+// wait for every outstanding VMEM op; names three 8-register groups so their consumers stay below the wait
+__device__ __forceinline__ void wait_vm_all(float (&a)[8], float (&b)[8], float (&c)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]),
+                   "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+}
 template <int N>
 __device__ __forceinline__ void wait_vm(f32x4 &r0) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "i"(N));

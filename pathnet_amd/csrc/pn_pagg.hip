@@ -83,7 +83,7 @@ struct GemmParams {
     int kchunk;  // K range per blockIdx.z
 };
 
-template <bool A_KCONTIG, bool B_KCONTIG>
+template <bool A_KCONTIG, bool B_KCONTIG, bool GATE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __shared__ float As[GEMM_KT * GEMM_PITCH];
     __shared__ float Bs[GEMM_KT * GEMM_PITCH];
@@ -96,42 +96,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
 
-    // software pipeline: the next K tile's global loads are issued before the MFMAs of the current one
-    float ra[8], rb[8];
-    auto gload = [&](int k0) {
+    // Software pipeline: the next K tile's 8+8(+8) global loads are issued (branch-free, clamped addresses;
+    // asm-pinned so hipcc cannot sink them) before the MFMAs of the current tile; out-of-range elements and
+    // gated-off elements become zeros when the tile is written to LDS.
+    float ra[8], rb[8], rg[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rg[i] = 1.0f;
+    auto issue = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int idx = tid + 256 * i;
-            {
-                const int m = A_KCONTIG ? (idx >> 5) : (idx & 63);
-                const int k = A_KCONTIG ? (idx & 31) : (idx >> 6);
-                const int gm = m0 + m, gk = k0 + k;
-                float v = 0.0f;
-                if (gm < p.M && gk < kend) {
-                    const int64_t at = (int64_t)gm * p.sAm + (int64_t)gk * p.sAk;
-                    v = p.A[at];
-                    if (p.gateA && !(p.gateA[at] > 0.0f)) v = 0.0f;
-                }
-                ra[i] = v;
-            }
-            {
-                const int n = B_KCONTIG ? (idx >> 5) : (idx & 63);
-                const int k = B_KCONTIG ? (idx & 31) : (idx >> 6);
-                const int gn = n0 + n, gk = k0 + k;
-                rb[i] = (gn < p.N && gk < kend) ? p.B[(int64_t)gn * p.sBn + (int64_t)gk * p.sBk] : 0.0f;
-            }
+            const int am = A_KCONTIG ? (idx >> 5) : (idx & 63), ak = A_KCONTIG ? (idx & 31) : (idx >> 6);
+            const int64_t at = (int64_t)min(m0 + am, p.M - 1) * p.sAm + (int64_t)min(k0 + ak, kend - 1) * p.sAk;
+            async_load_b32(ra[i], p.A + at);
+            if (GATE) async_load_b32(rg[i], p.gateA + at);
+            const int bn = B_KCONTIG ? (idx >> 5) : (idx & 63), bk = B_KCONTIG ? (idx & 31) : (idx >> 6);
+            async_load_b32(rb[i], p.B + (int64_t)min(n0 + bn, p.N - 1) * p.sBn + (int64_t)min(k0 + bk, kend - 1) * p.sBk);
         }
     };
-    if (kbeg < kend) gload(kbeg);
+    if (kbeg < kend) issue(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GEMM_KT) {
+        wait_vm_all(ra, rb, rg);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int idx = tid + 256 * i;
-            As[(A_KCONTIG ? (idx & 31) : (idx >> 6)) * GEMM_PITCH + (A_KCONTIG ? (idx >> 5) : (idx & 63))] = ra[i];
-            Bs[(B_KCONTIG ? (idx & 31) : (idx >> 6)) * GEMM_PITCH + (B_KCONTIG ? (idx >> 5) : (idx & 63))] = rb[i];
+            const int am = A_KCONTIG ? (idx >> 5) : (idx & 63), ak = A_KCONTIG ? (idx & 31) : (idx >> 6);
+            const int bn = B_KCONTIG ? (idx >> 5) : (idx & 63), bk = B_KCONTIG ? (idx & 31) : (idx >> 6);
+            const bool a_ok = (m0 + am < p.M) && (k0 + ak < kend) && (!GATE || rg[i] > 0.0f);
+            const bool b_ok = (n0 + bn < p.N) && (k0 + bk < kend);
+            As[ak * GEMM_PITCH + am] = a_ok ? ra[i] : 0.0f;
+            Bs[bk * GEMM_PITCH + bn] = b_ok ? rb[i] : 0.0f;
         }
         __syncthreads();
-        if (k0 + GEMM_KT < kend) gload(k0 + GEMM_KT);
+        issue(min(k0 + GEMM_KT, kend - 1));   // last trip: harmless re-load, drained below
 #pragma unroll
         for (int kk = 0; kk < GEMM_KT / 2; kk++) {
             const float a = As[(2 * kk + hk) * GEMM_PITCH + wm * 32 + li];
@@ -140,6 +137,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         }
         __syncthreads();
     }
+    if (kbeg < kend) wait_vm_all(ra, rb, rg);
     const int col = n0 + wn * 32 + li;
     if (col >= p.N) return;
     const float bias = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.0f;
@@ -159,6 +157,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
+template <bool GATE>
+void launch_gemm_variant(hipStream_t stream, dim3 grid, bool ak, bool bk, const GemmParams &p) {
+    if (ak && bk)
+        hipLaunchKernelGGL((gemm_kernel<true, true, GATE>), grid, dim3(256), 0, stream, p);
+    else if (ak && !bk)
+        hipLaunchKernelGGL((gemm_kernel<true, false, GATE>), grid, dim3(256), 0, stream, p);
+    else if (!ak && bk)
+        hipLaunchKernelGGL((gemm_kernel<false, true, GATE>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel<false, false, GATE>), grid, dim3(256), 0, stream, p);
+}
+
 int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
                 int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
                 int mode, int ksplit) {
@@ -172,15 +182,12 @@ int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, co
     p.kchunk = kchunk;
     const int nz = K > 0 ? (K + kchunk - 1) / kchunk : 1;
     dim3 grid((N + GEMM_BN - 1) / GEMM_BN, (M + GEMM_BM - 1) / GEMM_BM, nz);
+    if (K <= 0 || M <= 0 || N <= 0) PN_FAIL(PN_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     const bool ak = (sAk == 1), bk = (sBk == 1);
-    if (ak && bk)
-        hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, stream, p);
-    else if (ak && !bk)
-        hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, stream, p);
-    else if (!ak && bk)
-        hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    if (gateA)
+        launch_gemm_variant<true>(stream, grid, ak, bk, p);
     else
-        hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, stream, p);
+        launch_gemm_variant<false>(stream, grid, ak, bk, p);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -281,12 +288,24 @@ __global__ __launch_bounds__(256) void gather_kernel(int variant, const float *_
 // with Wcat = [W_ih | W_hh] ([G*H, 2H]).  The lane half (lane>>5) selects the x or the h part, so one
 // MFMA step multiplies x_t by W_ih in lanes 0-31 and h_{t-1} by W_hh in lanes 32-63 and sums both.
 // ================================================================================================
+// A second copy for step 0 (h_{-1} = 0, only W_ih matters, K = H split over the lane halves):
+//   Wp0[((w*G + g)*(H/8) + s4)*64 + lane][e] = W_ih[g*H + 32*w + (lane&31)][(lane>>5)*H/2 + 4*s4 + e]
 __global__ void pack_fwd_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G,
                                 float *__restrict__ Wp, float *__restrict__ biasc) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)G * H * 2 * H;
     if (idx < (int64_t)G * H) biasc[idx] = b_ih[idx] + b_hh[idx];
+    if (idx >= total && idx < total + (int64_t)G * H * H) {
+        const int64_t j = idx - total;
+        const int e = j & 3, lane = (j >> 2) & 63;
+        int64_t rest = j >> 8;
+        const int s4 = rest % (H / 8);
+        rest /= (H / 8);
+        const int g = rest % G, w = rest / G;
+        Wp[idx] = w_ih[(int64_t)(g * H + 32 * w + (lane & 31)) * H + (lane >> 5) * (H / 2) + 4 * s4 + e];
+        return;
+    }
     if (idx >= total) return;
     const int e = idx & 3, lane = (idx >> 2) & 63;
     int64_t rest = idx >> 8;
@@ -403,43 +422,51 @@ __global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqF
         // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T : lanes 0-31 walk the x half of K, lanes 32-63 the h half
         // B fragments stream L2 -> VGPR one k-step (G KB per wave) ahead of the MFMAs that use them: two
         // register sets, the loads of step s+1 are issued before the MFMAs of step s (async_load_b128 keeps
-        // hipcc from sinking them to their use).
-        constexpr int KSTEPS = H / 4;
-        static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
-        const f32x4 *wb = reinterpret_cast<const f32x4 *>(p.Wp) + ((int64_t)wave * G * KSTEPS) * 64 + lane;
-        f32x4 b0[G], b1[G];
+        // hipcc from sinking them to their use).  Step 0 has h_{-1} = 0: only the x half of K, both lane halves
+        // walk it (KH = H/2 per half) against the step-0 packing of W_ih.
+        auto k_loop = [&](auto ksteps_tag, const float *wpack) {
+            constexpr int KSTEPS = decltype(ksteps_tag)::value;       // k-steps of 4 per lane half
+            constexpr int KH = 4 * KSTEPS;                            // K extent per lane half
+            static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
+            const f32x4 *wb = reinterpret_cast<const f32x4 *>(wpack) + ((int64_t)wave * G * KSTEPS) * 64 + lane;
+            f32x4 b0[G], b1[G];
 #pragma unroll
-        for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS) * 64);
-        auto mfma_step = [&](int s4, const f32x4 (&b)[G]) {
-            float4 a[MTILES];
+            for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS) * 64);
+            auto mfma_step = [&](int s4, const f32x4 (&b)[G]) {
+                float4 a[MTILES];
 #pragma unroll
-            for (int mt = 0; mt < MTILES; mt++)
-                a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * H + 4 * s4]);
+                for (int mt = 0; mt < MTILES; mt++)
+                    a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * KH + 4 * s4]);
 #pragma unroll
-            for (int mt = 0; mt < MTILES; mt++) {
+                for (int mt = 0; mt < MTILES; mt++) {
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].x, b[g][0], acc[mt][g]);
+                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].x, b[g][0], acc[mt][g]);
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].y, b[g][1], acc[mt][g]);
+                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].y, b[g][1], acc[mt][g]);
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].z, b[g][2], acc[mt][g]);
+                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].z, b[g][2], acc[mt][g]);
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].w, b[g][3], acc[mt][g]);
-            }
-        };
+                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].w, b[g][3], acc[mt][g]);
+                }
+            };
 #pragma unroll 1
-        for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
+            for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
 #pragma unroll
-            for (int g = 0; g < G; g++) async_load_b128(b1[g], wb + ((int64_t)g * KSTEPS + s4 + 1) * 64);
-            wait_frag<G, G>(b0);                      // b0 landed; b1's G loads may stay in flight
-            mfma_step(s4, b0);
-            const int sn = min(s4 + 2, KSTEPS - 2);   // last trip re-loads a fragment nobody reads (keeps counts uniform)
+                for (int g = 0; g < G; g++) async_load_b128(b1[g], wb + ((int64_t)g * KSTEPS + s4 + 1) * 64);
+                wait_frag<G, G>(b0);                      // b0 landed; b1's G loads may stay in flight
+                mfma_step(s4, b0);
+                const int sn = min(s4 + 2, KSTEPS - 2);   // last trip re-loads a fragment nobody reads
 #pragma unroll
-            for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS + sn) * 64);
-            wait_frag<G, G>(b1);
-            mfma_step(s4 + 1, b1);
-        }
-        wait_frag<0, G>(b0);                          // drain before the registers are reused
+                for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS + sn) * 64);
+                wait_frag<G, G>(b1);
+                mfma_step(s4 + 1, b1);
+            }
+            wait_frag<0, G>(b0);                          // drain before the registers are reused
+        };
+        if (t == 0)
+            k_loop(std::integral_constant<int, H / 8>{}, p.Wp + (size_t)G * H * 2 * H);
+        else
+            k_loop(std::integral_constant<int, H / 4>{}, p.Wp);
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
 
         // ---- cell update in registers; h_t goes back to LDS for the next step ----------------------
@@ -1069,7 +1096,7 @@ WsLayout ws_layout(const pn_pagg_shape &s) {
     w.rowidx = take(P * L * 4);
     w.egoidx = take(P * 4);
     w.slotof = take(P * 4);
-    w.Wp = take(G * H * 2 * H * 4);
+    w.Wp = take(G * H * 3 * H * 4);
     w.biasc = take(G * H * 4);
     w.hn = take(P * H * 4);
     w.saved = take(P * L * SV * H * 4);
@@ -1257,7 +1284,7 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s.variant, a->ids,
                            a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
         PN_CHECK_HIP(hipGetLastError());
-        const int64_t nw = (int64_t)G * H * 2 * H;
+        const int64_t nw = (int64_t)G * H * 3 * H;     // [W_ih | W_hh] fragments + the step-0 W_ih fragments
         hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
                            a->b_ih, a->b_hh, H, G, Wp, biasc);
         PN_CHECK_HIP(hipGetLastError());
