@@ -184,7 +184,7 @@ def main():
     smp = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev)
     torch.manual_seed(0)
     model = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.7).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=0.005, weight_decay=0.0005)
+    opt = torch.optim.Adam(model.parameters(), lr=0.005, weight_decay=0.0005, fused=True)   # same update, one kernel
     lossf = torch.nn.CrossEntropyLoss()
     Y = torch.from_numpy(wl["Y"]).to(dev)
 
@@ -274,19 +274,20 @@ def main():
 
     P = S * W
     G4 = 4
-    # LSTM = L*16*H^2 flops per path ([x;h] (2H) x 4H gate columns per step).  The backward
-    # kernels are charged only what the math requires: h_{-1} = 0, so the dh_{-1} product (seq_bwd) and the
-    # W_hh gradient of the t = 0 rows (wgrad) are not algorithmic work: (2L-1)/(2L) of the forward figure.
-    flops_seq = 2.0 * P * L * (2 * H) * (G4 * H)
-    algo = {"seq_fwd": flops_seq, "seq_bwd": flops_seq * (2 * L - 1) / (2 * L),
-            "wgrad": flops_seq * (2 * L - 1) / (2 * L)}
+    # LSTM = L*16*H^2 flops per path ([x;h] (2H) x 4H gate columns per step).  The kernels are
+    # charged only what the math requires: h_{-1} = 0, so the W_hh product of step 0 (seq_fwd), the dh_{-1}
+    # product (seq_bwd) and the W_hh gradient of the t = 0 rows (wgrad) are not algorithmic work:
+    # (2L-1)/(2L) of that figure = (2L-1)*8*H^2 = 0.918 MFLOP per path and kernel at L=4, H=128.
+    flops_seq = 2.0 * P * L * (2 * H) * (G4 * H) * (2 * L - 1) / (2 * L)
+    algo = {"seq_fwd": flops_seq, "seq_bwd": flops_seq, "wgrad": flops_seq}
     if dominant in algo:
         achieved = algo[dominant] / (dom_ms * 1e-3) / 1e12
         roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(dom[1]),
                     "algorithmic_flops_per_launch": algo[dominant],
-                    "note": "fp32-input MFMA (1e-5 parity forces fp32); flops = L*16*H^2 per path (SURVEY.md §8d)"}
+                    "note": "fp32-input MFMA (1e-5 parity forces fp32); flops = (2L-1)*8*H^2 per path = SURVEY.md "
+                            "§8d's L*16*H^2 minus the step-0 products with h_{-1} = 0"}
     else:
         roofline = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None, "traffic": None, "avg_launch_ms": round(dom_ms, 4)}

@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
 #include <type_traits>
 
 #include "pn_internal.h"
@@ -49,6 +50,9 @@ using namespace pn;
 #endif
 #ifndef PN_BWD_MT
 #define PN_BWD_MT 32
+#endif
+#ifndef PN_BWD_EXPERIMENT
+#define PN_BWD_EXPERIMENT 0  // timing experiments only (1, 2: gather-backward scatter replaced / removed)
 #endif
 #ifndef PN_BWD_DEPTH
 #define PN_BWD_DEPTH 4
@@ -534,17 +538,30 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
     const float inv_w = 1.0f / (float)p.W;
 
     if (p.variant != PN_VARIANT_PAGG) {
+        // attention scores, 8 members at a time: lane = (member lane>>3, eighth of H lane&7); the eight partial
+        // dot products of a member are summed with three xor-shuffles
         const float ab = p.att_b[0];
-        for (int mem = 0; mem < p.W; mem++) {
-            const int64_t s = (int64_t)g * p.W + mem;
-            const float *h = p.hn + s * H;
-            const float *e = p.ego_tab + (int64_t)p.egoidx[s] * H;
-            float part = 0.0f;
-            for (int j = lane; j < H; j += 64) part += h[j] * p.att_w[j] + e[j] * p.att_w[H + j];
-            const float score = wave_sum(part) + ab;
-            if (lane == 0) {
-                sc[mem] = score;
-                p.rawsc[s] = score;
+        const int m8 = lane >> 3, part = lane & 7, jw = H / 8;
+        for (int m0 = 0; m0 < p.W; m0 += 8) {
+            const int mem = m0 + m8;
+            const int memc = min(mem, p.W - 1);
+            const int64_t s = (int64_t)g * p.W + memc;
+            const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + s * H + part * jw);
+            const float4 *e4 = reinterpret_cast<const float4 *>(p.ego_tab + (int64_t)p.egoidx[s] * H + part * jw);
+            const float4 *a4 = reinterpret_cast<const float4 *>(p.att_w + part * jw);
+            const float4 *b4 = reinterpret_cast<const float4 *>(p.att_w + H + part * jw);
+            float acc = 0.0f;
+            for (int j = 0; j < jw / 4; j++) {
+                const float4 hv = h4[j], ev = e4[j], av = a4[j], bv = b4[j];
+                acc += hv.x * av.x + hv.y * av.y + hv.z * av.z + hv.w * av.w;
+                acc += ev.x * bv.x + ev.y * bv.y + ev.z * bv.z + ev.w * bv.w;
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (part == 0 && mem < p.W) {
+                sc[mem] = acc + ab;
+                p.rawsc[(int64_t)g * p.W + mem] = acc + ab;
             }
         }
     }
@@ -675,12 +692,23 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
             dp[j] = b * inv_w;
         }
         __builtin_amdgcn_wave_barrier();
-        for (int mem = 0; mem < W; mem++) {
-            const float *h = p.hn + ((int64_t)g * W + mem) * H;
-            float part = 0.0f;
-            for (int j = lane; j < H; j += 64) part += dp[j] * h[j];
-            part = wave_sum(part);
-            if (lane == 0) dco[mem] = part;
+        {
+            const int m8 = lane >> 3, part = lane & 7, jw = H / 8;
+            for (int m0 = 0; m0 < W; m0 += 8) {
+                const int mem = m0 + m8;
+                const float4 *h4 =
+                    reinterpret_cast<const float4 *>(p.hn + ((int64_t)g * W + min(mem, W - 1)) * H + part * jw);
+                float acc = 0.0f;
+                for (int j = 0; j < jw / 4; j++) {
+                    const float4 hv = h4[j];
+                    const float *d = dp + part * jw + 4 * j;
+                    acc += hv.x * d[0] + hv.y * d[1] + hv.z * d[2] + hv.w * d[3];
+                }
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                acc += __shfl_xor(acc, 4, 64);
+                if (part == 0 && mem < W) dco[mem] = acc;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (p.variant == PN_VARIANT_HETERO) {
@@ -896,7 +924,13 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
                         dx *= p.mask[e];
                     else if (p.p_drop > 0.0f)
                         dx *= dropout1(p.seed, e, 1u, p.p_drop);
+#if PN_BWD_EXPERIMENT == 1
+                    p.dZ[(int64_t)(q0 + row) * H + col] = dx;    // EXPERIMENT ONLY (wrong results): plain store instead of the scatter
+#elif PN_BWD_EXPERIMENT == 2
+                    if (dx == 123.456f) p.dZ[0] = dx;              // EXPERIMENT ONLY: no scatter at all
+#else
                     atomicAdd(&p.dZ[(int64_t)s_rowidx[row * p.L + t] * H + col], dx);
+#endif
                 }
                 dh[mt][r] = acc[mt][1][r];
             }
@@ -1397,7 +1431,7 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     }
 
     // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out)
-    StageTimer *tm_fc2 = new StageTimer(ST_FC2_GRAD, stream);
+    auto tm_fc2 = std::make_unique<StageTimer>(ST_FC2_GRAD, stream);
     if (a->g_fc2_w) {
         if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
         if (int rc = launch_gemm(stream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
@@ -1406,7 +1440,7 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     }
     if (a->g_fc2_b)
         if (int rc = launch_colsum(stream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
-    delete tm_fc2;
+    tm_fc2.reset();
 
     // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
     {
@@ -1466,7 +1500,6 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     }
 
     // recurrent weight / bias gradients: [g_W_ih | g_W_hh] = dG^T . XH, g_b = colsum(dG)
-    StageTimer *tm_bias = nullptr;
     if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
         WgradParams wp{};
         wp.dG = dG;
@@ -1492,10 +1525,9 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
             PN_CHECK_HIP(hipGetLastError());
         }
     }
-    delete tm_bias;
     // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh
     const float *zgate = homo ? Z : nullptr;
-    StageTimer *tm_bank = new StageTimer(ST_BANK_BWD, stream);
+    auto tm_bank = std::make_unique<StageTimer>(ST_BANK_BWD, stream);
     if (int rc = launch_gemm(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, s.N, H, L * H, 0,
                              GEMM_ADD, 1))
         return rc;
@@ -1506,7 +1538,7 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     if (a->g_bank_b)
         if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, s.N, L * H, a->g_bank_b)) return rc;
 
-    delete tm_bank;
+    tm_bank.reset();
     if (a->Xh_in) return PN_OK;   // the caller finishes fc0 after the reduce-scatter of g_Xh
     // fc0 backward (ReLU gate for HOMO)
     const float *xgate = homo ? Xh : nullptr;

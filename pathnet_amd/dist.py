@@ -50,10 +50,9 @@ class HipOps:
         a.shape = M._shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
         a.Xh_in = Xh.data_ptr()
         a.ids, a.codes, a.sel = ids.data_ptr(), codes.data_ptr(), sel.data_ptr()
-        for k in M._PARAM_ORDER:
-            if k in ("fc0_w", "fc0_b"):
-                continue
+        for k in M._HEAD_PARAMS[2:]:
             setattr(a, k, p[k].data_ptr() if p.get(k) is not None else None)
+        a.bank_w, a.bank_b = cfg["bank_w"].data_ptr(), cfg["bank_b"].data_ptr()
         a.p_seq, a.p_cls, a.seed = cfg["p_seq"], cfg["p_cls"], cfg["seed"]
         return a
 
@@ -71,6 +70,8 @@ class HipOps:
         return out, (cfg, Xh, ids, codes, sel, p, ws)
 
     def backward(self, state, g_out):
+        """-> (g_Xh [N,H], grads): grads maps the head parameter names (without fc0) to tensors and
+        "bank_w"/"bank_b" to the stacked [L,H,H] / [L,H] gradients."""
         lib = _lib.load()
         cfg, Xh, ids, codes, sel, p, ws = state
         dev = Xh.device
@@ -80,9 +81,10 @@ class HipOps:
         a.g_out = g_out.data_ptr()
         g_Xh = torch.empty_like(Xh)
         a.g_Xh = g_Xh.data_ptr()
-        grads = {}
-        for k in M._PARAM_ORDER:
-            if k in ("fc0_w", "fc0_b") or p.get(k) is None:
+        grads = {"bank_w": torch.empty_like(cfg["bank_w"]), "bank_b": torch.empty_like(cfg["bank_b"])}
+        a.g_bank_w, a.g_bank_b = grads["bank_w"].data_ptr(), grads["bank_b"].data_ptr()
+        for k in M._HEAD_PARAMS[2:]:
+            if p.get(k) is None:
                 continue
             grads[k] = torch.empty_like(p[k])
             setattr(a, "g_" + k, grads[k].data_ptr())
@@ -108,7 +110,7 @@ class HipOps:
 class _ShardedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, cfg, X_loc, ids, codes, sel, *params):
-        p = dict(zip(M._PARAM_ORDER, params))
+        p = M._split_params(params, cfg["L"])
         ops, group = runner.ops, runner.group
         Xh_loc = ops.project(cfg["variant"], X_loc, p["fc0_w"], p["fc0_b"])
         world = dist.get_world_size(group) if runner.distributed else 1
@@ -136,8 +138,10 @@ class _ShardedFn(torch.autograd.Function):
         else:
             g_loc = g_Xh
         grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w)
-        return (None, None, None, None, None, None) + tuple(
-            grads.get(k) if pres else None for k, pres in zip(M._PARAM_ORDER, ctx.present))
+        L = cfg["L"]
+        head = tuple(grads.get(k) if pres else None for k, pres in zip(M._HEAD_PARAMS, ctx.present[:10]))
+        return (None, None, None, None, None, None) + head + tuple(grads["bank_w"][d] for d in range(L)) + tuple(
+            grads["bank_b"][d] for d in range(L))
 
 
 class ShardedAggregator:
@@ -164,16 +168,11 @@ class ShardedAggregator:
         m = self.module
         dev = X_loc.device
         ids, codes, sel, S = M._as_index_tensors(neis, layer_type, sel_global, num_w, walk_len, dev)
-        bank_w, bank_b = m._bank()
-        cell = m._cell()
-        att = getattr(m, "attw", None)
+        fw, fb, params = m._param_inputs()
         p = m.dropout_p() if m.training else 0.0
         cfg = dict(variant=m.variant, N=self.n_total, F=X_loc.shape[1], H=m.hidden_size, C=m.out_size, S=S,
-                   W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p,
+                   W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb,
                    seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
-        params = (m.fc0.weight, m.fc0.bias, bank_w, bank_b, cell.weight_ih_l0, cell.weight_hh_l0, cell.bias_ih_l0,
-                  cell.bias_hh_l0, att.weight.reshape(-1) if att is not None else None,
-                  att.bias if att is not None else None, m.fc2.weight, m.fc2.bias)
         return _ShardedFn.apply(self, cfg, X_loc.contiguous().float(), ids, codes, sel, *params)
 
     def allreduce_grads(self, average=True):

@@ -23,8 +23,7 @@ from . import _lib
 dropout = 0.7
 
 _VARIANT = {"hetero": _lib.VARIANT_HETERO, "homo": _lib.VARIANT_HOMO, "pagg": _lib.VARIANT_PAGG}
-_PARAM_ORDER = ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w",
-                "fc2_b")
+_HEAD_PARAMS = ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b")
 
 
 def _shape(variant, N, F, H, C, S, W, L):
@@ -38,38 +37,51 @@ def workspace_bytes(variant, N, F, H, C, S, W, L):
     return n.value
 
 
+def _split_params(params, L):
+    """Function inputs -> dict of the tensors the C ABI wants.  `params` is
+    (fc0_w, fc0_b, w_ih, w_hh, b_ih, b_hh, att_w, att_b, fc2_w, fc2_b, bank_w_0..L-1, bank_b_0..L-1);
+    the bank entries are views of one contiguous [L,H,H] / [L,H] buffer (see _Aggregator._bank)."""
+    names = ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b")
+    p = dict(zip(names, params[:10]))
+    p["bank_ws"], p["bank_bs"] = params[10:10 + L], params[10 + L:10 + 2 * L]
+    return p
+
+
 class _PaggFunction(torch.autograd.Function):
     """forward/backward through pn_pagg_forward / pn_pagg_backward."""
 
     @staticmethod
-    def forward(ctx, cfg, X, ids, codes, sel, *params):
-        lib = _lib.load()
-        p = dict(zip(_PARAM_ORDER, params))
-        dev = X.device
-        out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
-        sh = _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
-        nbytes = ctypes.c_int64(0)
-        _lib.check(lib.pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(nbytes)))
-        ws = cfg.get("workspace")
-        if ws is None or ws.numel() < nbytes.value or ws.device != dev:
-            ws = torch.empty(max(nbytes.value, 1), dtype=torch.uint8, device=dev)
+    def _args(cfg, X, ids, codes, sel, p):
         a = _lib.PaggArgs()
-        a.shape = sh
+        a.shape = _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
         a.X, a.ids, a.codes, a.sel = X.data_ptr(), ids.data_ptr(), codes.data_ptr(), sel.data_ptr()
-        for k in _PARAM_ORDER:
+        for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b"):
             setattr(a, k, p[k].data_ptr() if p[k] is not None else None)
+        a.bank_w, a.bank_b = cfg["bank_w"].data_ptr(), cfg["bank_b"].data_ptr()
         a.p_seq, a.p_cls, a.seed = cfg["p_seq"], cfg["p_cls"], cfg["seed"]
         ms, mc = cfg.get("mask_seq"), cfg.get("mask_cls")
         a.mask_seq = ms.data_ptr() if ms is not None else None
         a.mask_cls = mc.data_ptr() if mc is not None else None
+        return a
+
+    @staticmethod
+    def forward(ctx, cfg, X, ids, codes, sel, *params):
+        lib = _lib.load()
+        p = _split_params(params, cfg["L"])
+        dev = X.device
+        out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
+        nbytes = workspace_bytes(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
+        ws = cfg.get("workspace")
+        if ws is None or ws.numel() < nbytes or ws.device != dev:
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
         a.out = out.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         if cfg["S"] > 0:
-            _lib.check(lib.pn_pagg_forward(ctypes.byref(a), stream))
-        ctx.cfg, ctx.ws, ctx.masks = cfg, ws, (ms, mc)
-        ctx.save_for_backward(X, ids, codes, sel, *[t for t in params if t is not None])
+            _lib.check(lib.pn_pagg_forward(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        ctx.cfg, ctx.ws = cfg, ws
         ctx.present = [t is not None for t in params]
+        ctx.save_for_backward(X, ids, codes, sel, *[t for t in params if t is not None])
         return out
 
     @staticmethod
@@ -80,35 +92,33 @@ class _PaggFunction(torch.autograd.Function):
         X, ids, codes, sel = saved[:4]
         it = iter(saved[4:])
         params = [next(it) if pres else None for pres in ctx.present]
-        p = dict(zip(_PARAM_ORDER, params))
+        L = cfg["L"]
+        p = _split_params(params, L)
         g_out = g_out.contiguous().float()
-        sh = _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
-        a = _lib.PaggArgs()
-        a.shape = sh
-        a.X, a.ids, a.codes, a.sel = X.data_ptr(), ids.data_ptr(), codes.data_ptr(), sel.data_ptr()
+        a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
         grads = {}
-        for k in _PARAM_ORDER:
-            setattr(a, k, p[k].data_ptr() if p[k] is not None else None)
+        for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b"):
             if p[k] is not None:
                 grads[k] = torch.empty_like(p[k])
                 setattr(a, "g_" + k, grads[k].data_ptr())
+        g_bank_w, g_bank_b = torch.empty_like(cfg["bank_w"]), torch.empty_like(cfg["bank_b"])
+        a.g_bank_w, a.g_bank_b = g_bank_w.data_ptr(), g_bank_b.data_ptr()
         gX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
         a.g_X = gX.data_ptr() if gX is not None else None
-        a.p_seq, a.p_cls, a.seed = cfg["p_seq"], cfg["p_cls"], cfg["seed"]
-        ms, mc = ctx.masks
-        a.mask_seq = ms.data_ptr() if ms is not None else None
-        a.mask_cls = mc.data_ptr() if mc is not None else None
         a.workspace, a.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
         a.g_out = g_out.data_ptr()
-        stream = ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
         if cfg["S"] > 0:
-            _lib.check(lib.pn_pagg_backward(ctypes.byref(a), stream))
+            _lib.check(lib.pn_pagg_backward(ctypes.byref(a),
+                                            ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)))
         else:
-            for g in grads.values():
+            for g in list(grads.values()) + [g_bank_w, g_bank_b]:
                 g.zero_()
             if gX is not None:
                 gX.zero_()
-        return (None, gX, None, None, None) + tuple(grads.get(k) for k in _PARAM_ORDER)
+        head = tuple(grads.get(k) for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b",
+                                            "fc2_w", "fc2_b"))
+        return (None, gX, None, None, None) + head + tuple(g_bank_w[d] for d in range(L)) + tuple(
+            g_bank_b[d] for d in range(L))
 
 
 def _as_index_tensors(neis, layer_type, indices, num_w, walk_len, device):
@@ -141,6 +151,7 @@ class _Aggregator(nn.Module):
         self._ws_eval = None
         self._mask_seq = None     # test hook: explicit dropout masks (reference order)
         self._mask_cls = None
+        self._bank_flat = (None, None)
 
     # ---- dropout probability: ctor argument, else the module-level global like the reference -------
     def dropout_p(self):
@@ -149,11 +160,41 @@ class _Aggregator(nn.Module):
     def set_dropout(self, p):
         self._dropout = p
 
-    def _bank(self):
+    def _bank_layers(self):
         raise NotImplementedError
 
     def _cell(self):
         raise NotImplementedError
+
+    def _bank(self):
+        """The L distance layers as ONE contiguous [L,H,H] / [L,H] pair (what the kernels read), without a
+        per-step torch.stack: the layers' weight/bias Parameters are re-pointed to be views of two flat
+        buffers.  Anything that re-creates the parameters (.to(), .cuda()) is detected by address and the
+        buffers are rebuilt.  state_dict keys and Parameter identities are unchanged."""
+        lins = self._bank_layers()
+        H = self.hidden_size
+        fw, fb = self._bank_flat
+        ok = (fw is not None and fw.device == lins[0].weight.device and
+              all(l.weight.data_ptr() == fw.data_ptr() + d * H * H * 4 and l.bias.data_ptr() == fb.data_ptr() + d * H * 4
+                  for d, l in enumerate(lins)))
+        if not ok:
+            with torch.no_grad():
+                fw = torch.stack([l.weight.detach() for l in lins]).contiguous()
+                fb = torch.stack([l.bias.detach() for l in lins]).contiguous()
+                for d, l in enumerate(lins):
+                    l.weight.data = fw[d]
+                    l.bias.data = fb[d]
+            self._bank_flat = (fw, fb)
+        return fw, fb, [l.weight for l in lins], [l.bias for l in lins]
+
+    def _param_inputs(self):
+        fw, fb, ws, bs = self._bank()
+        cell = self._cell()
+        att = getattr(self, "attw", None)
+        head = (self.fc0.weight, self.fc0.bias, cell.weight_ih_l0, cell.weight_hh_l0, cell.bias_ih_l0, cell.bias_hh_l0,
+                att.weight if att is not None else None, att.bias if att is not None else None,
+                self.fc2.weight, self.fc2.bias)
+        return fw, fb, head + tuple(ws) + tuple(bs)
 
     def forward(self, X, neis, num_w, walk_len, indices, layer_type, indxx=None):
         dev = X.device
@@ -161,14 +202,14 @@ class _Aggregator(nn.Module):
             raise RuntimeError("pathnet_amd aggregators run on the GPU only (X is on %s); no CPU fallback" % dev)
         X = X.contiguous().float()
         ids, codes, sel, S = _as_index_tensors(neis, layer_type, indices, num_w, walk_len, dev)
-        bank_w, bank_b = self._bank()
-        cell = self._cell()
-        att = getattr(self, "attw", None)
+        fw, fb, params = self._param_inputs()
         training = self.training
         p = self.dropout_p() if training else 0.0
         cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=self.hidden_size, C=self.out_size, S=S,
-                   W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None,
+                   W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
                    seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
+        if len(params) != 10 + 2 * cfg["L"]:
+            raise ValueError("walk_len=%d but the module has %d distance layers" % (cfg["L"], (len(params) - 10) // 2))
         if training and (self._mask_seq is not None or self._mask_cls is not None):
             cfg["mask_seq"], cfg["mask_cls"] = self._mask_seq, self._mask_cls
             cfg["p_seq"] = cfg["p_cls"] = 0.0
@@ -177,10 +218,6 @@ class _Aggregator(nn.Module):
             if self._ws_eval is None or self._ws_eval.numel() < need or self._ws_eval.device != dev:
                 self._ws_eval = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
             cfg["workspace"] = self._ws_eval
-        params = (self.fc0.weight, self.fc0.bias, bank_w, bank_b, cell.weight_ih_l0, cell.weight_hh_l0,
-                  cell.bias_ih_l0, cell.bias_hh_l0,
-                  att.weight.reshape(-1) if att is not None else None, att.bias if att is not None else None,
-                  self.fc2.weight, self.fc2.bias)
         return _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
 
 
@@ -198,8 +235,8 @@ class PathNet(_Aggregator):
         self.attw = nn.Linear(2 * hidden_size, 1)
         self.Lrelu = nn.LeakyReLU()
 
-    def _bank(self):
-        return torch.stack([l.weight for l in self.nets]), torch.stack([l.bias for l in self.nets])
+    def _bank_layers(self):
+        return list(self.nets)
 
     def _cell(self):
         return self.LSTM
@@ -233,9 +270,8 @@ class PAGG(_Aggregator):
         for lin in (self.fc0, self.fc2, self.nei0, self.nei1, self.nei2, self.nei3):
             nn.init.xavier_uniform_(lin.weight)
 
-    def _bank(self):
-        ls = (self.nei0, self.nei1, self.nei2, self.nei3)
-        return torch.stack([l.weight for l in ls]), torch.stack([l.bias for l in ls])
+    def _bank_layers(self):
+        return [self.nei0, self.nei1, self.nei2, self.nei3]
 
     def _cell(self):
         return self.RNN

@@ -41,14 +41,17 @@ class OracleOps:
 
     def _forward(self, cfg, Xh, ids, codes, sel, p):
         bank, cell = self._names()
-        leaf = {k: (v.detach().clone().requires_grad_(True) if v is not None else None) for k, v in p.items()}
+        leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()
+                if k not in ("bank_ws", "bank_bs") and v is not None}
+        leaf["bank_w"] = cfg["bank_w"].detach().clone().requires_grad_(True)
+        leaf["bank_b"] = cfg["bank_b"].detach().clone().requires_grad_(True)
         params = {"fc2.weight": leaf["fc2_w"], "fc2.bias": leaf["fc2_b"],
                   cell + ".weight_ih_l0": leaf["w_ih"], cell + ".weight_hh_l0": leaf["w_hh"],
                   cell + ".bias_ih_l0": leaf["b_ih"], cell + ".bias_hh_l0": leaf["b_hh"]}
         for d, name in enumerate(bank):
             params[name + ".weight"] = leaf["bank_w"][d]
             params[name + ".bias"] = leaf["bank_b"][d]
-        if leaf.get("att_w") is not None:
+        if "att_w" in leaf:
             params["attw.weight"] = leaf["att_w"].reshape(1, -1)
             params["attw.bias"] = leaf["att_b"]
         Xh = Xh.detach().clone().requires_grad_(True)
@@ -58,7 +61,7 @@ class OracleOps:
 
     def backward(self, state, g_out):
         out, Xh, leaf = state
-        keys = [k for k, v in leaf.items() if v is not None and k not in ("fc0_w", "fc0_b")]
+        keys = [k for k in leaf if k not in ("fc0_w", "fc0_b")]
         gs = torch.autograd.grad(out, [Xh] + [leaf[k] for k in keys], g_out, allow_unused=True)
         return gs[0], {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(keys, gs[1:])}
 

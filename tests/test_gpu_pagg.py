@@ -329,3 +329,37 @@ def test_training_loop_reduces_loss():
         first = loss.item() if first is None else first
         last = loss.item()
     assert last < 0.5 * first, (first, last)
+
+
+# ------------------------------------------------------------------------------------------------
+# node-sharded entry points (Xh_in / g_Xh / pn_linear_backward) on one GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["homo", "hetero", "pagg"])
+def test_sharded_runner_hip_ops_match_plain_module(variant):
+    """ShardedAggregator with the HIP backend and no process group = the plain module: exercises the
+    projected-features entry (Xh_in), the g_Xh output and pn_linear_backward that the multi-GPU path uses."""
+    from pathnet_amd import dist as pdist
+    torch.manual_seed(31)
+    rng = np.random.default_rng(31)
+    N, F, H, C, W, L, S = 150, 40, 128, 5, 40, 4, 70
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    X = torch.rand(N, F).cuda()
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    G = torch.randn(S, C).cuda()
+    out_a = run_module(m, X, ids, codes, mask, W, L)
+    (out_a * G).sum().backward()
+    grads_a = {k: v.grad.clone() for k, v in m.named_parameters()}
+    m.zero_grad()
+    runner = pdist.ShardedAggregator(m, N, 0, N)
+    out_b = runner(X, torch.as_tensor(ids.reshape(S, -1)), W, L, torch.as_tensor(sel.astype(np.int32)),
+                   torch.as_tensor(codes))
+    (out_b * G).sum().backward()
+    assert (out_a - out_b).abs().max().item() < 1e-6
+    for k, v in m.named_parameters():
+        ref = grads_a[k]
+        assert (v.grad - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), k
