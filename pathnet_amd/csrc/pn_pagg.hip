@@ -61,6 +61,20 @@ using namespace pn;
 #define PN_BWD_WAVES 2
 #endif
 
+#ifndef PN_TRACE_PHASES
+#define PN_TRACE_PHASES 0   // 1: tuning builds only -- wave 0 of every workgroup stamps s_memtime at phase boundaries
+#endif
+#if PN_TRACE_PHASES
+__device__ long long *g_trace_buf = nullptr;   // [blocks][64] stamps, set with pn_debug_set_trace
+#define PN_STAMP(slot)                                                                  \
+    do {                                                                                \
+        if (g_trace_buf && threadIdx.x == 0 && (slot) < 64)                             \
+            g_trace_buf[(size_t)blockIdx.x * 64 + (slot)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define PN_STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 // ================================================================================================
@@ -406,11 +420,13 @@ __global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqF
     gather_issue(0);
 #endif
     for (int t = 0; t < p.L; t++) {
+        PN_STAMP(4 * t + 0);
 #if !PN_FWD_PREFETCH_X
         gather_issue(t);
 #endif
         gather_commit(t);
         __syncthreads();
+        PN_STAMP(4 * t + 1);
 #if PN_FWD_PREFETCH_X
         if (t + 1 < p.L) gather_issue(t + 1);
 #endif
@@ -472,6 +488,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqF
         else
             k_loop(std::integral_constant<int, H / 4>{}, p.Wp);
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
+        PN_STAMP(4 * t + 2);
 
         // ---- cell update in registers; h_t goes back to LDS for the next step ----------------------
 #pragma unroll
@@ -505,6 +522,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqF
                         p.xh[((int64_t)q * p.L + t + 1) * 2 * H + H + col] = h;
                 }
             }
+        PN_STAMP(4 * t + 3);
     }
 }
 
@@ -723,10 +741,27 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
             for (int mem = lane; mem < W; mem += 64) dsc[mem] = p.variant == PN_VARIANT_HOMO ? dco[mem] : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
+        // The attention-ego gradient of consecutive members usually lands on the same table row (all W paths of a
+        // node start at that node): it is accumulated in registers and flushed with one atomic per row change.
+        int64_t cur_row = -1;
+        float ego_acc[4] = {0.f, 0.f, 0.f, 0.f};
+        auto flush = [&]() {
+            if (cur_row < 0) return;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int j = lane + 64 * i;
+                if (j < H) atomicAdd(&p.dego[cur_row + j], ego_acc[i]);
+                ego_acc[i] = 0.0f;
+            }
+        };
         for (int mem = 0; mem < W; mem++) {
             const int64_t s = (int64_t)g * W + mem;
             const float ds = dsc[mem], cf = p.coef[s];
             const int64_t erow = p.variant == PN_VARIANT_PAGG ? 0 : (int64_t)p.egoidx[s] * H;
+            if (p.variant != PN_VARIANT_PAGG && erow != cur_row) {   // wave-uniform
+                flush();
+                cur_row = erow;
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int j = lane + 64 * i;
@@ -736,13 +771,14 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                         dh += ds * p.att_w[j];
                         gaw_h[i] += ds * p.hn[s * H + j];
                         gaw_e[i] += ds * p.ego_tab[erow + j];
-                        atomicAdd(&p.dego[erow + j], ds * p.att_w[H + j]);
+                        ego_acc[i] += ds * p.att_w[H + j];
                     }
                     p.dhn[s * H + j] = dh;
                 }
             }
             gab += ds;
         }
+        if (p.variant != PN_VARIANT_PAGG) flush();
     }
     if (p.variant == PN_VARIANT_PAGG) return;   // block-uniform
 #pragma unroll
@@ -803,6 +839,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
         }
 
     for (int t = p.L - 1; t >= 0; t--) {
+        PN_STAMP(4 * (p.L - 1 - t) + 0);
         // ---- cell backward.  All loads of a half tile are issued together (unconditionally, padded rows read a
         //      clamped row and are zeroed afterwards) so the wave pays one memory round trip, not one per element.
 #pragma unroll
@@ -856,6 +893,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
                 }
             }
         __syncthreads();
+        PN_STAMP(4 * (p.L - 1 - t) + 1);
 
         // ---- [dx_t ; dh_{t-1}] = dG_t . [W_ih | W_hh]; the dh half is not needed at t = 0 ------------------------
         f32x16 acc[MTILES][2];
@@ -911,6 +949,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
         else
             k_loop(std::integral_constant<int, 1>{});
         __syncthreads();
+        PN_STAMP(4 * (p.L - 1 - t) + 2);
 
 #pragma unroll
         for (int mt = 0; mt < MTILES; mt++)
@@ -934,6 +973,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
                 }
                 dh[mt][r] = acc[mt][1][r];
             }
+        PN_STAMP(4 * (p.L - 1 - t) + 3);
     }
 }
 
@@ -1238,6 +1278,13 @@ int pn_linear_backward(const float *dY, const float *gate, const float *X, const
     }
     return PN_OK;
 }
+
+#if PN_TRACE_PHASES
+int pn_debug_set_trace(long long *dev_buf) {
+    PN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &dev_buf, sizeof dev_buf));
+    return PN_OK;
+}
+#endif
 
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
     if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_debug_offsets: null");
