@@ -388,8 +388,8 @@ __global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqF
             const int q = q0 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < p.P) {
-                const int ri = p.rowidx[(int64_t)q * p.L + t];
-                v = Z4[(int64_t)ri * (H / 4) + c4];
+                const uint32_t ri = (uint32_t)p.rowidx[(uint32_t)q * (uint32_t)p.L + t];
+                v = Z4[ri * (uint32_t)(H / 4) + c4];
                 if (p.mask) {
                     const float4 m = reinterpret_cast<const float4 *>(
                         p.mask)[((int64_t)t * p.P + p.slotof[q]) * (H / 4) + c4];
@@ -410,9 +410,12 @@ __global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqF
             const int q = q0 + row;
             *reinterpret_cast<float4 *>(&lds[row * PITCH + 4 * c4]) = xr[i];
             if (p.xh && q < p.P) {
-                float4 *xo = reinterpret_cast<float4 *>(p.xh + ((int64_t)q * p.L + t) * 2 * H);
-                xo[c4] = xr[i];
-                if (t == 0) xo[H / 4 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+                // 32-bit element offsets (check_shape bounds every tensor below 2^32 elements): one VGPR per
+                // address on a uniform base instead of a 64-bit pointer pair
+                float4 *xo4 = reinterpret_cast<float4 *>(p.xh);
+                const uint32_t xo = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4;
+                xo4[xo] = xr[i];
+                if (t == 0) xo4[xo + H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -507,19 +510,20 @@ __global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqF
                     cst[mt][r] = c;
                     h = og * tanhf_(c);
                     if (p.saved && q < p.P) {
-                        float *sv = p.saved + (((int64_t)q * p.L + t) * SV) * H + col;
-                        sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+                        const uint32_t so = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
+                        p.saved[so] = ig; p.saved[so + H] = fg; p.saved[so + 2 * H] = gg; p.saved[so + 3 * H] = og;
+                        p.saved[so + 4 * H] = c;
                     }
                 } else {
                     h = tanhf_(acc[mt][0][r]);
-                    if (p.saved && q < p.P) p.saved[((int64_t)q * p.L + t) * H + col] = h;
+                    if (p.saved && q < p.P) p.saved[((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)H + col] = h;
                 }
                 lds[row * PITCH + H + col] = h;
                 if (q < p.P) {
                     if (t == p.L - 1)
-                        p.hn[(int64_t)q * H + col] = h;
+                        p.hn[(uint32_t)q * (uint32_t)H + col] = h;
                     else if (p.xh)
-                        p.xh[((int64_t)q * p.L + t + 1) * 2 * H + H + col] = h;
+                        p.xh[((uint32_t)q * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col] = h;
                 }
             }
         PN_STAMP(4 * t + 3);
@@ -832,10 +836,10 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
         for (int r = 0; r < 16; r++) {
             const int q = q0 + mt * 32 + acc_row(r, lane);
             const int qc = min(q, p.P - 1);
-            const float dh0 = p.dhn[(int64_t)qc * H + col];     // unconditional load, select afterwards
+            const float dh0 = p.dhn[(uint32_t)qc * (uint32_t)H + col];     // unconditional load, select afterwards
             dh[mt][r] = q < p.P ? dh0 : 0.0f;
             dc[mt][r] = 0.0f;
-            cnext[mt][r] = G == 4 ? p.saved[(((int64_t)qc * p.L + (p.L - 1)) * SV + 4) * H + col] : 0.0f;
+            cnext[mt][r] = G == 4 ? p.saved[(((uint32_t)qc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col] : 0.0f;
         }
 
     for (int t = p.L - 1; t >= 0; t--) {
@@ -851,12 +855,13 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
                 for (int e = 0; e < 8; e++) {
                     const int r = half * 8 + e;
                     const int qc = min(q0 + mt * 32 + acc_row(r, lane), p.P - 1);
-                    const float *sv = p.saved + (((int64_t)qc * p.L + t) * SV) * H + col;
+                    const uint32_t so = ((uint32_t)qc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
                     if (G == 4) {
-                        vi[e] = sv[0]; vf[e] = sv[H]; vg[e] = sv[2 * H]; vo[e] = sv[3 * H];
-                        vc[e] = t > 0 ? sv[4 * H - (int64_t)SV * H] : 0.0f;     // c_{t-1}
+                        vi[e] = p.saved[so]; vf[e] = p.saved[so + H]; vg[e] = p.saved[so + 2 * H];
+                        vo[e] = p.saved[so + 3 * H];
+                        vc[e] = t > 0 ? p.saved[so - H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
                     } else {
-                        vi[e] = sv[0];                                            // h_t
+                        vi[e] = p.saved[so];                                      // h_t
                     }
                 }
 #pragma unroll
@@ -866,7 +871,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
                     const int q = q0 + row;
                     const bool ok = q < p.P;
                     float *l = &lds[row * PITCH + col];
-                    float *d = p.dG + ((int64_t)min(q, p.P - 1) * p.L + t) * GH + col;
+                    float *d = p.dG + (((uint32_t)min(q, p.P - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col);
                     if (G == 4) {
                         const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
                         const float tc = tanhf_(cnext[mt][r]);
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
 #elif PN_BWD_EXPERIMENT == 2
                     if (dx == 123.456f) p.dZ[0] = dx;              // EXPERIMENT ONLY: no scatter at all
 #else
-                    atomicAdd(&p.dZ[(int64_t)s_rowidx[row * p.L + t] * H + col], dx);
+                    atomicAdd(&p.dZ[(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col], dx);
 #endif
                 }
                 dh[mt][r] = acc[mt][1][r];
@@ -1208,6 +1213,10 @@ int check_shape(const pn_pagg_shape &s) {
         PN_FAIL(PN_ERR_ARG, "PAGG has exactly four distance layers nei0..nei3 (copy.py:310-313); L=%d", s.L);
     if ((int64_t)s.S * s.W * s.L > 2000000000LL || (int64_t)s.N * s.L > 2000000000LL)
         PN_FAIL(PN_ERR_ARG, "index space exceeds int32; split the node set");
+    // the recurrent kernels address their per-path tensors with 32-bit element offsets
+    if ((int64_t)s.S * s.W * s.L * 5 * s.H >= (1LL << 32) || (int64_t)s.N * s.L * s.H >= (1LL << 32))
+        PN_FAIL(PN_ERR_ARG, "S*W*L*5*H = %lld elements exceeds 2^32: aggregate the masked nodes in batches",
+                (long long)s.S * s.W * s.L * 5 * s.H);
     return PN_OK;
 }
 
