@@ -363,3 +363,52 @@ def test_sharded_runner_hip_ops_match_plain_module(variant):
     for k, v in m.named_parameters():
         ref = grads_a[k]
         assert (v.grad - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item()), k
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size configurations (BASELINE.json configs): size-independent properties
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["homo", "pagg"])
+def test_pubmed_scale_batch_invariance_and_oracle_subset(variant):
+    """Pubmed-size forward+backward (N=19717, F=500, 9464 masked nodes = 378 560 paths).  For the homo / PAGG
+    classes a node's logits depend only on its own paths, so (a) any sub-batch must reproduce the rows of the
+    full batch, and (b) a small sub-batch is checked against the CPU oracle."""
+    torch.manual_seed(41)
+    rng = np.random.default_rng(41)
+    N, F, H, C, W, L = 19717, 500, 128, 3, 40, 4
+    S = 9464
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    X = torch.rand(N, F)
+    Xd = X.cuda()
+    sel = np.sort(rng.permutation(N)[:S])
+    mask = np.zeros(N, bool)
+    mask[sel] = True
+    ids = rng.integers(0, N, (S, W, L)).astype(np.int32)
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :]).astype(np.uint8)
+    d_ids, d_codes = torch.as_tensor(ids).cuda(), torch.as_tensor(codes).cuda()
+    out = m(Xd, d_ids, W, L, torch.as_tensor(sel.astype(np.int32)).cuda(), d_codes, None)
+    assert out.shape == (S, C) and torch.isfinite(out).all()
+    out.sum().backward()
+    g_full = {k: v.grad.clone() for k, v in m.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in g_full.values())
+    pick = np.sort(rng.permutation(S)[:64])
+    with torch.no_grad():
+        sub = m(Xd, d_ids[pick], W, L, torch.as_tensor(sel[pick].astype(np.int32)).cuda(), d_codes[pick], None)
+    assert (sub - out[pick].detach()).abs().max().item() < 2e-6          # batch-composition invariance
+    want = po.forward(variant, {k: v.detach().cpu() for k, v in m.state_dict().items()}, X, ids[pick], codes[pick],
+                      sel[pick], W, L)
+    assert (sub.cpu() - want).abs().max().item() < TOL_OUT
+    # linearity of the backward in the upstream gradient: grad(2*G) == 2*grad(G)
+    m.zero_grad()
+    out2 = m(Xd, d_ids, W, L, torch.as_tensor(sel.astype(np.int32)).cuda(), d_codes, None)
+    (2.0 * out2).sum().backward()
+    for k, v in m.named_parameters():
+        ref = 2.0 * g_full[k]
+        assert (v.grad - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item()), k
+
+
+def test_rejects_batches_beyond_32bit_offsets():
+    from pathnet_amd import _lib, modules
+    with pytest.raises(_lib.PnError):
+        modules.workspace_bytes("homo", 1000, 16, 128, 3, 50000, 40, 4)      # S*W*L*5*H >= 2^32

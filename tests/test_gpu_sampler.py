@@ -134,3 +134,19 @@ def test_cli_output_is_byte_identical_to_reference_program(tmp_path):
                     "--epochs", "3", "--per-epoch"], cwd=cwd, env=env, check=True)
     cat = b"".join(open(os.path.join(cwd, "syn_%d_%d_%d_merw.txt" % (W, L, e)), "rb").read() for e in range(3))
     assert cat == ref[:len(cat)]
+
+
+def test_pubmed_scale_philox_bit_exact_vs_oracle():
+    """configs[2]: Pubmed-size graph (19 717 nodes, dense hop table 389 MB in HBM), one epoch = 788 680 paths."""
+    from pathnet_amd import DRAW_PHILOX, MerwSampler
+    n, u, v, p = synthetic_graph(19717, 5, 3)
+    W, L = 40, 4
+    smp = MerwSampler(n, u, v, p, L)
+    ids, codes = smp.sample(W, 2024, epoch_begin=7, epoch_count=1, draw_source=DRAW_PHILOX)
+    oi, oc = merw.sample_full(n, u, v, p, W, L, merw.DRAW_PHILOX, 2024, epoch_begin=7, epoch_count=1)
+    assert (ids.cpu().numpy() == oi).all() and (codes.cpu().numpy() == oc).all()
+    # node window = what one of 8 ranks would sample
+    lo, cnt = 3 * (n // 8), n // 8
+    ids_w, codes_w = smp.sample(W, 2024, epoch_begin=7, epoch_count=1, node_begin=lo, node_count=cnt,
+                                draw_source=DRAW_PHILOX)
+    assert (ids_w.cpu().numpy() == oi[:, lo:lo + cnt]).all() and (codes_w.cpu().numpy() == oc[:, lo:lo + cnt]).all()
