@@ -75,6 +75,14 @@ int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, con
  * every node a walk of length seq_len can visit.  The emitted distance code is dis - 1. */
 int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t seq_len, uint8_t *dis);
 
+/* Sorted, duplicate-free adjacency in CSR form (host): for reverse = 0 the out-neighbours of every node
+ * (row "u v p" puts v into list u), for reverse = 1 the in-neighbours.  Used instead of the dense hop
+ * table when n*n bytes is too much (the reference's dis[N][N], gen_merw.cpp:10, caps n at 100050):
+ * the walker then derives dis[st][x] - 1 exactly from these lists (see pn_sampler_tables).
+ * Call with cap = 0 to get *count (and off[]); then with cap >= *count. */
+int pn_csr_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t reverse, int64_t *off,
+                 int32_t *adj, int64_t cap, int64_t *count);
+
 /* The first `count` values rand() returns after srand(seed), starting at stream position `first`
  * (host, int32).  Uses the same jump algebra as the device generator (glibc TYPE_3 recurrence as
  * a polynomial over Z/2^32), so any window of the reference's draw stream (gen_merw.cpp:88-89) can
@@ -94,7 +102,14 @@ typedef struct pn_sampler_tables {
     int64_t total;           /* alias triples */
     const int64_t *off;      /* dev [n+1]  prefix into the triple array */
     const int32_t *triples;  /* dev [total*4] packed {A, B, thr, 0} (one 16-byte load per roll) */
-    const uint8_t *dis;      /* dev [n*n]  dense hop table from pn_hops_dense */
+    const uint8_t *dis;      /* dev [n*n]  dense hop table from pn_hops_dense, or NULL: */
+    /* dis == NULL selects on-the-fly hop codes (any n): exact hops(st -> x) by meeting in the middle of the
+     * <=2-hop out-ball of the source (a hash table in LDS, built once per source node) and a bounded
+     * search over the in-neighbours of x.  Needs both CSR lists from pn_csr_build (device copies). */
+    const int64_t *adj_off;  /* dev [n+1] */
+    const int32_t *adj;      /* dev out-neighbours, sorted per node */
+    const int64_t *radj_off; /* dev [n+1] */
+    const int32_t *radj;     /* dev in-neighbours, sorted per node */
 } pn_sampler_tables;
 
 /* Pack host A/B/thr arrays into the 16-byte device layout (host helper, dst is a host buffer of

@@ -35,7 +35,8 @@ class DeviceInfo(ctypes.Structure):
 
 
 class SamplerTables(ctypes.Structure):
-    _fields_ = [("n", ctypes.c_int32), ("total", ctypes.c_int64), ("off", vp), ("triples", vp), ("dis", vp)]
+    _fields_ = [("n", ctypes.c_int32), ("total", ctypes.c_int64), ("off", vp), ("triples", vp), ("dis", vp),
+                ("adj_off", vp), ("adj", vp), ("radj_off", vp), ("radj", vp)]
 
 
 class PaggShape(ctypes.Structure):
@@ -65,6 +66,8 @@ SIGNATURES = {
                                       c_f64p, c_u32p, ctypes.c_int64, c_i64p]),
     "pn_alias_pack": (ctypes.c_int, [ctypes.c_int64, c_i32p, c_i32p, c_u32p, c_i32p]),
     "pn_hops_dense": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, ctypes.c_int32, c_u8p]),
+    "pn_csr_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, ctypes.c_int32, c_i64p, c_i32p,
+                                    ctypes.c_int64, c_i64p]),
     "pn_glibc_draws": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64, c_i32p]),
     "pn_sample_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_int32, c_i64p]),

@@ -257,6 +257,38 @@ int pn_alias_pack(int64_t total, const int32_t *A, const int32_t *B, const uint3
     return PN_OK;
 }
 
+int pn_csr_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t reverse, int64_t *off,
+                 int32_t *adj, int64_t cap, int64_t *count) {
+    if (n < 0 || m < 0 || !off || !count || (m > 0 && (!u || !v))) PN_FAIL(PN_ERR_ARG, "pn_csr_build: bad argument");
+    const int32_t *src = reverse ? v : u, *dst = reverse ? u : v;
+    std::vector<int64_t> start((size_t)n + 1, 0);
+    for (int64_t e = 0; e < m; e++) {
+        if (u[e] < 0 || u[e] >= n || v[e] < 0 || v[e] >= n)
+            PN_FAIL(PN_ERR_ARG, "edge row %lld out of range", (long long)e);
+        start[(size_t)src[e] + 1]++;
+    }
+    for (int32_t i = 0; i < n; i++) start[(size_t)i + 1] += start[i];
+    std::vector<int64_t> cursor(start.begin(), start.end() - 1);
+    std::vector<int32_t> raw((size_t)m);
+    for (int64_t e = 0; e < m; e++) raw[(size_t)cursor[src[e]]++] = dst[e];
+    int64_t total = 0;
+    for (int32_t i = 0; i < n; i++) {
+        int32_t *b = raw.data() + start[i], *e = raw.data() + start[(size_t)i + 1];
+        std::sort(b, e);
+        e = std::unique(b, e);
+        off[i] = total;
+        for (int32_t *q = b; q < e; q++) {
+            if (total < cap && adj) adj[total] = *q;
+            total++;
+        }
+    }
+    off[n] = total;
+    *count = total;
+    if (cap != 0 && cap < total)
+        PN_FAIL(PN_ERR_CAPACITY, "adjacency buffer holds %lld entries, need %lld", (long long)cap, (long long)total);
+    return PN_OK;
+}
+
 int pn_glibc_draws(uint32_t seed, uint64_t first, int64_t count, int32_t *out) {
     if (count < 0 || (count > 0 && !out)) PN_FAIL(PN_ERR_ARG, "pn_glibc_draws: bad argument");
     GlibcState st = glibc_apply(glibc_poly_xpow(first), glibc_seed_state(seed));

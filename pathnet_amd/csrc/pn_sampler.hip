@@ -176,6 +176,182 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     }
 }
 
+// =================================================================================================
+// On-the-fly hop codes (dis == NULL): the walker for graphs whose dense n*n hop table does not fit.
+//
+// One wavefront per source node st.  It first builds the out-ball of st of radius RF <= 2 with exact
+// distances in a private LDS hash table (level-synchronous, insert-if-absent keeps the smaller level).
+// hops(st -> x) for a walk node x at step t (known to be <= t) is then
+//     min( t,  df(x),  min over in-neighbour chains  x <- c1 <- ... <- ck  of  k + df(ck) )
+// with df = distance in the ball.  This is exact: a shortest path of length d has its node at position
+// min(d, RF) inside the ball, at backward depth d - min(d, RF) from x; every other candidate is the
+// length of a real path, i.e. an upper bound.  The backward search is depth-limited by the best bound found so
+// far (best - 1 - RF), which for L <= RF + 2 (L = 4) means no search at all and for L = 6 two levels.
+// A hub whose 2-ball overflows the table falls back to RF = 1 or 0 (deeper backward search, still exact).
+// =================================================================================================
+constexpr int kOtfWaves = 4;                  // source nodes per workgroup
+constexpr int kOtfCap = 2048;                 // hash slots per wave (8 KB)
+constexpr uint32_t kOtfEmpty = 0xFFFFFFFFu;
+constexpr int kOtfMaxDepth = 8;
+
+struct OtfParams {
+    WalkParams w;
+    const int64_t *adj_off;
+    const int32_t *adj;
+    const int64_t *radj_off;
+    const int32_t *radj;
+};
+
+__device__ __forceinline__ uint32_t otf_hash(uint32_t x) {
+    x *= 0x9E3779B1u;
+    return (x ^ (x >> 15)) & (kOtfCap - 1);
+}
+// returns true if (node, d) was newly inserted
+__device__ __forceinline__ bool otf_insert(uint32_t *tab, int32_t node, int d) {
+    uint32_t h = otf_hash((uint32_t)node);
+    const uint32_t packed = ((uint32_t)node << 3) | (uint32_t)d;
+    for (int probe = 0; probe < kOtfCap; probe++) {
+        const uint32_t old = atomicCAS(&tab[h], kOtfEmpty, packed);
+        if (old == kOtfEmpty) return true;
+        if ((old >> 3) == (uint32_t)node) return false;     // already there with a level <= d
+        h = (h + 1) & (kOtfCap - 1);
+    }
+    return false;
+}
+__device__ __forceinline__ int otf_lookup(const uint32_t *tab, int32_t node) {
+    uint32_t h = otf_hash((uint32_t)node);
+    for (int probe = 0; probe < kOtfCap; probe++) {
+        const uint32_t v = tab[h];
+        if (v == kOtfEmpty) return -1;
+        if ((v >> 3) == (uint32_t)node) return (int)(v & 7u);
+        h = (h + 1) & (kOtfCap - 1);
+    }
+    return -1;
+}
+
+template <int DRAW>
+__global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams op) {
+    __shared__ uint32_t s_tab[kOtfWaves][kOtfCap];
+    __shared__ int s_cnt[kOtfWaves];
+    __shared__ uint32_t s_cur[kOtfWaves][kOtfMaxDepth][64];   // per lane DFS cursor / end per level (CSR positions)
+    __shared__ uint32_t s_end[kOtfWaves][kOtfMaxDepth][64];
+    const WalkParams &p = op.w;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int st_l = blockIdx.x * kOtfWaves + wave;
+    if (st_l >= p.node_count) return;                       // wave-uniform; no block barriers below
+    const int32_t st = p.node_begin + st_l;
+    uint32_t *tab = s_tab[wave];
+
+    // ---- out-ball of st, radius rf (largest of 2, 1, 0 that keeps the table at most half full) ----------
+    int rf = 2;
+    for (;; rf--) {
+        for (int i = lane; i < kOtfCap; i += 64) tab[i] = kOtfEmpty;
+        if (lane == 0) s_cnt[wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            otf_insert(tab, st, 0);
+            s_cnt[wave] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int64_t b0 = op.adj_off[st], e0 = op.adj_off[st + 1];
+        bool overflow = false;
+        if (rf >= 1) {
+            if (e0 - b0 > kOtfCap / 2) overflow = true;
+            if (!overflow) {
+                for (int64_t j = b0 + lane; j < e0; j += 64)
+                    if (otf_insert(tab, op.adj[j], 1)) atomicAdd(&s_cnt[wave], 1);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (rf >= 2 && !overflow) {
+            for (int64_t j = b0; j < e0 && !overflow; j++) {
+                const int32_t a = op.adj[j];
+                const int64_t b1 = op.adj_off[a], e1 = op.adj_off[a + 1];
+                if (s_cnt[wave] + (e1 - b1) > kOtfCap / 2) {    // could exceed half load: give up this radius
+                    overflow = true;
+                    break;
+                }
+                for (int64_t k = b1 + lane; k < e1; k += 64)
+                    if (otf_insert(tab, op.adj[k], 2)) atomicAdd(&s_cnt[wave], 1);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!overflow || rf == 0) break;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- walks: lane = walk index (loop when W > 64), all epochs of the window -------------------------
+    for (int64_t e_l = 0; e_l < p.epoch_count; e_l++) {
+        for (int wi = lane; wi < p.W; wi += 64) {
+            const int64_t g = (e_l * p.node_count + st_l) * p.W + wi;
+            const uint64_t walk = ((uint64_t)(p.epoch_begin + e_l) * (uint64_t)p.n + (uint64_t)st) * (uint64_t)p.W + wi;
+            rocrand_state_philox4x32_10 rng;
+            uint4 word = {0, 0, 0, 0};
+            if (DRAW == PN_DRAW_PHILOX) rocrand_init(p.seed, walk, 0, &rng);
+            const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * 2 * (int64_t)p.L : nullptr;
+            int32_t *out_ids = p.ids + g * p.L;
+            uint8_t *out_codes = p.codes + g * p.L;
+            int32_t x = st;
+            for (int32_t t = 0; t < p.L; t++) {
+                // ---- exact hop code of x ------------------------------------------------------------------
+                int best = t;
+                if (x == st) best = 0;
+                if (best > 0) {
+                    const int d0 = otf_lookup(tab, x);
+                    if (d0 >= 0 && d0 < best) best = d0;
+                    // depth-limited DFS over in-neighbour chains; a level k can only help while k <= best - 1 - rf
+                    if (best - 1 - rf >= 1) {
+                        int d = 0;
+                        s_cur[wave][0][lane] = (uint32_t)op.radj_off[x];
+                        s_end[wave][0][lane] = (uint32_t)op.radj_off[x + 1];
+                        while (d >= 0) {
+                            const uint32_t cur = s_cur[wave][d][lane];
+                            if (cur >= s_end[wave][d][lane] || d + 1 > best - 1 - rf) {
+                                d--;
+                                continue;
+                            }
+                            s_cur[wave][d][lane] = cur + 1;
+                            const int32_t c = op.radj[cur];
+                            const int k = d + 1;
+                            const int dc = otf_lookup(tab, c);
+                            if (dc >= 0 && k + dc < best) best = k + dc;
+                            if (k + 1 <= best - 1 - rf && d + 1 < kOtfMaxDepth) {
+                                d++;
+                                s_cur[wave][d][lane] = (uint32_t)op.radj_off[c];
+                                s_end[wave][d][lane] = (uint32_t)op.radj_off[c + 1];
+                            }
+                        }
+                    }
+                }
+                out_ids[t] = x;
+                out_codes[t] = (uint8_t)best;
+                // ---- roll (same as the dense-table walker) ------------------------------------------------
+                const int64_t o0 = p.off[x];
+                const int32_t len = (int32_t)(p.off[x + 1] - o0);
+                uint32_t r0, r1;
+                if (DRAW == PN_DRAW_GLIBC_REPLAY) {
+                    r0 = (uint32_t)my_draws[2 * t];
+                    r1 = (uint32_t)my_draws[2 * t + 1];
+                } else {
+                    if ((t & 1) == 0) word = rocrand4(&rng);
+                    r0 = ((t & 1) ? word.z : word.x) >> 1;
+                    r1 = ((t & 1) ? word.w : word.y) >> 1;
+                }
+                if (len <= 0) {
+                    if (p.status) atomicExch(p.status, PN_ERR_EMPTY_TABLE);
+                    for (int32_t k = t + 1; k < p.L; k++) {
+                        out_ids[k] = x;
+                        out_codes[k] = out_codes[t];
+                    }
+                    break;
+                }
+                const int4 tr = p.triples[o0 + (int64_t)(r0 % (uint32_t)len)];
+                x = (r1 >= (uint32_t)tr.z) ? tr.x : tr.y;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace pn {
@@ -276,8 +452,12 @@ int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t d
                     int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
                     uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!tb || !tb->off || !tb->triples || !tb->dis || !ids || !codes)
-        PN_FAIL(PN_ERR_ARG, "pn_sample_paths: null table or output");
+    if (!tb || !tb->off || !tb->triples || !ids || !codes) PN_FAIL(PN_ERR_ARG, "pn_sample_paths: null table or output");
+    const bool otf = tb->dis == nullptr;
+    if (otf && (!tb->adj_off || !tb->adj || !tb->radj_off || !tb->radj))
+        PN_FAIL(PN_ERR_ARG, "pn_sample_paths: neither a dense hop table nor the CSR lists for on-the-fly hop codes");
+    if (otf && (tb->n >= (1 << 28) || L > 8))
+        PN_FAIL(PN_ERR_ARG, "on-the-fly hop codes support n < 2^28 and L <= 8 (n=%d L=%d)", tb->n, L);
     if (W < 1 || L < 1 || epoch_begin < 0 || epoch_count < 0 || node_begin < 0 || node_count < 0 ||
         (int64_t)node_begin + node_count > tb->n)
         PN_FAIL(PN_ERR_ARG, "pn_sample_paths: bad window (n=%d W=%d L=%d nodes [%d,+%d))", tb->n, W, L, node_begin,
@@ -352,13 +532,25 @@ int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t d
         PN_CHECK_HIP(hipGetLastError());
         wp.draws = d_draws;
         pn::StageTimer tm(pn::ST_SAMPLER_WALK, stream);
-        const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
-        hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_GLIBC_REPLAY>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+        if (otf) {
+            OtfParams op{wp, tb->adj_off, tb->adj, tb->radj_off, tb->radj};
+            hipLaunchKernelGGL(merw_walk_otf_kernel<PN_DRAW_GLIBC_REPLAY>, dim3((node_count + kOtfWaves - 1) / kOtfWaves),
+                               dim3(kOtfWaves * 64), 0, stream, op);
+        } else {
+            const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
+            hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_GLIBC_REPLAY>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+        }
         PN_CHECK_HIP(hipGetLastError());
     } else if (draw_source == PN_DRAW_PHILOX) {
         pn::StageTimer tm(pn::ST_SAMPLER_WALK, stream);
-        const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
-        hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_PHILOX>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+        if (otf) {
+            OtfParams op{wp, tb->adj_off, tb->adj, tb->radj_off, tb->radj};
+            hipLaunchKernelGGL(merw_walk_otf_kernel<PN_DRAW_PHILOX>, dim3((node_count + kOtfWaves - 1) / kOtfWaves),
+                               dim3(kOtfWaves * 64), 0, stream, op);
+        } else {
+            const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
+            hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_PHILOX>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+        }
         PN_CHECK_HIP(hipGetLastError());
     } else {
         PN_FAIL(PN_ERR_ARG, "unknown draw source %d", draw_source);

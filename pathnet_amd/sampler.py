@@ -66,6 +66,21 @@ def hops_dense(n, u, v, seq_len):
     return dis
 
 
+def csr_build(n, u, v, reverse=False):
+    """Sorted duplicate-free neighbour lists: off int64 [n+1], adj int32 (out-neighbours, or in-neighbours)."""
+    lib = _lib.load()
+    u = np.ascontiguousarray(u, np.int32)
+    v = np.ascontiguousarray(v, np.int32)
+    off = np.zeros(n + 1, np.int64)
+    cnt = ctypes.c_int64(0)
+    args = (n, len(u), _lib.np_ptr(u, ctypes.c_int32), _lib.np_ptr(v, ctypes.c_int32), 1 if reverse else 0,
+            _lib.np_ptr(off, ctypes.c_int64))
+    _lib.check(lib.pn_csr_build(*args, None, 0, ctypes.byref(cnt)))
+    adj = np.empty(max(cnt.value, 1), np.int32)
+    _lib.check(lib.pn_csr_build(*args, _lib.np_ptr(adj, ctypes.c_int32), cnt.value, ctypes.byref(cnt)))
+    return off, adj[:cnt.value]
+
+
 def glibc_draws(seed, first, count):
     out = np.empty(count, np.int32)
     _lib.check(_lib.load().pn_glibc_draws(seed & 0xFFFFFFFF, first, count, _lib.np_ptr(out, ctypes.c_int32)))
@@ -75,7 +90,11 @@ def glibc_draws(seed, first, count):
 class MerwSampler:
     """Device-resident sampler tables for one graph and one path length."""
 
-    def __init__(self, n, u, v, p, seq_len, device="cuda"):
+    DENSE_LIMIT_BYTES = 8 << 30     # hops="auto": dense n*n table up to 8 GB (n <= 92681), else on the fly
+
+    def __init__(self, n, u, v, p, seq_len, device="cuda", hops="auto"):
+        """hops: "dense" = the reference's dis[n][n] byte table in HBM; "otf" = exact hop codes derived on the
+        fly from CSR lists (any n); "auto" picks dense while n*n <= DENSE_LIMIT_BYTES."""
         self.n, self.L = int(n), int(seq_len)
         self.device = torch.device(device)
         off, A, B, S, thr = build_alias(n, u, v, p)
@@ -83,18 +102,31 @@ class MerwSampler:
         packed = np.empty(max(len(A), 1) * 4, np.int32)
         _lib.check(_lib.load().pn_alias_pack(len(A), _lib.np_ptr(A, ctypes.c_int32), _lib.np_ptr(B, ctypes.c_int32),
                                              _lib.np_ptr(thr, ctypes.c_uint32), _lib.np_ptr(packed, ctypes.c_int32)))
-        dis = hops_dense(n, u, v, seq_len)
+        if hops == "auto":
+            hops = "dense" if self.n * self.n <= self.DENSE_LIMIT_BYTES else "otf"
+        if hops not in ("dense", "otf"):
+            raise ValueError("hops must be 'dense', 'otf' or 'auto'")
+        self.hops = hops
         self.d_off = torch.from_numpy(off).to(self.device)
         self.d_triples = torch.from_numpy(packed).to(self.device)
-        self.d_dis = torch.from_numpy(dis).to(self.device)
+        self.d_dis = self.d_adj_off = self.d_adj = self.d_radj_off = self.d_radj = None
+        if hops == "dense":
+            self.d_dis = torch.from_numpy(hops_dense(n, u, v, seq_len)).to(self.device)
+        else:
+            if seq_len > 8:
+                raise ValueError("on-the-fly hop codes support path lengths up to 8")
+            ao, aa = csr_build(n, u, v, reverse=False)
+            ro, ra = csr_build(n, u, v, reverse=True)
+            self.d_adj_off, self.d_adj = torch.from_numpy(ao).to(self.device), torch.from_numpy(aa).to(self.device)
+            self.d_radj_off, self.d_radj = torch.from_numpy(ro).to(self.device), torch.from_numpy(ra).to(self.device)
         self.total = len(A)
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._ws = None
 
     @classmethod
-    def from_edge_file(cls, path, seq_len, device="cuda"):
+    def from_edge_file(cls, path, seq_len, device="cuda", hops="auto"):
         n, u, v, p = read_edge_file(path)
-        return cls(n, u, v, p, seq_len, device=device)
+        return cls(n, u, v, p, seq_len, device=device, hops=hops)
 
     def sample(self, W, seed, epoch_begin=0, epoch_count=1, node_begin=0, node_count=None,
                draw_source=DRAW_PHILOX, check=True, out=None):
@@ -112,8 +144,9 @@ class MerwSampler:
         _lib.check(lib.pn_sample_workspace_bytes(W, L, draw_source, epoch_count, node_count, ctypes.byref(need)))
         if need.value and (self._ws is None or self._ws.numel() < need.value):
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
-        tb = _lib.SamplerTables(self.n, self.total, self.d_off.data_ptr(), self.d_triples.data_ptr(),
-                                self.d_dis.data_ptr())
+        dp = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
+        tb = _lib.SamplerTables(self.n, self.total, self.d_off.data_ptr(), self.d_triples.data_ptr(), dp(self.d_dis),
+                                dp(self.d_adj_off), dp(self.d_adj), dp(self.d_radj_off), dp(self.d_radj))
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if check:
             self._status.zero_()

@@ -108,3 +108,15 @@ def test_workspace_query_and_shape_validation():
 def test_sampler_cli_wrong_argc(capsys):
     assert sampler.main(["only", "two"]) == 0      # reference prints to stderr and returns 0 (gen_merw.cpp:128-132)
     assert "Incorrect number of parameters" in capsys.readouterr().err
+
+
+def test_csr_build_sorted_unique_both_directions():
+    g = golden("sampler_synthetic97_12_5.npz")
+    n, u, v = int(g["n"]), g["u"], g["v"]
+    for rev in (False, True):
+        off, adj = sampler.csr_build(n, u, v, reverse=rev)
+        src, dst = (v, u) if rev else (u, v)
+        for node in (0, 3, 50, n - 1):
+            want = np.unique(dst[src == node])
+            assert (adj[off[node]:off[node + 1]] == want).all()
+        assert off[-1] == len(adj)

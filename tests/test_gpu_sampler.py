@@ -150,3 +150,78 @@ def test_pubmed_scale_philox_bit_exact_vs_oracle():
     ids_w, codes_w = smp.sample(W, 2024, epoch_begin=7, epoch_count=1, node_begin=lo, node_count=cnt,
                                 draw_source=DRAW_PHILOX)
     assert (ids_w.cpu().numpy() == oi[:, lo:lo + cnt]).all() and (codes_w.cpu().numpy() == oc[:, lo:lo + cnt]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# on-the-fly hop codes (no dense n*n table): must give the same codes as the reference's bfs()
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_files("sampler_*.npz"))
+def test_otf_hop_codes_glibc_replay_match_reference_golden(name):
+    from pathnet_amd import DRAW_GLIBC_REPLAY, MerwSampler
+    g = golden(name)
+    smp = MerwSampler(int(g["n"]), g["u"], g["v"], g["p"], int(g["L"]), hops="otf")
+    ids, codes = smp.sample(int(g["W"]), int(g["seed"]), epoch_count=int(g["epochs"]), draw_source=DRAW_GLIBC_REPLAY)
+    assert (ids.cpu().numpy() == g["ids"]).all()
+    bad = np.argwhere(codes.cpu().numpy() != g["codes"])
+    assert bad.size == 0, "first code mismatch at %s" % (bad[0],)
+
+
+def hub_and_directed_graph(n, seed):
+    """A graph that stresses the on-the-fly search: two hubs with degree > 1100 (their 1- and 2-balls overflow the
+    LDS table, forcing the radius-1 / radius-0 fallbacks), one-way edges (in-lists != out-lists), a ring."""
+    rng = np.random.default_rng(seed)
+    src, dst = [], []
+    for a in range(n):
+        src += [a, a]
+        dst += [a, (a + 1) % n]                    # self loop + one-way ring
+    for hub in (5, 77):
+        leaves = rng.permutation(n)[:1200]
+        src += [hub] * len(leaves) + leaves.tolist()
+        dst += leaves.tolist() + [hub] * len(leaves)
+    extra = rng.integers(0, n, (3 * n, 2))
+    src += extra[:, 0].tolist()
+    dst += extra[:, 1].tolist()                    # one-way random edges
+    src, dst = np.array(src, np.int32), np.array(dst, np.int32)
+    key = np.unique(src.astype(np.int64) * n + dst)
+    src, dst = (key // n).astype(np.int32), (key % n).astype(np.int32)
+    deg = np.bincount(src, minlength=n)
+    p = 1.0 / deg[src]
+    return n, src, dst, p
+
+
+@pytest.mark.parametrize("L,W", [(4, 40), (6, 12), (3, 5)])
+def test_otf_hop_codes_match_dense_on_hubs_and_directed_edges(L, W):
+    from pathnet_amd import DRAW_PHILOX, MerwSampler
+    n, u, v, p = hub_and_directed_graph(4000, 9)
+    dense = MerwSampler(n, u, v, p, L, hops="dense")
+    otf = MerwSampler(n, u, v, p, L, hops="otf")
+    a_ids, a_codes = dense.sample(W, 77, epoch_count=2, draw_source=DRAW_PHILOX)
+    b_ids, b_codes = otf.sample(W, 77, epoch_count=2, draw_source=DRAW_PHILOX)
+    assert torch.equal(a_ids, b_ids)
+    bad = torch.nonzero(a_codes != b_codes)
+    assert bad.numel() == 0, "first mismatch %s dense %d otf %d" % (
+        bad[0].tolist(), int(a_codes[tuple(bad[0])]), int(b_codes[tuple(bad[0])]))
+    oi, oc = merw.sample_full(n, u, v, p, W, L, merw.DRAW_PHILOX, 77, epoch_count=2)
+    assert (b_ids.cpu().numpy() == oi).all() and (b_codes.cpu().numpy() == oc).all()
+
+
+def test_otf_large_graph_beyond_the_reference_cap():
+    """n = 400 000 > the reference's compiled-in 100 050 (a dense table would be 160 GB): structural invariants plus
+    exact BFS hop counts from scipy for a sample of source nodes."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import dijkstra
+    from pathnet_amd import DRAW_PHILOX, MerwSampler
+    n, u, v, p = synthetic_graph(400000, 8, 12)
+    W, L = 40, 6
+    smp = MerwSampler(n, u, v, p, L, hops="auto")
+    assert smp.hops == "otf"
+    nodes = 2000
+    ids, codes = smp.sample(W, 5, node_begin=1234, node_count=nodes, draw_source=DRAW_PHILOX)
+    ids, codes = ids.cpu().numpy()[0], codes.cpu().numpy()[0]
+    assert (ids[:, :, 0] == (1234 + np.arange(nodes))[:, None]).all() and (codes[..., 0] == 0).all()
+    assert (codes <= np.arange(L)[None, None, :]).all()
+    A = sp.csr_matrix((np.ones(len(u), np.int8), (u, v)), shape=(n, n))
+    for s in (0, 17, 999, 1999):
+        dist = dijkstra(A, unweighted=True, indices=1234 + s, limit=L)
+        want = dist[ids[s]]
+        assert (codes[s] == want).all(), (s, codes[s][:3], want[:3])
