@@ -199,6 +199,9 @@ typedef struct pn_pagg_args {
      * finished with pn_linear_backward) instead of g_fc0_* / g_X. */
     const float *Xh_in;
     float *g_Xh;
+    /* inference: non-zero skips writing the saved-for-backward tensors (gates, cell states, [x|h] rows --
+     * ~3.6 KB per path step); pn_pagg_backward must not follow such a forward. */
+    int32_t no_save;
 } pn_pagg_args;
 
 int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes);

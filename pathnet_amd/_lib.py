@@ -53,7 +53,7 @@ class PaggArgs(ctypes.Structure):
                  ("g_out", vp), ("g_X", vp)] +
                 [("g_" + k, vp) for k in ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w",
                                           "att_b", "fc2_w", "fc2_b")] +
-                [("Xh_in", vp), ("g_Xh", vp)])
+                [("Xh_in", vp), ("g_Xh", vp), ("no_save", ctypes.c_int32)])
 
 
 # name -> (restype, argtypes): every symbol include/pathnet_hip.h declares

@@ -39,9 +39,6 @@ using namespace pn;
 #ifndef PN_FWD_MT
 #define PN_FWD_MT 32        // sequence slots per workgroup, forward
 #endif
-#ifndef PN_FWD_DEPTH
-#define PN_FWD_DEPTH 1      // k-steps of weight fragments in flight, forward
-#endif
 #ifndef PN_FWD_WAVES
 #define PN_FWD_WAVES 2      // __launch_bounds__ min waves per SIMD, forward
 #endif
@@ -53,9 +50,6 @@ using namespace pn;
 #endif
 #ifndef PN_BWD_EXPERIMENT
 #define PN_BWD_EXPERIMENT 0  // timing experiments only (1, 2: gather-backward scatter replaced / removed)
-#endif
-#ifndef PN_BWD_DEPTH
-#define PN_BWD_DEPTH 4
 #endif
 #ifndef PN_BWD_WAVES
 #define PN_BWD_WAVES 2
@@ -356,7 +350,8 @@ struct SeqFwdParams {
 };
 
 template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64, PN_FWD_WAVES) void seq_fwd_kernel(SeqFwdParams p) {
+// (H = 32 is a single wave per workgroup: no register cap there, a spill next to the asm loads would be a hazard)
+__global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_fwd_kernel(SeqFwdParams p) {
     constexpr int NW = H / 32, NT = NW * 64, MTILES = MT / 32, PITCH = 2 * H + 4, SV = (G == 4 ? 5 : 1);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
@@ -1107,11 +1102,6 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const floa
     }
 }
 
-__global__ void copy_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i];
-}
-
 int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t ld, int M, int N, float *out) {
     if (M <= 0 || N <= 0) return PN_OK;
     int ysplit = (M + 511) / 512;
@@ -1386,8 +1376,8 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     sp.Wp = Wp;
     sp.biasc = biasc;
     sp.hn = hn;
-    sp.saved = saved;
-    sp.xh = reinterpret_cast<float *>(ws + w.xh);
+    sp.saved = a->no_save ? nullptr : saved;
+    sp.xh = a->no_save ? nullptr : reinterpret_cast<float *>(ws + w.xh);
     sp.P = P;
     sp.L = L;
     sp.p_drop = a->p_seq;

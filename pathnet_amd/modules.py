@@ -77,6 +77,7 @@ class _PaggFunction(torch.autograd.Function):
         a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
         a.out = out.data_ptr()
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        a.no_save = 0 if cfg.get("grad", True) else 1       # torch.no_grad() forwards skip the saved tensors
         if cfg["S"] > 0:
             _lib.check(lib.pn_pagg_forward(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         ctx.cfg, ctx.ws = cfg, ws
@@ -213,7 +214,8 @@ class _Aggregator(nn.Module):
         if training and (self._mask_seq is not None or self._mask_cls is not None):
             cfg["mask_seq"], cfg["mask_cls"] = self._mask_seq, self._mask_cls
             cfg["p_seq"] = cfg["p_cls"] = 0.0
-        if not torch.is_grad_enabled():
+        cfg["grad"] = torch.is_grad_enabled()
+        if not cfg["grad"]:
             need = workspace_bytes(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"], cfg["L"])
             if self._ws_eval is None or self._ws_eval.numel() < need or self._ws_eval.device != dev:
                 self._ws_eval = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)

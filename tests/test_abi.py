@@ -120,3 +120,17 @@ def test_csr_build_sorted_unique_both_directions():
             want = np.unique(dst[src == node])
             assert (adj[off[node]:off[node + 1]] == want).all()
         assert off[-1] == len(adj)
+
+
+def test_no_kernel_spills_registers():
+    """The recurrent kernels prefetch weight fragments with asm loads whose destination registers the compiler must
+    not spill between the load and its wait (cdna_hip_programming.md §5.7): require zero scratch in every kernel."""
+    import subprocess
+    src = os.path.join(ROOT, "pathnet_amd", "csrc")
+    for f in ("pn_pagg.hip", "pn_sampler.hip"):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                            "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(src, f), "-o", "/dev/null"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-500:]
+        sizes = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)
+        assert sizes and all(int(x) == 0 for x in sizes), (f, sizes)
