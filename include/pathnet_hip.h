@@ -142,6 +142,13 @@ int pn_paths_write_text(const char *path, const int32_t *ids, const uint8_t *cod
 /* cap = 0: count lines only (ids/codes may be NULL).  Otherwise fills up to cap paths. */
 int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths);
 
+/* Binary sidecar of the same content (the reference re-parses 10^7..10^8 text lines per run,
+ * PathNet_run.py:418-423 / :325-334).  Layout: 32-byte header {char magic[8] = "PNPATHS1", int32 L, int32 reserved,
+ * int64 npaths, int64 reserved}, then npaths*L int32 ids, then npaths*L uint8 codes.  Lossless w.r.t. the text. */
+int pn_paths_write_bin(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L);
+/* cap = 0: read only the header (*npaths, *L_out).  Otherwise fills ids/codes (cap >= npaths). */
+int pn_paths_read_bin(const char *path, int32_t *L_out, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths);
+
 /* ================================================================================================
  * Aggregator ("PAGG"): the forward() of PathNet (PathNet_run.py:172-211), PathNet_homo (:239-278)
  * and PAGG (baseline/GPRGNN/src/copy.py:327-359), and its backward (autograd in the reference,

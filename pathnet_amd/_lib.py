@@ -77,6 +77,8 @@ SIGNATURES = {
     "pn_paths_write_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_int32]),
     "pn_paths_read_text": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, c_i32p, c_u8p, ctypes.c_int64, c_i64p]),
+    "pn_paths_write_bin": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32]),
+    "pn_paths_read_bin": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i32p, c_u8p, ctypes.c_int64, c_i64p]),
     "pn_pagg_workspace_bytes": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
     "pn_pagg_forward": (ctypes.c_int, [ctypes.POINTER(PaggArgs), vp]),
     "pn_pagg_backward": (ctypes.c_int, [ctypes.POINTER(PaggArgs), vp]),

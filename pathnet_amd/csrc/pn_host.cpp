@@ -446,4 +446,60 @@ int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes
     return PN_OK;
 }
 
+namespace {
+struct BinHeader {
+    char magic[8];
+    int32_t L;
+    int32_t reserved0;
+    int64_t npaths;
+    int64_t reserved1;
+};
+static_assert(sizeof(BinHeader) == 32, "header is 32 bytes");
+const char kBinMagic[8] = {'P', 'N', 'P', 'A', 'T', 'H', 'S', '1'};
+}  // namespace
+
+int pn_paths_write_bin(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L) {
+    if (!path || npaths < 0 || L < 1 || (npaths > 0 && (!ids || !codes)))
+        PN_FAIL(PN_ERR_ARG, "pn_paths_write_bin: bad argument");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) PN_FAIL(PN_ERR_IO, "cannot open %s for writing: %s", path, std::strerror(errno));
+    BinHeader h{};
+    std::memcpy(h.magic, kBinMagic, 8);
+    h.L = L;
+    h.npaths = npaths;
+    const size_t n = (size_t)npaths * (size_t)L;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    ok = ok && (n == 0 || std::fwrite(ids, sizeof(int32_t), n, f) == n);
+    ok = ok && (n == 0 || std::fwrite(codes, 1, n, f) == n);
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) PN_FAIL(PN_ERR_IO, "short write to %s", path);
+    return PN_OK;
+}
+
+int pn_paths_read_bin(const char *path, int32_t *L_out, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) {
+    if (!path || !npaths || !L_out) PN_FAIL(PN_ERR_ARG, "pn_paths_read_bin: bad argument");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) PN_FAIL(PN_ERR_IO, "cannot read path file %s: %s", path, std::strerror(errno));
+    BinHeader h{};
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kBinMagic, 8) != 0 || h.L < 1 || h.npaths < 0) {
+        std::fclose(f);
+        PN_FAIL(PN_ERR_FORMAT, "%s is not a PNPATHS1 file", path);
+    }
+    *npaths = h.npaths;
+    *L_out = h.L;
+    if (cap == 0) {
+        std::fclose(f);
+        return PN_OK;
+    }
+    if (cap < h.npaths || !ids || !codes) {
+        std::fclose(f);
+        PN_FAIL(PN_ERR_CAPACITY, "path buffers hold %lld paths, file has %lld", (long long)cap, (long long)h.npaths);
+    }
+    const size_t n = (size_t)h.npaths * (size_t)h.L;
+    const bool ok = (n == 0) || (std::fread(ids, sizeof(int32_t), n, f) == n && std::fread(codes, 1, n, f) == n);
+    std::fclose(f);
+    if (!ok) PN_FAIL(PN_ERR_FORMAT, "%s is truncated", path);
+    return PN_OK;
+}
+
 }  // extern "C"

@@ -36,6 +36,30 @@ def read_paths(path, L):
     return ids, codes
 
 
+def write_paths_binary(path, ids, codes):
+    """Binary sidecar ("PNPATHS1": 32-byte header, int32 ids, uint8 codes) -- same content as the text file."""
+    ids = np.ascontiguousarray(np.asarray(ids), dtype=np.int32)
+    codes = np.ascontiguousarray(np.asarray(codes), dtype=np.uint8)
+    L = ids.shape[-1]
+    if codes.shape != ids.shape:
+        raise ValueError("ids and codes must have the same shape")
+    _lib.check(_lib.load().pn_paths_write_bin(str(path).encode(), _lib.np_ptr(ids, ctypes.c_int32),
+                                              _lib.np_ptr(codes, ctypes.c_uint8), ids.size // L if L else 0, L))
+
+
+def read_paths_binary(path):
+    """-> (ids [npaths, L] int32, codes [npaths, L] uint8)."""
+    lib = _lib.load()
+    n, L = ctypes.c_int64(0), ctypes.c_int32(0)
+    _lib.check(lib.pn_paths_read_bin(str(path).encode(), ctypes.byref(L), None, None, 0, ctypes.byref(n)))
+    ids = np.empty((n.value, L.value), dtype=np.int32)
+    codes = np.empty((n.value, L.value), dtype=np.uint8)
+    if n.value:
+        _lib.check(lib.pn_paths_read_bin(str(path).encode(), ctypes.byref(L), _lib.np_ptr(ids, ctypes.c_int32),
+                                         _lib.np_ptr(codes, ctypes.c_uint8), n.value, ctypes.byref(n)))
+    return ids, codes
+
+
 def whole_run_name(root, name, W, L, marker="merw"):
     """PathNet_run.py:415-416: '{paths_root}{name}_{W}_{L}_{marker}.txt'"""
     return "%s%s_%d_%d_%s.txt" % (root, name, W, L, marker)

@@ -164,12 +164,13 @@ def main(argv=None):
     """Drop-in for ./gen_merw and ./gen_epoch_merw (argv: <data_name> <path_num> <path_length>)."""
     argv = list(sys.argv[1:] if argv is None else argv)
     per_epoch = "--per-epoch" in argv
+    binary = "--binary" in argv          # also write the PNPATHS1 sidecar(s) next to the text file(s)
     opts = {"--seed": None, "--epochs": "1000", "--draw": "glibc", "--in": None, "--out-root": "./"}
     pos = []
     i = 0
     while i < len(argv):
         a = argv[i]
-        if a == "--per-epoch":
+        if a in ("--per-epoch", "--binary"):
             i += 1
         elif a in opts:
             opts[a] = argv[i + 1]
@@ -196,9 +197,16 @@ def main(argv=None):
         ids, codes = ids.cpu().numpy(), codes.cpu().numpy()
         for k in range(ec):
             if per_epoch:
-                pathfile.write_paths(pathfile.per_epoch_name(root, name, W, L, e0 + k), ids[k], codes[k])
+                fn = pathfile.per_epoch_name(root, name, W, L, e0 + k)
+                pathfile.write_paths(fn, ids[k], codes[k])
+                if binary:
+                    pathfile.write_paths_binary(fn[:-4] + ".bin", ids[k], codes[k])
             else:
                 pathfile.write_paths(whole, ids[k], codes[k], append=(e0 + k) > 0)
+        if binary and not per_epoch:
+            if epochs > chunk:
+                raise SystemExit("--binary without --per-epoch needs the whole run in one chunk; use --per-epoch")
+            pathfile.write_paths_binary(whole[:-4] + ".bin", ids, codes)
     return 0
 
 

@@ -134,3 +134,19 @@ def test_no_kernel_spills_registers():
         assert r.returncode == 0, r.stderr[-500:]
         sizes = re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)
         assert sizes and all(int(x) == 0 for x in sizes), (f, sizes)
+
+
+def test_binary_path_file_is_lossless_and_rejects_garbage(tmp_path):
+    g = golden("sampler_cornell_40_4.npz")
+    ids, codes = g["ids"][0], g["codes"][0]
+    fb, ft = os.path.join(tmp_path, "p.bin"), os.path.join(tmp_path, "p.txt")
+    pathfile.write_paths_binary(fb, ids, codes)
+    i2, c2 = pathfile.read_paths_binary(fb)
+    assert (i2 == ids.reshape(-1, 4)).all() and (c2 == codes.reshape(-1, 4)).all()
+    pathfile.write_paths(ft, i2, c2)                       # binary -> text == reference text
+    assert open(ft, "rb").read() == merw.format_text(ids, codes)
+    assert os.path.getsize(fb) == 32 + ids.size * 5
+    open(fb, "wb").write(b"not a path file at all, definitely not")
+    with pytest.raises(_lib.PnError) as e:
+        pathfile.read_paths_binary(fb)
+    assert e.value.code == _lib.PN_ERR_FORMAT
