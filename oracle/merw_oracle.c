@@ -9,7 +9,7 @@
  * (SURVEY.md §8c).  This restatement is pinned instead against the *unmodified* reference
  * program compiled from /root/reference/preprocess/gen_merw.cpp into oracle/_ref/ and run
  * under a fixed-seed time() shim (tests/test_oracle_sampler.py), and against the fixtures in
- * tests/golden/ that were produced by that same binary (tools/make_golden_sampler.py).
+ * tests/golden/ that were produced by that same binary (tests/golden/make_golden_sampler.py).
  *
  * Reference lines restated (all in /root/reference/preprocess/gen_merw.cpp):
  *   :95-99,  :162-172  edge list -> per-node neighbour / probability lists, file order

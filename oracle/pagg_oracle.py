@@ -10,8 +10,8 @@ reference path aggregator forward, for the three classes that share the
 
 Parity pinning: the reference ships no numeric golden vectors for this path.
 This restatement is pinned (a) in this container against the reference classes themselves,
-loaded with ``ast`` from /root/reference (tests/test_oracle_pagg.py, tools/ref_extract.py) and
-(b) everywhere against tests/golden/pagg_*.npz, which tools/make_golden_pagg.py produced by
+loaded with ``ast`` from /root/reference (tests/test_oracle_pagg.py, tests/ref_extract.py) and
+(b) everywhere against tests/golden/pagg_*.npz, which tests/golden/make_golden_pagg.py produced by
 running those reference classes.
 
 The restatement is written as an index *plan* + dense math so that it documents the reference's

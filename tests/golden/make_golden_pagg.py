@@ -1,5 +1,5 @@
 """Generate tests/golden/pagg_*.npz by running the reference aggregator classes themselves
-(ast-loaded from /root/reference, see tools/ref_extract.py) on seeded inputs, in eval() mode
+(ast-loaded from /root/reference, see tests/ref_extract.py) on seeded inputs, in eval() mode
 (dropout inactive), forward and backward.  Run in the build container only.
 
 Each fixture: shapes, X, ids [S,W,L], codes [S,W,L], mask [N], every state_dict tensor
@@ -13,11 +13,13 @@ import warnings
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.ref_extract import reference_classes  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from ref_extract import reference_classes  # noqa: E402
 
 warnings.filterwarnings("ignore")
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.path.dirname(os.path.abspath(__file__))
 CLASS = {"hetero": "PathNet", "homo": "PathNet_homo", "pagg": "PAGG"}
 
 

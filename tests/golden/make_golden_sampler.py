@@ -1,6 +1,6 @@
 """Generate tests/golden/sampler_*.npz by running the UNMODIFIED reference sampler
 (oracle/_ref/gen_merw, compiled from /root/reference/preprocess/gen_merw.cpp) under the fixed-seed
-time() shim.  Run in the build container only:  python tools/make_golden_sampler.py
+time() shim.  Run in the build container only:  python tests/golden/make_golden_sampler.py
 
 Each fixture holds the parsed edge list (n, u, v, p -- test input data, not source code), the seed,
 W, L, the first `epochs` epochs of reference output parsed to ids/codes, and the md5 of those bytes.
@@ -11,11 +11,13 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import merw  # noqa: E402
 
 REF_EDGE = "/root/reference/edge_input"
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def parse_text(txt, L):

@@ -64,7 +64,7 @@ def test_plan_hetero_quirks():
 def test_oracle_matches_live_reference_classes(variant, cname):
     import warnings
     warnings.filterwarnings("ignore")
-    from tools.ref_extract import reference_classes
+    from ref_extract import reference_classes
     cls = reference_classes(0.0)
     torch.manual_seed(3)
     rng = np.random.default_rng(3)
