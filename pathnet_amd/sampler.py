@@ -193,7 +193,13 @@ def main(argv=None):
     chunk = max(1, min(epochs, (64 << 20) // max(1, smp.n * W * L * 5)))
     for e0 in range(0, epochs, chunk):
         ec = min(chunk, epochs - e0)
-        ids, codes = smp.sample(W, seed, epoch_begin=e0, epoch_count=ec, draw_source=draw)
+        try:
+            ids, codes = smp.sample(W, seed, epoch_begin=e0, epoch_count=ec, draw_source=draw)
+        except _lib.PnError as ex:
+            if ex.code != _lib.PN_ERR_EMPTY_TABLE:
+                raise
+            print("ERROR:: A.size() == 0 in Alias Table", file=sys.stderr)      # gen_merw.cpp:84-87: message + exit(0)
+            return 0
         ids, codes = ids.cpu().numpy(), codes.cpu().numpy()
         for k in range(ec):
             if per_epoch:

@@ -225,3 +225,15 @@ def test_otf_large_graph_beyond_the_reference_cap():
         dist = dijkstra(A, unweighted=True, indices=1234 + s, limit=L)
         want = dist[ids[s]]
         assert (codes[s] == want).all(), (s, codes[s][:3], want[:3])
+
+
+def test_cli_empty_table_behaves_like_the_reference(tmp_path):
+    """gen_merw.cpp:84-87: a walk that reaches a node without outgoing rows prints the message and exits 0."""
+    os.makedirs(os.path.join(tmp_path, "preprocess"))
+    os.makedirs(os.path.join(tmp_path, "edge_input"))
+    with open(os.path.join(tmp_path, "edge_input", "dead.in"), "w") as f:
+        f.write("3 4\n0 2 0.5\n0 2 0.5\n1 0 0.5\n1 0 0.5\n")
+    r = subprocess.run([sys.executable, "-m", "pathnet_amd.sampler", "dead", "4", "3", "--seed", "1", "--epochs", "2"],
+                       cwd=os.path.join(tmp_path, "preprocess"), env=dict(os.environ, PYTHONPATH=ROOT),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "A.size() == 0 in Alias Table" in r.stderr
