@@ -412,3 +412,35 @@ def test_rejects_batches_beyond_32bit_offsets():
     from pathnet_amd import _lib, modules
     with pytest.raises(_lib.PnError):
         modules.workspace_bytes("homo", 1000, 16, 128, 3, 50000, 40, 4)      # S*W*L*5*H >= 2^32
+
+
+def test_cora_config_forward_backward_full_parity():
+    """BASELINE.json configs[1] at its real size (N=2708, F=1433, C=7, hid=128, W=40, L=4, 1300 masked nodes =
+    52 000 paths): every logit and every gradient against the CPU oracle (training mode, injected masks)."""
+    torch.manual_seed(51)
+    rng = np.random.default_rng(51)
+    N, F, H, C, W, L, S = 2708, 1433, 128, 7, 40, 4, 1300
+    m = build_module("homo", F, H, C, L, N, None).train()
+    X = (torch.rand(N, F) < 0.0127).float()
+    X = X / X.sum(1, keepdim=True).clamp(min=1.0)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    pdrop = 0.7
+    drop_seq = (torch.rand(L, S * W, H) >= pdrop).float() / (1 - pdrop)
+    drop_cls = (torch.rand(S, 2 * H) >= pdrop).float() / (1 - pdrop)
+    m._mask_seq, m._mask_cls = drop_seq.cuda(), drop_cls.cuda()
+    G = torch.randn(S, C) / S
+    out = run_module(m, X.cuda(), ids, codes, mask, W, L)
+    (out * G.cuda()).sum().backward()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = po.forward("homo", pr, X, ids, codes, sel, W, L, drop_seq=drop_seq, drop_cls=drop_cls)
+    (want * G).sum().backward()
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT
+    for k, v in m.named_parameters():
+        ref = pr[k].grad
+        err = (v.grad.cpu() - ref).abs().max().item()
+        assert err < 3e-5 * max(1.0, ref.abs().max().item()) + 1e-7, (k, err, ref.abs().max().item())
