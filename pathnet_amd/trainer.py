@@ -1,0 +1,103 @@
+"""Training-loop glue: the reference's ``train_fixed_indices``
+(/root/reference/PathNet_run.py:281-403) with everything resident on the GPU.
+
+Same recipe: model by dataset name (:286-291), Adam(lr, weight_decay) + CrossEntropyLoss (:295-297), one training
+step per epoch on that epoch's paths (:336-352), validation every epoch (:355-366), test + checkpoint whenever
+the validation accuracy improves (:368-389), checkpoint renamed with time stamp and round at the end (:398-401),
+returns (macro-F1, micro-F1, macro recall, macro precision, accuracy) of the selected epoch (:403).
+
+What changes is only where the data lives: paths are int32/uint8 device tensors -- either pre-sampled
+[epochs, N, W, L] tensors or a MerwSampler that walks each epoch's paths on the GPU just before the step (no
+text file, no per-epoch Python parse, PathNet_run.py:317-334) -- masks are index tensors on the device, and the
+metrics (sklearn in the reference, :384-389) are computed on the device as well.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import modules
+from .sampler import DRAW_PHILOX
+
+HOMO_DATASETS = ("cora", "citeseer", "pubmed")          # PathNet_run.py:286
+
+
+def classification_metrics(y_true, y_pred, num_classes):
+    """-> (macro F1, micro F1, macro recall, macro precision, accuracy) with scikit-learn's conventions
+    (labels = classes present in y_true or y_pred; 0/0 counts as 0)."""
+    y_true, y_pred = y_true.reshape(-1).long(), y_pred.reshape(-1).long()
+    conf = torch.bincount(y_true * num_classes + y_pred, minlength=num_classes * num_classes).view(
+        num_classes, num_classes).double()
+    tp = conf.diag()
+    support, predicted = conf.sum(1), conf.sum(0)
+    present = (support + predicted) > 0
+    prec = torch.where(predicted > 0, tp / predicted.clamp(min=1), torch.zeros_like(tp))
+    rec = torch.where(support > 0, tp / support.clamp(min=1), torch.zeros_like(tp))
+    f1 = torch.where(prec + rec > 0, 2 * prec * rec / (prec + rec).clamp(min=1e-300), torch.zeros_like(tp))
+    k = present.sum().clamp(min=1)
+    acc = tp.sum() / conf.sum().clamp(min=1)
+    return (float((f1 * present).sum() / k), float(acc), float((rec * present).sum() / k),
+            float((prec * present).sum() / k), float(acc))
+
+
+def _index_tensor(mask_or_index, device):
+    if isinstance(mask_or_index, np.ndarray):
+        t = torch.from_numpy(np.flatnonzero(mask_or_index) if mask_or_index.dtype == np.bool_ else mask_or_index)
+    else:
+        t = torch.as_tensor(mask_or_index)
+        if t.dtype == torch.bool:
+            t = torch.nonzero(t, as_tuple=False).flatten()
+    return t.to(device=device, dtype=torch.int64)
+
+
+def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices, test_indices, num_w, hid_size,
+                        walk_len, paths, round_i=0, *, epochs=1000, lr=0.005, weight_decay=0.0005, dropout=0.7,
+                        device="cuda:0", save_dir="./saved_models", sampler_seed=0, model=None, verbose=False):
+    """paths: (ids, codes) tensors [epochs, N, W, L] (int32 / uint8, any device) or a MerwSampler.
+    Returns (test macro-F1, micro-F1, macro recall, macro precision, accuracy) at the best-validation epoch."""
+    dev = torch.device(device)
+    X = torch.as_tensor(X).to(dev).float()
+    Y = torch.as_tensor(Y).to(dev).long()
+    tr, va, te = (_index_tensor(m, dev) for m in (train_indices, val_indices, test_indices))
+    if model is None:
+        cls = modules.PathNet_homo if data_name in HOMO_DATASETS else modules.PathNet
+        model = cls(X.shape[-1], hid_size, num_classes, walk_len, dropout=dropout).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+    lossf = torch.nn.CrossEntropyLoss()
+    from_sampler = hasattr(paths, "sample")
+    if not from_sampler:
+        ids_all, codes_all = (torch.as_tensor(t).to(dev) for t in paths)
+    os.makedirs(save_dir, exist_ok=True)
+    ckpt = os.path.join(save_dir, data_name + ".pth")
+    best_val, result = 0.0, (0.0, 0.0, 0.0, 0.0, 0.0)
+    tr32, va32, te32 = tr.to(torch.int32), va.to(torch.int32), te.to(torch.int32)
+    for epoch in range(epochs):
+        if from_sampler:
+            ids, codes = paths.sample(num_w, sampler_seed, epoch_begin=epoch, epoch_count=1, draw_source=DRAW_PHILOX,
+                                      check=(epoch == 0))
+            ids, codes = ids[0], codes[0]
+        else:
+            ids, codes = ids_all[epoch], codes_all[epoch]
+        model.train()
+        out = model(X, ids.index_select(0, tr), num_w, walk_len, tr32, codes.index_select(0, tr), None)
+        loss = lossf(out, Y[tr])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            model.eval()
+            pred = model(X, ids.index_select(0, va), num_w, walk_len, va32, codes.index_select(0, va), None).argmax(1)
+            val_acc = float((pred == Y[va]).double().mean())
+            if best_val < val_acc:
+                best_val = val_acc
+                torch.save(model.state_dict(), ckpt)
+                pred = model(X, ids.index_select(0, te), num_w, walk_len, te32, codes.index_select(0, te),
+                             None).argmax(1)
+                result = classification_metrics(Y[te], pred, num_classes)
+        if verbose and (epoch % 50 == 0 or epoch == epochs - 1):
+            print("epoch %d loss %.4f val_acc %.4f test_acc %.4f" % (epoch, float(loss), val_acc, result[4]))
+    if os.path.exists(ckpt):
+        os.rename(ckpt, os.path.join(save_dir, data_name + time.strftime("%Y-%m-%d_%H:%M:%S", time.localtime())
+                                     + str(round_i) + ".pth"))
+    return result
