@@ -93,6 +93,7 @@ struct GemmParams {
     int M, N, K;
     int relu, mode;
     int kchunk;  // K range per blockIdx.z
+    float *rowsum;  // optional [M]: += sum_k A(m,k) (after gating) -- the bias gradient that goes with a dW GEMM
 };
 
 template <bool A_KCONTIG, bool B_KCONTIG, bool GATE>
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     // asm-pinned so hipcc cannot sink them) before the MFMAs of the current tile; out-of-range elements and
     // gated-off elements become zeros when the tile is written to LDS.
     float ra[8], rb[8], rg[8];
+    float rsum = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; i++) rg[i] = 1.0f;
     auto issue = [&](int k0) {
@@ -141,6 +143,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         }
         __syncthreads();
         issue(min(k0 + GEMM_KT, kend - 1));   // last trip: harmless re-load, drained below
+        if (p.rowsum && blockIdx.x == 0 && tid < GEMM_BM) {
+#pragma unroll
+            for (int k = 0; k < GEMM_KT; k++) rsum += As[k * GEMM_PITCH + tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < GEMM_KT / 2; kk++) {
             const float a = As[(2 * kk + hk) * GEMM_PITCH + wm * 32 + li];
@@ -150,6 +156,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         __syncthreads();
     }
     if (kbeg < kend) wait_vm_all(ra, rb, rg);
+    if (p.rowsum && blockIdx.x == 0 && tid < GEMM_BM && m0 + tid < p.M) atomicAdd(&p.rowsum[m0 + tid], rsum);
     const int col = n0 + wn * 32 + li;
     if (col >= p.N) return;
     const float bias = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.0f;
@@ -183,9 +190,9 @@ void launch_gemm_variant(hipStream_t stream, dim3 grid, bool ak, bool bk, const 
 
 int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
                 int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
-                int mode, int ksplit) {
+                int mode, int ksplit, float *rowsum = nullptr) {
     if (M <= 0 || N <= 0) return PN_OK;
-    GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0};
+    GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0, rowsum};
     if (ksplit < 1) ksplit = 1;
     if (mode != GEMM_ATOMIC) ksplit = 1;
     int kchunk = (K + ksplit - 1) / ksplit;
@@ -1102,6 +1109,30 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const floa
     }
 }
 
+// zero-fill of up to 12 buffers in one launch (the accumulated gradients of a backward)
+struct ZeroList {
+    float *ptr[12];
+    unsigned long long count[12];
+    int n;
+};
+__global__ __launch_bounds__(256) void zero_kernel(ZeroList z) {
+    for (int b = 0; b < z.n; b++) {
+        float *p = z.ptr[b];
+        const unsigned long long cnt = z.count[b];
+        // 16-byte stores on the aligned body, scalars on the ragged ends
+        const unsigned long long head = min(cnt, (unsigned long long)((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4);
+        const unsigned long long body4 = (cnt - head) / 4;
+        float4 *p4 = reinterpret_cast<float4 *>(p + head);
+        for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < body4;
+             i += (unsigned long long)gridDim.x * blockDim.x)
+            p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (blockIdx.x == 0) {
+            for (unsigned long long i = threadIdx.x; i < head; i += blockDim.x) p[i] = 0.0f;
+            for (unsigned long long i = head + body4 * 4 + threadIdx.x; i < cnt; i += blockDim.x) p[i] = 0.0f;
+        }
+    }
+}
+
 int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t ld, int M, int N, float *out) {
     if (M <= 0 || N <= 0) return PN_OK;
     int ysplit = (M + 511) / 512;
@@ -1447,19 +1478,34 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     float *dG = reinterpret_cast<float *>(ws + w.dG), *dZ = reinterpret_cast<float *>(ws + w.dZ);
     float *dXh = a->Xh_in ? a->g_Xh : reinterpret_cast<float *>(ws + w.dXh);
     float *dhn = reinterpret_cast<float *>(ws + w.dhn);
-    // gradient buffers that are accumulated into: a NULL output is redirected to scratch (dl1 region)
-    float *scratch = reinterpret_cast<float *>(ws + w.dl1);
-    (void)scratch;
-
+    // every buffer the kernels below accumulate into (atomics / += / split-K) is cleared by ONE launch
+    ZeroList zl{};
     auto zero = [&](float *ptr, size_t count) -> int {
-        if (ptr && count) PN_CHECK_HIP(hipMemsetAsync(ptr, 0, count * sizeof(float), stream));
+        if (ptr && count) {
+            if (zl.n >= 12) PN_FAIL(PN_ERR_ARG, "internal: zero list overflow");
+            zl.ptr[zl.n] = ptr;
+            zl.count[zl.n] = count;
+            zl.n++;
+        }
         return PN_OK;
     };
+    auto flush_zero = [&]() -> int {
+        if (zl.n) {
+            hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, stream, zl);
+            PN_CHECK_HIP(hipGetLastError());
+            zl.n = 0;
+        }
+        return PN_OK;
+    };
+    float *scratch = reinterpret_cast<float *>(ws + w.dl1);
     if (int rc = zero(dZ, (size_t)s.N * L * H)) return rc;
     if (int rc = zero(dXh, (size_t)s.N * H)) return rc;
     if (int rc = zero(a->g_att_w, has_att ? (size_t)2 * H : 0)) return rc;
     if (int rc = zero(a->g_att_b, has_att ? 1 : 0)) return rc;
+    if (has_att && (!a->g_att_w || !a->g_att_b))
+        if (int rc = zero(scratch, (size_t)2 * H + 1)) return rc;
     if (int rc = zero(a->g_fc2_b, (size_t)s.C)) return rc;
+    if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
     if (int rc = zero(a->g_bank_w, (size_t)L * H * H)) return rc;
     if (int rc = zero(a->g_bank_b, (size_t)L * H)) return rc;
     if (!a->Xh_in) {
@@ -1467,25 +1513,25 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         if (int rc = zero(a->g_fc0_b, (size_t)H)) return rc;
     }
     if (s.S == 0) {
+        if (int rc = flush_zero()) return rc;
         if (int rc = zero(a->g_w_ih, (size_t)GH * H)) return rc;
         if (int rc = zero(a->g_w_hh, (size_t)GH * H)) return rc;
         if (int rc = zero(a->g_b_ih, (size_t)GH)) return rc;
-        if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
         if (int rc = zero(a->g_b_hh, (size_t)GH)) return rc;
         if (int rc = zero(a->g_X, (size_t)s.N * s.F)) return rc;
-        return PN_OK;
+        return flush_zero();
     }
+    if (int rc = flush_zero()) return rc;
 
     // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out)
     auto tm_fc2 = std::make_unique<StageTimer>(ST_FC2_GRAD, stream);
-    if (a->g_fc2_w) {
-        if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
+    if (a->g_fc2_w) {        // g_fc2_b = row sums of the A operand (g_out^T)
         if (int rc = launch_gemm(stream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
-                                 2 * H, s.S, 0, GEMM_ATOMIC, (s.S + 127) / 128))
+                                 2 * H, s.S, 0, GEMM_ATOMIC, (s.S + 127) / 128, a->g_fc2_b))
             return rc;
-    }
-    if (a->g_fc2_b)
+    } else if (a->g_fc2_b) {
         if (int rc = launch_colsum(stream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
+    }
     tm_fc2.reset();
 
     // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
@@ -1514,8 +1560,6 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         // attention gradients are optional outputs: fall back to scratch so the kernel needs no branches
         pp.g_att_w = a->g_att_w ? a->g_att_w : scratch;
         pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
-        if (has_att && (!a->g_att_w || !a->g_att_b))
-            if (int rc = zero(scratch, (size_t)2 * H + 1)) return rc;
         const size_t lds_bytes = (size_t)(4 * (2 * s.W + H) + 8 * H) * sizeof(float);
         StageTimer tm(ST_POOL_BWD, stream);
         hipLaunchKernelGGL(pool_bwd_kernel, dim3((s.S + 3) / 4), dim3(256), lds_bytes, stream, pp);
@@ -1577,24 +1621,26 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     if (int rc = launch_gemm(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, s.N, H, L * H, 0,
                              GEMM_ADD, 1))
         return rc;
-    if (a->g_bank_w)
+    if (a->g_bank_w) {       // g_bank_b rides along as the row sums of the same (gated) A operand
         if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, s.N,
-                                 0, GEMM_ATOMIC, (s.N + 255) / 256))
+                                 0, GEMM_ATOMIC, (s.N + 255) / 256, a->g_bank_b))
             return rc;
-    if (a->g_bank_b)
+    } else if (a->g_bank_b) {
         if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, s.N, L * H, a->g_bank_b)) return rc;
+    }
 
     tm_bank.reset();
     if (a->Xh_in) return PN_OK;   // the caller finishes fc0 after the reduce-scatter of g_Xh
     // fc0 backward (ReLU gate for HOMO)
     const float *xgate = homo ? Xh : nullptr;
     StageTimer tm_fc0(ST_FC0_BWD, stream);
-    if (a->g_fc0_w)
+    if (a->g_fc0_w) {
         if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, s.F, a->g_fc0_w, s.F, nullptr, H, s.F, s.N, 0,
-                                 GEMM_ATOMIC, (s.N + 511) / 512))
+                                 GEMM_ATOMIC, (s.N + 255) / 256, a->g_fc0_b))
             return rc;
-    if (a->g_fc0_b)
+    } else if (a->g_fc0_b) {
         if (int rc = launch_colsum(stream, dXh, xgate, H, s.N, H, a->g_fc0_b)) return rc;
+    }
     if (a->g_X)
         if (int rc = launch_gemm(stream, dXh, H, 1, xgate, a->fc0_w, 1, s.F, a->g_X, s.F, nullptr, s.N, s.F, H, 0,
                                  GEMM_STORE, 1))
