@@ -624,6 +624,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
     const float *ego = p.Xh + (int64_t)p.sel[g] * H;
     for (int j = lane; j < H; j += 64) {
         float acc = 0.0f;
+#pragma unroll 8
         for (int mem = 0; mem < p.W; mem++) acc += sc[mem] * p.hn[((int64_t)g * p.W + mem) * H + j];
         float a = ego[j], b = acc * inv_w;
         if (p.mask) {
@@ -760,6 +761,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 ego_acc[i] = 0.0f;
             }
         };
+#pragma unroll 4
         for (int mem = 0; mem < W; mem++) {
             const int64_t s = (int64_t)g * W + mem;
             const float ds = dsc[mem], cf = p.coef[s];
