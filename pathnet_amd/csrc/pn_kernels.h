@@ -17,6 +17,38 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// ---- fp32 products on the bf16 matrix pipe ------------------------------------------------------------------
+// gfx950's fp32-input MFMA runs at 1/16 of the bf16 rate (64 vs 1024 flop/cycle/SIMD).  An fp32 value is the
+// exact sum of three bf16 values (8 significant bits each, round-to-nearest residuals: x = x0 + x1 + x2 with
+// |x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|), so  a.b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + O(2^-24 |a||b|):
+// six bf16 MFMAs with fp32 accumulation give an fp32-accurate product (the dropped terms are below one fp32 ulp of
+// |a||b|; measured 2e-9 of sum|a||b| against 2e-7 for an fp32 FMA chain) at 16/6 of the fp32 MFMA rate.
+// Range is bf16's = fp32's: no scaling, no overflow hazard.  (A value that rounds to +-inf in bf16 -- |x| > 3.39e38
+// -- yields NaN instead of inf.)
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][j = l & 31]
+// as 8 bf16 in 4 VGPRs; the accumulator layout is that of mfma32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
+                                                   0, 0);
+}
+// v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even), `lo` in bits 0-15
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+// (a, b) -> three packed bf16 pairs with a = a0 + a1 + a2 exactly (same for b); the subtractions are exact
+__device__ __forceinline__ void split3(float a, float b, uint32_t &p0, uint32_t &p1, uint32_t &p2) {
+    p0 = cvt_pk_bf16(a, b);
+    float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = cvt_pk_bf16(ra, rb);
+    ra -= __uint_as_float(p1 << 16);
+    rb -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(ra, rb);
+}
+
 // ---- weight-fragment loads the compiler must not re-schedule -------------------------------------------
 // hipcc sinks ordinary loads of loop-invariant-addressable data next to their first use (it re-issues the
 // load instead of carrying registers around the loop), which turns a software prefetch into a load -> wait ->
@@ -29,6 +61,27 @@ __device__ __forceinline__ void async_load_b128(f32x4 &dst, const void *ptr) {
 }
 __device__ __forceinline__ void async_load_b32(float &dst, const void *ptr) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void async_load_b128(u32x4 &dst, const void *ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(u32x4 &r0) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(u32x4 &r0, u32x4 &r1) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "i"(N));
+}
+template <int N>
+__device__ __forceinline__ void wait_vm(u32x4 &r0, u32x4 &r1, u32x4 &r2, u32x4 &r3) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "i"(N));
+}
+template <int N, int G>
+__device__ __forceinline__ void wait_frag(u32x4 (&b)[G]) {
+    if constexpr (G == 1) wait_vm<N>(b[0]);
+    else if constexpr (G == 2) wait_vm<N>(b[0], b[1]);
+    else wait_vm<N>(b[0], b[1], b[2], b[3]);
 }
 // wait for every outstanding VMEM op; names three 8-register groups so their consumers stay below the wait
 __device__ __forceinline__ void wait_vm_all(float (&a)[8], float (&b)[8], float (&c)[8]) {

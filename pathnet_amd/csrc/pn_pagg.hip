@@ -55,6 +55,12 @@ using namespace pn;
 #define PN_BWD_WAVES 2
 #endif
 
+#ifndef PN_SEQ_BF16X3
+#define PN_SEQ_BF16X3 1     // recurrent forward GEMM on the bf16 pipe (3-way split, 6 products); 0: fp32-input MFMA
+#endif
+#ifndef PN_WGRAD_BF16X3
+#define PN_WGRAD_BF16X3 1   // weight-gradient GEMM on the bf16 pipe (3-way split, 6 products); 0: fp32-input MFMA
+#endif
 #ifndef PN_TRACE_PHASES
 #define PN_TRACE_PHASES 0   // 1: tuning builds only -- wave 0 of every workgroup stamps s_memtime at phase boundaries
 #endif
@@ -528,6 +534,220 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
                         p.xh[((uint32_t)q * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col] = h;
                 }
             }
+        PN_STAMP(4 * t + 3);
+    }
+}
+
+// ================================================================================================
+// The same recurrence on the bf16 matrix pipe (pn_kernels.h: fp32 = three bf16 planes, six MFMAs per product).
+//   Weights: pack_fwd3_kernel splits [W_ih | W_hh] once per forward into B fragments of v_mfma_f32_32x32x16_bf16,
+//     Wp3[(((w*KS + s)*3 + plane)*G + g)*64 + lane] (16 bytes) =
+//         plane of Wcat[g*H + 32w + (lane & 31)][16 s + 8 (lane >> 5) .. +7],        KS = 2H/16 k-steps,
+//     so the 3*G loads of one k-step are 3*G consecutive KB; step 0 (h_{-1} = 0) simply stops after the x half.
+//   A operand: LDS holds the three planes of the tile [32][x_t | h_{t-1}] as bf16, row pitch 4H + 16 bytes
+//     (conflict-free ds_read_b128).  x is split when the gathered rows are committed, h in the cell update.
+// ================================================================================================
+__global__ void pack_fwd3_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G,
+                                 u32x4 *__restrict__ Wp, float *__restrict__ biasc) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < G * H) biasc[idx] = b_ih[idx] + b_hh[idx];
+    const int KS = H / 8, NW = H / 32;
+    if (idx >= NW * KS * G * 64) return;
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int g = rest % G;
+    rest /= G;
+    const int s = rest % KS, w = rest / KS;
+    const int row = g * H + 32 * w + (lane & 31), k = 16 * s + 8 * (lane >> 5);
+    const float *src = k < H ? w_ih + (int64_t)row * H + k : w_hh + (int64_t)row * H + (k - H);
+    const float4 v0 = reinterpret_cast<const float4 *>(src)[0], v1 = reinterpret_cast<const float4 *>(src)[1];
+    u32x4 q0, q1, q2;
+    uint32_t x0, x1, x2;
+    split3(v0.x, v0.y, x0, x1, x2); q0[0] = x0; q1[0] = x1; q2[0] = x2;
+    split3(v0.z, v0.w, x0, x1, x2); q0[1] = x0; q1[1] = x1; q2[1] = x2;
+    split3(v1.x, v1.y, x0, x1, x2); q0[2] = x0; q1[2] = x1; q2[2] = x2;
+    split3(v1.z, v1.w, x0, x1, x2); q0[3] = x0; q1[3] = x1; q2[3] = x2;
+    u32x4 *dst = Wp + ((int64_t)(w * KS + s) * 3 * G + g) * 64 + lane;
+    dst[0] = q0;
+    dst[G * 64] = q1;
+    dst[2 * G * 64] = q2;
+}
+
+template <int H, int G, int MT>
+__global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_fwd3_kernel(SeqFwdParams p) {
+    static_assert(MT == 32, "one 32-row MFMA tile per workgroup");
+    constexpr int NW = H / 32, NT = NW * 64, SV = (G == 4 ? 5 : 1);
+    constexpr int KS = H / 8;                 // k-steps of 16 over [x | h]
+    constexpr int PB = 4 * H + 16;            // plane row pitch in bytes
+    constexpr int PLANE = 32 * PB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int q0 = blockIdx.x * MT;
+    const int col = 32 * wave + li;
+
+    f32x16 cst;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
+    float bias[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) bias[g] = p.biasc[g * H + col];
+
+    const float4 *Z4 = reinterpret_cast<const float4 *>(p.Z);
+    constexpr int NLD = MT / 8;   // float4 per thread = MT * (H/4) / NT
+    float4 xr[NLD];
+    auto gather_issue = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + NT * i;
+            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+            const int q = q0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < p.P) {
+                const uint32_t ri = (uint32_t)p.rowidx[(uint32_t)q * (uint32_t)p.L + t];
+                v = Z4[ri * (uint32_t)(H / 4) + c4];
+                if (p.mask) {
+                    const float4 m = reinterpret_cast<const float4 *>(
+                        p.mask)[((int64_t)t * p.P + p.slotof[q]) * (H / 4) + c4];
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                } else if (p.p_drop > 0.0f) {
+                    const float4 m = dropout4(p.seed, ((uint64_t)t * p.P + p.slotof[q]) * (H / 4) + c4, 1u, p.p_drop);
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            }
+            xr[i] = v;
+        }
+    };
+    auto gather_commit = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid + NT * i;
+            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+            const int q = q0 + row;
+            uint32_t a0, a1, a2, b0, b1, b2;
+            split3(xr[i].x, xr[i].y, a0, a1, a2);
+            split3(xr[i].z, xr[i].w, b0, b1, b2);
+            unsigned char *d = ldsb + row * PB + 8 * c4;
+            *reinterpret_cast<uint2 *>(d) = make_uint2(a0, b0);
+            *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a2, b2);
+            if (p.xh && q < p.P) {
+                float4 *xo4 = reinterpret_cast<float4 *>(p.xh);
+                const uint32_t xo = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4;
+                xo4[xo] = xr[i];
+                if (t == 0) xo4[xo + H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    for (int t = 0; t < p.L; t++) {
+        PN_STAMP(4 * t + 0);
+        gather_issue(t);
+        gather_commit(t);
+        __syncthreads();
+        PN_STAMP(4 * t + 1);
+
+        f32x16 acc[G];
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[g][r] = bias[g];
+
+        // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T.  Weight fragments stream L2 -> VGPR ahead of their MFMAs: the
+        //      plane-0 fragments (needed first) ping-pong between two register sets one k-step ahead, planes 1 and 2
+        //      are re-fetched into their own registers as soon as the MFMAs that read them are issued (2/3 of a k-step
+        //      ahead).  vmcnt is in order: [P0(s) P1(s) P2(s) P0(s+1)] in flight at the top of k-step s.
+        {
+            const int nsteps = t == 0 ? KS / 2 : KS;
+            const u32x4 *wb = reinterpret_cast<const u32x4 *>(p.Wp) + (int64_t)wave * KS * 3 * G * 64 + lane;
+            const unsigned char *arow = ldsb + li * PB + 16 * hk;
+            u32x4 P0a[G], P0b[G], P1[G], P2[G];
+            auto load = [&](u32x4 (&B)[G], int s, int pl) {
+#pragma unroll
+                for (int g = 0; g < G; g++) async_load_b128(B[g], wb + ((int64_t)s * 3 * G + pl * G + g) * 64);
+            };
+            auto kstep = [&](int s, u32x4 (&P0)[G], u32x4 (&P0next)[G]) {
+                load(P0next, min(s + 1, nsteps - 1), 0);
+                u32x4 a[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) a[pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE + 32 * s);
+                wait_frag<3 * G, G>(P0);
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[pl], P0[g], acc[g]);
+                wait_frag<2 * G, G>(P1);
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[pl], P1[g], acc[g]);
+                load(P1, min(s + 1, nsteps - 1), 1);
+                wait_frag<2 * G, G>(P2);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P2[g], acc[g]);
+                load(P2, min(s + 1, nsteps - 1), 2);
+            };
+            load(P0a, 0, 0);
+            load(P1, 0, 1);
+            load(P2, 0, 2);
+#pragma unroll 1
+            for (int s = 0; s < nsteps; s += 2) {
+                kstep(s, P0a, P0b);
+                kstep(s + 1, P0b, P0a);
+            }
+            wait_frag<0, G>(P0a);                         // drain (harmless re-loads of the last k-step)
+            wait_frag<0, G>(P1);
+            wait_frag<0, G>(P2);
+        }
+        __syncthreads();  // every wave is done reading x_t / h_{t-1}
+        PN_STAMP(4 * t + 2);
+
+        // ---- cell update in registers; h_t goes back to LDS (split) for the next step ----------------------
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = acc_row(r, lane);
+            int q = q0 + row;
+            asm volatile("" : "+v"(q));     // recompute the row offsets here: hoisted out of the t loop they spill
+            float h;
+            if (G == 4) {
+                const float ig = sigmoidf_(acc[0][r]);
+                const float fg = sigmoidf_(acc[G > 1 ? 1 : 0][r]);
+                const float gg = tanhf_(acc[G > 2 ? 2 : 0][r]);
+                const float og = sigmoidf_(acc[G > 3 ? 3 : 0][r]);
+                const float c = fg * cst[r] + ig * gg;
+                cst[r] = c;
+                h = og * tanhf_(c);
+                if (p.saved && q < p.P) {
+                    const uint32_t so = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
+                    p.saved[so] = ig; p.saved[so + H] = fg; p.saved[so + 2 * H] = gg; p.saved[so + 3 * H] = og;
+                    p.saved[so + 4 * H] = c;
+                }
+            } else {
+                h = tanhf_(acc[0][r]);
+                if (p.saved && q < p.P) p.saved[((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)H + col] = h;
+            }
+            hv[r] = h;
+            if (q < p.P) {
+                if (t == p.L - 1)
+                    p.hn[(uint32_t)q * (uint32_t)H + col] = h;
+                else if (p.xh)
+                    p.xh[((uint32_t)q * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col] = h;
+            }
+        }
+        if (t + 1 < p.L) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
+                uint32_t h0, h1, h2;
+                split3(hv[r], hv[r + 1], h0, h1, h2);
+                unsigned char *d = ldsb + acc_row(r, lane) * PB + 2 * (H + col);
+                *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
+                *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
+                *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
+                *reinterpret_cast<uint16_t *>(d + PLANE + PB) = (uint16_t)(h1 >> 16);
+                *reinterpret_cast<uint16_t *>(d + 2 * PLANE) = (uint16_t)h2;
+                *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(h2 >> 16);
+            }
+        }
         PN_STAMP(4 * t + 3);
     }
 }
@@ -1087,6 +1307,142 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradParams p) {
     if (blockIdx.x == 0 && tid < WG_BM && m0 + tid < p.GH) p.part_b[(int64_t)blockIdx.z * p.GH + m0 + tid] = bsum;
 }
 
+// ---- the same GEMM on the bf16 matrix pipe (pn_kernels.h: six bf16 MFMAs = one fp32-accurate product) -----------
+// Both operands have the reduction dimension (rows) outermost, the bf16 MFMA wants 8 consecutive k per lane.  A
+// thread therefore fetches an 8-row x 4-column fp32 block (8 coalesced 16-byte loads), splits the 32 values into
+// their three bf16 planes in registers and writes, per column, one 16-byte k-octet per plane: the in-register
+// transposition costs nothing.  LDS image per (plane, operand, k-octet kb = 0..3 of the 32-row K tile): 256 columns,
+// column c at 16-byte slot (c & 3) * 68 + (c >> 2) -- consecutive lanes write consecutive slots (conflict-free
+// ds_write_b128) and the 16-lane groups of the fragment ds_read_b128 hit 16 distinct bank quads.
+constexpr int W3_BLK = 4 * 68;                          // slots per k-octet block
+constexpr int W3_PLANE = 2 * 4 * W3_BLK;                // slots per plane (2 operands x 4 k-octets)
+constexpr int W3_LDS_BYTES = 3 * W3_PLANE * 16;         // 104 448 B
+
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * WG_BM, n0 = blockIdx.x * WG_BN;
+    const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
+    const int64_t rend = min(p.R, rbeg + p.rows_per_split);
+    if (rbeg >= rend) return;   // block-uniform
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // staging task of this thread: k-octet ro of the K tile, operand op, columns 4*cql .. +3
+    const int ro = tid >> 7, cq = tid & 127, op = cq >> 6, cql = cq & 63;
+    const float *src = op == 0 ? p.dG : p.xh;
+    const int ld = op == 0 ? p.GH : p.H2;
+    const int c0 = (op == 0 ? m0 : n0) + 4 * cql;
+    const bool c_ok = c0 < ld;
+    const float *srcc = src + (c_ok ? c0 : 0);
+    f32x4 rg[8];
+    auto issue = [&](int64_t k0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) async_load_b128(rg[e], srcc + min(k0 + 8 * ro + e, rend - 1) * ld);
+    };
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};     // column sums of dG over this thread's rows (bias gradient)
+    u32x4 *stage = lds4 + (op * 4 + ro) * W3_BLK + cql;
+    const int sa = (li & 3) * 68 + (li >> 2) + wm * 16, sb = (li & 3) * 68 + (li >> 2) + wn * 32;
+
+    issue(rbeg);
+    for (int64_t k0 = rbeg; k0 < rend; k0 += WG_KT) {
+        wait_vm<0>(rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], rg[6], rg[7]);
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (!(c_ok && k0 + 8 * ro + e < rend)) rg[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u32x4 q0, q1, q2;
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                uint32_t x0, x1, x2;
+                split3(rg[2 * h][j], rg[2 * h + 1][j], x0, x1, x2);
+                q0[h] = x0; q1[h] = x1; q2[h] = x2;
+                bs[j] += rg[2 * h][j] + rg[2 * h + 1][j];
+            }
+            stage[j * 68] = q0;
+            stage[W3_PLANE + j * 68] = q1;
+            stage[2 * W3_PLANE + j * 68] = q2;
+        }
+        __syncthreads();
+        issue(min(k0 + WG_KT, rend - 1));   // next tile in flight under the MFMAs (last trip: harmless re-load)
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const u32x4 *fa = lds4 + (kk * 2 + hk) * W3_BLK + sa;             // operand 0 (dG^T)
+            const u32x4 *fb = lds4 + (4 + kk * 2 + hk) * W3_BLK + sb;         // operand 1 ([x|h])
+            u32x4 a0[2], a1[2], b0[4], b1[4];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a0[i] = fa[i * 8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b0[j] = fb[j * 8];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b1[j] = fb[W3_PLANE + j * 8];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; i++) a1[i] = fa[W3_PLANE + i * 8];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b1[j], acc[i][j]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) b1[j] = fb[2 * W3_PLANE + j * 8];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; i++) a1[i] = fa[2 * W3_PLANE + i * 8];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    wait_vm<0>(rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], rg[6], rg[7]);   // drain the trailing prefetch
+    float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wn * 128 + j * 32 + li;
+            if (n >= p.H2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (m < p.GH) pw[(int64_t)m * p.H2 + n] = acc[i][j][r];
+            }
+        }
+    // bias gradient: the four k-octet owners of a column add up through LDS
+    if (blockIdx.x != 0) return;   // block-uniform
+    float *fl = reinterpret_cast<float *>(lds4);
+    if (op == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) fl[ro * WG_BM + 4 * cql + j] = bs[j];
+    }
+    __syncthreads();
+    if (tid < WG_BM && m0 + tid < p.GH)
+        p.part_b[(int64_t)blockIdx.z * p.GH + m0 + tid] =
+            (fl[tid] + fl[WG_BM + tid]) + (fl[2 * WG_BM + tid] + fl[3 * WG_BM + tid]);
+}
+
 // sums the split partials and scatters them into the reference layouts g_W_ih [GH,H], g_W_hh [GH,H], g_b_*
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const float *__restrict__ part_b, int nsplit,
                                     int GH, int H, float *__restrict__ g_w_ih, float *__restrict__ g_w_hh,
@@ -1246,8 +1602,13 @@ int check_shape(const pn_pagg_shape &s) {
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
     constexpr int MT = PN_FWD_MT;
+#if PN_SEQ_BF16X3
+    constexpr size_t lds_bytes = (size_t)3 * MT * (4 * H + 16);
+    auto kern = seq_fwd3_kernel<H, G, MT>;
+#else
     constexpr size_t lds_bytes = (size_t)MT * (2 * H + 4) * 4;
     auto kern = seq_fwd_kernel<H, G, MT>;
+#endif
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
     const int blocks = (sp.P + MT - 1) / MT;
@@ -1397,9 +1758,14 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s.variant, a->ids,
                            a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
         PN_CHECK_HIP(hipGetLastError());
+#if PN_SEQ_BF16X3
+        hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((G * H * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
+                           a->w_hh, a->b_ih, a->b_hh, H, G, reinterpret_cast<u32x4 *>(Wp), biasc);
+#else
         const int64_t nw = (int64_t)G * H * 3 * H;     // [W_ih | W_hh] fragments + the step-0 W_ih fragments
         hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
                            a->b_ih, a->b_hh, H, G, Wp, biasc);
+#endif
         PN_CHECK_HIP(hipGetLastError());
     }
     SeqFwdParams sp{};
@@ -1608,8 +1974,16 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
         {
             StageTimer tm(ST_WGRAD, stream);
+#if PN_WGRAD_BF16X3
+            static const hipError_t lds_attr = hipFuncSetAttribute(
+                reinterpret_cast<const void *>(wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+            PN_CHECK_HIP(lds_attr);
+            hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
+                               dim3(WG_THREADS), W3_LDS_BYTES, stream, wp);
+#else
             hipLaunchKernelGGL(wgrad_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
                                dim3(WG_THREADS), 0, stream, wp);
+#endif
             PN_CHECK_HIP(hipGetLastError());
             const int64_t nred = (int64_t)GH * 2 * H + GH;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, stream,

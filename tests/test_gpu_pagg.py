@@ -267,6 +267,53 @@ def test_backward_matches_oracle_random(variant, H, W, S, N, F, C, train):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+def test_accuracy_against_float64_truth(variant):
+    """The recurrent GEMMs run fp32 products as six bf16 MFMAs (pn_kernels.h).  Measured against a float64
+    evaluation of the oracle, the HIP path may not be less accurate than a few times the fp32 CPU restatement."""
+    import json, os
+    torch.manual_seed(5)
+    rng = np.random.default_rng(6)
+    H, W, S, N, F, C, L = 128, 40, 120, 300, 200, 6, 4
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    X = torch.rand(N, F)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    G = torch.randn(S, C)
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    (out * G.cuda()).sum().backward()
+    got = {k: v.grad.cpu().double() for k, v in m.named_parameters()}
+    got["X"], got["out"] = Xd.grad.cpu().double(), out.detach().cpu().double()
+
+    def oracle(dtype):
+        pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        Xo = X.clone().requires_grad_(True)
+        y = po.forward(variant, pr, Xo, ids, codes, sel, W, L, dtype=dtype)
+        (y * G.to(dtype)).sum().backward()
+        r = {k: v.grad.double() for k, v in pr.items()}
+        r["X"], r["out"] = Xo.grad.double(), y.detach().double()
+        return r
+
+    truth, cpu32 = oracle(torch.float64), oracle(torch.float32)
+    report, bad = {}, {}
+    for k in truth:
+        scale = max(1e-30, truth[k].abs().max().item())
+        e_hip = (got[k] - truth[k]).abs().max().item() / scale
+        e_cpu = (cpu32[k] - truth[k]).abs().max().item() / scale
+        report[k] = {"hip": e_hip, "cpu_fp32": e_cpu}
+        if not e_hip <= max(8 * e_cpu, 2e-6):
+            bad[k] = report[k]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/accuracy_%s.json" % variant, "w") as f:
+        json.dump(report, f, indent=1)
+    assert not bad, bad
+
+
 def test_builtin_dropout_backward_is_consistent_with_forward():
     """With the built-in Philox masks the backward must regenerate exactly the forward's mask:
     check d(out)/d(params) by finite differences along one random direction, same seed."""
