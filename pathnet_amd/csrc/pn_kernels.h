@@ -65,6 +65,24 @@ __device__ __forceinline__ void async_load_b32(float &dst, const void *ptr) {
 __device__ __forceinline__ void async_load_b128(u32x4 &dst, const void *ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory");
 }
+// the same load with a scalar base: address = sbase (SGPR pair, wave-uniform) + voff (one VGPR) + IMM (< 4096).
+// A stream of fragments then costs one offset register in total instead of a 64-bit pointer per fragment.
+template <int IMM>
+__device__ __forceinline__ void async_load_b128_s(u32x4 &dst, const void *sbase, uint32_t voff) {
+    static_assert(IMM >= 0 && IMM < 4096, "13-bit signed instruction offset");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+// G (1, 2 or 4) consecutive 1 KB fragments starting at sbase
+template <int G>
+__device__ __forceinline__ void async_load_frags(u32x4 (&b)[G], const void *sbase, uint32_t voff) {
+    static_assert(G == 1 || G == 2 || G == 4, "fragment groups of 1, 2 or 4");
+    async_load_b128_s<0>(b[0], sbase, voff);
+    if constexpr (G > 1) async_load_b128_s<1024>(b[1], sbase, voff);
+    if constexpr (G > 2) {
+        async_load_b128_s<2048>(b[2], sbase, voff);
+        async_load_b128_s<3072>(b[3], sbase, voff);
+    }
+}
 template <int N>
 __device__ __forceinline__ void wait_vm(u32x4 &r0) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "i"(N));

@@ -658,12 +658,14 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
         //      ahead).  vmcnt is in order: [P0(s) P1(s) P2(s) P0(s+1)] in flight at the top of k-step s.
         {
             const int nsteps = t == 0 ? KS / 2 : KS;
-            const u32x4 *wb = reinterpret_cast<const u32x4 *>(p.Wp) + (int64_t)wave * KS * 3 * G * 64 + lane;
+            // wave-uniform stream base in SGPRs, one VGPR of lane offset (pn_kernels.h: async_load_frags)
+            const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.Wp) +
+                                      (size_t)__builtin_amdgcn_readfirstlane(wave) * (KS * 3 * G * 1024);
+            const uint32_t voff = lane * 16;
             const unsigned char *arow = ldsb + li * PB + 16 * hk;
             u32x4 P0a[G], P0b[G], P1[G], P2[G];
             auto load = [&](u32x4 (&B)[G], int s, int pl) {
-#pragma unroll
-                for (int g = 0; g < G; g++) async_load_b128(B[g], wb + ((int64_t)s * 3 * G + pl * G + g) * 64);
+                async_load_frags<G>(B, wb + (size_t)(s * 3 + pl) * (G * 1024), voff);
             };
             auto kstep = [&](int s, u32x4 (&P0)[G], u32x4 (&P0next)[G]) {
                 load(P0next, min(s + 1, nsteps - 1), 0);
@@ -1206,6 +1208,249 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqB
     }
 }
 
+// ---- the same BPTT on the bf16 matrix pipe (pn_kernels.h) --------------------------------------------------------
+//   [dx_t | dh_{t-1}] = dG_t [32, G*H] . [W_ih | W_hh]:  K = G*H gate columns, wave w owns columns 32w..32w+31 of dx and of dh.
+//   Weights: pack_bwd3_kernel, B fragments grouped in units of two k-steps (kk) x two output halves (nt),
+//     WpT3[(((w*NU + u)*3 + plane)*4 + kk*2 + nt)*64 + lane] (16 bytes) =
+//         plane of Wcat[k = 32u + 16kk + 8(lane >> 5) .. +7][n = nt*H + 32w + (lane & 31)],      NU = G*H/32 units.
+//   A operand: the three bf16 planes of dG_t in LDS.  All four LSTM gates would take 3 x 32 x 4H x 2 B = 96 KB per
+//     workgroup (one workgroup per CU); the tile therefore holds one gate pair at a time -- (i, f) then (g, o), K = 2H
+//     each, 50 KB -- and the k loop runs in two passes with the (g, o) gradients parked in registers meanwhile.
+__global__ void pack_bwd3_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int H, int G,
+                                 u32x4 *__restrict__ WpT) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int GH = G * H, NU = GH / 32, NW = H / 32;
+    if (idx >= NW * NU * 4 * 64) return;
+    const int lane = idx & 63, f = (idx >> 6) & 3;
+    int rest = idx >> 8;
+    const int u = rest % NU, w = rest / NU;
+    const int kk = f >> 1, nt = f & 1;
+    const int k = 32 * u + 16 * kk + 8 * (lane >> 5), n = 32 * w + (lane & 31);
+    const float *src = (nt == 0 ? w_ih : w_hh) + (int64_t)k * H + n;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = src[(int64_t)e * H];
+    u32x4 q0, q1, q2;
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+        uint32_t x0, x1, x2;
+        split3(v[2 * h], v[2 * h + 1], x0, x1, x2);
+        q0[h] = x0; q1[h] = x1; q2[h] = x2;
+    }
+    u32x4 *dst = WpT + ((int64_t)(w * NU + u) * 3 * 4 + f) * 64 + lane;
+    dst[0] = q0;
+    dst[4 * 64] = q1;
+    dst[8 * 64] = q2;
+}
+
+template <int H, int G, int MT>
+__global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(SeqBwdParams p) {
+    static_assert(MT == 32, "one 32-row MFMA tile per workgroup");
+    constexpr int NT = H / 32 * 64, GH = G * H, SV = (G == 4 ? 5 : 1);
+    constexpr int NPASS = G == 4 ? 2 : 1, KP = GH / NPASS;      // K extent of one pass (one gate pair)
+    constexpr int PB = 2 * KP + 16, PLANE = 32 * PB;            // plane row pitch / plane size, bytes
+    constexpr int NU = GH / 32, NUP = NU / NPASS;               // units of two k-steps, total / per pass
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);   // [MT][L] gather rows of this tile
+    int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int q0 = blockIdx.x * MT;
+    const int col = 32 * wave + li;
+
+    for (int i = tid; i < MT * p.L; i += NT) {
+        const int q = q0 + i / p.L;
+        s_rowidx[i] = q < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
+    }
+    for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
+
+    f32x16 dh, dc, cnext;   // cnext: c_t of the step processed next (= c_{t-1} now)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int q = q0 + acc_row(r, lane);
+        const int qc = min(q, p.P - 1);
+        const float dh0 = p.dhn[(uint32_t)qc * (uint32_t)H + col];     // unconditional load, select afterwards
+        dh[r] = q < p.P ? dh0 : 0.0f;
+        dc[r] = 0.0f;
+        cnext[r] = G == 4 ? p.saved[(((uint32_t)qc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col] : 0.0f;
+    }
+
+    // the bf16 planes of two tile rows (accumulator registers r, r+1) of gate slot gs (0 or 1) of the resident pair
+    auto put_pair = [&](int r, int lane_t, int gs, float v0, float v1) {
+        uint32_t x0, x1, x2;
+        split3(v0, v1, x0, x1, x2);
+        unsigned char *d = ldsb + acc_row(r, lane_t) * PB + 2 * (gs * H + col);
+        *reinterpret_cast<uint16_t *>(d) = (uint16_t)x0;
+        *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(x0 >> 16);
+        *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)x1;
+        *reinterpret_cast<uint16_t *>(d + PLANE + PB) = (uint16_t)(x1 >> 16);
+        *reinterpret_cast<uint16_t *>(d + 2 * PLANE) = (uint16_t)x2;
+        *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(x2 >> 16);
+    };
+
+    for (int t = p.L - 1; t >= 0; t--) {
+        PN_STAMP(4 * (p.L - 1 - t) + 0);
+        // (row numbers are re-derived from an opaque copy of the lane id in every step: as loop invariants the
+        //  per-row offsets would occupy ~40 registers across the MFMA loops and spill)
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        // ---- cell backward.  All loads of a half tile are issued together (unconditionally, padded rows read a
+        //      clamped row and are zeroed afterwards) so the wave pays one memory round trip, not one per element.
+        float ag[16], ao[16];      // (g, o) gate gradients wait here for the second pass
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            float vi[8], vf[8], vg[8], vo[8], vc[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int r = half * 8 + e;
+                const int qc = min(q0 + acc_row(r, lane_t), p.P - 1);
+                const uint32_t so = ((uint32_t)qc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
+                if (G == 4) {
+                    vi[e] = p.saved[so]; vf[e] = p.saved[so + H]; vg[e] = p.saved[so + 2 * H];
+                    vo[e] = p.saved[so + 3 * H];
+                    vc[e] = t > 0 ? p.saved[so - H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
+                } else {
+                    vi[e] = p.saved[so];                                      // h_t
+                }
+            }
+            float ai[8], af[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int r = half * 8 + e;
+                const int q = q0 + acc_row(r, lane_t);
+                const bool ok = q < p.P;
+                float *d = p.dG + (((uint32_t)min(q, p.P - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col);
+                if (G == 4) {
+                    const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
+                    const float tc = tanhf_(cnext[r]);
+                    const float dhv = dh[r];
+                    const float d_o = dhv * tc;
+                    const float dct = dc[r] + dhv * og * (1.0f - tc * tc);
+                    float a_i = dct * gg * ig * (1.0f - ig);
+                    float a_f = dct * cprev * fg * (1.0f - fg);
+                    float a_g = dct * ig * (1.0f - gg * gg);
+                    float a_o = d_o * og * (1.0f - og);
+                    if (!ok) a_i = a_f = a_g = a_o = 0.0f;
+                    dc[r] = dct * fg;
+                    cnext[r] = cprev;
+                    ai[e] = a_i; af[e] = a_f; ag[r] = a_g; ao[r] = a_o;
+                    if (ok) {
+                        d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
+                    }
+                } else {
+                    const float h = vi[e];
+                    const float a = ok ? dh[r] * (1.0f - h * h) : 0.0f;
+                    ai[e] = a;
+                    if (ok) d[0] = a;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                put_pair(half * 8 + e, lane_t, 0, ai[e], ai[e + 1]);
+                if (G == 4) put_pair(half * 8 + e, lane_t, 1, af[e], af[e + 1]);
+            }
+        }
+        __syncthreads();
+        PN_STAMP(4 * (p.L - 1 - t) + 1);
+
+        // ---- [dx_t ; dh_{t-1}] = dG_t . [W_ih | W_hh]; the dh half is not needed at t = 0 ------------------------
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
+        const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.WpT) +
+                                  (size_t)__builtin_amdgcn_readfirstlane(wave) * (NU * 12 * 1024);
+        const uint32_t voff = lane * 16;
+        const unsigned char *arow = ldsb + li * PB + 16 * hk;
+        // units [ub, ue) of the weight stream against the resident gate pair; same fragment pipeline as seq_fwd3_kernel
+        auto run = [&](auto ntn_tag, const int ub, const int ue) {
+            constexpr int NTN = decltype(ntn_tag)::value, NF = 2 * NTN;       // fragments per plane and unit
+            u32x4 P0a[NF], P0b[NF], P1[NF], P2[NF];
+            auto load = [&](u32x4 (&B)[NF], int u, int pl) {      // fragment kk*2 + nt of the unit's plane
+                const unsigned char *sb = wb + (size_t)(u * 3 + pl) * 4096;
+                if constexpr (NTN == 2) {
+                    async_load_frags<4>(B, sb, voff);
+                } else {
+                    async_load_b128_s<0>(B[0], sb, voff);
+                    async_load_b128_s<2048>(B[1], sb, voff);
+                }
+            };
+            auto unit = [&](int u, u32x4 (&P0)[NF], u32x4 (&P0next)[NF]) {
+                const int un = min(u + 1, ue - 1);
+                load(P0next, un, 0);
+                u32x4 a[2][3];
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++)
+                        a[kk][pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE + 64 * (u - ub) + 32 * kk);
+                wait_frag<3 * NF, NF>(P0);
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                    for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][pl], P0[f], acc[f % NTN]);
+                wait_frag<2 * NF, NF>(P1);
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][pl], P1[f], acc[f % NTN]);
+                load(P1, un, 1);
+                wait_frag<2 * NF, NF>(P2);
+#pragma unroll
+                for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][0], P2[f], acc[f % NTN]);
+                load(P2, un, 2);
+            };
+            load(P0a, ub, 0);
+            load(P1, ub, 1);
+            load(P2, ub, 2);
+#pragma unroll 1
+            for (int u = ub; u < ue; u += 2) {
+                unit(u, P0a, P0b);
+                if (NUP % 2 == 0 || u + 1 < ue) unit(u + 1, P0b, P0a);
+            }
+            wait_frag<0, NF>(P0a);       // drain (harmless re-loads of the last unit)
+            wait_frag<0, NF>(P0b);
+            wait_frag<0, NF>(P1);
+            wait_frag<0, NF>(P2);
+        };
+        if (t > 0)
+            run(std::integral_constant<int, 2>{}, 0, NUP);
+        else
+            run(std::integral_constant<int, 1>{}, 0, NUP);
+        if (NPASS == 2) {
+            __syncthreads();             // every wave is done with the (i, f) planes
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                put_pair(r, lane_t, 0, ag[r], ag[r + 1]);
+                put_pair(r, lane_t, 1, ao[r], ao[r + 1]);
+            }
+            __syncthreads();
+            if (t > 0)
+                run(std::integral_constant<int, 2>{}, NUP, NU);
+            else
+                run(std::integral_constant<int, 1>{}, NUP, NU);
+        }
+        __syncthreads();
+        PN_STAMP(4 * (p.L - 1 - t) + 2);
+
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = acc_row(r, lane_t);
+            if (q0 + row < p.P) {
+                float dx = acc[0][r];
+                const uint64_t e = ((uint64_t)t * p.P + s_slotof[row]) * H + col;
+                if (p.mask)
+                    dx *= p.mask[e];
+                else if (p.p_drop > 0.0f)
+                    dx *= dropout1(p.seed, e, 1u, p.p_drop);
+                atomicAdd(&p.dZ[(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col], dx);
+            }
+            dh[r] = acc[1][r];
+        }
+        PN_STAMP(4 * (p.L - 1 - t) + 3);
+    }
+}
+
 // ---- recurrent weight gradients:  [g_W_ih | g_W_hh]  [G*H, 2H] = dG^T [G*H, R] . XH [R, 2H],  R = P*L rows,
 //      plus the bias gradient colsum(dG).  Both operands are row-major with the reduction dimension
 //      outermost, i.e. already "K-major": tiles go global -> LDS with coalesced 16-byte loads and no
@@ -1505,8 +1750,13 @@ int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t
 template <int H, int G>
 int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int MT = PN_BWD_MT;
+#if PN_SEQ_BF16X3
+    const size_t lds_bytes = (size_t)3 * MT * (2 * (G == 4 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4;
+    auto kern = seq_bwd3_kernel<H, G, MT>;
+#else
     const size_t lds_bytes = (size_t)MT * (G * H + 4) * 4 + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_bwd_kernel<H, G, MT>;
+#endif
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
     const int blocks = (sp.P + MT - 1) / MT;
@@ -1561,7 +1811,7 @@ WsLayout ws_layout(const pn_pagg_shape &s) {
     w.coef = take(P * 4);
     w.rawsc = take(P * 4);
     w.layer1 = take(S * 2 * H * 4);
-    w.WpT = take(G * H * 2 * H * 4);
+    w.WpT = take(G * H * 3 * H * 4);
     w.dG = take(P * L * G * H * 4);
     w.dZ = take(N * L * H * 4);
     w.dXh = take(N * H * 4);
@@ -1938,8 +2188,14 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     {
         StageTimer tm(ST_SEQ_BWD, stream);
         const int64_t nw = (int64_t)GH * 2 * H;
+#if PN_SEQ_BF16X3
+        (void)nw;
+        hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
+                           a->w_hh, H, G, reinterpret_cast<u32x4 *>(WpT));
+#else
         hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
                            H, G, WpT);
+#endif
         PN_CHECK_HIP(hipGetLastError());
         SeqBwdParams sp{};
         sp.saved = saved;
