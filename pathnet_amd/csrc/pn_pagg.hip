@@ -42,25 +42,13 @@ using namespace pn;
 #ifndef PN_FWD_WAVES
 #define PN_FWD_WAVES 2      // __launch_bounds__ min waves per SIMD, forward
 #endif
-#ifndef PN_FWD_PREFETCH_X
-#define PN_FWD_PREFETCH_X 0 // 1: fetch the x_{t+1} rows under the MFMAs of step t (measured slower: r01 tune3)
-#endif
 #ifndef PN_BWD_MT
 #define PN_BWD_MT 32
-#endif
-#ifndef PN_BWD_EXPERIMENT
-#define PN_BWD_EXPERIMENT 0  // timing experiments only (1, 2: gather-backward scatter replaced / removed)
 #endif
 #ifndef PN_BWD_WAVES
 #define PN_BWD_WAVES 2
 #endif
 
-#ifndef PN_SEQ_BF16X3
-#define PN_SEQ_BF16X3 1     // recurrent forward GEMM on the bf16 pipe (3-way split, 6 products); 0: fp32-input MFMA
-#endif
-#ifndef PN_WGRAD_BF16X3
-#define PN_WGRAD_BF16X3 1   // weight-gradient GEMM on the bf16 pipe (3-way split, 6 products); 0: fp32-input MFMA
-#endif
 #ifndef PN_TRACE_PHASES
 #define PN_TRACE_PHASES 0   // 1: tuning builds only -- wave 0 of every workgroup stamps s_memtime at phase boundaries
 #endif
@@ -306,46 +294,6 @@ __global__ __launch_bounds__(256) void gather_kernel(int variant, const float *_
     }
 }
 
-// ================================================================================================
-// recurrent weights repacked into MFMA B-fragment order so that every fragment load is one fully
-// coalesced 1 KB global_load_dwordx4 per wave:
-//   Wp[((w*G + g)*(H/4) + s4)*64 + lane][e] = Wcat[g*H + 32*w + (lane&31)][(lane>>5)*H + 4*s4 + e]
-// with Wcat = [W_ih | W_hh] ([G*H, 2H]).  The lane half (lane>>5) selects the x or the h part, so one
-// MFMA step multiplies x_t by W_ih in lanes 0-31 and h_{t-1} by W_hh in lanes 32-63 and sums both.
-// ================================================================================================
-// A second copy for step 0 (h_{-1} = 0, only W_ih matters, K = H split over the lane halves):
-//   Wp0[((w*G + g)*(H/8) + s4)*64 + lane][e] = W_ih[g*H + 32*w + (lane&31)][(lane>>5)*H/2 + 4*s4 + e]
-__global__ void pack_fwd_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
-                                const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G,
-                                float *__restrict__ Wp, float *__restrict__ biasc) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)G * H * 2 * H;
-    if (idx < (int64_t)G * H) biasc[idx] = b_ih[idx] + b_hh[idx];
-    if (idx >= total && idx < total + (int64_t)G * H * H) {
-        const int64_t j = idx - total;
-        const int e = j & 3, lane = (j >> 2) & 63;
-        int64_t rest = j >> 8;
-        const int s4 = rest % (H / 8);
-        rest /= (H / 8);
-        const int g = rest % G, w = rest / G;
-        Wp[idx] = w_ih[(int64_t)(g * H + 32 * w + (lane & 31)) * H + (lane >> 5) * (H / 2) + 4 * s4 + e];
-        return;
-    }
-    if (idx >= total) return;
-    const int e = idx & 3, lane = (idx >> 2) & 63;
-    int64_t rest = idx >> 8;
-    const int s4 = rest % (H / 4);
-    rest /= (H / 4);
-    const int g = rest % G, w = rest / G;
-    const int row = g * H + 32 * w + (lane & 31), k = 4 * s4 + e;
-    Wp[idx] = (lane >> 5) == 0 ? w_ih[(int64_t)row * H + k] : w_hh[(int64_t)row * H + k];
-}
-
-// ================================================================================================
-// seq_fwd_kernel: gather + dropout + LSTM/RNN over the L steps of MT sequence slots.
-//   block = H/32 waves; wave w owns hidden units [32w, 32w+32) of every gate; LDS holds the
-//   A tile [MT][x_t (H) | h_{t-1} (H)] (+4 floats of row padding: conflict-free ds_read_b128).
-// ================================================================================================
 struct SeqFwdParams {
     const float *Z;         // [N*L, H] bank output (post activation)
     const int32_t *rowidx;  // [P, L]
@@ -361,182 +309,6 @@ struct SeqFwdParams {
     uint64_t seed;
     const float *mask;      // [L, P, H] explicit mask (reference order: original slot q) or null
 };
-
-template <int H, int G, int MT>
-// (H = 32 is a single wave per workgroup: no register cap there, a spill next to the asm loads would be a hazard)
-__global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_fwd_kernel(SeqFwdParams p) {
-    constexpr int NW = H / 32, NT = NW * 64, MTILES = MT / 32, PITCH = 2 * H + 4, SV = (G == 4 ? 5 : 1);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
-    const int q0 = blockIdx.x * MT;
-    const int col = 32 * wave + li;
-
-    for (int idx = tid; idx < MT * H; idx += NT) lds[(idx / H) * PITCH + H + (idx % H)] = 0.0f;
-
-    f32x16 cst[MTILES];
-#pragma unroll
-    for (int mt = 0; mt < MTILES; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) cst[mt][r] = 0.0f;
-    float bias[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) bias[g] = p.biasc[g * H + col];
-
-    const float4 *Z4 = reinterpret_cast<const float4 *>(p.Z);
-
-    // ---- coalesced row gather of x_t (H*4 bytes per row) with the dropout mask fused in.  The rows of step
-    //      t+1 are fetched into registers while the MFMAs of step t run (PN_FWD_PREFETCH_X) -----------------
-    constexpr int NLD = MT / 8;   // float4 per thread = MT * (H/4) / NT
-    float4 xr[NLD];
-    auto gather_issue = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-            const int idx = tid + NT * i;
-            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-            const int q = q0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < p.P) {
-                const uint32_t ri = (uint32_t)p.rowidx[(uint32_t)q * (uint32_t)p.L + t];
-                v = Z4[ri * (uint32_t)(H / 4) + c4];
-                if (p.mask) {
-                    const float4 m = reinterpret_cast<const float4 *>(
-                        p.mask)[((int64_t)t * p.P + p.slotof[q]) * (H / 4) + c4];
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                } else if (p.p_drop > 0.0f) {
-                    const float4 m = dropout4(p.seed, ((uint64_t)t * p.P + p.slotof[q]) * (H / 4) + c4, 1u, p.p_drop);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
-            }
-            xr[i] = v;
-        }
-    };
-    auto gather_commit = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-            const int idx = tid + NT * i;
-            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-            const int q = q0 + row;
-            *reinterpret_cast<float4 *>(&lds[row * PITCH + 4 * c4]) = xr[i];
-            if (p.xh && q < p.P) {
-                // 32-bit element offsets (check_shape bounds every tensor below 2^32 elements): one VGPR per
-                // address on a uniform base instead of a 64-bit pointer pair
-                float4 *xo4 = reinterpret_cast<float4 *>(p.xh);
-                const uint32_t xo = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4;
-                xo4[xo] = xr[i];
-                if (t == 0) xo4[xo + H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-#if PN_FWD_PREFETCH_X
-    gather_issue(0);
-#endif
-    for (int t = 0; t < p.L; t++) {
-        PN_STAMP(4 * t + 0);
-#if !PN_FWD_PREFETCH_X
-        gather_issue(t);
-#endif
-        gather_commit(t);
-        __syncthreads();
-        PN_STAMP(4 * t + 1);
-#if PN_FWD_PREFETCH_X
-        if (t + 1 < p.L) gather_issue(t + 1);
-#endif
-
-        f32x16 acc[MTILES][G];
-#pragma unroll
-        for (int mt = 0; mt < MTILES; mt++)
-#pragma unroll
-            for (int g = 0; g < G; g++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[mt][g][r] = bias[g];
-
-        // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T : lanes 0-31 walk the x half of K, lanes 32-63 the h half
-        // B fragments stream L2 -> VGPR one k-step (G KB per wave) ahead of the MFMAs that use them: two
-        // register sets, the loads of step s+1 are issued before the MFMAs of step s (async_load_b128 keeps
-        // hipcc from sinking them to their use).  Step 0 has h_{-1} = 0: only the x half of K, both lane halves
-        // walk it (KH = H/2 per half) against the step-0 packing of W_ih.
-        auto k_loop = [&](auto ksteps_tag, const float *wpack) {
-            constexpr int KSTEPS = decltype(ksteps_tag)::value;       // k-steps of 4 per lane half
-            constexpr int KH = 4 * KSTEPS;                            // K extent per lane half
-            static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
-            const f32x4 *wb = reinterpret_cast<const f32x4 *>(wpack) + ((int64_t)wave * G * KSTEPS) * 64 + lane;
-            f32x4 b0[G], b1[G];
-#pragma unroll
-            for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS) * 64);
-            auto mfma_step = [&](int s4, const f32x4 (&b)[G]) {
-                float4 a[MTILES];
-#pragma unroll
-                for (int mt = 0; mt < MTILES; mt++)
-                    a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * KH + 4 * s4]);
-#pragma unroll
-                for (int mt = 0; mt < MTILES; mt++) {
-#pragma unroll
-                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].x, b[g][0], acc[mt][g]);
-#pragma unroll
-                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].y, b[g][1], acc[mt][g]);
-#pragma unroll
-                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].z, b[g][2], acc[mt][g]);
-#pragma unroll
-                    for (int g = 0; g < G; g++) acc[mt][g] = mfma32(a[mt].w, b[g][3], acc[mt][g]);
-                }
-            };
-#pragma unroll 1
-            for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
-#pragma unroll
-                for (int g = 0; g < G; g++) async_load_b128(b1[g], wb + ((int64_t)g * KSTEPS + s4 + 1) * 64);
-                wait_frag<G, G>(b0);                      // b0 landed; b1's G loads may stay in flight
-                mfma_step(s4, b0);
-                const int sn = min(s4 + 2, KSTEPS - 2);   // last trip re-loads a fragment nobody reads
-#pragma unroll
-                for (int g = 0; g < G; g++) async_load_b128(b0[g], wb + ((int64_t)g * KSTEPS + sn) * 64);
-                wait_frag<G, G>(b1);
-                mfma_step(s4 + 1, b1);
-            }
-            wait_frag<0, G>(b0);                          // drain before the registers are reused
-        };
-        if (t == 0)
-            k_loop(std::integral_constant<int, H / 8>{}, p.Wp + (size_t)G * H * 2 * H);
-        else
-            k_loop(std::integral_constant<int, H / 4>{}, p.Wp);
-        __syncthreads();  // every wave is done reading x_t / h_{t-1}
-        PN_STAMP(4 * t + 2);
-
-        // ---- cell update in registers; h_t goes back to LDS for the next step ----------------------
-#pragma unroll
-        for (int mt = 0; mt < MTILES; mt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = mt * 32 + acc_row(r, lane);
-                const int q = q0 + row;
-                float h;
-                if (G == 4) {
-                    const float ig = sigmoidf_(acc[mt][0][r]);
-                    const float fg = sigmoidf_(acc[mt][G > 1 ? 1 : 0][r]);
-                    const float gg = tanhf_(acc[mt][G > 2 ? 2 : 0][r]);
-                    const float og = sigmoidf_(acc[mt][G > 3 ? 3 : 0][r]);
-                    const float c = fg * cst[mt][r] + ig * gg;
-                    cst[mt][r] = c;
-                    h = og * tanhf_(c);
-                    if (p.saved && q < p.P) {
-                        const uint32_t so = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
-                        p.saved[so] = ig; p.saved[so + H] = fg; p.saved[so + 2 * H] = gg; p.saved[so + 3 * H] = og;
-                        p.saved[so + 4 * H] = c;
-                    }
-                } else {
-                    h = tanhf_(acc[mt][0][r]);
-                    if (p.saved && q < p.P) p.saved[((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)H + col] = h;
-                }
-                lds[row * PITCH + H + col] = h;
-                if (q < p.P) {
-                    if (t == p.L - 1)
-                        p.hn[(uint32_t)q * (uint32_t)H + col] = h;
-                    else if (p.xh)
-                        p.xh[((uint32_t)q * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col] = h;
-                }
-            }
-        PN_STAMP(4 * t + 3);
-    }
-}
 
 // ================================================================================================
 // The same recurrence on the bf16 matrix pipe (pn_kernels.h: fp32 = three bf16 planes, six MFMAs per product).
@@ -876,22 +648,6 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
 // ================================================================================================
 // BACKWARD
 // ================================================================================================
-// recurrent weights in B-fragment order for  [dx_t ; dh_{t-1}] = dG_t . [W_ih | W_hh]   (K = G*H):
-//   WpT[((w*2 + nt)*(GH/8) + s4)*64 + lane][e] = Wcat[k = (lane>>5)*GH/2 + 4*s4 + e][n = nt*H + 32*w + (lane&31)]
-__global__ void pack_bwd_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int H, int G,
-                                float *__restrict__ WpT) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int GH = G * H;
-    if (idx >= (int64_t)GH * 2 * H) return;
-    const int e = idx & 3, lane = (idx >> 2) & 63;
-    int64_t rest = idx >> 8;
-    const int s4 = rest % (GH / 8);
-    rest /= (GH / 8);
-    const int nt = rest % 2, w = rest / 2;
-    const int k = (lane >> 5) * (GH / 2) + 4 * s4 + e, n = 32 * w + (lane & 31);
-    WpT[idx] = nt == 0 ? w_ih[(int64_t)k * H + n] : w_hh[(int64_t)k * H + n];
-}
-
 // ---- pooling / attention / classifier backward: one wavefront per group -------------------------
 struct PoolBwdParams {
     int variant, S, W, H, C;
@@ -1039,175 +795,6 @@ struct SeqBwdParams {
     const float *mask;
 };
 
-template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd_kernel(SeqBwdParams p) {
-    constexpr int NT = H / 32 * 64, MTILES = MT / 32, GH = G * H, PITCH = GH + 4, SV = (G == 4 ? 5 : 1);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    int *s_rowidx = reinterpret_cast<int *>(lds + MT * PITCH);   // [MT][L] gather rows of this tile
-    int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
-    const int q0 = blockIdx.x * MT;
-    const int col = 32 * wave + li;
-
-    for (int i = tid; i < MT * p.L; i += NT) {
-        const int q = q0 + i / p.L;
-        s_rowidx[i] = q < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
-    }
-    for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
-
-    f32x16 dh[MTILES], dc[MTILES], cnext[MTILES];   // cnext: c_t of the step processed next (= c_{t-1} now)
-#pragma unroll
-    for (int mt = 0; mt < MTILES; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int q = q0 + mt * 32 + acc_row(r, lane);
-            const int qc = min(q, p.P - 1);
-            const float dh0 = p.dhn[(uint32_t)qc * (uint32_t)H + col];     // unconditional load, select afterwards
-            dh[mt][r] = q < p.P ? dh0 : 0.0f;
-            dc[mt][r] = 0.0f;
-            cnext[mt][r] = G == 4 ? p.saved[(((uint32_t)qc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col] : 0.0f;
-        }
-
-    for (int t = p.L - 1; t >= 0; t--) {
-        PN_STAMP(4 * (p.L - 1 - t) + 0);
-        // ---- cell backward.  All loads of a half tile are issued together (unconditionally, padded rows read a
-        //      clamped row and are zeroed afterwards) so the wave pays one memory round trip, not one per element.
-#pragma unroll
-        for (int mt = 0; mt < MTILES; mt++)
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                float vi[8], vf[8], vg[8], vo[8], vc[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int r = half * 8 + e;
-                    const int qc = min(q0 + mt * 32 + acc_row(r, lane), p.P - 1);
-                    const uint32_t so = ((uint32_t)qc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
-                    if (G == 4) {
-                        vi[e] = p.saved[so]; vf[e] = p.saved[so + H]; vg[e] = p.saved[so + 2 * H];
-                        vo[e] = p.saved[so + 3 * H];
-                        vc[e] = t > 0 ? p.saved[so - H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
-                    } else {
-                        vi[e] = p.saved[so];                                      // h_t
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const int r = half * 8 + e;
-                    const int row = mt * 32 + acc_row(r, lane);
-                    const int q = q0 + row;
-                    const bool ok = q < p.P;
-                    float *l = &lds[row * PITCH + col];
-                    float *d = p.dG + (((uint32_t)min(q, p.P - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col);
-                    if (G == 4) {
-                        const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
-                        const float tc = tanhf_(cnext[mt][r]);
-                        const float dhv = dh[mt][r];
-                        const float d_o = dhv * tc;
-                        const float dct = dc[mt][r] + dhv * og * (1.0f - tc * tc);
-                        float a_i = dct * gg * ig * (1.0f - ig);
-                        float a_f = dct * cprev * fg * (1.0f - fg);
-                        float a_g = dct * ig * (1.0f - gg * gg);
-                        float a_o = d_o * og * (1.0f - og);
-                        if (!ok) a_i = a_f = a_g = a_o = 0.0f;
-                        dc[mt][r] = dct * fg;
-                        cnext[mt][r] = cprev;
-                        l[0] = a_i; l[H] = a_f; l[2 * (G > 1 ? H : 0)] = a_g; l[3 * (G > 1 ? H : 0)] = a_o;
-                        if (ok) {
-                            d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
-                        }
-                    } else {
-                        const float h = vi[e];
-                        const float a = ok ? dh[mt][r] * (1.0f - h * h) : 0.0f;
-                        l[0] = a;
-                        if (ok) d[0] = a;
-                    }
-                }
-            }
-        __syncthreads();
-        PN_STAMP(4 * (p.L - 1 - t) + 1);
-
-        // ---- [dx_t ; dh_{t-1}] = dG_t . [W_ih | W_hh]; the dh half is not needed at t = 0 ------------------------
-        f32x16 acc[MTILES][2];
-#pragma unroll
-        for (int mt = 0; mt < MTILES; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.0f;
-        constexpr int KSTEPS = GH / 8;
-        static_assert(KSTEPS % 2 == 0, "two k-steps per trip");
-        const f32x4 *wb = reinterpret_cast<const f32x4 *>(p.WpT) + ((int64_t)wave * 2 * KSTEPS) * 64 + lane;
-        auto mfma_step = [&](int s4, const f32x4 (&b)[2], const int ntn) {
-            float4 a[MTILES];
-#pragma unroll
-            for (int mt = 0; mt < MTILES; mt++)
-                a[mt] = *reinterpret_cast<const float4 *>(&lds[(mt * 32 + li) * PITCH + hk * (GH / 2) + 4 * s4]);
-#pragma unroll
-            for (int mt = 0; mt < MTILES; mt++) {
-                acc[mt][0] = mfma32(a[mt].x, b[0][0], acc[mt][0]);
-                if (ntn > 1) acc[mt][1] = mfma32(a[mt].x, b[1][0], acc[mt][1]);
-                acc[mt][0] = mfma32(a[mt].y, b[0][1], acc[mt][0]);
-                if (ntn > 1) acc[mt][1] = mfma32(a[mt].y, b[1][1], acc[mt][1]);
-                acc[mt][0] = mfma32(a[mt].z, b[0][2], acc[mt][0]);
-                if (ntn > 1) acc[mt][1] = mfma32(a[mt].z, b[1][2], acc[mt][1]);
-                acc[mt][0] = mfma32(a[mt].w, b[0][3], acc[mt][0]);
-                if (ntn > 1) acc[mt][1] = mfma32(a[mt].w, b[1][3], acc[mt][1]);
-            }
-        };
-        auto k_loop = [&](auto ntn_tag) {
-            constexpr int NTN = decltype(ntn_tag)::value;
-            f32x4 b0[2], b1[2];
-#pragma unroll
-            for (int nt = 0; nt < 2; nt++) async_load_b128(b0[nt], wb + ((int64_t)(nt < NTN ? nt : 0) * KSTEPS) * 64);
-#pragma unroll 1
-            for (int s4 = 0; s4 < KSTEPS; s4 += 2) {
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++)
-                    async_load_b128(b1[nt], wb + ((int64_t)(nt < NTN ? nt : 0) * KSTEPS + s4 + 1) * 64);
-                wait_frag<2, 2>(b0);
-                mfma_step(s4, b0, NTN);
-                const int sn = min(s4 + 2, KSTEPS - 2);
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++)
-                    async_load_b128(b0[nt], wb + ((int64_t)(nt < NTN ? nt : 0) * KSTEPS + sn) * 64);
-                wait_frag<2, 2>(b1);
-                mfma_step(s4 + 1, b1, NTN);
-            }
-            wait_frag<0, 2>(b0);
-        };
-        if (t > 0)
-            k_loop(std::integral_constant<int, 2>{});
-        else
-            k_loop(std::integral_constant<int, 1>{});
-        __syncthreads();
-        PN_STAMP(4 * (p.L - 1 - t) + 2);
-
-#pragma unroll
-        for (int mt = 0; mt < MTILES; mt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = mt * 32 + acc_row(r, lane);
-                if (q0 + row < p.P) {
-                    float dx = acc[mt][0][r];
-                    const uint64_t e = ((uint64_t)t * p.P + s_slotof[row]) * H + col;
-                    if (p.mask)
-                        dx *= p.mask[e];
-                    else if (p.p_drop > 0.0f)
-                        dx *= dropout1(p.seed, e, 1u, p.p_drop);
-#if PN_BWD_EXPERIMENT == 1
-                    p.dZ[(int64_t)(q0 + row) * H + col] = dx;    // EXPERIMENT ONLY (wrong results): plain store instead of the scatter
-#elif PN_BWD_EXPERIMENT == 2
-                    if (dx == 123.456f) p.dZ[0] = dx;              // EXPERIMENT ONLY: no scatter at all
-#else
-                    atomicAdd(&p.dZ[(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col], dx);
-#endif
-                }
-                dh[mt][r] = acc[mt][1][r];
-            }
-        PN_STAMP(4 * (p.L - 1 - t) + 3);
-    }
-}
-
 // ---- the same BPTT on the bf16 matrix pipe (pn_kernels.h) --------------------------------------------------------
 //   [dx_t | dh_{t-1}] = dG_t [32, G*H] . [W_ih | W_hh]:  K = G*H gate columns, wave w owns columns 32w..32w+31 of dx and of dh.
 //   Weights: pack_bwd3_kernel, B fragments grouped in units of two k-steps (kk) x two output halves (nt),
@@ -1250,6 +837,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
     constexpr int NPASS = G == 4 ? 2 : 1, KP = GH / NPASS;      // K extent of one pass (one gate pair)
     constexpr int PB = 2 * KP + 16, PLANE = 32 * PB;            // plane row pitch / plane size, bytes
     constexpr int NU = GH / 32, NUP = NU / NPASS;               // units of two k-steps, total / per pass
+    constexpr bool CARRY_C = H < 256;   // c_t stays in registers from one step to the next (H = 256: re-read, 16 registers short)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);   // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
@@ -1271,7 +859,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
         const float dh0 = p.dhn[(uint32_t)qc * (uint32_t)H + col];     // unconditional load, select afterwards
         dh[r] = q < p.P ? dh0 : 0.0f;
         dc[r] = 0.0f;
-        cnext[r] = G == 4 ? p.saved[(((uint32_t)qc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col] : 0.0f;
+        cnext[r] = G == 4 && CARRY_C ? p.saved[(((uint32_t)qc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col] : 0.0f;
     }
 
     // the bf16 planes of two tile rows (accumulator registers r, r+1) of gate slot gs (0 or 1) of the resident pair
@@ -1298,7 +886,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
         float ag[16], ao[16];      // (g, o) gate gradients wait here for the second pass
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            float vi[8], vf[8], vg[8], vo[8], vc[8];
+            float vi[8], vf[8], vg[8], vo[8], vc[8], vn[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int r = half * 8 + e;
@@ -1308,6 +896,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
                     vi[e] = p.saved[so]; vf[e] = p.saved[so + H]; vg[e] = p.saved[so + 2 * H];
                     vo[e] = p.saved[so + 3 * H];
                     vc[e] = t > 0 ? p.saved[so - H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
+                    vn[e] = CARRY_C ? cnext[r] : p.saved[so + 4 * H];        // c_t
                 } else {
                     vi[e] = p.saved[so];                                      // h_t
                 }
@@ -1321,7 +910,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
                 float *d = p.dG + (((uint32_t)min(q, p.P - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col);
                 if (G == 4) {
                     const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
-                    const float tc = tanhf_(cnext[r]);
+                    const float tc = tanhf_(vn[e]);
                     const float dhv = dh[r];
                     const float d_o = dhv * tc;
                     const float dct = dc[r] + dhv * og * (1.0f - tc * tc);
@@ -1331,7 +920,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
                     float a_o = d_o * og * (1.0f - og);
                     if (!ok) a_i = a_f = a_g = a_o = 0.0f;
                     dc[r] = dct * fg;
-                    cnext[r] = cprev;
+                    if (CARRY_C) cnext[r] = cprev;
                     ai[e] = a_i; af[e] = a_f; ag[r] = a_g; ao[r] = a_o;
                     if (ok) {
                         d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
@@ -1457,7 +1046,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
 //      transposition.  128x128 output tile per workgroup (4 waves x (2x2) 32x32 MFMA tiles), the R rows
 //      are split over blockIdx.z; partial tiles go to a [split][G*H][2H] buffer and are summed by
 //      wgrad_reduce_kernel (deterministic, no atomics). -----------------------------------------------
-constexpr int WG_BM = 256, WG_BN = 256, WG_KT = 32, WG_PITCH = 260, WG_THREADS = 512;
+constexpr int WG_BM = 256, WG_BN = 256, WG_KT = 32, WG_THREADS = 512;
 
 struct WgradParams {
     const float *dG;   // [R, GH]
@@ -1468,89 +1057,6 @@ struct WgradParams {
     float *part_w;     // [nsplit, GH, 2H]
     float *part_b;     // [nsplit, GH]
 };
-
-// 256 x 256 output tile per workgroup: with 2H <= 256 the dG rows are read from HBM exactly once and the
-// [x|h] rows once per 256 gate columns.  8 waves as 4 (m) x 2 (n), each 64 x 128 = 2 x 4 MFMA tiles.
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_kernel(WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float As[WG_KT * WG_PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[WG_KT * WG_PITCH];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * WG_BM, n0 = blockIdx.x * WG_BN;
-    const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
-    const int64_t rend = min(p.R, rbeg + p.rows_per_split);
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-    float bsum = 0.0f;
-
-    // a thread moves 4 x 16 bytes of each operand per K tile: row k = i*8 + tid/64, columns 4*(tid%64)..+3.
-    // Out-of-range rows/columns load a clamped (valid) address and are zeroed when written to LDS.
-    const int lk = tid >> 6, lc = (tid & 63) * 4;
-    const bool a_ok = m0 + lc < p.GH, b_ok = n0 + lc < p.H2;
-    const int a_col = a_ok ? m0 + lc : 0, b_col = b_ok ? n0 + lc : 0;
-    f32x4 ra[4], rb[4];
-    auto issue = [&](int64_t k0) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int64_t row = min(k0 + i * 8 + lk, rend - 1);
-            async_load_b128(ra[i], p.dG + row * p.GH + a_col);
-            async_load_b128(rb[i], p.xh + row * p.H2 + b_col);
-        }
-    };
-    if (rbeg >= rend) return;   // block-uniform
-    issue(rbeg);
-    for (int64_t k0 = rbeg; k0 < rend; k0 += WG_KT) {
-        wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool row_ok = k0 + i * 8 + lk < rend;
-            f32x4 va = ra[i], vb = rb[i];
-            if (!(row_ok && a_ok)) va = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!(row_ok && b_ok)) vb = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(&As[(i * 8 + lk) * WG_PITCH + lc]) = va;
-            *reinterpret_cast<f32x4 *>(&Bs[(i * 8 + lk) * WG_PITCH + lc]) = vb;
-        }
-        __syncthreads();
-        issue(min(k0 + WG_KT, rend - 1));   // next tile in flight under the MFMAs (last trip: harmless re-load)
-        if (tid < WG_BM) {
-#pragma unroll
-            for (int k = 0; k < WG_KT; k++) bsum += As[k * WG_PITCH + tid];
-        }
-#pragma unroll
-        for (int kk = 0; kk < WG_KT / 2; kk++) {
-            float a[2], b[4];
-#pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = As[(2 * kk + hk) * WG_PITCH + wm * 64 + i * 32 + li];
-#pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = Bs[(2 * kk + hk) * WG_PITCH + wn * 128 + j * 32 + li];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-    wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);   // drain the trailing prefetch
-    float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int n = n0 + wn * 128 + j * 32 + li;
-            if (n >= p.H2) continue;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (m < p.GH) pw[(int64_t)m * p.H2 + n] = acc[i][j][r];
-            }
-        }
-    if (blockIdx.x == 0 && tid < WG_BM && m0 + tid < p.GH) p.part_b[(int64_t)blockIdx.z * p.GH + m0 + tid] = bsum;
-}
 
 // ---- the same GEMM on the bf16 matrix pipe (pn_kernels.h: six bf16 MFMAs = one fp32-accurate product) -----------
 // Both operands have the reduction dimension (rows) outermost, the bf16 MFMA wants 8 consecutive k per lane.  A
@@ -1750,13 +1256,8 @@ int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t
 template <int H, int G>
 int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int MT = PN_BWD_MT;
-#if PN_SEQ_BF16X3
     const size_t lds_bytes = (size_t)3 * MT * (2 * (G == 4 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_bwd3_kernel<H, G, MT>;
-#else
-    const size_t lds_bytes = (size_t)MT * (G * H + 4) * 4 + (size_t)(MT * sp.L + MT) * 4;
-    auto kern = seq_bwd_kernel<H, G, MT>;
-#endif
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
     const int blocks = (sp.P + MT - 1) / MT;
@@ -1852,13 +1353,8 @@ int check_shape(const pn_pagg_shape &s) {
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
     constexpr int MT = PN_FWD_MT;
-#if PN_SEQ_BF16X3
     constexpr size_t lds_bytes = (size_t)3 * MT * (4 * H + 16);
     auto kern = seq_fwd3_kernel<H, G, MT>;
-#else
-    constexpr size_t lds_bytes = (size_t)MT * (2 * H + 4) * 4;
-    auto kern = seq_fwd_kernel<H, G, MT>;
-#endif
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
     const int blocks = (sp.P + MT - 1) / MT;
@@ -2008,14 +1504,8 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
         hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s.variant, a->ids,
                            a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
         PN_CHECK_HIP(hipGetLastError());
-#if PN_SEQ_BF16X3
         hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((G * H * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
                            a->w_hh, a->b_ih, a->b_hh, H, G, reinterpret_cast<u32x4 *>(Wp), biasc);
-#else
-        const int64_t nw = (int64_t)G * H * 3 * H;     // [W_ih | W_hh] fragments + the step-0 W_ih fragments
-        hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
-                           a->b_ih, a->b_hh, H, G, Wp, biasc);
-#endif
         PN_CHECK_HIP(hipGetLastError());
     }
     SeqFwdParams sp{};
@@ -2187,15 +1677,8 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     // BPTT + gather-backward scatter
     {
         StageTimer tm(ST_SEQ_BWD, stream);
-        const int64_t nw = (int64_t)GH * 2 * H;
-#if PN_SEQ_BF16X3
-        (void)nw;
         hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
                            a->w_hh, H, G, reinterpret_cast<u32x4 *>(WpT));
-#else
-        hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh,
-                           H, G, WpT);
-#endif
         PN_CHECK_HIP(hipGetLastError());
         SeqBwdParams sp{};
         sp.saved = saved;
@@ -2230,16 +1713,11 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
         {
             StageTimer tm(ST_WGRAD, stream);
-#if PN_WGRAD_BF16X3
             static const hipError_t lds_attr = hipFuncSetAttribute(
                 reinterpret_cast<const void *>(wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
             PN_CHECK_HIP(lds_attr);
             hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
                                dim3(WG_THREADS), W3_LDS_BYTES, stream, wp);
-#else
-            hipLaunchKernelGGL(wgrad_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
-                               dim3(WG_THREADS), 0, stream, wp);
-#endif
             PN_CHECK_HIP(hipGetLastError());
             const int64_t nred = (int64_t)GH * 2 * H + GH;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, stream,
