@@ -304,6 +304,8 @@ struct SeqFwdParams {
     float *saved;           // [P, L, SV, H]  SV = 5 (i,f,g,o,c) for LSTM, 1 (h_t) for RNN; may be null
     float *xh;              // [P, L, 2H]     the recurrent GEMM's input rows [x_t (after dropout) | h_{t-1}]:
                             //                the weight-gradient GEMM of the backward reads them back; may be null
+    uint8_t *keep;          // [P, L, H/4]    built-in dropout: keep bits of columns 4c .. 4c+3 in bits 0-3 (the backward
+                            //                reads them instead of re-drawing the Philox stream); may be null
     int P, L;
     float p_drop;
     uint64_t seed;
@@ -350,13 +352,20 @@ template <int H, int G, int MT>
 __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_fwd3_kernel(SeqFwdParams p) {
     static_assert(MT == 32, "one 32-row MFMA tile per workgroup");
     constexpr int NW = H / 32, NT = NW * 64, SV = (G == 4 ? 5 : 1);
-    constexpr int KS = H / 8;                 // k-steps of 16 over [x | h]
-    constexpr int PB = 4 * H + 16;            // plane row pitch in bytes
-    constexpr int PLANE = 32 * PB;
+    constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
+    constexpr int PB = 2 * H + 16;            // row pitch of a half tile (x or h), bytes: conflict-free ds_read_b128
+    constexpr int PLANE = 32 * PB, HALF = 3 * PLANE;
+    // LDS: x planes of step t | x planes of step t+1 (written while step t computes) | h planes | row indices
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    unsigned char *ldsH = ldsb + 2 * HALF;
+    int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * HALF);   // [MT][L] gather rows of this tile
+    int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int q0 = blockIdx.x * MT;
     const int col = 32 * wave + li;
+
+    for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = q0 + i / p.L < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
+    for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
 
     f32x16 cst;
 #pragma unroll
@@ -364,58 +373,84 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
     float bias[G];
 #pragma unroll
     for (int g = 0; g < G; g++) bias[g] = p.biasc[g * H + col];
+    const float keep_scale = 1.0f / (1.0f - p.p_drop);
+    const bool builtin_drop = !p.mask && p.p_drop > 0.0f;
+    __syncthreads();
 
-    const float4 *Z4 = reinterpret_cast<const float4 *>(p.Z);
+    // ---- coalesced row gather of x_{t+1} (H*4 bytes per row), in flight while step t computes: the loads are asm
+    //      (hipcc would sink them to their use after the k loop), the dropout keep bits are drawn right behind them
+    //      -- under the latency of the first weight fragments -- and applied when the rows are committed to LDS.
     constexpr int NLD = MT / 8;   // float4 per thread = MT * (H/4) / NT
-    float4 xr[NLD];
+    f32x4 xr[NLD];
+    uint32_t keepbits = 0;        // 4 bits per row of this thread
     auto gather_issue = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
             const int idx = tid + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-            const int q = q0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < p.P) {
-                const uint32_t ri = (uint32_t)p.rowidx[(uint32_t)q * (uint32_t)p.L + t];
-                v = Z4[ri * (uint32_t)(H / 4) + c4];
-                if (p.mask) {
-                    const float4 m = reinterpret_cast<const float4 *>(
-                        p.mask)[((int64_t)t * p.P + p.slotof[q]) * (H / 4) + c4];
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                } else if (p.p_drop > 0.0f) {
-                    const float4 m = dropout4(p.seed, ((uint64_t)t * p.P + p.slotof[q]) * (H / 4) + c4, 1u, p.p_drop);
-                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-                }
-            }
-            xr[i] = v;
+            async_load_b128(xr[i], p.Z + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (H / 4) + c4) * 4);
         }
+        uint32_t bits = 0;
+        if (builtin_drop) {
+#pragma unroll
+            for (int i = 0; i < NLD; i++) {
+                const int idx = tid + NT * i;
+                const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+                const float4 m = dropout4(p.seed, ((uint64_t)t * p.P + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
+                bits |= ((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) |
+                         (m.w != 0.f ? 8u : 0u)) << (4 * i);
+            }
+        }
+        asm volatile("" : "+v"(bits));      // drawn here, not sunk to the commit
+        keepbits = bits;
     };
-    auto gather_commit = [&](int t) {
+    auto gather_commit = [&](int t, unsigned char *ldsX) {
+        wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
             const int idx = tid + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
             const int q = q0 + row;
+            float4 v = make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
+            if (q >= p.P) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.mask) {
+                if (q < p.P) {
+                    const float4 m = reinterpret_cast<const float4 *>(
+                        p.mask)[((int64_t)t * p.P + s_slotof[row]) * (H / 4) + c4];
+                    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+                }
+            } else if (builtin_drop) {
+                const uint32_t b = keepbits >> (4 * i);
+                v.x = b & 1u ? v.x * keep_scale : 0.0f;
+                v.y = b & 2u ? v.y * keep_scale : 0.0f;
+                v.z = b & 4u ? v.z * keep_scale : 0.0f;
+                v.w = b & 8u ? v.w * keep_scale : 0.0f;
+                if (p.keep && q < p.P) p.keep[((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(H / 4) + c4] = (uint8_t)(b & 15u);
+            }
             uint32_t a0, a1, a2, b0, b1, b2;
-            split3(xr[i].x, xr[i].y, a0, a1, a2);
-            split3(xr[i].z, xr[i].w, b0, b1, b2);
-            unsigned char *d = ldsb + row * PB + 8 * c4;
+            split3(v.x, v.y, a0, a1, a2);
+            split3(v.z, v.w, b0, b1, b2);
+            unsigned char *d = ldsX + row * PB + 8 * c4;
             *reinterpret_cast<uint2 *>(d) = make_uint2(a0, b0);
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
             *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a2, b2);
             if (p.xh && q < p.P) {
+                // 32-bit element offsets (check_shape bounds every tensor below 2^32 elements)
                 float4 *xo4 = reinterpret_cast<float4 *>(p.xh);
                 const uint32_t xo = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4;
-                xo4[xo] = xr[i];
+                xo4[xo] = v;
                 if (t == 0) xo4[xo + H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
+    gather_issue(0);
+    gather_commit(0, ldsb);
+    __syncthreads();
+
     for (int t = 0; t < p.L; t++) {
         PN_STAMP(4 * t + 0);
-        gather_issue(t);
-        gather_commit(t);
-        __syncthreads();
+        unsigned char *ldsX = ldsb + (t & 1) * HALF;
+        if (t + 1 < p.L) gather_issue(t + 1);
         PN_STAMP(4 * t + 1);
 
         f32x16 acc[G];
@@ -428,22 +463,25 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
         //      plane-0 fragments (needed first) ping-pong between two register sets one k-step ahead, planes 1 and 2
         //      are re-fetched into their own registers as soon as the MFMAs that read them are issued (2/3 of a k-step
         //      ahead).  vmcnt is in order: [P0(s) P1(s) P2(s) P0(s+1)] in flight at the top of k-step s.
+        //      Step 0 has h_{-1} = 0: it stops after the x half of K.
         {
-            const int nsteps = t == 0 ? KS / 2 : KS;
+            const int nsteps = t == 0 ? KX : KS;
             // wave-uniform stream base in SGPRs, one VGPR of lane offset (pn_kernels.h: async_load_frags)
             const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.Wp) +
                                       (size_t)__builtin_amdgcn_readfirstlane(wave) * (KS * 3 * G * 1024);
             const uint32_t voff = lane * 16;
-            const unsigned char *arow = ldsb + li * PB + 16 * hk;
+            const unsigned char *arow_x = ldsX + li * PB + 16 * hk;
+            const unsigned char *arow_h = ldsH + li * PB + 16 * hk - 32 * KX;
             u32x4 P0a[G], P0b[G], P1[G], P2[G];
             auto load = [&](u32x4 (&B)[G], int s, int pl) {
                 async_load_frags<G>(B, wb + (size_t)(s * 3 + pl) * (G * 1024), voff);
             };
             auto kstep = [&](int s, u32x4 (&P0)[G], u32x4 (&P0next)[G]) {
                 load(P0next, min(s + 1, nsteps - 1), 0);
+                const unsigned char *arow = (s < KX ? arow_x : arow_h) + 32 * s;
                 u32x4 a[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++) a[pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE + 32 * s);
+                for (int pl = 0; pl < 3; pl++) a[pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE);
                 wait_frag<3 * G, G>(P0);
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
@@ -513,7 +551,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
             for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
                 uint32_t h0, h1, h2;
                 split3(hv[r], hv[r + 1], h0, h1, h2);
-                unsigned char *d = ldsb + acc_row(r, lane) * PB + 2 * (H + col);
+                unsigned char *d = ldsH + acc_row(r, lane) * PB + 2 * col;
                 *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
                 *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
                 *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
@@ -521,6 +559,8 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
                 *reinterpret_cast<uint16_t *>(d + 2 * PLANE) = (uint16_t)h2;
                 *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(h2 >> 16);
             }
+            gather_commit(t + 1, ldsb + ((t + 1) & 1) * HALF);
+            __syncthreads();
         }
         PN_STAMP(4 * t + 3);
     }
@@ -784,6 +824,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 // ---- BPTT through the recurrent cell, fused with the gather-backward scatter ---------------------
 struct SeqBwdParams {
     const float *saved;     // [P, L, SV, H]
+    const uint8_t *keep;    // [P, L, H/4] keep bits of the forward's built-in dropout, or null
     const float *dhn;       // [P, H]
     const int32_t *rowidx, *slotof;
     const float *WpT;
@@ -831,16 +872,17 @@ __global__ void pack_bwd3_kernel(const float *__restrict__ w_ih, const float *__
 }
 
 template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(SeqBwdParams p) {
+__global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_bwd3_kernel(SeqBwdParams p) {
     static_assert(MT == 32, "one 32-row MFMA tile per workgroup");
     constexpr int NT = H / 32 * 64, GH = G * H, SV = (G == 4 ? 5 : 1);
     constexpr int NPASS = G == 4 ? 2 : 1, KP = GH / NPASS;      // K extent of one pass (one gate pair)
     constexpr int PB = 2 * KP + 16, PLANE = 32 * PB;            // plane row pitch / plane size, bytes
     constexpr int NU = GH / 32, NUP = NU / NPASS;               // units of two k-steps, total / per pass
-    constexpr bool CARRY_C = H < 256;   // c_t stays in registers from one step to the next (H = 256: re-read, 16 registers short)
+    constexpr bool CARRY_C = false;     // true: c_t stays in registers from one step to the next (16 registers the kernel does not have)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);   // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
+    uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_slotof + MT); // [2][MT][H/4] dropout keep bits of step t (t & 1)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int q0 = blockIdx.x * MT;
     const int col = 32 * wave + li;
@@ -851,6 +893,7 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
     }
     for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
 
+    const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     f32x16 dh, dc, cnext;   // cnext: c_t of the step processed next (= c_{t-1} now)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -881,6 +924,16 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
         //  per-row offsets would occupy ~40 registers across the MFMA loops and spill)
         int lane_t = lane;
         asm volatile("" : "+v"(lane_t));
+        if (p.keep) {      // this step's keep bytes (MT rows x H/4) -> LDS, read by the scatter phase below
+            int tid_t = tid;
+            asm volatile("" : "+v"(tid_t));    // (offsets re-derived per step, see lane_t)
+            for (int i = tid_t; i < MT * (H / 16); i += NT) {
+                const int row = i / (H / 16), w = i - row * (H / 16);
+                const uint32_t q = (uint32_t)min(q0 + row, p.P - 1);
+                reinterpret_cast<uint32_t *>(s_keep + (t & 1) * MT * (H / 4))[i] =
+                    reinterpret_cast<const uint32_t *>(p.keep + (q * (uint32_t)p.L + t) * (uint32_t)(H / 4))[w];
+            }
+        }
         // ---- cell backward.  All loads of a half tile are issued together (unconditionally, padded rows read a
         //      clamped row and are zeroed afterwards) so the wave pays one memory round trip, not one per element.
         float ag[16], ao[16];      // (g, o) gate gradients wait here for the second pass
@@ -1027,11 +1080,10 @@ __global__ __launch_bounds__(H / 32 * 64, PN_BWD_WAVES) void seq_bwd3_kernel(Seq
             const int row = acc_row(r, lane_t);
             if (q0 + row < p.P) {
                 float dx = acc[0][r];
-                const uint64_t e = ((uint64_t)t * p.P + s_slotof[row]) * H + col;
                 if (p.mask)
-                    dx *= p.mask[e];
-                else if (p.p_drop > 0.0f)
-                    dx *= dropout1(p.seed, e, 1u, p.p_drop);
+                    dx *= p.mask[((uint64_t)t * p.P + s_slotof[row]) * H + col];
+                else if (p.keep)
+                    dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col >> 2)] >> (col & 3)) & 1 ? dx * keep_scale : 0.0f;
                 atomicAdd(&p.dZ[(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col], dx);
             }
             dh[r] = acc[1][r];
@@ -1256,7 +1308,8 @@ int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t
 template <int H, int G>
 int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int MT = PN_BWD_MT;
-    const size_t lds_bytes = (size_t)3 * MT * (2 * (G == 4 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4;
+    const size_t lds_bytes = (size_t)3 * MT * (2 * (G == 4 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4 +
+                             (size_t)2 * MT * (H / 4);
     auto kern = seq_bwd3_kernel<H, G, MT>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
@@ -1282,7 +1335,7 @@ int dispatch_seq_bwd(hipStream_t stream, int H, const SeqBwdParams &sp) {
 // ================================================================================================
 struct WsLayout {
     size_t Xh, Z, rowidx, egoidx, slotof, Wp, biasc, hn, saved, coef, rawsc, layer1;  // forward
-    size_t xh;                                                                        // forward (saved)
+    size_t xh, keep;                                                                  // forward (saved)
     size_t WpT, dG, dZ, dXh, dhn, dl1, wpart;                                         // backward
     int wgrad_split;
     size_t total;
@@ -1319,6 +1372,7 @@ WsLayout ws_layout(const pn_pagg_shape &s) {
     w.dhn = take(P * H * 4);
     w.dl1 = take(S * 2 * H * 4);
     w.xh = take(P * L * 2 * H * 4);
+    w.keep = take(P * L * (H / 4));
     {
         // split of the P*L rows of the weight-gradient GEMM: enough workgroups to fill 256 CUs ~3x
         const size_t rows = P * L, tiles = ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN);
@@ -1353,7 +1407,7 @@ int check_shape(const pn_pagg_shape &s) {
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
     constexpr int MT = PN_FWD_MT;
-    constexpr size_t lds_bytes = (size_t)3 * MT * (4 * H + 16);
+    const size_t lds_bytes = (size_t)9 * MT * (2 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_fwd3_kernel<H, G, MT>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
@@ -1517,6 +1571,7 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     sp.hn = hn;
     sp.saved = a->no_save ? nullptr : saved;
     sp.xh = a->no_save ? nullptr : reinterpret_cast<float *>(ws + w.xh);
+    sp.keep = (a->no_save || a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : reinterpret_cast<uint8_t *>(ws + w.keep);
     sp.P = P;
     sp.L = L;
     sp.p_drop = a->p_seq;
@@ -1682,6 +1737,7 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         PN_CHECK_HIP(hipGetLastError());
         SeqBwdParams sp{};
         sp.saved = saved;
+        sp.keep = (a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : reinterpret_cast<const uint8_t *>(ws + w.keep);
         sp.dhn = dhn;
         sp.rowidx = rowidx;
         sp.slotof = slotof;

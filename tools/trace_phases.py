@@ -20,6 +20,8 @@ torch.manual_seed(0)
 model = pathnet_amd.PathNet_homo(wl["F"], wl["H"], wl["C"], wl["L"], dropout=0.7).to(dev).train()
 X = torch.from_numpy(wl["X"]).to(dev)
 sel = torch.from_numpy(np.flatnonzero(wl["mask"]).astype(np.int64)).to(dev)
+if os.environ.get("PN_TRACE_NODES"):        # fewer workgroups: how much of a phase is contention?
+    sel = sel[:int(os.environ["PN_TRACE_NODES"])]
 ids, codes = smp.sample(wl["W"], 1, epoch_count=1)
 ids, codes = ids[0].index_select(0, sel), codes[0].index_select(0, sel)
 G = torch.randn(sel.numel(), wl["C"], device=dev)
