@@ -36,14 +36,12 @@
 using namespace pn;
 
 // tuning knobs of the two recurrent kernels (tools/tune_seq.sh builds variants with -D...)
-#ifndef PN_FWD_MT
-#define PN_FWD_MT 32        // sequence slots per workgroup, forward
+#ifndef PN_SEQ_RG
+#define PN_SEQ_RG 1         // row groups (of 32 sequence slots) per workgroup of the recurrent kernels (2: measured
+                            // slower, profiles/README.md)
 #endif
 #ifndef PN_FWD_WAVES
 #define PN_FWD_WAVES 2      // __launch_bounds__ min waves per SIMD, forward
-#endif
-#ifndef PN_BWD_MT
-#define PN_BWD_MT 32
 #endif
 #ifndef PN_BWD_WAVES
 #define PN_BWD_WAVES 2
@@ -348,21 +346,26 @@ __global__ void pack_fwd3_kernel(const float *__restrict__ w_ih, const float *__
     dst[2 * G * 64] = q2;
 }
 
-template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_fwd3_kernel(SeqFwdParams p) {
-    static_assert(MT == 32, "one 32-row MFMA tile per workgroup");
-    constexpr int NW = H / 32, NT = NW * 64, SV = (G == 4 ? 5 : 1);
+// RG row groups of 32 sequence slots per workgroup.  The waves (rg, w) of the RG groups walk the same weight stream
+// in step (they meet at every barrier), so the fragments one of them pulls from L2 are L1 hits for the others: the
+// L2 -> CU weight traffic, which bounds this kernel (4.4 GB per launch at RG = 1 on the bench workload, ~15 TB/s),
+// drops by the factor RG.
+template <int H, int G, int RG>
+__global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_FWD_WAVES) void seq_fwd3_kernel(SeqFwdParams p) {
+    constexpr int MT = 32 * RG;
+    constexpr int NW = H / 32, NT = NW * 64 * RG, SV = (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
     constexpr int PB = 2 * H + 16;            // row pitch of a half tile (x or h), bytes: conflict-free ds_read_b128
-    constexpr int PLANE = 32 * PB, HALF = 3 * PLANE;
-    // LDS: x planes of step t | x planes of step t+1 (written while step t computes) | h planes | row indices
+    constexpr int PLANE = MT * PB, HALF = 3 * PLANE;
+    // LDS: x planes | h planes | row indices
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    unsigned char *ldsH = ldsb + 2 * HALF;
-    int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * HALF);   // [MT][L] gather rows of this tile
+    unsigned char *ldsH = ldsb + HALF;
+    int *s_rowidx = reinterpret_cast<int *>(ldsb + 2 * HALF);   // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int ws = wave % NW, r0 = 32 * (wave / NW);            // column slice / first tile row of this wave
     const int q0 = blockIdx.x * MT;
-    const int col = 32 * wave + li;
+    const int col = 32 * ws + li;
 
     for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = q0 + i / p.L < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
     for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
@@ -380,13 +383,15 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
     // ---- coalesced row gather of x_{t+1} (H*4 bytes per row), in flight while step t computes: the loads are asm
     //      (hipcc would sink them to their use after the k loop), the dropout keep bits are drawn right behind them
     //      -- under the latency of the first weight fragments -- and applied when the rows are committed to LDS.
-    constexpr int NLD = MT / 8;   // float4 per thread = MT * (H/4) / NT
+    constexpr int NLD = 4;        // float4 per thread = MT * (H/4) / NT
     f32x4 xr[NLD];
     uint32_t keepbits = 0;        // 4 bits per row of this thread
+    int tid_g = tid;              // opaque copy, refreshed per step: the per-row offsets derived from it would
+                                  // otherwise live (and spill) across the MFMA loop as loop invariants
     auto gather_issue = [&](int t) {
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
-            const int idx = tid + NT * i;
+            const int idx = tid_g + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
             async_load_b128(xr[i], p.Z + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (H / 4) + c4) * 4);
         }
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
         if (builtin_drop) {
 #pragma unroll
             for (int i = 0; i < NLD; i++) {
-                const int idx = tid + NT * i;
+                const int idx = tid_g + NT * i;
                 const int row = idx / (H / 4), c4 = idx - row * (H / 4);
                 const float4 m = dropout4(p.seed, ((uint64_t)t * p.P + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
                 bits |= ((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) |
@@ -404,11 +409,11 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
         asm volatile("" : "+v"(bits));      // drawn here, not sunk to the commit
         keepbits = bits;
     };
-    auto gather_commit = [&](int t, unsigned char *ldsX) {
+    auto gather_commit = [&](int t) {
         wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
-            const int idx = tid + NT * i;
+            const int idx = tid_g + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
             const int q = q0 + row;
             float4 v = make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
             uint32_t a0, a1, a2, b0, b1, b2;
             split3(v.x, v.y, a0, a1, a2);
             split3(v.z, v.w, b0, b1, b2);
-            unsigned char *d = ldsX + row * PB + 8 * c4;
+            unsigned char *d = ldsb + row * PB + 8 * c4;
             *reinterpret_cast<uint2 *>(d) = make_uint2(a0, b0);
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
             *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a2, b2);
@@ -444,12 +449,12 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
         }
     };
     gather_issue(0);
-    gather_commit(0, ldsb);
+    gather_commit(0);
     __syncthreads();
 
     for (int t = 0; t < p.L; t++) {
         PN_STAMP(4 * t + 0);
-        unsigned char *ldsX = ldsb + (t & 1) * HALF;
+        asm volatile("" : "+v"(tid_g));
         if (t + 1 < p.L) gather_issue(t + 1);
         PN_STAMP(4 * t + 1);
 
@@ -468,10 +473,10 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
             const int nsteps = t == 0 ? KX : KS;
             // wave-uniform stream base in SGPRs, one VGPR of lane offset (pn_kernels.h: async_load_frags)
             const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.Wp) +
-                                      (size_t)__builtin_amdgcn_readfirstlane(wave) * (KS * 3 * G * 1024);
+                                      (size_t)__builtin_amdgcn_readfirstlane(ws) * (KS * 3 * G * 1024);
             const uint32_t voff = lane * 16;
-            const unsigned char *arow_x = ldsX + li * PB + 16 * hk;
-            const unsigned char *arow_h = ldsH + li * PB + 16 * hk - 32 * KX;
+            const unsigned char *arow_x = ldsb + (r0 + li) * PB + 16 * hk;
+            const unsigned char *arow_h = ldsH + (r0 + li) * PB + 16 * hk - 32 * KX;
             u32x4 P0a[G], P0b[G], P1[G], P2[G];
             auto load = [&](u32x4 (&B)[G], int s, int pl) {
                 async_load_frags<G>(B, wb + (size_t)(s * 3 + pl) * (G * 1024), voff);
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
         float hv[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int row = acc_row(r, lane);
+            const int row = r0 + acc_row(r, lane);
             int q = q0 + row;
             asm volatile("" : "+v"(q));     // recompute the row offsets here: hoisted out of the t loop they spill
             float h;
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
             for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
                 uint32_t h0, h1, h2;
                 split3(hv[r], hv[r + 1], h0, h1, h2);
-                unsigned char *d = ldsH + acc_row(r, lane) * PB + 2 * col;
+                unsigned char *d = ldsH + (r0 + acc_row(r, lane)) * PB + 2 * col;
                 *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
                 *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
                 *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
@@ -559,7 +564,8 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_FWD_WAVES) void seq_f
                 *reinterpret_cast<uint16_t *>(d + 2 * PLANE) = (uint16_t)h2;
                 *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(h2 >> 16);
             }
-            gather_commit(t + 1, ldsb + ((t + 1) & 1) * HALF);
+            asm volatile("" : "+v"(tid_g));
+            gather_commit(t + 1);     // (every wave is past its reads of x_t)
             __syncthreads();
         }
         PN_STAMP(4 * t + 3);
@@ -871,12 +877,13 @@ __global__ void pack_bwd3_kernel(const float *__restrict__ w_ih, const float *__
     dst[8 * 64] = q2;
 }
 
-template <int H, int G, int MT>
-__global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_bwd3_kernel(SeqBwdParams p) {
-    static_assert(MT == 32, "one 32-row MFMA tile per workgroup");
-    constexpr int NT = H / 32 * 64, GH = G * H, SV = (G == 4 ? 5 : 1);
+// RG row groups per workgroup share the weight stream through L1, as in seq_fwd3_kernel.
+template <int H, int G, int RG>
+__global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_WAVES) void seq_bwd3_kernel(SeqBwdParams p) {
+    constexpr int MT = 32 * RG, NW = H / 32;
+    constexpr int NT = NW * 64 * RG, GH = G * H, SV = (G == 4 ? 5 : 1);
     constexpr int NPASS = G == 4 ? 2 : 1, KP = GH / NPASS;      // K extent of one pass (one gate pair)
-    constexpr int PB = 2 * KP + 16, PLANE = 32 * PB;            // plane row pitch / plane size, bytes
+    constexpr int PB = 2 * KP + 16, PLANE = MT * PB;            // plane row pitch / plane size, bytes
     constexpr int NU = GH / 32, NUP = NU / NPASS;               // units of two k-steps, total / per pass
     constexpr bool CARRY_C = false;     // true: c_t stays in registers from one step to the next (16 registers the kernel does not have)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -884,8 +891,9 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_b
     int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
     uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_slotof + MT); // [2][MT][H/4] dropout keep bits of step t (t & 1)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int ws = wave % NW, r0 = 32 * (wave / NW);             // column slice / first tile row of this wave
     const int q0 = blockIdx.x * MT;
-    const int col = 32 * wave + li;
+    const int col = 32 * ws + li;
 
     for (int i = tid; i < MT * p.L; i += NT) {
         const int q = q0 + i / p.L;
@@ -897,7 +905,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_b
     f32x16 dh, dc, cnext;   // cnext: c_t of the step processed next (= c_{t-1} now)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const int q = q0 + acc_row(r, lane);
+        const int q = q0 + r0 + acc_row(r, lane);
         const int qc = min(q, p.P - 1);
         const float dh0 = p.dhn[(uint32_t)qc * (uint32_t)H + col];     // unconditional load, select afterwards
         dh[r] = q < p.P ? dh0 : 0.0f;
@@ -909,7 +917,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_b
     auto put_pair = [&](int r, int lane_t, int gs, float v0, float v1) {
         uint32_t x0, x1, x2;
         split3(v0, v1, x0, x1, x2);
-        unsigned char *d = ldsb + acc_row(r, lane_t) * PB + 2 * (gs * H + col);
+        unsigned char *d = ldsb + (r0 + acc_row(r, lane_t)) * PB + 2 * (gs * H + col);
         *reinterpret_cast<uint16_t *>(d) = (uint16_t)x0;
         *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(x0 >> 16);
         *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)x1;
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_b
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int r = half * 8 + e;
-                const int qc = min(q0 + acc_row(r, lane_t), p.P - 1);
+                const int qc = min(q0 + r0 + acc_row(r, lane_t), p.P - 1);
                 const uint32_t so = ((uint32_t)qc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
                 if (G == 4) {
                     vi[e] = p.saved[so]; vf[e] = p.saved[so + H]; vg[e] = p.saved[so + 2 * H];
@@ -958,7 +966,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_b
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int r = half * 8 + e;
-                const int q = q0 + acc_row(r, lane_t);
+                const int q = q0 + r0 + acc_row(r, lane_t);
                 const bool ok = q < p.P;
                 float *d = p.dG + (((uint32_t)min(q, p.P - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col);
                 if (G == 4) {
@@ -1001,9 +1009,9 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_b
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
         const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.WpT) +
-                                  (size_t)__builtin_amdgcn_readfirstlane(wave) * (NU * 12 * 1024);
+                                  (size_t)__builtin_amdgcn_readfirstlane(ws) * (NU * 12 * 1024);
         const uint32_t voff = lane * 16;
-        const unsigned char *arow = ldsb + li * PB + 16 * hk;
+        const unsigned char *arow = ldsb + (r0 + li) * PB + 16 * hk;
         // units [ub, ue) of the weight stream against the resident gate pair; same fragment pipeline as seq_fwd3_kernel
         auto run = [&](auto ntn_tag, const int ub, const int ue) {
             constexpr int NTN = decltype(ntn_tag)::value, NF = 2 * NTN;       // fragments per plane and unit
@@ -1077,7 +1085,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWD_WAVES) void seq_b
 
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int row = acc_row(r, lane_t);
+            const int row = r0 + acc_row(r, lane_t);
             if (q0 + row < p.P) {
                 float dx = acc[0][r];
                 if (p.mask)
@@ -1307,14 +1315,15 @@ int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t
 
 template <int H, int G>
 int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
-    constexpr int MT = PN_BWD_MT;
+    constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;
+    constexpr int MT = 32 * RG;
     const size_t lds_bytes = (size_t)3 * MT * (2 * (G == 4 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4 +
                              (size_t)2 * MT * (H / 4);
-    auto kern = seq_bwd3_kernel<H, G, MT>;
+    auto kern = seq_bwd3_kernel<H, G, RG>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
     const int blocks = (sp.P + MT - 1) / MT;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64), lds_bytes, stream, sp);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64 * RG), lds_bytes, stream, sp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -1406,13 +1415,14 @@ int check_shape(const pn_pagg_shape &s) {
 
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
-    constexpr int MT = PN_FWD_MT;
-    const size_t lds_bytes = (size_t)9 * MT * (2 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
-    auto kern = seq_fwd3_kernel<H, G, MT>;
+    constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;      // H = 256: one row group already fills the LDS
+    constexpr int MT = 32 * RG;
+    const size_t lds_bytes = (size_t)6 * MT * (2 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
+    auto kern = seq_fwd3_kernel<H, G, RG>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
     const int blocks = (sp.P + MT - 1) / MT;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64), lds_bytes, stream, sp);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64 * RG), lds_bytes, stream, sp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }

@@ -3,7 +3,7 @@
 # usage (on the GPU box): bash tools/pmc_passes.sh <outdir> [kernel-regex]
 set -u
 OUT=${1:-gpurun_out/pmc}
-RE=${2:-"seq_fwd|seq_bwd|wgrad_kernel|gather_kernel|merw_walk"}
+RE=${2:-"seq_fwd|seq_bwd|wgrad3_kernel|gather_kernel|merw_walk"}
 export TMPDIR=/tmp
 mkdir -p $OUT
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
