@@ -12,7 +12,8 @@ def main():
     for f in sorted(glob.glob(root + "/pass*/*counter_collection.csv")):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                name = row["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                name = name.split("(")[0].split("<")[0].strip()
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     lines = []
     for k, cs in acc.items():
