@@ -41,10 +41,10 @@ using namespace pn;
                             // slower, profiles/README.md)
 #endif
 #ifndef PN_FWD_WAVES
-#define PN_FWD_WAVES 2      // __launch_bounds__ min waves per SIMD, forward
+#define PN_FWD_WAVES 3      // __launch_bounds__ min waves per SIMD = workgroups per CU, forward (3: 168 registers)
 #endif
 #ifndef PN_BWD_WAVES
-#define PN_BWD_WAVES 2
+#define PN_BWD_WAVES 2      // backward: 2 (a 168-register build re-reads the (g, o) gradients and A fragments: slower)
 #endif
 
 #ifndef PN_TRACE_PHASES
@@ -350,13 +350,21 @@ __global__ void pack_fwd3_kernel(const float *__restrict__ w_ih, const float *__
 // in step (they meet at every barrier), so the fragments one of them pulls from L2 are L1 hits for the others: the
 // L2 -> CU weight traffic, which bounds this kernel (4.4 GB per launch at RG = 1 on the bench workload, ~15 TB/s),
 // drops by the factor RG.
+// waves per SIMD the forward kernel is compiled for: H = 256 fills the LDS with one workgroup of 8 waves, H = 32 is
+// a single wave per workgroup (no register cap: a spill next to the asm loads would be a hazard)
+template <int H, int RG>
+constexpr int fwd_waves() { return H == 32 && RG == 1 ? 1 : (H >= 256 || RG > 1) ? 2 : PN_FWD_WAVES; }
+
 template <int H, int G, int RG>
-__global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_FWD_WAVES) void seq_fwd3_kernel(SeqFwdParams p) {
+__global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fwd3_kernel(SeqFwdParams p) {
     constexpr int MT = 32 * RG;
     constexpr int NW = H / 32, NT = NW * 64 * RG, SV = (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
     constexpr int PB = 2 * H + 16;            // row pitch of a half tile (x or h), bytes: conflict-free ds_read_b128
     constexpr int PLANE = MT * PB, HALF = 3 * PLANE;
+    // three workgroups per CU (168 registers): no register room for the x_{t+1} rows or a second plane-0 fragment set,
+    // the third workgroup covers those latencies instead
+    constexpr bool PREFETCH_X = fwd_waves<H, RG>() < 3, PING_PONG = fwd_waves<H, RG>() < 3;
     // LDS: x planes | h planes | row indices
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     unsigned char *ldsH = ldsb + HALF;
@@ -373,10 +381,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_FWD_W
     f32x16 cst;
 #pragma unroll
     for (int r = 0; r < 16; r++) cst[r] = 0.0f;
-    float bias[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) bias[g] = p.biasc[g * H + col];
-    const float keep_scale = 1.0f / (1.0f - p.p_drop);
+    const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     const bool builtin_drop = !p.mask && p.p_drop > 0.0f;
     __syncthreads();
 
@@ -455,14 +460,16 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_FWD_W
     for (int t = 0; t < p.L; t++) {
         PN_STAMP(4 * t + 0);
         asm volatile("" : "+v"(tid_g));
-        if (t + 1 < p.L) gather_issue(t + 1);
+        if (PREFETCH_X && t + 1 < p.L) gather_issue(t + 1);
         PN_STAMP(4 * t + 1);
 
         f32x16 acc[G];
 #pragma unroll
-        for (int g = 0; g < G; g++)
+        for (int g = 0; g < G; g++) {
+            const float bias = p.biasc[g * H + col];      // (re-read per step: G registers less across the kernel)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[g][r] = bias[g];
+            for (int r = 0; r < 16; r++) acc[g][r] = bias;
+        }
 
         // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T.  Weight fragments stream L2 -> VGPR ahead of their MFMAs: the
         //      plane-0 fragments (needed first) ping-pong between two register sets one k-step ahead, planes 1 and 2
@@ -481,35 +488,44 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_FWD_W
             auto load = [&](u32x4 (&B)[G], int s, int pl) {
                 async_load_frags<G>(B, wb + (size_t)(s * 3 + pl) * (G * 1024), voff);
             };
+            // PING_PONG: vmcnt (in order) sees [P0(s) P1(s) P2(s) P0(s+1)] at the top of k-step s;
+            // otherwise one register set per plane, [P0(s) P1(s) P2(s)]
             auto kstep = [&](int s, u32x4 (&P0)[G], u32x4 (&P0next)[G]) {
-                load(P0next, min(s + 1, nsteps - 1), 0);
+                const int sn = min(s + 1, nsteps - 1);
+                if (PING_PONG) load(P0next, sn, 0);
                 const unsigned char *arow = (s < KX ? arow_x : arow_h) + 32 * s;
                 u32x4 a[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++) a[pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE);
-                wait_frag<3 * G, G>(P0);
+                wait_frag<(PING_PONG ? 3 : 2) * G, G>(P0);
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++)
 #pragma unroll
                     for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[pl], P0[g], acc[g]);
+                if (!PING_PONG) load(P0, sn, 0);
                 wait_frag<2 * G, G>(P1);
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++)
 #pragma unroll
                     for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[pl], P1[g], acc[g]);
-                load(P1, min(s + 1, nsteps - 1), 1);
+                load(P1, sn, 1);
                 wait_frag<2 * G, G>(P2);
 #pragma unroll
                 for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P2[g], acc[g]);
-                load(P2, min(s + 1, nsteps - 1), 2);
+                load(P2, sn, 2);
             };
             load(P0a, 0, 0);
             load(P1, 0, 1);
             load(P2, 0, 2);
 #pragma unroll 1
             for (int s = 0; s < nsteps; s += 2) {
-                kstep(s, P0a, P0b);
-                kstep(s + 1, P0b, P0a);
+                if (PING_PONG) {
+                    kstep(s, P0a, P0b);
+                    kstep(s + 1, P0b, P0a);
+                } else {
+                    kstep(s, P0a, P0a);
+                    kstep(s + 1, P0a, P0a);
+                }
             }
             wait_frag<0, G>(P0a);                         // drain (harmless re-loads of the last k-step)
             wait_frag<0, G>(P1);
@@ -565,6 +581,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_FWD_W
                 *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(h2 >> 16);
             }
             asm volatile("" : "+v"(tid_g));
+            if (!PREFETCH_X) gather_issue(t + 1);
             gather_commit(t + 1);     // (every wave is past its reads of x_t)
             __syncthreads();
         }
