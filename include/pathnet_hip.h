@@ -236,6 +236,28 @@ int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_
 int pn_linear_backward(const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
                        int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream);
 
+/* ---- training-step glue: the loss and the optimizer of PathNet_run.py:295-297, :346-352 ------
+ * Mean softmax cross entropy over `rows` rows of `classes` logits (torch.nn.CrossEntropyLoss(), :297; int64 class
+ * targets, no ignore_index / label smoothing -- the reference uses neither): *loss (device float) receives the mean,
+ * g_logits [rows, classes] (may be NULL) d loss / d logits = (softmax - onehot) / rows. */
+int pn_cross_entropy(const float *logits, const int64_t *target, int32_t rows, int32_t classes, float *loss,
+                     float *g_logits, void *stream);
+
+/* One Adam update of a list of tensors in a single launch, with the semantics of torch.optim.Adam(lr, betas, eps,
+ * weight_decay) (:295-296): g += weight_decay * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ * p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).  `step` counts from 1.  All pointers are device
+ * fp32 arrays of `count` elements; exp_avg / exp_avg_sq are the caller-owned optimizer state (zero before step 1). */
+#define PN_ADAM_MAX_TENSORS 32
+typedef struct pn_adam_tensor {
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t count;
+} pn_adam_tensor;
+int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int64_t step, void *stream);
+
 /* Byte offsets inside the aggregator workspace of the intermediates tests look at:
  * out[0] Xh [N,H], out[1] Z [N,L,H], out[2] hn [P,H] (pooling-group order), out[3] layer1 [S,2H]. */
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]);

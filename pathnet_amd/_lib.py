@@ -57,6 +57,12 @@ class PaggArgs(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/pathnet_hip.h declares
+class AdamTensor(ctypes.Structure):
+    """struct pn_adam_tensor"""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("count", ctypes.c_int64)]
+
+
 SIGNATURES = {
     "pn_abi_version": (ctypes.c_int, []),
     "pn_last_error": (ctypes.c_char_p, []),
@@ -93,6 +99,9 @@ SIGNATURES = {
     "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp,
                                           vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
+    "pn_cross_entropy": (ctypes.c_int, [vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]),
+    "pn_adam_step": (ctypes.c_int, [ctypes.POINTER(AdamTensor), ctypes.c_int32, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int64, vp]),
 }
 
 _lib = None

@@ -1,0 +1,92 @@
+"""Loss and optimizer of the reference's training step (/root/reference/PathNet_run.py:295-297, :346-352) as single
+launches of the HIP library (``pn_cross_entropy``, ``pn_adam_step``): same arithmetic as ``torch.nn.CrossEntropyLoss()``
+and ``torch.optim.Adam(lr, betas, eps, weight_decay)``, ~10 us instead of ~100 us per step on the bench workload."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        if not logits.is_cuda:
+            raise RuntimeError("pathnet_amd.cross_entropy: logits must be on the GPU (there is no CPU fallback)")
+        lib = _lib.load()
+        x = logits.contiguous().float()
+        t = target.to(device=x.device, dtype=torch.int64).contiguous()
+        if x.dim() != 2 or t.shape != (x.shape[0],):
+            raise ValueError("cross_entropy: logits [rows, classes] and int targets [rows] expected")
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        g = torch.empty_like(x) if logits.requires_grad else None
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pn_cross_entropy(_lib.ptr(x), _lib.ptr(t), x.shape[0], x.shape[1], _lib.ptr(loss),
+                                            _lib.ptr(g), _stream()))
+        ctx.g = g
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return (ctx.g * grad_out if ctx.g is not None else None), None
+
+
+def cross_entropy(logits, target):
+    """Mean softmax cross entropy, = ``torch.nn.functional.cross_entropy(logits, target)``."""
+    return _CrossEntropy.apply(logits, target)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for ``torch.nn.CrossEntropyLoss()`` as the reference constructs it (PathNet_run.py:297)."""
+
+    def forward(self, logits, target):
+        return cross_entropy(logits, target)
+
+
+class Adam(torch.optim.Optimizer):
+    """Drop-in for ``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` (no amsgrad / maximize): one launch
+    per step over all parameters.  State keys match torch's (``step``, ``exp_avg``, ``exp_avg_sq``)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("Adam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            todo = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("pathnet_amd.Adam: contiguous fp32 GPU parameters only")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                todo.append((p, p.grad.contiguous(), st))
+            # tensors that have taken the same number of steps share a launch (normally: all of them)
+            by_step = {}
+            for item in todo:
+                by_step.setdefault(item[2]["step"], []).append(item)
+            for step, items in by_step.items():
+                arr = (_lib.AdamTensor * len(items))()
+                for i, (p, g, st) in enumerate(items):
+                    arr[i] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                             st["exp_avg_sq"].data_ptr(), p.numel())
+                with torch.cuda.device(items[0][0].device):
+                    _lib.check(lib.pn_adam_step(arr, len(items), group["lr"], group["betas"][0], group["betas"][1],
+                                                group["eps"], group["weight_decay"], step, _stream()))
+        return loss

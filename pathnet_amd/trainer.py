@@ -17,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-from . import modules
+from . import modules, optim
 from .sampler import DRAW_PHILOX
 
 HOMO_DATASETS = ("cora", "citeseer", "pubmed")          # PathNet_run.py:286
@@ -63,8 +63,8 @@ def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices
     if model is None:
         cls = modules.PathNet_homo if data_name in HOMO_DATASETS else modules.PathNet
         model = cls(X.shape[-1], hid_size, num_classes, walk_len, dropout=dropout).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
-    lossf = torch.nn.CrossEntropyLoss()
+    opt = optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)     # = torch.optim.Adam, one launch
+    lossf = optim.CrossEntropyLoss()                                          # = torch.nn.CrossEntropyLoss()
     from_sampler = hasattr(paths, "sample")
     if not from_sampler:
         ids_all, codes_all = (torch.as_tensor(t).to(dev) for t in paths)

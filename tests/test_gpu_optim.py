@@ -1,0 +1,57 @@
+"""Loss and optimizer launches (pn_cross_entropy, pn_adam_step) against torch's own implementations."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,classes", [(1299, 7), (1, 2), (70000, 5), (33, 300)])
+def test_cross_entropy_matches_torch(rows, classes):
+    import pathnet_amd
+    torch.manual_seed(rows)
+    x = (torch.randn(rows, classes) * 3).cuda().requires_grad_(True)
+    t = torch.randint(0, classes, (rows,)).cuda()
+    loss = pathnet_amd.cross_entropy(x, t)
+    loss.backward()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(xr, t.cpu())
+    want.backward()
+    assert abs(loss.item() - want.item()) < 2e-6 * max(1.0, abs(want.item()))
+    gmax = xr.grad.abs().max().item()
+    assert (x.grad.cpu().double() - xr.grad).abs().max().item() < 2e-6 * gmax
+    # the module form, scaled upstream gradient
+    x.grad = None
+    (pathnet_amd.CrossEntropyLoss()(x, t) * 3.0).backward()
+    assert (x.grad.cpu().double() - 3.0 * xr.grad).abs().max().item() < 6e-6 * gmax
+
+
+def test_adam_matches_torch_optim_adam():
+    import pathnet_amd
+    torch.manual_seed(3)
+    shapes = [(128, 1433), (128,), (512, 128), (7, 256), (1,), (3, 5, 7)] + [(17,)] * 40    # > PN_ADAM_MAX_TENSORS
+    ours = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().cpu().double().clone()) for p in ours]
+    o1 = pathnet_amd.Adam(ours, lr=0.005, weight_decay=0.0005)
+    o2 = torch.optim.Adam(ref, lr=0.005, weight_decay=0.0005)
+    for it in range(25):
+        for p, q in zip(ours, ref):
+            g = torch.randn(*p.shape)
+            if it % 7 == 3 and p.numel() == 17:
+                p.grad, q.grad = None, None          # parameters without a gradient are skipped, as in torch
+            else:
+                p.grad, q.grad = g.cuda(), g.double()
+        o1.step()
+        o2.step()
+    for p, q in zip(ours, ref):
+        assert (p.detach().cpu().double() - q.detach()).abs().max().item() < 2e-6
+    st = o1.state[ours[0]]
+    assert st["step"] == 25 and set(st) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_adam_rejects_cpu_parameters():
+    import pathnet_amd
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError):
+        pathnet_amd.Adam([p]).step()
