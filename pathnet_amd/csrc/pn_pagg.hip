@@ -47,6 +47,10 @@ using namespace pn;
 #define PN_BWD_WAVES 2      // backward: 2 (a 168-register build re-reads the (g, o) gradients and A fragments: slower)
 #endif
 
+#ifndef PN_BWD_NB
+#define PN_BWD_NB 16        // cell backward: accumulator elements per batch of saved-gate loads (16: one memory round
+                            // trip per step; 8: two, measured 2 % slower)
+#endif
 #ifndef PN_TRACE_PHASES
 #define PN_TRACE_PHASES 0   // 1: tuning builds only -- wave 0 of every workgroup stamps s_memtime at phase boundaries
 #endif
@@ -902,6 +906,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
     constexpr int NPASS = G == 4 ? 2 : 1, KP = GH / NPASS;      // K extent of one pass (one gate pair)
     constexpr int PB = 2 * KP + 16, PLANE = MT * PB;            // plane row pitch / plane size, bytes
     constexpr int NU = GH / 32, NUP = NU / NPASS;               // units of two k-steps, total / per pass
+    constexpr int NB = PN_BWD_NB;       // accumulator elements per batch of saved-tensor loads in the cell backward
     constexpr bool CARRY_C = false;     // true: c_t stays in registers from one step to the next (16 registers the kernel does not have)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);   // [MT][L] gather rows of this tile
@@ -959,15 +964,15 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                     reinterpret_cast<const uint32_t *>(p.keep + (q * (uint32_t)p.L + t) * (uint32_t)(H / 4))[w];
             }
         }
-        // ---- cell backward.  All loads of a half tile are issued together (unconditionally, padded rows read a
+        // ---- cell backward.  All loads of a batch of NB accumulator elements are issued together (unconditionally, padded rows read a
         //      clamped row and are zeroed afterwards) so the wave pays one memory round trip, not one per element.
         float ag[16], ao[16];      // (g, o) gate gradients wait here for the second pass
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            float vi[8], vf[8], vg[8], vo[8], vc[8], vn[8];
+        for (int half = 0; half < 16 / NB; half++) {
+            float vi[NB], vf[NB], vg[NB], vo[NB], vc[NB], vn[NB];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int r = half * 8 + e;
+            for (int e = 0; e < NB; e++) {
+                const int r = half * NB + e;
                 const int qc = min(q0 + r0 + acc_row(r, lane_t), p.P - 1);
                 const uint32_t so = ((uint32_t)qc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
                 if (G == 4) {
@@ -979,10 +984,10 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                     vi[e] = p.saved[so];                                      // h_t
                 }
             }
-            float ai[8], af[8];
+            float ai[NB], af[NB];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const int r = half * 8 + e;
+            for (int e = 0; e < NB; e++) {
+                const int r = half * NB + e;
                 const int q = q0 + r0 + acc_row(r, lane_t);
                 const bool ok = q < p.P;
                 float *d = p.dG + (((uint32_t)min(q, p.P - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col);
@@ -1011,9 +1016,9 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                put_pair(half * 8 + e, lane_t, 0, ai[e], ai[e + 1]);
-                if (G == 4) put_pair(half * 8 + e, lane_t, 1, af[e], af[e + 1]);
+            for (int e = 0; e < NB; e += 2) {
+                put_pair(half * NB + e, lane_t, 0, ai[e], ai[e + 1]);
+                if (G == 4) put_pair(half * NB + e, lane_t, 1, af[e], af[e + 1]);
             }
         }
         __syncthreads();
@@ -1029,8 +1034,10 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                                   (size_t)__builtin_amdgcn_readfirstlane(ws) * (NU * 12 * 1024);
         const uint32_t voff = lane * 16;
         const unsigned char *arow = ldsb + (r0 + li) * PB + 16 * hk;
-        // units [ub, ue) of the weight stream against the resident gate pair; same fragment pipeline as seq_fwd3_kernel
-        auto run = [&](auto ntn_tag, const int ub, const int ue) {
+        // The weight stream runs through both passes without a break: the last unit of the (i, f) pass prefetches the
+        // first unit of the (g, o) pass, whose fragments are then in flight across the two barriers in between.  Same
+        // fragment pipeline as seq_fwd3_kernel: vmcnt (in order) sees [P0(u) P1(u) P2(u) P0(u+1)] at the top of unit u.
+        auto mfma_phase = [&](auto ntn_tag) {
             constexpr int NTN = decltype(ntn_tag)::value, NF = 2 * NTN;       // fragments per plane and unit
             u32x4 P0a[NF], P0b[NF], P1[NF], P2[NF];
             auto load = [&](u32x4 (&B)[NF], int u, int pl) {      // fragment kk*2 + nt of the unit's plane
@@ -1042,8 +1049,8 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                     async_load_b128_s<2048>(B[1], sb, voff);
                 }
             };
-            auto unit = [&](int u, u32x4 (&P0)[NF], u32x4 (&P0next)[NF]) {
-                const int un = min(u + 1, ue - 1);
+            auto unit = [&](int u, int ub, u32x4 (&P0)[NF], u32x4 (&P0next)[NF]) {
+                const int un = min(u + 1, NU - 1);
                 load(P0next, un, 0);
                 u32x4 a[2][3];
 #pragma unroll
@@ -1067,13 +1074,27 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                 for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][0], P2[f], acc[f % NTN]);
                 load(P2, un, 2);
             };
-            load(P0a, ub, 0);
-            load(P1, ub, 1);
-            load(P2, ub, 2);
+            load(P0a, 0, 0);
+            load(P1, 0, 1);
+            load(P2, 0, 2);
+#pragma unroll
+            for (int pass = 0; pass < NPASS; pass++) {
+                const int ub = pass * NUP, ue = ub + NUP;
+                if (pass > 0) {
+                    __syncthreads();             // every wave is done with the (i, f) planes
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        put_pair(r, lane_t, 0, ag[r], ag[r + 1]);
+                        put_pair(r, lane_t, 1, ao[r], ao[r + 1]);
+                    }
+                    __syncthreads();
+                }
+                static_assert(NPASS == 1 || NUP % 2 == 0, "the plane-0 ping-pong must be in phase at the pass boundary");
 #pragma unroll 1
-            for (int u = ub; u < ue; u += 2) {
-                unit(u, P0a, P0b);
-                if (NUP % 2 == 0 || u + 1 < ue) unit(u + 1, P0b, P0a);
+                for (int u = ub; u < ue; u += 2) {
+                    unit(u, ub, P0a, P0b);
+                    if (NUP % 2 == 0 || u + 1 < ue) unit(u + 1, ub, P0b, P0a);
+                }
             }
             wait_frag<0, NF>(P0a);       // drain (harmless re-loads of the last unit)
             wait_frag<0, NF>(P0b);
@@ -1081,22 +1102,9 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
             wait_frag<0, NF>(P2);
         };
         if (t > 0)
-            run(std::integral_constant<int, 2>{}, 0, NUP);
+            mfma_phase(std::integral_constant<int, 2>{});
         else
-            run(std::integral_constant<int, 1>{}, 0, NUP);
-        if (NPASS == 2) {
-            __syncthreads();             // every wave is done with the (i, f) planes
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                put_pair(r, lane_t, 0, ag[r], ag[r + 1]);
-                put_pair(r, lane_t, 1, ao[r], ao[r + 1]);
-            }
-            __syncthreads();
-            if (t > 0)
-                run(std::integral_constant<int, 2>{}, NUP, NU);
-            else
-                run(std::integral_constant<int, 1>{}, NUP, NU);
-        }
+            mfma_phase(std::integral_constant<int, 1>{});
         __syncthreads();
         PN_STAMP(4 * (p.L - 1 - t) + 2);
 
