@@ -51,6 +51,12 @@ using namespace pn;
 #define PN_BWD_NB 16        // cell backward: accumulator elements per batch of saved-gate loads (16: one memory round
                             // trip per step; 8: two, measured 2 % slower)
 #endif
+#ifndef PN_BWD_REVERSE
+#define PN_BWD_REVERSE 1
+#endif
+#ifndef PN_WGRAD_STRIDED
+#define PN_WGRAD_STRIDED 1
+#endif
 #ifndef PN_TRACE_PHASES
 #define PN_TRACE_PHASES 0   // 1: tuning builds only -- wave 0 of every workgroup stamps s_memtime at phase boundaries
 #endif
@@ -914,7 +920,9 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
     uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_slotof + MT); // [2][MT][H/4] dropout keep bits of step t (t & 1)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int ws = wave % NW, r0 = 32 * (wave / NW);             // column slice / first tile row of this wave
-    const int q0 = blockIdx.x * MT;
+    // PN_BWD_REVERSE: tiles in descending order -- the forward wrote the saved tensors of the last tiles last, they
+    // are the ones still in the 256 MB Infinity Cache when the backward starts
+    const int q0 = (PN_BWD_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * MT;
     const int col = 32 * ws + li;
 
     for (int i = tid; i < MT * p.L; i += NT) {
@@ -1159,8 +1167,14 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * WG_BM, n0 = blockIdx.x * WG_BN;
+#if PN_WGRAD_STRIDED
+    // split z takes the K tiles z, z + nz, z + 2 nz, ...: every workgroup starts on the low rows, which the (reversed)
+    // BPTT kernel wrote last and which are still in the Infinity Cache
+    const int64_t rbeg = (int64_t)blockIdx.z * WG_KT, rend = p.R, kstep = (int64_t)gridDim.z * WG_KT;
+#else
     const int64_t rbeg = (int64_t)blockIdx.z * p.rows_per_split;
-    const int64_t rend = min(p.R, rbeg + p.rows_per_split);
+    const int64_t rend = min(p.R, rbeg + p.rows_per_split), kstep = WG_KT;
+#endif
     if (rbeg >= rend) return;   // block-uniform
     f32x16 acc[2][4];
 #pragma unroll
@@ -1187,7 +1201,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
     const int sa = (li & 3) * 68 + (li >> 2) + wm * 16, sb = (li & 3) * 68 + (li >> 2) + wn * 32;
 
     issue(rbeg);
-    for (int64_t k0 = rbeg; k0 < rend; k0 += WG_KT) {
+    for (int64_t k0 = rbeg; k0 < rend; k0 += kstep) {
         wait_vm<0>(rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], rg[6], rg[7]);
 #pragma unroll
         for (int e = 0; e < 8; e++)
@@ -1207,7 +1221,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
             stage[2 * W3_PLANE + j * 68] = q2;
         }
         __syncthreads();
-        issue(min(k0 + WG_KT, rend - 1));   // next tile in flight under the MFMAs (last trip: harmless re-load)
+        issue(min(k0 + kstep, rend - 1));   // next tile in flight under the MFMAs (last trip: harmless re-load)
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const u32x4 *fa = lds4 + (kk * 2 + hk) * W3_BLK + sa;             // operand 0 (dG^T)
@@ -1799,7 +1813,12 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         int64_t rps = (wp.R + nz - 1) / nz;
         rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
         wp.rows_per_split = rps;
+#if PN_WGRAD_STRIDED
+        const int64_t ntiles = (wp.R + WG_KT - 1) / WG_KT;
+        const int nz_used = (int)(ntiles < nz ? ntiles : nz);
+#else
         const int nz_used = (int)((wp.R + rps - 1) / rps);
+#endif
         wp.part_w = reinterpret_cast<float *>(ws + w.wpart);
         wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
         {
