@@ -52,6 +52,8 @@ def main():
             d = json.loads(res[0][7:])
             print("%-60s fwd %.3f bwd %.3f wgrad %.3f | total %.3f" % (spec, d.get("seq_fwd", -1), d.get("seq_bwd", -1),
                                                                       d.get("wgrad", -1), sum(d.values())))
+            if os.environ.get("PN_TUNE_ALL"):
+                print("    " + " ".join("%s %.3f" % kv for kv in d.items()))
         else:
             print("%-60s FAILED %s" % (spec, r.stderr[-300:]))
 
