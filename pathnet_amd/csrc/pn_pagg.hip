@@ -1243,10 +1243,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
                 for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; i++) a1[i] = fa[W3_PLANE + i * 8];
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
+            // a1.b1 before a1.b0: the plane-2 fragments can then be fetched into the registers of b1 (and next of a1)
+            // under the MFMAs that follow, instead of stalling the matrix pipe for two LDS round trips per k-step
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1256,9 +1254,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; i++) a1[i] = fa[2 * W3_PLANE + i * 8];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
