@@ -370,15 +370,14 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     constexpr int MT = 32 * RG;
     constexpr int NW = H / 32, NT = NW * 64 * RG, SV = (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
-    constexpr int PB = 2 * H + 16;            // row pitch of a half tile (x or h), bytes: conflict-free ds_read_b128
-    constexpr int PLANE = MT * PB, HALF = 3 * PLANE;
+    constexpr int PB = 4 * H + 16;            // row pitch of a plane of the tile [x | h], bytes: conflict-free ds_read_b128
+    constexpr int PLANE = MT * PB;
     // three workgroups per CU (168 registers): no register room for the x_{t+1} rows or a second plane-0 fragment set,
     // the third workgroup covers those latencies instead
     constexpr bool PREFETCH_X = fwd_waves<H, RG>() < 3, PING_PONG = fwd_waves<H, RG>() < 3;
-    // LDS: x planes | h planes | row indices
+    // LDS: three bf16 planes of the tile [MT][x_t | h_{t-1}] | row indices
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    unsigned char *ldsH = ldsb + HALF;
-    int *s_rowidx = reinterpret_cast<int *>(ldsb + 2 * HALF);   // [MT][L] gather rows of this tile
+    int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);  // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int ws = wave % NW, r0 = 32 * (wave / NW);            // column slice / first tile row of this wave
@@ -492,38 +491,48 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.Wp) +
                                       (size_t)__builtin_amdgcn_readfirstlane(ws) * (KS * 3 * G * 1024);
             const uint32_t voff = lane * 16;
-            const unsigned char *arow_x = ldsb + (r0 + li) * PB + 16 * hk;
-            const unsigned char *arow_h = ldsH + (r0 + li) * PB + 16 * hk - 32 * KX;
+            const unsigned char *arow = ldsb + (r0 + li) * PB + 16 * hk;
             u32x4 P0a[G], P0b[G], P1[G], P2[G];
             auto load = [&](u32x4 (&B)[G], int s, int pl) {
                 async_load_frags<G>(B, wb + (size_t)(s * 3 + pl) * (G * 1024), voff);
             };
             // PING_PONG: vmcnt (in order) sees [P0(s) P1(s) P2(s) P0(s+1)] at the top of k-step s;
             // otherwise one register set per plane, [P0(s) P1(s) P2(s)]
+            // A fragments are software-pipelined without extra registers: within a k-step the products run
+            // a2.P0, a1.P0, a0.P0 | a1.P1, a0.P1 | a0.P2, so plane 2 of the A tile is dead after the first G MFMAs, plane
+            // 1 after the P1 group, plane 0 at the end -- each is re-read for k-step s+1 right there, and the next
+            // k-step again starts with a2 (read longest ago) and needs a0 (read last) only after 2G MFMAs.
+            u32x4 a[3];
+            auto aread = [&](int s, int pl) {
+                return *reinterpret_cast<const u32x4 *>(arow + 32 * s + pl * PLANE);
+            };
             auto kstep = [&](int s, u32x4 (&P0)[G], u32x4 (&P0next)[G]) {
                 const int sn = min(s + 1, nsteps - 1);
                 if (PING_PONG) load(P0next, sn, 0);
-                const unsigned char *arow = (s < KX ? arow_x : arow_h) + 32 * s;
-                u32x4 a[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++) a[pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE);
                 wait_frag<(PING_PONG ? 3 : 2) * G, G>(P0);
 #pragma unroll
-                for (int pl = 0; pl < 3; pl++)
+                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[2], P0[g], acc[g]);
+                a[2] = aread(sn, 2);
 #pragma unroll
-                    for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[pl], P0[g], acc[g]);
+                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[1], P0[g], acc[g]);
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P0[g], acc[g]);
                 if (!PING_PONG) load(P0, sn, 0);
                 wait_frag<2 * G, G>(P1);
 #pragma unroll
-                for (int pl = 0; pl < 2; pl++)
+                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[1], P1[g], acc[g]);
+                a[1] = aread(sn, 1);
 #pragma unroll
-                    for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[pl], P1[g], acc[g]);
+                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P1[g], acc[g]);
                 load(P1, sn, 1);
                 wait_frag<2 * G, G>(P2);
 #pragma unroll
                 for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P2[g], acc[g]);
+                a[0] = aread(sn, 0);
                 load(P2, sn, 2);
             };
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) a[pl] = aread(0, pl);
             load(P0a, 0, 0);
             load(P1, 0, 1);
             load(P2, 0, 2);
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
                 uint32_t h0, h1, h2;
                 split3(hv[r], hv[r + 1], h0, h1, h2);
-                unsigned char *d = ldsH + (r0 + acc_row(r, lane)) * PB + 2 * col;
+                unsigned char *d = ldsb + (r0 + acc_row(r, lane)) * PB + 2 * (H + col);
                 *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
                 *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
                 *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
@@ -1057,29 +1066,42 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                     async_load_b128_s<2048>(B[1], sb, voff);
                 }
             };
-            auto unit = [&](int u, int ub, u32x4 (&P0)[NF], u32x4 (&P0next)[NF]) {
-                const int un = min(u + 1, NU - 1);
-                load(P0next, un, 0);
-                u32x4 a[2][3];
+            // A fragments pipelined in place, as in seq_fwd3_kernel: products run a2.P0, a1.P0, a0.P0 | a1.P1, a0.P1 |
+            // a0.P2 and each plane of the A tile is re-read for the next unit right after its last use.  The last unit
+            // of a pass does not read ahead (the tile is rewritten behind the barrier); the first one reads up front.
+            u32x4 a[2][3];
+            auto aread = [&](int ul, int pl) {          // ul = unit index within the pass
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++)
+                    a[kk][pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE + 64 * ul + 32 * kk);
+            };
+            auto group = [&](const u32x4 (&B)[NF], int pl) {
 #pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
-                        a[kk][pl] = *reinterpret_cast<const u32x4 *>(arow + pl * PLANE + 64 * (u - ub) + 32 * kk);
+                for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][pl], B[f], acc[f % NTN]);
+            };
+            auto unit = [&](int u, int ub, u32x4 (&P0)[NF], u32x4 (&P0next)[NF]) {
+                const int un = min(u + 1, NU - 1);
+                const int ul = u - ub;
+                const bool ahead = ul + 1 < NUP;        // block-uniform
+                load(P0next, un, 0);
+                if (ul == 0) {
+                    aread(0, 0);
+                    aread(0, 1);
+                    aread(0, 2);
+                }
                 wait_frag<3 * NF, NF>(P0);
-#pragma unroll
-                for (int pl = 0; pl < 3; pl++)
-#pragma unroll
-                    for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][pl], P0[f], acc[f % NTN]);
+                group(P0, 2);
+                if (ahead) aread(ul + 1, 2);
+                group(P0, 1);
+                group(P0, 0);
                 wait_frag<2 * NF, NF>(P1);
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-                    for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][pl], P1[f], acc[f % NTN]);
+                group(P1, 1);
+                if (ahead) aread(ul + 1, 1);
+                group(P1, 0);
                 load(P1, un, 1);
                 wait_frag<2 * NF, NF>(P2);
-#pragma unroll
-                for (int f = 0; f < NF; f++) acc[f % NTN] = mfma_bf16(a[f / NTN][0], P2[f], acc[f % NTN]);
+                group(P2, 0);
+                if (ahead) aread(ul + 1, 0);
                 load(P2, un, 2);
             };
             load(P0a, 0, 0);
@@ -1458,7 +1480,7 @@ template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
     constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;      // H = 256: one row group already fills the LDS
     constexpr int MT = 32 * RG;
-    const size_t lds_bytes = (size_t)6 * MT * (2 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
+    const size_t lds_bytes = (size_t)3 * MT * (4 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_fwd3_kernel<H, G, RG>;
     PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds_bytes));
