@@ -81,7 +81,7 @@ namespace {
 //   ds_read_b32 of 32 consecutive floats per half-wave.
 // ================================================================================================
 constexpr int GEMM_BM = 64, GEMM_BN = 64, GEMM_KT = 32, GEMM_PITCH = 65;
-enum { GEMM_STORE = 0, GEMM_ADD = 1, GEMM_ATOMIC = 2 };
+enum { GEMM_STORE = 0, GEMM_ADD = 1, GEMM_ATOMIC = 2, GEMM_PARTIAL = 3 };   // PARTIAL: raw sums of K chunk z to C[z][M][ldc]
 
 struct GemmParams {
     const float *A;
@@ -161,12 +161,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (p.rowsum && blockIdx.x == 0 && tid < GEMM_BM && m0 + tid < p.M) atomicAdd(&p.rowsum[m0 + tid], rsum);
     const int col = n0 + wn * 32 + li;
     if (col >= p.N) return;
-    const float bias = (p.bias && blockIdx.z == 0) ? p.bias[col] : 0.0f;
+    const float bias = (p.bias && blockIdx.z == 0 && p.mode != GEMM_PARTIAL) ? p.bias[col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = m0 + wm * 32 + acc_row(r, lane);
         if (row >= p.M) continue;
         float v = acc[r] + bias;
+        if (p.mode == GEMM_PARTIAL) {
+            p.C[((int64_t)blockIdx.z * p.M + row) * p.ldc + col] = v;
+            continue;
+        }
         if (p.relu) v = fmaxf(v, 0.0f);
         float *dst = p.C + (int64_t)row * p.ldc + col;
         if (p.mode == GEMM_STORE)
@@ -196,7 +200,7 @@ int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, co
     if (M <= 0 || N <= 0) return PN_OK;
     GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0, rowsum};
     if (ksplit < 1) ksplit = 1;
-    if (mode != GEMM_ATOMIC) ksplit = 1;
+    if (mode != GEMM_ATOMIC && mode != GEMM_PARTIAL) ksplit = 1;
     int kchunk = (K + ksplit - 1) / ksplit;
     kchunk = ((kchunk + GEMM_KT - 1) / GEMM_KT) * GEMM_KT;
     if (kchunk < GEMM_KT) kchunk = GEMM_KT;
@@ -209,6 +213,51 @@ int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, co
         launch_gemm_variant<true>(stream, grid, ak, bk, p);
     else
         launch_gemm_variant<false>(stream, grid, ak, bk, p);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+// ---- deterministic split-K for the STORE / ADD GEMMs -------------------------------------------------------------
+// The node-level GEMMs (fc0: 2708 x 128 x 1433, the bank backward) are 86 workgroups of 64 x 64 -- a third of the
+// CUs, each walking all of K alone, one wave per SIMD.  With K cut into nz chunks there are nz times as many
+// workgroups; the chunk sums go to a [nz][M][N] buffer and one small kernel adds them up in a fixed order and applies
+// bias / ReLU / accumulate.
+__global__ __launch_bounds__(256) void gemm_finish_kernel(const float *__restrict__ part, int nz, int M, int N,
+                                                          const float *__restrict__ bias, int relu, int mode,
+                                                          float *__restrict__ C, int64_t ldc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
+    float v = bias ? bias[col] : 0.0f;
+    for (int z = 0; z < nz; z++) v += part[(int64_t)z * M * N + i];
+    if (relu) v = fmaxf(v, 0.0f);
+    float *dst = C + (int64_t)row * ldc + col;
+    if (mode == GEMM_ADD)
+        *dst += v;
+    else
+        *dst = v;
+}
+
+// max K chunks of a split GEMM (sizes the partial buffer)
+constexpr int GEMM_MAX_SPLIT = 8;
+
+int launch_gemm_split(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
+                      int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
+                      int mode, float *partial) {
+    const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
+    int nz = tiles > 0 ? (512 + tiles - 1) / tiles : 1;                // aim at ~2 workgroups per CU
+    if (nz > GEMM_MAX_SPLIT) nz = GEMM_MAX_SPLIT;
+    if (nz > K / (2 * GEMM_KT)) nz = K / (2 * GEMM_KT);                // at least two K tiles per chunk
+    if (nz <= 1 || !partial || M <= 0 || N <= 0)
+        return launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 1);
+    int kchunk = (K + nz - 1) / nz;
+    kchunk = (kchunk + GEMM_KT - 1) / GEMM_KT * GEMM_KT;
+    nz = (K + kchunk - 1) / kchunk;
+    if (int rc = launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, partial, N, nullptr, M, N, K, 0, GEMM_PARTIAL, nz))
+        return rc;
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, nz, M, N,
+                       bias, relu, mode, C, ldc);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -1409,6 +1458,7 @@ struct WsLayout {
     size_t Xh, Z, rowidx, egoidx, slotof, Wp, biasc, hn, saved, coef, rawsc, layer1;  // forward
     size_t xh, keep;                                                                  // forward (saved)
     size_t WpT, dG, dZ, dXh, dhn, dl1, wpart;                                         // backward
+    size_t gpart;                                                                     // split-K partial sums of the node GEMMs
     int wgrad_split;
     size_t total;
 };
@@ -1455,6 +1505,7 @@ WsLayout ws_layout(const pn_pagg_shape &s) {
         w.wgrad_split = (int)nz;
         w.wpart = take(nz * (G * H * 2 * H + G * H) * 4);
     }
+    w.gpart = take((size_t)GEMM_MAX_SPLIT * N * H * 4);
     w.total = at;
     return w;
 }
@@ -1614,8 +1665,9 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
     if (!a->Xh_in) {
         StageTimer tm(ST_FC0, stream);
-        if (int rc = launch_gemm(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1, reinterpret_cast<float *>(ws + w.Xh),
-                                 H, a->fc0_b, s.N, H, s.F, homo, GEMM_STORE, 1))
+        if (int rc = launch_gemm_split(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1,
+                                       reinterpret_cast<float *>(ws + w.Xh), H, a->fc0_b, s.N, H, s.F, homo, GEMM_STORE,
+                                       reinterpret_cast<float *>(ws + w.gpart)))
             return rc;
     }
     // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
@@ -1862,8 +1914,8 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh
     const float *zgate = homo ? Z : nullptr;
     auto tm_bank = std::make_unique<StageTimer>(ST_BANK_BWD, stream);
-    if (int rc = launch_gemm(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, s.N, H, L * H, 0,
-                             GEMM_ADD, 1))
+    if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, s.N, H, L * H,
+                                   0, GEMM_ADD, reinterpret_cast<float *>(ws + w.gpart)))
         return rc;
     if (a->g_bank_w) {       // g_bank_b rides along as the row sums of the same (gated) A operand
         if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, s.N,
