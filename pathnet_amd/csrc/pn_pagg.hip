@@ -14,15 +14,20 @@
 //        after which "gather + select" is a single row gather  Z[node(q,t)*L + code(q,t)].
 //        Same dot products per emitted row, ~S*W*L/N times fewer FLOPs, no [P*L, L, H] temporary.
 //   X[neis] gather, flip / view quirks :179-184 / :246     -> plan_kernel (index plan only)
-//   dropout, nn.LSTM / nn.RNN          :194-195 / :264-265 -> seq_fwd_kernel: coalesced 4*H-byte row
-//        gather into an LDS path tile, fp32 MFMA (v_mfma_f32_32x32x2_f32) for [x_t ; h_{t-1}] x
-//        [W_ih ; W_hh]^T, cell math in registers, h_t back to LDS, L steps without leaving the CU.
+//   dropout, nn.LSTM / nn.RNN          :194-195 / :264-265 -> seq_fwd3_kernel: coalesced 4*H-byte row
+//        gather into an LDS path tile (three bf16 planes), bf16 MFMA (v_mfma_f32_32x32x16_bf16, six per fp32
+//        product) for [x_t ; h_{t-1}] x [W_ih ; W_hh]^T, cell math in registers, h_t back to LDS, L steps without
+//        leaving the CU.
 //   attention over the W paths, mean, concat ego, dropout, fc2
 //                                    :196-210 / :266-277  -> pool_fwd_kernel: one wavefront per
 //        node, wave shuffles for the per-path dot products and the reduction over W.
+//   backward: pool_bwd_kernel, seq_bwd3_kernel (BPTT + atomic scatter of the gather backward), wgrad3_kernel
+//        (dG^T . [x|h]), gemm_kernel for the bank / fc0 gradients.
 //
-// Precision: everything is fp32 with fp32 accumulation (the f32-input MFMA is an exact FMA chain),
-// because the contract is 1e-5 on fp32 logits against the reference CPU path.
+// Precision: inputs, outputs, accumulation and all element-wise math are fp32.  The node-level GEMMs use the
+// fp32-input MFMA (an exact FMA chain); the three recurrent GEMMs evaluate every fp32 product as six bf16 MFMAs over
+// exact three-plane splits of both operands (pn_kernels.h), which is as accurate as an fp32 FMA chain -- the contract
+// is 1e-5 on fp32 logits against the reference CPU path, tests measure 3e-7 against float64.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
