@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(HERE, "_build", "libmerw_oracle.so")
 SHIM_PATH = os.path.join(HERE, "_build", "libtimeshim.so")
 REF_GEN_MERW = os.path.join(HERE, "_ref", "gen_merw")
 REF_GEN_EPOCH_MERW = os.path.join(HERE, "_ref", "gen_epoch_merw")
+REF_GEN = os.path.join(HERE, "_ref", "gen")                    # uniform random walks (gen.cpp)
+REF_GEN_EPOCH = os.path.join(HERE, "_ref", "gen_epoch")
 
 DRAW_GLIBC = 0
 DRAW_PHILOX = 1
@@ -49,6 +51,12 @@ def lib():
                               ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                               ctypes.c_int32, i32p, u8p]
         L.mo_walk.restype = ctypes.c_int
+        L.mo_uniform_build.argtypes = [ctypes.c_int32, ctypes.c_int64, i32p, i32p, i64p, i32p, ctypes.c_int64]
+        L.mo_uniform_build.restype = ctypes.c_int64
+        L.mo_walk_uniform.argtypes = [ctypes.c_int32, i64p, i32p, u8p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int,
+                                      ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                      i32p, u8p]
+        L.mo_walk_uniform.restype = ctypes.c_int
         L.mo_format_text.argtypes = [i32p, u8p, ctypes.c_int64, ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64]
         L.mo_format_text.restype = ctypes.c_int64
         _lib = L
@@ -159,6 +167,90 @@ def sample_full(n, u, v, p, W, L, draw_source, seed, **kw):
     off, A, B, S = alias_build(n, u, v, p)
     dis = bfs_dense(n, u, v, L)
     return walk(n, off, A, B, S, dis, W, L, draw_source, seed, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# the uniform random-walk sampler (gen.cpp / gen_epoch.cpp), restated in merw_oracle.c
+# ------------------------------------------------------------------------------------------------
+def read_pair_file(path):
+    """-> n, u[int32 m], v[int32 m]: "n m" then m pairs, read like gen.cpp:80-92 reads them (scanf("%d%d"))."""
+    tok = open(path).read().split()
+    n, m = int(tok[0]), int(tok[1])
+    a = np.array(tok[2:2 + 2 * m], dtype=np.int64).reshape(m, 2)
+    return n, a[:, 0].astype(np.int32), a[:, 1].astype(np.int32)
+
+
+def write_pair_file(path, n, u, v):
+    with open(path, "w") as f:
+        f.write("%d %d\n" % (n, len(u)))
+        for a, b in zip(u, v):
+            f.write("%d %d\n" % (a, b))
+
+
+def uniform_build(n, u, v):
+    """-> off[int64 n+1], nbr[int32]: self loop first, then both directions of every pair in file order."""
+    u = np.ascontiguousarray(u, np.int32)
+    v = np.ascontiguousarray(v, np.int32)
+    total = lib().mo_uniform_build(n, len(u), _p(u, ctypes.c_int32), _p(v, ctypes.c_int32), None, None, 0)
+    if total < 0:
+        raise ValueError("node id out of range")
+    off = np.zeros(n + 1, np.int64)
+    nbr = np.zeros(total, np.int32)
+    lib().mo_uniform_build(n, len(u), _p(u, ctypes.c_int32), _p(v, ctypes.c_int32), _p(off, ctypes.c_int64),
+                           _p(nbr, ctypes.c_int32), total)
+    return off, nbr
+
+
+def sample_uniform(n, u, v, W, L, draw_source, seed, epoch_begin=0, epoch_count=1, node_begin=0, node_count=None):
+    """Pair list -> (ids, codes): the whole gen.cpp pipeline through the restatement."""
+    if node_count is None:
+        node_count = n - node_begin
+    off, nbr = uniform_build(n, u, v)
+    src = np.repeat(np.arange(n, dtype=np.int32), np.diff(off))
+    dis = bfs_dense(n, src, nbr, L)                                  # the same BFS over the expanded lists
+    ids = np.empty((epoch_count, node_count, W, L), dtype=np.int32)
+    codes = np.empty((epoch_count, node_count, W, L), dtype=np.uint8)
+    rc = lib().mo_walk_uniform(n, _p(off, ctypes.c_int64), _p(nbr, ctypes.c_int32), _p(dis, ctypes.c_uint8), W, L,
+                               draw_source, seed, epoch_begin, epoch_count, node_begin, node_count,
+                               _p(ids, ctypes.c_int32), _p(codes, ctypes.c_uint8))
+    if rc != 0:
+        raise RuntimeError("mo_walk_uniform rc=%d" % rc)
+    return ids, codes
+
+
+def run_ref_uniform(pair_file, W, L, seed, name="g", max_bytes=None):
+    """Run oracle/_ref/gen (unmodified gen.cpp) with srand pinned to `seed`; returns the bytes of
+    `<name>_<W>_<L>_nsl.txt`, truncated to max_bytes (the program always walks 1000 epochs)."""
+    tmp = tempfile.mkdtemp(prefix="pn_ref_")
+    try:
+        os.makedirs(os.path.join(tmp, "preprocess"))
+        os.makedirs(os.path.join(tmp, "edge_input"))
+        shutil.copy(pair_file, os.path.join(tmp, "edge_input", name + "_nsl.in"))      # gen.cpp:52-56
+        cwd = os.path.join(tmp, "preprocess")
+        out_name = "%s_%d_%d_nsl.txt" % (name, W, L)                                  # gen.cpp:58-68
+        env = dict(os.environ, LD_PRELOAD=SHIM_PATH, PN_FAKE_TIME=str(seed))
+        cmd = [REF_GEN, name, str(W), str(L)]
+        if max_bytes is None:
+            subprocess.run(cmd, cwd=cwd, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(os.path.join(cwd, out_name), "rb") as f:
+                return f.read()
+        os.mkfifo(os.path.join(cwd, out_name))
+        proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        chunks, got = [], 0
+        try:
+            with open(os.path.join(cwd, out_name), "rb") as f:
+                while got < max_bytes:
+                    b = f.read(min(1 << 20, max_bytes - got))
+                    if not b:
+                        break
+                    chunks.append(b)
+                    got += len(b)
+        finally:
+            proc.kill()
+            proc.wait()
+        return b"".join(chunks)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 # ------------------------------------------------------------------------------------------------

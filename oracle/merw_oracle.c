@@ -276,6 +276,81 @@ int mo_walk(int32_t n, const int64_t *off, const int32_t *A, const int32_t *B, c
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The uniform random-walk sampler ("RW-PathNet" ablation), /root/reference/preprocess/gen.cpp and
+ * gen_epoch.cpp.  Same program as gen_merw.cpp except for the graph and the step:
+ *   graph, gen.cpp:83-94: E[i] starts with the self loop i; every input pair (u, v) with u != v
+ *     appends v to E[u] and u to E[v], in file order, duplicates kept.
+ *     mo_uniform_build writes the lists as CSR (off[n+1], nbr[]); cap = 0 only sizes.  Returns the
+ *     total length, or -1 on a node id outside [0, n).
+ *   hop table, gen.cpp:18-40: the BFS of gen_merw.cpp over E  ->  mo_bfs_dense on the expanded lists.
+ *   step, gen.cpp:113-114: ONE rand() per step, u = E[u][rand() % E[u].size()]; the last step of a
+ *     walk still draws.  Draw index of (epoch e, source st, walk i, step t) = ((e*n + st)*W + i)*L + t.
+ * ---------------------------------------------------------------------------------------- */
+int64_t mo_uniform_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int64_t *off,
+                         int32_t *nbr, int64_t cap)
+{
+    int64_t i, total = 0;
+    int64_t *cnt = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+    if (!cnt) return -1;
+    for (i = 0; i < n; i++) cnt[i] = 1;
+    for (i = 0; i < m; i++) {
+        if (u[i] < 0 || u[i] >= n || v[i] < 0 || v[i] >= n) { free(cnt); return -1; }
+        if (u[i] == v[i]) continue;
+        cnt[u[i]]++; cnt[v[i]]++;
+    }
+    for (i = 0; i < n; i++) total += cnt[i];
+    if (cap >= total && off && nbr) {
+        int64_t at = 0;
+        for (i = 0; i < n; i++) { off[i] = at; at += cnt[i]; cnt[i] = off[i]; }
+        off[n] = at;
+        for (i = 0; i < n; i++) nbr[cnt[i]++] = (int32_t)i;
+        for (i = 0; i < m; i++) {
+            if (u[i] == v[i]) continue;
+            nbr[cnt[u[i]]++] = v[i];
+            nbr[cnt[v[i]]++] = u[i];
+        }
+    }
+    free(cnt);
+    return total;
+}
+
+int mo_walk_uniform(int32_t n, const int64_t *off, const int32_t *nbr, const uint8_t *dis, int32_t W,
+                    int32_t L, int draw_source, uint64_t seed, int64_t epoch_begin, int64_t epoch_count,
+                    int32_t node_begin, int32_t node_count, int32_t *ids, uint8_t *codes)
+{
+    mo_glibc_t g;
+    int64_t e, out = 0;
+    uint64_t consumed = 0;
+    if (draw_source == MO_DRAW_GLIBC) mo_glibc_seed(&g, (uint32_t)seed);
+    for (e = epoch_begin; e < epoch_begin + epoch_count; e++) {
+        int32_t st;
+        for (st = node_begin; st < node_begin + node_count; st++) {
+            int32_t i;
+            for (i = 0; i < W; i++) {
+                uint64_t walk = ((uint64_t)e * (uint64_t)n + (uint64_t)st) * (uint64_t)W + (uint64_t)i;
+                int32_t x = st, t;
+                if (draw_source == MO_DRAW_GLIBC) {
+                    uint64_t want = walk * (uint64_t)L;
+                    while (consumed < want) { (void)mo_glibc_next(&g); consumed++; }
+                }
+                for (t = 0; t < L; t++) {
+                    int64_t len = off[x + 1] - off[x];
+                    int32_t r0;
+                    ids[out] = x;
+                    codes[out] = (uint8_t)(dis[(size_t)st * (size_t)n + (size_t)x] - 1);
+                    out++;
+                    if (len == 0) return -2;          /* cannot happen: every list holds its self loop */
+                    if (draw_source == MO_DRAW_GLIBC) { r0 = mo_glibc_next(&g); consumed++; }
+                    else r0 = (int32_t)(mo_philox_draw(seed, walk, (uint64_t)t) >> 1);
+                    x = nbr[off[x] + (int64_t)(r0 % (int32_t)len)];
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Text line, gen_merw.cpp:189-206:  "[" v0 ", " v1 ", " ... v_{L-1} ", " d0 ", " ... d_{L-1} "]\n"
  * Writes npaths lines into buf (cap bytes); returns bytes written or -1 if cap is too small.
  * ---------------------------------------------------------------------------------------- */

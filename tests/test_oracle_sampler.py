@@ -97,3 +97,34 @@ def test_oracle_bit_exact_on_shipped_graphs(name):
     ids, codes = merw.sample_full(n, u, v, p, 40, 4, merw.DRAW_GLIBC, 5, epoch_count=2)
     txt = merw.format_text(ids, codes)
     assert merw.run_ref(f, 40, 4, 5, max_bytes=len(txt)) == txt
+
+
+# ---- the uniform random-walk sampler (gen.cpp), SURVEY.md §8 f-4 ------------------------------------------------
+@pytest.mark.parametrize("name", golden_files("uniform_*.npz"))
+def test_uniform_oracle_reproduces_reference_golden(name):
+    g = golden(name)
+    n, W, L, seed, E = int(g["n"]), int(g["W"]), int(g["L"]), int(g["seed"]), int(g["epochs"])
+    ids, codes = merw.sample_uniform(n, g["u"], g["v"], W, L, merw.DRAW_GLIBC, seed, epoch_count=E)
+    assert (ids == g["ids"]).all()
+    assert (codes == g["codes"]).all()
+    assert hashlib.md5(merw.format_text(ids, codes)).hexdigest() == str(g["md5"])
+
+
+def test_uniform_graph_build_keeps_self_loop_first_and_parallel_edges():
+    # gen.cpp:83-94: link(i, i) for every node, then both directions of every pair with u != v, in file order
+    off, nbr = merw.uniform_build(4, np.array([0, 1, 2, 0, 3], np.int32), np.array([1, 0, 2, 1, 0], np.int32))
+    lists = [nbr[off[i]:off[i + 1]].tolist() for i in range(4)]
+    assert lists == [[0, 1, 1, 1, 3], [1, 0, 0, 0], [2], [3, 0]]
+
+
+@pytest.mark.skipif(not os.path.exists(merw.REF_GEN), reason="oracle/_ref/gen not built (reference sources absent)")
+def test_uniform_oracle_matches_reference_binary_on_a_fresh_graph(tmp_path):
+    rng = np.random.default_rng(77)
+    n = 41
+    u = np.concatenate([np.arange(n), rng.integers(0, n, 60)]).astype(np.int32)
+    v = np.concatenate([(np.arange(n) + 1) % n, rng.integers(0, n, 60)]).astype(np.int32)
+    f = os.path.join(tmp_path, "x_nsl.in")
+    merw.write_pair_file(f, n, u, v)
+    ids, codes = merw.sample_uniform(n, u, v, 6, 5, merw.DRAW_GLIBC, 31337, epoch_count=2)
+    txt = merw.format_text(ids, codes)
+    assert merw.run_ref_uniform(f, 6, 5, 31337, max_bytes=len(txt)) == txt
