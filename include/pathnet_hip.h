@@ -61,6 +61,18 @@ int pn_device_query(pn_device_info *out);
  * Call with cap = 0 to read only n and m; then with cap >= m to fill u, v, p (host, file order). */
 int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, double *p, int64_t cap);
 
+/* ---- the uniform random-walk sampler ("RW-PathNet" ablation): preprocess/gen.cpp, gen_epoch.cpp ------------------
+ * Pair file "<n> <m>" then m pairs "u v", read the way gen.cpp:80-92 reads it (scanf("%d%d")).  cap = 0 reads only
+ * n and m; cap >= m fills u, v (host, file order). */
+int pn_pairs_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, int64_t cap);
+
+/* The graph gen.cpp:83-94 walks on: list i starts with the self loop i, every pair with u != v then appends v to list
+ * u and u to list v, in file order, repeated pairs kept.  off[n+1] prefixes the lists; packed[total*4] is the list
+ * in the walker's 16-byte triple layout {nbr, nbr, 0, 0}; src/nbr (each [total], may be NULL) is the same graph as a
+ * directed edge list for pn_hops_dense / pn_csr_build.  cap = 0 only sizes (*total). */
+int pn_uniform_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int64_t *off, int32_t *packed,
+                     int32_t *src, int32_t *nbr, int64_t cap, int64_t *total);
+
 /* Alias tables of every node, bit-identical to AliasTable::init (gen_merw.cpp:23-79) run on the
  * per-node lists that link() (:95-99) builds in file order.  off[n+1] is the per-node prefix of the
  * triple arrays.  A/B are the two candidate next nodes, S the fp64 split value, and
@@ -110,6 +122,9 @@ typedef struct pn_sampler_tables {
     const int32_t *adj;      /* dev out-neighbours, sorted per node */
     const int64_t *radj_off; /* dev [n+1] */
     const int32_t *radj;     /* dev in-neighbours, sorted per node */
+    /* draws per walk step: 0 or 2 = the MERW alias roll (slot draw + probability draw, gen_merw.cpp:81-91);
+     * 1 = the uniform sampler's single rand() % deg (gen.cpp:113-114) over tables from pn_uniform_build. */
+    int32_t draws_per_step;
 } pn_sampler_tables;
 
 /* Pack host A/B/thr arrays into the 16-byte device layout (host helper, dst is a host buffer of

@@ -36,7 +36,7 @@ class DeviceInfo(ctypes.Structure):
 
 class SamplerTables(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("total", ctypes.c_int64), ("off", vp), ("triples", vp), ("dis", vp),
-                ("adj_off", vp), ("adj", vp), ("radj_off", vp), ("radj", vp)]
+                ("adj_off", vp), ("adj", vp), ("radj_off", vp), ("radj", vp), ("draws_per_step", ctypes.c_int32)]
 
 
 class PaggShape(ctypes.Structure):
@@ -68,6 +68,9 @@ SIGNATURES = {
     "pn_last_error": (ctypes.c_char_p, []),
     "pn_device_query": (ctypes.c_int, [ctypes.POINTER(DeviceInfo)]),
     "pn_edges_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, c_f64p, ctypes.c_int64]),
+    "pn_pairs_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, ctypes.c_int64]),
+    "pn_uniform_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, c_i64p, c_i32p, c_i32p, c_i32p,
+                                        ctypes.c_int64, c_i64p]),
     "pn_alias_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, c_f64p, c_i64p, c_i32p, c_i32p,
                                       c_f64p, c_u32p, ctypes.c_int64, c_i64p]),
     "pn_alias_pack": (ctypes.c_int, [ctypes.c_int64, c_i32p, c_i32p, c_u32p, c_i32p]),

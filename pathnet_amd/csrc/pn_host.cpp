@@ -159,6 +159,84 @@ int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// the uniform random-walk sampler's input and graph (gen.cpp:80-94, gen_epoch.cpp)
+// ------------------------------------------------------------------------------------------------
+int pn_pairs_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, int64_t cap) {
+    if (!path || !n || !m) PN_FAIL(PN_ERR_ARG, "pn_pairs_read_text: null argument");
+    std::string txt;
+    if (!slurp(path, txt)) PN_FAIL(PN_ERR_IO, "cannot read pair file %s: %s", path, std::strerror(errno));
+    const char *s = txt.c_str();
+    char *end = nullptr;
+    long nn = std::strtol(s, &end, 10);
+    if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: missing node count", path);
+    s = end;
+    long long mm = std::strtoll(s, &end, 10);
+    if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: missing pair count", path);
+    s = end;
+    if (nn < 0 || mm < 0) PN_FAIL(PN_ERR_FORMAT, "%s: negative header", path);
+    *n = (int32_t)nn;
+    *m = (int64_t)mm;
+    if (cap == 0) return PN_OK;
+    if (cap < mm) PN_FAIL(PN_ERR_CAPACITY, "pair buffers hold %lld rows, file has %lld", (long long)cap, mm);
+    if (!u || !v) PN_FAIL(PN_ERR_ARG, "pn_pairs_read_text: null output with cap > 0");
+    for (long long i = 0; i < mm; i++) {
+        long a = std::strtol(s, &end, 10);
+        if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: pair %lld truncated", path, i);
+        s = end;
+        long b = std::strtol(s, &end, 10);
+        if (end == s) PN_FAIL(PN_ERR_FORMAT, "%s: pair %lld truncated", path, i);
+        s = end;
+        u[i] = (int32_t)a;
+        v[i] = (int32_t)b;
+    }
+    return PN_OK;
+}
+
+int pn_uniform_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int64_t *off, int32_t *packed,
+                     int32_t *src, int32_t *nbr, int64_t cap, int64_t *total) {
+    if (n < 0 || m < 0 || (m > 0 && (!u || !v)) || !total) PN_FAIL(PN_ERR_ARG, "pn_uniform_build: bad argument");
+    std::vector<int64_t> at((size_t)n + 1, 0);
+    for (int32_t i = 0; i < n; i++) at[i] = 1;                       // link(i, i), gen.cpp:83-84
+    for (int64_t i = 0; i < m; i++) {
+        if (u[i] < 0 || u[i] >= n || v[i] < 0 || v[i] >= n)
+            PN_FAIL(PN_ERR_FORMAT, "pair %lld (%d, %d) outside [0, %d)", (long long)i, u[i], v[i], n);
+        if (u[i] == v[i]) continue;                                  // :90-91
+        at[u[i]]++;
+        at[v[i]]++;
+    }
+    int64_t sum = 0;
+    for (int32_t i = 0; i < n; i++) sum += at[i];
+    *total = sum;
+    if (cap == 0) return PN_OK;
+    if (cap < sum) PN_FAIL(PN_ERR_CAPACITY, "neighbour buffers hold %lld entries, graph has %lld", (long long)cap,
+                           (long long)sum);
+    if (!off || !packed) PN_FAIL(PN_ERR_ARG, "pn_uniform_build: null output with cap > 0");
+    int64_t run = 0;
+    for (int32_t i = 0; i < n; i++) {
+        off[i] = run;
+        run += at[i];
+        at[i] = off[i];
+    }
+    off[n] = run;
+    auto put = [&](int32_t a, int32_t b) {
+        const int64_t k = at[a]++;
+        packed[4 * k] = b;
+        packed[4 * k + 1] = b;
+        packed[4 * k + 2] = 0;
+        packed[4 * k + 3] = 0;
+        if (src) src[k] = a;
+        if (nbr) nbr[k] = b;
+    };
+    for (int32_t i = 0; i < n; i++) put(i, i);
+    for (int64_t i = 0; i < m; i++) {
+        if (u[i] == v[i]) continue;
+        put(u[i], v[i]);                                             // link(u, v); link(v, u), :92-93
+        put(v[i], u[i]);
+    }
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // alias tables
 // ------------------------------------------------------------------------------------------------
 // smallest draw r in [0, 2^31) with (1.0 * r / RAND_MAX) > s, or 2^31 if there is none.  The quotient

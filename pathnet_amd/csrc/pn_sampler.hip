@@ -98,9 +98,27 @@ struct WalkParams {
     int32_t node_begin, node_count;
     int32_t *ids;
     uint8_t *codes;
-    const int32_t *draws;  // GLIBC only: [epoch_count][node_count*W*2L]
+    const int32_t *draws;  // GLIBC only: [epoch_count][node_count*W*dps*L]
     int32_t *status;
+    int32_t dps;           // draws per step: 2 = alias roll (gen_merw.cpp:81-91), 1 = uniform rand() % deg (gen.cpp:113-114)
 };
+
+// The draws of step t of a walk.  Alias roll: draws 2t, 2t+1 of the walk's stream; uniform: draw t.  Philox words
+// come four at a time: draw q is word q & 3 of block q >> 2.
+template <int DRAW>
+__device__ __forceinline__ void step_draws(const int dps, const int32_t *my_draws, rocrand_state_philox4x32_10 &rng,
+                                           uint4 &word, int32_t t, uint32_t &r0, uint32_t &r1) {
+    if (DRAW == PN_DRAW_GLIBC_REPLAY) {
+        r0 = (uint32_t)my_draws[dps * t];
+        r1 = dps == 1 ? 0u : (uint32_t)my_draws[2 * t + 1];
+    } else {
+        const int q0 = dps * t;                                   // index of the step's first draw in the walk's stream
+        if ((q0 & 3) == 0) word = rocrand4(&rng);                 // (one call site: a new block of four words)
+        const int k = q0 & 3;                                     // alias roll: k is 0 or 2
+        r0 = (k == 0 ? word.x : k == 1 ? word.y : k == 2 ? word.z : word.w) >> 1;
+        r1 = dps == 1 ? 0u : (k == 0 ? word.y : word.w) >> 1;
+    }
+}
 
 template <int DRAW>
 __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
@@ -138,7 +156,7 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     rocrand_state_philox4x32_10 rng;
     uint4 word = {0, 0, 0, 0};
     if (DRAW == PN_DRAW_PHILOX) rocrand_init(p.seed, walk, 0, &rng);
-    const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * 2 * (int64_t)p.L : nullptr;
+    const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * p.dps * (int64_t)p.L : nullptr;
 
     const uint8_t *dis_row = p.dis + (size_t)st * (size_t)p.n;
     int32_t *out_ids = p.ids + g * p.L;
@@ -150,14 +168,7 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
         const int64_t o0 = p.off[x];
         const int32_t len = (int32_t)(p.off[x + 1] - o0);
         uint32_t r0, r1;
-        if (DRAW == PN_DRAW_GLIBC_REPLAY) {
-            r0 = (uint32_t)my_draws[2 * t];
-            r1 = (uint32_t)my_draws[2 * t + 1];
-        } else {
-            if ((t & 1) == 0) word = rocrand4(&rng);   // draws 2t, 2t+1 = words (2t)&3, (2t+1)&3 of block t>>1
-            r0 = ((t & 1) ? word.z : word.x) >> 1;
-            r1 = ((t & 1) ? word.w : word.y) >> 1;
-        }
+        step_draws<DRAW>(p.dps, my_draws, rng, word, t, r0, r1);
         if (len <= 0) {
             if (p.status) atomicExch(p.status, PN_ERR_EMPTY_TABLE);
             for (int32_t k = t + 1; k < p.L; k++) {
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
             rocrand_state_philox4x32_10 rng;
             uint4 word = {0, 0, 0, 0};
             if (DRAW == PN_DRAW_PHILOX) rocrand_init(p.seed, walk, 0, &rng);
-            const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * 2 * (int64_t)p.L : nullptr;
+            const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * p.dps * (int64_t)p.L : nullptr;
             int32_t *out_ids = p.ids + g * p.L;
             uint8_t *out_codes = p.codes + g * p.L;
             int32_t x = st;
@@ -329,14 +340,7 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
                 const int64_t o0 = p.off[x];
                 const int32_t len = (int32_t)(p.off[x + 1] - o0);
                 uint32_t r0, r1;
-                if (DRAW == PN_DRAW_GLIBC_REPLAY) {
-                    r0 = (uint32_t)my_draws[2 * t];
-                    r1 = (uint32_t)my_draws[2 * t + 1];
-                } else {
-                    if ((t & 1) == 0) word = rocrand4(&rng);
-                    r0 = ((t & 1) ? word.z : word.x) >> 1;
-                    r1 = ((t & 1) ? word.w : word.y) >> 1;
-                }
+                step_draws<DRAW>(p.dps, my_draws, rng, word, t, r0, r1);
                 if (len <= 0) {
                     if (p.status) atomicExch(p.status, PN_ERR_EMPTY_TABLE);
                     for (int32_t k = t + 1; k < p.L; k++) {
@@ -481,6 +485,10 @@ int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t d
     wp.ids = ids;
     wp.codes = codes;
     wp.status = status_flag;
+    const int dps = tb->draws_per_step == 1 ? 1 : 2;
+    if (tb->draws_per_step != 0 && tb->draws_per_step != 1 && tb->draws_per_step != 2)
+        PN_FAIL(PN_ERR_ARG, "pn_sample_paths: draws_per_step = %d (0, 1 or 2)", tb->draws_per_step);
+    wp.dps = dps;
 
     if (draw_source == PN_DRAW_GLIBC_REPLAY) {
         int64_t need = 0;
@@ -488,12 +496,12 @@ int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t d
         if (!workspace || workspace_bytes < need)
             PN_FAIL(PN_ERR_CAPACITY, "sampler workspace holds %lld bytes, need %lld", (long long)workspace_bytes,
                     (long long)need);
-        const int64_t seg_len = (int64_t)node_count * W * 2 * L;
+        const int64_t seg_len = (int64_t)node_count * W * dps * L;     // (the workspace is sized for dps = 2)
         const int64_t nblk = fill_blocks(seg_len);
         // host: one state per epoch of the window + the block / thread jump polynomials
         std::vector<uint32_t> host((size_t)(epoch_count + nblk + kFillThreads) * 31);
-        const uint64_t stride = 2ull * L * W * (uint64_t)tb->n;            // draws per epoch
-        const uint64_t first = stride * (uint64_t)epoch_begin + 2ull * L * W * (uint64_t)node_begin;
+        const uint64_t stride = (uint64_t)dps * L * W * (uint64_t)tb->n;   // draws per epoch
+        const uint64_t first = stride * (uint64_t)epoch_begin + (uint64_t)dps * L * W * (uint64_t)node_begin;
         pn::GlibcState base = pn::glibc_seed_state((uint32_t)seed);
         pn::GlibcPoly pos = pn::glibc_poly_xpow(first);
         const pn::GlibcPoly step = pn::glibc_poly_xpow(stride);

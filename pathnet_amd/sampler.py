@@ -35,6 +35,39 @@ def read_edge_file(path):
     return n.value, u, v, p
 
 
+def read_pair_file(path):
+    """-> (n, u int32[m], v int32[m]) in file order: the uniform sampler's 2-column input (gen.cpp:80-92)."""
+    lib = _lib.load()
+    n, m = ctypes.c_int32(0), ctypes.c_int64(0)
+    _lib.check(lib.pn_pairs_read_text(str(path).encode(), ctypes.byref(n), ctypes.byref(m), None, None, 0))
+    u = np.empty(m.value, np.int32)
+    v = np.empty(m.value, np.int32)
+    if m.value:
+        _lib.check(lib.pn_pairs_read_text(str(path).encode(), ctypes.byref(n), ctypes.byref(m),
+                                          _lib.np_ptr(u, ctypes.c_int32), _lib.np_ptr(v, ctypes.c_int32), m.value))
+    return n.value, u, v
+
+
+def build_uniform(n, u, v):
+    """The graph gen.cpp:83-94 walks on -> off[int64 n+1], packed int32 [total*4] walker table, and the same graph as
+    a directed edge list (src, nbr) for the hop table / CSR builders."""
+    lib = _lib.load()
+    u = np.ascontiguousarray(u, np.int32)
+    v = np.ascontiguousarray(v, np.int32)
+    total = ctypes.c_int64(0)
+    args = (n, len(u), _lib.np_ptr(u, ctypes.c_int32), _lib.np_ptr(v, ctypes.c_int32))
+    _lib.check(lib.pn_uniform_build(*args, None, None, None, None, 0, ctypes.byref(total)))
+    t = max(total.value, 1)
+    off = np.zeros(n + 1, np.int64)
+    packed = np.zeros(t * 4, np.int32)
+    src, nbr = np.zeros(t, np.int32), np.zeros(t, np.int32)
+    _lib.check(lib.pn_uniform_build(*args, _lib.np_ptr(off, ctypes.c_int64), _lib.np_ptr(packed, ctypes.c_int32),
+                                    _lib.np_ptr(src, ctypes.c_int32), _lib.np_ptr(nbr, ctypes.c_int32), total.value,
+                                    ctypes.byref(total)))
+    k = total.value
+    return off, packed, src[:k], nbr[:k]
+
+
 def build_alias(n, u, v, p):
     """AliasTable::init for every node (gen_merw.cpp:23-79) -> off[int64 n+1], A, B, S(float64), thr(uint32)."""
     lib = _lib.load()
@@ -92,16 +125,23 @@ class MerwSampler:
 
     DENSE_LIMIT_BYTES = 8 << 30     # hops="auto": dense n*n table up to 8 GB (n <= 92681), else on the fly
 
+    draws_per_step = 2              # the alias roll: slot draw + probability draw (gen_merw.cpp:81-91)
+
     def __init__(self, n, u, v, p, seq_len, device="cuda", hops="auto"):
         """hops: "dense" = the reference's dis[n][n] byte table in HBM; "otf" = exact hop codes derived on the
         fly from CSR lists (any n); "auto" picks dense while n*n <= DENSE_LIMIT_BYTES."""
-        self.n, self.L = int(n), int(seq_len)
-        self.device = torch.device(device)
         off, A, B, S, thr = build_alias(n, u, v, p)
         self.host = dict(off=off, A=A, B=B, S=S, thr=thr)
         packed = np.empty(max(len(A), 1) * 4, np.int32)
         _lib.check(_lib.load().pn_alias_pack(len(A), _lib.np_ptr(A, ctypes.c_int32), _lib.np_ptr(B, ctypes.c_int32),
                                              _lib.np_ptr(thr, ctypes.c_uint32), _lib.np_ptr(packed, ctypes.c_int32)))
+        self._upload(n, seq_len, device, hops, off, packed, len(A), u, v)
+
+    def _upload(self, n, seq_len, device, hops, off, packed, total, eu, ev):
+        """Device copies of the walker table (off, packed) and of the hop-code source built from the directed edge
+        list (eu -> ev): the dense table or the two CSR lists."""
+        self.n, self.L = int(n), int(seq_len)
+        self.device = torch.device(device)
         if hops == "auto":
             hops = "dense" if self.n * self.n <= self.DENSE_LIMIT_BYTES else "otf"
         if hops not in ("dense", "otf"):
@@ -111,15 +151,15 @@ class MerwSampler:
         self.d_triples = torch.from_numpy(packed).to(self.device)
         self.d_dis = self.d_adj_off = self.d_adj = self.d_radj_off = self.d_radj = None
         if hops == "dense":
-            self.d_dis = torch.from_numpy(hops_dense(n, u, v, seq_len)).to(self.device)
+            self.d_dis = torch.from_numpy(hops_dense(n, eu, ev, seq_len)).to(self.device)
         else:
             if seq_len > 8:
                 raise ValueError("on-the-fly hop codes support path lengths up to 8")
-            ao, aa = csr_build(n, u, v, reverse=False)
-            ro, ra = csr_build(n, u, v, reverse=True)
+            ao, aa = csr_build(n, eu, ev, reverse=False)
+            ro, ra = csr_build(n, eu, ev, reverse=True)
             self.d_adj_off, self.d_adj = torch.from_numpy(ao).to(self.device), torch.from_numpy(aa).to(self.device)
             self.d_radj_off, self.d_radj = torch.from_numpy(ro).to(self.device), torch.from_numpy(ra).to(self.device)
-        self.total = len(A)
+        self.total = int(total)
         self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._ws = None
 
@@ -146,7 +186,8 @@ class MerwSampler:
             self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         dp = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
         tb = _lib.SamplerTables(self.n, self.total, self.d_off.data_ptr(), self.d_triples.data_ptr(), dp(self.d_dis),
-                                dp(self.d_adj_off), dp(self.d_adj), dp(self.d_radj_off), dp(self.d_radj))
+                                dp(self.d_adj_off), dp(self.d_adj), dp(self.d_radj_off), dp(self.d_radj),
+                                self.draws_per_step)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if check:
             self._status.zero_()
@@ -160,17 +201,38 @@ class MerwSampler:
         return ids, codes
 
 
+class UniformSampler(MerwSampler):
+    """The uniform random-walk sampler of the "RW-PathNet" ablation (preprocess/gen.cpp, gen_epoch.cpp): same walker
+    and hop codes, but the graph is the symmetrised pair list with self loops (gen.cpp:83-94) and a step is ONE draw,
+    ``E[u][rand() % deg]`` (gen.cpp:113-114).  ``sample()`` is MerwSampler's; glibc-replay draws are bit-exact to the
+    reference binary."""
+
+    draws_per_step = 1
+
+    def __init__(self, n, u, v, seq_len, device="cuda", hops="auto"):
+        off, packed, src, nbr = build_uniform(n, u, v)
+        self.host = dict(off=off, nbr=nbr)
+        self._upload(n, seq_len, device, hops, off, packed, len(nbr), src, nbr)
+
+    @classmethod
+    def from_pair_file(cls, path, seq_len, device="cuda", hops="auto"):
+        n, u, v = read_pair_file(path)
+        return cls(n, u, v, seq_len, device=device, hops=hops)
+
+
 def main(argv=None):
-    """Drop-in for ./gen_merw and ./gen_epoch_merw (argv: <data_name> <path_num> <path_length>)."""
+    """Drop-in for ./gen_merw and ./gen_epoch_merw (argv: <data_name> <path_num> <path_length>); with --uniform for
+    ./gen and ./gen_epoch (the uniform random-walk sampler)."""
     argv = list(sys.argv[1:] if argv is None else argv)
     per_epoch = "--per-epoch" in argv
+    uniform = "--uniform" in argv        # gen.cpp / gen_epoch.cpp instead of gen_merw.cpp / gen_epoch_merw.cpp
     binary = "--binary" in argv          # also write the PNPATHS1 sidecar(s) next to the text file(s)
     opts = {"--seed": None, "--epochs": "1000", "--draw": "glibc", "--in": None, "--out-root": "./"}
     pos = []
     i = 0
     while i < len(argv):
         a = argv[i]
-        if a in ("--per-epoch", "--binary"):
+        if a in ("--per-epoch", "--binary", "--uniform"):
             i += 1
         elif a in opts:
             opts[a] = argv[i + 1]
@@ -182,14 +244,29 @@ def main(argv=None):
         print("ERROR: Incorrect number of parameters. ", file=sys.stderr)   # gen_merw.cpp:128-132
         return 0
     name, W, L = pos[0], int(pos[1]), int(pos[2])
-    edge = opts["--in"] or "../edge_input/%s.in" % name
     seed = int(opts["--seed"]) if opts["--seed"] is not None else int(time.time())  # srand(time(0)), :161
     epochs = int(opts["--epochs"])
     draw = DRAW_GLIBC_REPLAY if opts["--draw"] == "glibc" else DRAW_PHILOX
-    smp = MerwSampler.from_edge_file(edge, L)
-    print(name + ": " + str(smp.n), file=sys.stderr)                        # :164
     root = opts["--out-root"]
-    whole = pathfile.whole_run_name(root, name, W, L)
+    if uniform:
+        # gen.cpp:50-68 reads <name>_nsl.in and writes <name>_<W>_<L>_nsl.txt; gen_epoch.cpp:50-56,:84-95 reads <name>.in
+        # and writes <name>_<W>_<L>_<epoch>.txt
+        edge = opts["--in"] or ("../edge_input/%s.in" % name if per_epoch else "../edge_input/%s_nsl.in" % name)
+        whole = pathfile.whole_run_name(root, name, W, L, marker="nsl")
+        if not per_epoch:
+            print("File input: " + edge)                                     # gen.cpp:73-74
+            print("File output: " + whole)
+        n_, u_, v_ = read_pair_file(edge)
+        smp = UniformSampler(n_, u_, v_, L)
+        if per_epoch:
+            print("%d %d" % (smp.n, len(u_)))                                # gen_epoch.cpp:64
+        else:
+            print(smp.n, file=sys.stderr)                                    # gen.cpp:81
+    else:
+        edge = opts["--in"] or "../edge_input/%s.in" % name
+        smp = MerwSampler.from_edge_file(edge, L)
+        print(name + ": " + str(smp.n), file=sys.stderr)                    # :164
+        whole = pathfile.whole_run_name(root, name, W, L)
     chunk = max(1, min(epochs, (64 << 20) // max(1, smp.n * W * L * 5)))
     for e0 in range(0, epochs, chunk):
         ec = min(chunk, epochs - e0)
@@ -203,7 +280,8 @@ def main(argv=None):
         ids, codes = ids.cpu().numpy(), codes.cpu().numpy()
         for k in range(ec):
             if per_epoch:
-                fn = pathfile.per_epoch_name(root, name, W, L, e0 + k)
+                fn = ("%s%s_%d_%d_%d.txt" % (root, name, W, L, e0 + k) if uniform       # gen_epoch.cpp:84-95: no marker
+                      else pathfile.per_epoch_name(root, name, W, L, e0 + k))
                 pathfile.write_paths(fn, ids[k], codes[k])
                 if binary:
                     pathfile.write_paths_binary(fn[:-4] + ".bin", ids[k], codes[k])

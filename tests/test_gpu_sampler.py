@@ -237,3 +237,79 @@ def test_cli_empty_table_behaves_like_the_reference(tmp_path):
                        cwd=os.path.join(tmp_path, "preprocess"), env=dict(os.environ, PYTHONPATH=ROOT),
                        capture_output=True, text=True)
     assert r.returncode == 0 and "A.size() == 0 in Alias Table" in r.stderr
+
+
+# ---- the uniform random-walk sampler (gen.cpp / gen_epoch.cpp), SURVEY.md §8 f-4 ---------------------------------
+def make_uniform(g, L=None, hops="auto"):
+    from pathnet_amd import UniformSampler
+    return UniformSampler(int(g["n"]), g["u"], g["v"], int(g["L"]) if L is None else L, hops=hops)
+
+
+@pytest.mark.parametrize("name", golden_files("uniform_*.npz"))
+@pytest.mark.parametrize("hops", ["dense", "otf"])
+def test_uniform_glibc_replay_bit_exact_vs_reference_golden(name, hops):
+    from pathnet_amd import DRAW_GLIBC_REPLAY
+    g = golden(name)
+    smp = make_uniform(g, hops=hops)
+    ids, codes = smp.sample(int(g["W"]), int(g["seed"]), epoch_count=int(g["epochs"]), draw_source=DRAW_GLIBC_REPLAY)
+    ids, codes = ids.cpu().numpy(), codes.cpu().numpy()
+    bad = np.argwhere(ids != g["ids"])
+    assert bad.size == 0, "first mismatch at %s: got %s want %s" % (bad[0], ids[tuple(bad[0])], g["ids"][tuple(bad[0])])
+    assert (codes == g["codes"]).all()
+
+
+def test_uniform_windows_and_deep_stream_match_oracle():
+    from pathnet_amd import DRAW_GLIBC_REPLAY
+    g = golden("uniform_g300_40_4.npz")
+    n, W, L, seed = int(g["n"]), int(g["W"]), int(g["L"]), int(g["seed"])
+    smp = make_uniform(g)
+    ids, codes = smp.sample(W, seed, epoch_begin=1, epoch_count=1, node_begin=40, node_count=111,
+                            draw_source=DRAW_GLIBC_REPLAY)
+    assert (ids.cpu().numpy() == g["ids"][1:2, 40:151]).all() and (codes.cpu().numpy() == g["codes"][1:2, 40:151]).all()
+    ids, codes = smp.sample(W, 7, epoch_begin=998, epoch_count=2, draw_source=DRAW_GLIBC_REPLAY)
+    oi, oc = merw.sample_uniform(n, g["u"], g["v"], W, L, merw.DRAW_GLIBC, 7, epoch_begin=998, epoch_count=2)
+    assert (ids.cpu().numpy() == oi).all() and (codes.cpu().numpy() == oc).all()
+
+
+def test_uniform_philox_bit_exact_vs_oracle():
+    from pathnet_amd import DRAW_PHILOX
+    g = golden("uniform_g120_7_6.npz")
+    n, W, L = int(g["n"]), int(g["W"]), int(g["L"])
+    smp = make_uniform(g)
+    ids, codes = smp.sample(W, 0xC0FFEE, epoch_begin=3, epoch_count=2, draw_source=DRAW_PHILOX)
+    oi, oc = merw.sample_uniform(n, g["u"], g["v"], W, L, merw.DRAW_PHILOX, 0xC0FFEE, epoch_begin=3, epoch_count=2)
+    assert (ids.cpu().numpy() == oi).all() and (codes.cpu().numpy() == oc).all()
+    # one draw per step: every step lands on a neighbour (or the self loop) of the previous node
+    off, nbr = merw.uniform_build(n, g["u"], g["v"])
+    a = ids.cpu().numpy().reshape(-1, L)
+    for row in a[:500]:
+        for t in range(L - 1):
+            assert row[t + 1] in nbr[off[row[t]]:off[row[t] + 1]]
+
+
+def test_uniform_cli_output_is_byte_identical_to_reference_program(tmp_path):
+    """python -m pathnet_amd.sampler <name> <W> <L> --uniform  vs  ./gen <name> <W> <L> (same srand seed)."""
+    g = golden("uniform_ring37_5_4.npz")
+    n, W, L, seed, epochs = int(g["n"]), 6, 5, 4242, 4
+    os.makedirs(os.path.join(tmp_path, "preprocess"))
+    os.makedirs(os.path.join(tmp_path, "edge_input"))
+    pair = os.path.join(tmp_path, "edge_input", "syn_nsl.in")
+    merw.write_pair_file(pair, n, g["u"], g["v"])
+    cwd = os.path.join(tmp_path, "preprocess")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "pathnet_amd.sampler", "syn", str(W), str(L), "--uniform", "--seed",
+                        str(seed), "--epochs", str(epochs)], cwd=cwd, env=env, check=True, capture_output=True, text=True)
+    assert "File input: ../edge_input/syn_nsl.in" in r.stdout and "File output: ./syn_%d_%d_nsl.txt" % (W, L) in r.stdout
+    mine = open(os.path.join(cwd, "syn_%d_%d_nsl.txt" % (W, L)), "rb").read()
+    want = merw.format_text(*merw.sample_uniform(n, g["u"], g["v"], W, L, merw.DRAW_GLIBC, seed, epoch_count=epochs))
+    assert mine == want
+    if os.path.exists(merw.REF_GEN):
+        assert merw.run_ref_uniform(pair, W, L, seed, max_bytes=len(mine)) == mine
+    # gen_epoch.cpp: reads <name>.in, one file per epoch without a marker, prints "n m"
+    merw.write_pair_file(os.path.join(tmp_path, "edge_input", "syn.in"), n, g["u"], g["v"])
+    r = subprocess.run([sys.executable, "-m", "pathnet_amd.sampler", "syn", str(W), str(L), "--uniform", "--per-epoch",
+                        "--seed", str(seed), "--epochs", "3"], cwd=cwd, env=env, check=True, capture_output=True,
+                       text=True)
+    assert r.stdout.split() == [str(n), str(len(g["u"]))]
+    cat = b"".join(open(os.path.join(cwd, "syn_%d_%d_%d.txt" % (W, L, e)), "rb").read() for e in range(3))
+    assert cat == want[:len(cat)]
