@@ -251,6 +251,18 @@ int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_
 int pn_linear_backward(const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
                        int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream);
 
+/* ---- the MERW transition probabilities: what writes edge_input/<name>.in ----------------------
+ * preprocess/compute_merw.py:107-121 compute_merw(A), as init_rw.py:76 calls it: (lambda, psi) = dominant eigenpair of
+ * the symmetric adjacency matrix, p[k] = A[i,j] psi[j] / (lambda psi[i]) for every stored entry k = (i, j).
+ * A is CSR on the device (row_off [n+1], col [nnz], val [nnz] or NULL for all ones).  Power iteration on A + I in fp64,
+ * deterministic; converged when |A x - lambda x| <= tol (lambda + 1) (tol <= 0: 1e-13; max_iter < 1: 100000).
+ * Outputs: p dev [nnz], psi dev [n] (unit 2-norm, positive), *lambda and *iters on the host.  Fails with the residual in
+ * pn_last_error() when it does not converge (disconnected graph: the reference's own output is noise there). */
+int pn_merw_workspace_bytes(int32_t n, int64_t *bytes);
+int pn_merw_probabilities(int32_t n, int64_t nnz, const int64_t *row_off, const int32_t *col, const double *val,
+                          double *p, double *psi, double *lambda, int32_t max_iter, double tol, int32_t *iters,
+                          void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- training-step glue: the loss and the optimizer of PathNet_run.py:295-297, :346-352 ------
  * Mean softmax cross entropy over `rows` rows of `classes` logits (torch.nn.CrossEntropyLoss(), :297; int64 class
  * targets, no ignore_index / label smoothing -- the reference uses neither): *loss (device float) receives the mean,

@@ -102,6 +102,9 @@ SIGNATURES = {
     "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp,
                                           vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
+    "pn_merw_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, c_i64p]),
+    "pn_merw_probabilities": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, vp, vp, vp, vp, vp, c_f64p, ctypes.c_int32,
+                                             ctypes.c_double, c_i32p, vp, ctypes.c_int64, vp]),
     "pn_cross_entropy": (ctypes.c_int, [vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]),
     "pn_adam_step": (ctypes.c_int, [ctypes.POINTER(AdamTensor), ctypes.c_int32, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int64, vp]),

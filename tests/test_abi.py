@@ -127,7 +127,7 @@ def test_no_kernel_spills_registers():
     not spill between the load and its wait (cdna_hip_programming.md §5.7): require zero scratch in every kernel."""
     import subprocess
     src = os.path.join(ROOT, "pathnet_amd", "csrc")
-    for f in ("pn_pagg.hip", "pn_sampler.hip", "pn_train.hip"):
+    for f in ("pn_pagg.hip", "pn_sampler.hip", "pn_train.hip", "pn_merw.hip"):
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                             "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(src, f), "-o", "/dev/null"],
                            capture_output=True, text=True)
