@@ -72,8 +72,15 @@ __device__ long long *g_trace_buf = nullptr;   // [blocks][64] stamps, set with 
         if (g_trace_buf && threadIdx.x == 0 && (slot) < 64)                             \
             g_trace_buf[(size_t)blockIdx.x * 64 + (slot)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
+// the same for kernels whose workgroups are not indexed by blockIdx.x alone (tools/trace_wgrad.py)
+#define PN_STAMP_W(blk, slot)                                                            \
+    do {                                                                                \
+        if (g_trace_buf && threadIdx.x == 0 && (slot) < 64 && (slot) >= 0)              \
+            g_trace_buf[(size_t)(blk) * 64 + (slot)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define PN_STAMP(slot) do { } while (0)
+#define PN_STAMP_W(blk, slot) do { } while (0)
 #endif
 
 namespace {
@@ -1277,8 +1284,12 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
     const int sa = (li & 3) * 68 + (li >> 2) + wm * 16, sb = (li & 3) * 68 + (li >> 2) + wn * 32;
 
     issue(rbeg);
-    for (int64_t k0 = rbeg; k0 < rend; k0 += kstep) {
+    [[maybe_unused]] int tile_i = 0;     // (tuning builds stamp tiles 8..19, five stamps per tile)
+    [[maybe_unused]] const int wblk = blockIdx.z * gridDim.y + blockIdx.y;
+    for (int64_t k0 = rbeg; k0 < rend; k0 += kstep, tile_i++) {
+        PN_STAMP_W(wblk, (tile_i - 8) * 5 + 0);
         wait_vm<0>(rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], rg[6], rg[7]);
+        PN_STAMP_W(wblk, (tile_i - 8) * 5 + 1);
 #pragma unroll
         for (int e = 0; e < 8; e++)
             if (!(c_ok && k0 + 8 * ro + e < rend)) rg[e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1296,7 +1307,9 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
             stage[W3_PLANE + j * 68] = q1;
             stage[2 * W3_PLANE + j * 68] = q2;
         }
+        PN_STAMP_W(wblk, (tile_i - 8) * 5 + 2);
         __syncthreads();
+        PN_STAMP_W(wblk, (tile_i - 8) * 5 + 3);
         issue(min(k0 + kstep, rend - 1));   // next tile in flight under the MFMAs (last trip: harmless re-load)
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
@@ -1342,6 +1355,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
         }
+        PN_STAMP_W(wblk, (tile_i - 8) * 5 + 4);
         __syncthreads();
     }
     wait_vm<0>(rg[0], rg[1], rg[2], rg[3], rg[4], rg[5], rg[6], rg[7]);   // drain the trailing prefetch
