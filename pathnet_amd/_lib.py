@@ -126,7 +126,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if lib.pn_abi_version() != 1:
+        if lib.pn_abi_version() != 2:
             raise ImportError("libpathnet_hip.so ABI version mismatch")
         _lib = lib
     return _lib
