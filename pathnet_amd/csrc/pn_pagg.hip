@@ -697,6 +697,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
     float *sc = lds + wave * p.W;
     const int H = p.H;
     const float inv_w = 1.0f / (float)p.W;
+    // the ego rows of the group's members, fetched up front: the score loop then has no index -> row dependent load pair
+    int *s_erow = reinterpret_cast<int *>(lds + 4 * p.W) + wave * p.W;
+    if (p.variant != PN_VARIANT_PAGG) {
+        for (int mem = lane; mem < p.W; mem += 64) s_erow[mem] = p.egoidx[(int64_t)g * p.W + mem];
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
 
     if (p.variant != PN_VARIANT_PAGG) {
         // attention scores, 8 members at a time: lane = (member lane>>3, eighth of H lane&7); the eight partial
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
             const int memc = min(mem, p.W - 1);
             const int64_t s = (int64_t)g * p.W + memc;
             const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + s * H + part * jw);
-            const float4 *e4 = reinterpret_cast<const float4 *>(p.ego_tab + (int64_t)p.egoidx[s] * H + part * jw);
+            const float4 *e4 = reinterpret_cast<const float4 *>(p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
             const float4 *a4 = reinterpret_cast<const float4 *>(p.att_w + part * jw);
             const float4 *b4 = reinterpret_cast<const float4 *>(p.att_w + H + part * jw);
             float acc = 0.0f;
@@ -814,11 +821,20 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
     float *dsc = dco + W;
     float *dp = dsc + W;
     float *red = lds + 4 * (2 * W + H);      // [4][2H] per-wave attention-weight partials
+    int *s_erow = reinterpret_cast<int *>(lds + 4 * (2 * W + H) + 8 * H) + wave * W;   // [4][W] ego rows of the group
+    float *s_coef = lds + 4 * (2 * W + H) + 8 * H + 4 * W + wave * W;                  // [4][W]
     const int g = blockIdx.x * 4 + wave;
     const bool active = g < p.S;
     const float inv_w = 1.0f / (float)W;
     float gaw_h[4] = {0.f, 0.f, 0.f, 0.f}, gaw_e[4] = {0.f, 0.f, 0.f, 0.f}, gab = 0.0f;
 
+    if (active) {
+        for (int mem = lane; mem < W; mem += 64) {
+            const int64_t s = (int64_t)g * W + mem;
+            s_erow[mem] = p.variant == PN_VARIANT_PAGG ? 0 : p.egoidx[s];
+            s_coef[mem] = p.coef[s];
+        }
+    }
     if (active) {
         for (int j = lane; j < H; j += 64) {
             float a = 0.0f, b = 0.0f;
@@ -885,8 +901,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 #pragma unroll 4
         for (int mem = 0; mem < W; mem++) {
             const int64_t s = (int64_t)g * W + mem;
-            const float ds = dsc[mem], cf = p.coef[s];
-            const int64_t erow = p.variant == PN_VARIANT_PAGG ? 0 : (int64_t)p.egoidx[s] * H;
+            const float ds = dsc[mem], cf = s_coef[mem];
+            const int64_t erow = (int64_t)s_erow[mem] * H;
             if (p.variant != PN_VARIANT_PAGG && erow != cur_row) {   // wave-uniform
                 flush();
                 cur_row = erow;
@@ -1750,7 +1766,7 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     pp.out = a->out;
     {
         StageTimer tm(ST_POOL_FWD, stream);
-        hipLaunchKernelGGL(pool_fwd_kernel, dim3((s.S + 3) / 4), dim3(256), (size_t)4 * s.W * sizeof(float), stream,
+        hipLaunchKernelGGL(pool_fwd_kernel, dim3((s.S + 3) / 4), dim3(256), (size_t)8 * s.W * sizeof(float), stream,
                            pp);
     }
     PN_CHECK_HIP(hipGetLastError());
@@ -1867,7 +1883,7 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         // attention gradients are optional outputs: fall back to scratch so the kernel needs no branches
         pp.g_att_w = a->g_att_w ? a->g_att_w : scratch;
         pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
-        const size_t lds_bytes = (size_t)(4 * (2 * s.W + H) + 8 * H) * sizeof(float);
+        const size_t lds_bytes = (size_t)(4 * (2 * s.W + H) + 8 * H + 8 * s.W) * sizeof(float);
         StageTimer tm(ST_POOL_BWD, stream);
         hipLaunchKernelGGL(pool_bwd_kernel, dim3((s.S + 3) / 4), dim3(256), lds_bytes, stream, pp);
         PN_CHECK_HIP(hipGetLastError());
