@@ -455,9 +455,11 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     const bool builtin_drop = !p.mask && p.p_drop > 0.0f;
     __syncthreads();
 
-    // ---- coalesced row gather of x_{t+1} (H*4 bytes per row), in flight while step t computes: the loads are asm
-    //      (hipcc would sink them to their use after the k loop), the dropout keep bits are drawn right behind them
-    //      -- under the latency of the first weight fragments -- and applied when the rows are committed to LDS.
+    // ---- coalesced row gather of x_{t+1} (H*4 bytes per row).  With PREFETCH_X (two workgroups per CU) the loads
+    //      are issued before step t's k loop and stay in flight under it -- asm loads, hipcc would sink ordinary
+    //      ones to their use -- with the dropout keep bits drawn right behind them; with three workgroups per CU the
+    //      rows are fetched in the cell-update phase instead (the other workgroups cover the latency).  Either
+    //      way the mask is applied when the rows are committed to LDS.
     constexpr int NLD = 4;        // float4 per thread = MT * (H/4) / NT
     f32x4 xr[NLD];
     uint32_t keepbits = 0;        // 4 bits per row of this thread
