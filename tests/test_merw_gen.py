@@ -78,3 +78,20 @@ def test_generated_edge_file_feeds_the_sampler(tmp_path):
     n2, u2, v2, p2 = merw.read_edge_file(f)
     oi, oc = merw.sample_full(n2, u2, v2, p2, 40, 4, merw.DRAW_PHILOX, 5, epoch_count=2)
     assert n2 == n and (ids.cpu().numpy() == oi).all() and (codes.cpu().numpy() == oc).all()
+
+
+def test_edge_file_writer_prints_what_the_reference_prints(tmp_path):
+    """init_rw.py:78-86: header "n 2M", per edge_index column the rows "u v P[u,v]" and "v u P[v,u]", floats as Python
+    prints numpy float64 (the writer is host code: no GPU needed)."""
+    from pathnet_amd import merw_init as mi
+    g = golden("merwgen_g60.npz")
+    n, ei = int(g["n"]), g["edge_index"]
+    P, _, _ = mg.merw_matrix(mg.adjacency_dense(n, ei))
+    f = os.path.join(tmp_path, "g60.in")
+    mi.write_edge_input(f, n, ei, P[ei[0], ei[1]], P[ei[1], ei[0]])
+    assert open(f).read() == mg.format_edge_file(n, *mg.edge_rows(n, ei, P))
+    # and it parses back through the sampler's own reader
+    from pathnet_amd import sampler
+    n2, u2, v2, p2 = sampler.read_edge_file(f)
+    ru, rv, rp = mg.edge_rows(n, ei, P)
+    assert n2 == n and (u2 == ru).all() and (v2 == rv).all() and (p2 == rp).all()
