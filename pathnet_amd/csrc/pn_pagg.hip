@@ -1553,6 +1553,10 @@ int check_shape(const pn_pagg_shape &s) {
         PN_FAIL(PN_ERR_ARG, "hidden size %d not supported (32, 64, 128, 256)", s.H);
     if (s.N < 1 || s.F < 1 || s.C < 1 || s.S < 0 || s.W < 1 || s.L < 1 || s.L > 64)
         PN_FAIL(PN_ERR_ARG, "bad aggregator shape N=%d F=%d C=%d S=%d W=%d L=%d", s.N, s.F, s.C, s.S, s.W, s.L);
+    // the pooling kernels keep per-walk scores, coefficients and ego rows of four nodes in LDS (64 W + 48 H bytes)
+    if (64 * (int64_t)s.W + 48 * s.H > 64 * 1024)
+        PN_FAIL(PN_ERR_ARG, "W=%d walks per node exceed the pooling kernels' LDS budget (W <= %d at H=%d)", s.W,
+                (64 * 1024 - 48 * s.H) / 64, s.H);
     if (s.variant == PN_VARIANT_PAGG && s.L != 4)
         PN_FAIL(PN_ERR_ARG, "PAGG has exactly four distance layers nei0..nei3 (copy.py:310-313); L=%d", s.L);
     if ((int64_t)s.S * s.W * s.L > 2000000000LL || (int64_t)s.N * s.L > 2000000000LL)

@@ -103,6 +103,9 @@ def test_workspace_query_and_shape_validation():
         modules.workspace_bytes("homo", 100, 16, 100, 3, 10, 40, 4)      # H not supported
     with pytest.raises(_lib.PnError):
         modules.workspace_bytes("pagg", 100, 16, 64, 3, 10, 40, 5)        # PAGG has 4 distance layers
+    assert modules.workspace_bytes("homo", 100, 16, 256, 3, 10, 832, 4) > 0
+    with pytest.raises(_lib.PnError, match="LDS budget"):
+        modules.workspace_bytes("homo", 100, 16, 256, 3, 10, 833, 4)      # pooling kernels' LDS
 
 
 def test_sampler_cli_wrong_argc(capsys):
