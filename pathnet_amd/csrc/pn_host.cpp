@@ -9,13 +9,21 @@
 //   preprocess/gen_merw.cpp:101-123          bfs() / dis[][]
 //   preprocess/gen_merw.cpp:189-206          text line format;  PathNet_run.py:418-423 reader
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "pn_internal.h"
 
@@ -423,6 +431,33 @@ int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int3
 // ------------------------------------------------------------------------------------------------
 // path file
 // ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+// Host threads for the text formatter / parser (PN_HOST_THREADS overrides; never more than one per `grain` items).
+static int host_threads(int64_t items, int64_t grain) {
+    const char *e = std::getenv("PN_HOST_THREADS");
+    const int env = e ? std::atoi(e) : 0;
+    int64_t t = env > 0 ? env : (int64_t)std::thread::hardware_concurrency();
+    t = std::max<int64_t>(1, std::min<int64_t>(t, 32));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(t, items / std::max<int64_t>(grain, 1)));
+}
+
+// fn(0..T-1) on T threads (the caller is thread 0); a thread that cannot be created runs inline.
+template <class F>
+static void run_threads(int T, F &&fn) {
+    std::vector<std::thread> pool;
+    pool.reserve(T > 1 ? T - 1 : 0);
+    for (int i = 1; i < T; i++) {
+        try {
+            pool.emplace_back([&fn, i] { fn(i); });
+        } catch (const std::system_error &) {
+            fn(i);
+        }
+    }
+    fn(0);
+    for (auto &th : pool) th.join();
+}
+
 static inline char *put_uint(char *w, uint32_t x) {
     char tmp[12];
     int k = 0;
@@ -434,60 +469,129 @@ static inline char *put_uint(char *w, uint32_t x) {
     return w;
 }
 
+// "[v0, ..., v_{L-1}, d0, ..., d_{L-1}]\n" for paths [p0, p1) -> w; returns the end of the text
+static char *format_paths(char *w, const int32_t *ids, const uint8_t *codes, int64_t p0, int64_t p1, int32_t L) {
+    for (int64_t q = p0; q < p1; q++) {
+        *w++ = '[';
+        for (int32_t t = 0; t < L; t++) {
+            int32_t id = ids[q * L + t];
+            if (id < 0) {
+                *w++ = '-';
+                w = put_uint(w, (uint32_t)(-(int64_t)id));
+            } else
+                w = put_uint(w, (uint32_t)id);
+            *w++ = ',';
+            *w++ = ' ';
+        }
+        for (int32_t t = 0; t < L; t++) {
+            w = put_uint(w, codes[q * L + t]);
+            if (t + 1 < L) {
+                *w++ = ',';
+                *w++ = ' ';
+            }
+        }
+        *w++ = ']';
+        *w++ = '\n';
+    }
+    return w;
+}
+
+static inline int digits10(uint32_t x) {
+    return x < 10 ? 1 : x < 100 ? 2 : x < 1000 ? 3 : x < 10000 ? 4 : x < 100000 ? 5 : x < 1000000 ? 6
+         : x < 10000000 ? 7 : x < 100000000 ? 8 : x < 1000000000 ? 9 : 10;
+}
+
+// exact size of format_paths' output for paths [p0, p1)
+static int64_t text_bytes(const int32_t *ids, const uint8_t *codes, int64_t p0, int64_t p1, int32_t L) {
+    int64_t n = (p1 - p0) * (int64_t)(1 + 2 * L + 2 * (L - 1) + 2);     // "[", ", " per id, ", " between codes, "]\n"
+    for (int64_t k = p0 * L; k < p1 * L; k++) {
+        const int32_t id = ids[k];
+        n += id < 0 ? 1 + digits10((uint32_t)(-(int64_t)id)) : digits10((uint32_t)id);
+        n += digits10(codes[k]);
+    }
+    return n;
+}
+
+static bool pwrite_all(int fd, const char *buf, size_t n, int64_t at) {
+    while (n) {
+        ssize_t k = ::pwrite(fd, buf, n, (off_t)at);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        buf += k;
+        at += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+
+extern "C" {
+
+// Every host thread owns one contiguous range of the paths: a first pass sizes the text of each range (digit
+// counting only), the prefix sum gives each range its file offset, the second pass formats the range block by block
+// and writes the blocks in place -- no serial section, two thread spawns per call.
 int pn_paths_write_text(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L,
                         int32_t append) {
     if (!path || npaths < 0 || L < 1 || (npaths > 0 && (!ids || !codes)))
         PN_FAIL(PN_ERR_ARG, "pn_paths_write_text: bad argument");
-    FILE *f = std::fopen(path, append ? "ab" : "wb");
-    if (!f) PN_FAIL(PN_ERR_IO, "cannot open %s for writing: %s", path, std::strerror(errno));
-    const size_t line_max = (size_t)L * (12 + 5) + 4;
-    const int64_t chunk = 1 << 16;
-    std::vector<char> buf(line_max * (size_t)chunk);
-    for (int64_t p0 = 0; p0 < npaths; p0 += chunk) {
-        int64_t p1 = std::min(npaths, p0 + chunk);
-        char *w = buf.data();
-        for (int64_t q = p0; q < p1; q++) {
-            *w++ = '[';
-            for (int32_t t = 0; t < L; t++) {
-                int32_t id = ids[q * L + t];
-                if (id < 0) {
-                    *w++ = '-';
-                    w = put_uint(w, (uint32_t)(-(int64_t)id));
-                } else
-                    w = put_uint(w, (uint32_t)id);
-                *w++ = ',';
-                *w++ = ' ';
-            }
-            for (int32_t t = 0; t < L; t++) {
-                w = put_uint(w, codes[q * L + t]);
-                if (t + 1 < L) {
-                    *w++ = ',';
-                    *w++ = ' ';
-                }
-            }
-            *w++ = ']';
-            *w++ = '\n';
-        }
-        size_t nbytes = (size_t)(w - buf.data());
-        if (std::fwrite(buf.data(), 1, nbytes, f) != nbytes) {
-            std::fclose(f);
-            PN_FAIL(PN_ERR_IO, "short write to %s", path);
+    const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666);
+    if (fd < 0) PN_FAIL(PN_ERR_IO, "cannot open %s for writing: %s", path, std::strerror(errno));
+    int64_t at = 0;
+    if (append) {
+        at = (int64_t)::lseek(fd, 0, SEEK_END);
+        if (at < 0) {
+            ::close(fd);
+            PN_FAIL(PN_ERR_IO, "cannot seek in %s: %s", path, std::strerror(errno));
         }
     }
-    if (std::fclose(f) != 0) PN_FAIL(PN_ERR_IO, "close failed on %s", path);
+    const int T = host_threads(npaths, 1 << 14);
+    std::vector<int64_t> lo((size_t)T + 1), off((size_t)T + 1, 0);
+    for (int i = 0; i <= T; i++) lo[i] = npaths / T * i + std::min<int64_t>(i, npaths % T);
+    if (T > 1) run_threads(T, [&](int i) { off[i + 1] = text_bytes(ids, codes, lo[i], lo[i + 1], L); });
+    off[0] = at;
+    for (int i = 0; i < T; i++) off[i + 1] += off[i];
+    std::atomic<int> failed_errno(0);
+    run_threads(T, [&](int i) {
+        const size_t line_max = (size_t)L * (12 + 5) + 4;
+        const int64_t block = 1 << 14;
+        std::vector<char> buf(line_max * (size_t)std::min<int64_t>(block, std::max<int64_t>(lo[i + 1] - lo[i], 1)));
+        int64_t cursor = off[i];
+        for (int64_t p0 = lo[i]; p0 < lo[i + 1] && !failed_errno; p0 += block) {
+            const size_t len = (size_t)(format_paths(buf.data(), ids, codes, p0, std::min(lo[i + 1], p0 + block), L) -
+                                        buf.data());
+            if (!pwrite_all(fd, buf.data(), len, cursor)) failed_errno = errno ? errno : EIO;
+            cursor += (int64_t)len;
+        }
+    });
+    if (::close(fd) != 0 && !failed_errno) failed_errno = errno ? errno : EIO;
+    if (failed_errno) PN_FAIL(PN_ERR_IO, "short write to %s: %s", path, std::strerror(failed_errno));
     return PN_OK;
 }
 
-int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) {
-    if (!path || L < 1 || !npaths) PN_FAIL(PN_ERR_ARG, "pn_paths_read_text: bad argument");
-    std::string txt;
-    if (!slurp(path, txt)) PN_FAIL(PN_ERR_IO, "cannot read path file %s: %s", path, std::strerror(errno));
-    const char *s = txt.data(), *e = s + txt.size();
-    int64_t count = 0;
+}  // extern "C"
+
+namespace {
+enum ParseErr { PE_NONE = 0, PE_START, PE_FIELD, PE_FEWER, PE_END };
+struct ParseResult {
+    int64_t lines = 0;     // complete lines parsed before the range ended or failed
+    ParseErr err = PE_NONE;
+    int field = 0;
+};
+
+// Parses whole lines from [s, e); line `line0 + k` of the range goes to slot line0 + k while that is below cap.
+ParseResult parse_lines(const char *s, const char *e, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap,
+                        int64_t line0) {
+    ParseResult r;
     while (s < e) {
         // the reader slices line[1:-2] (PathNet_run.py:327): first char '[' and the last two "]\n"
-        if (*s != '[') PN_FAIL(PN_ERR_FORMAT, "%s: line %lld does not start with '['", path, (long long)count);
+        if (*s != '[') {
+            r.err = PE_START;
+            return r;
+        }
         s++;
+        const int64_t slot = line0 + r.lines;
+        const bool keep = cap > 0 && slot < cap;
         for (int32_t k = 0; k < 2 * L; k++) {
             while (s < e && *s == ' ') s++;
             bool neg = false;
@@ -495,28 +599,125 @@ int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes
                 neg = true;
                 s++;
             }
-            if (s >= e || *s < '0' || *s > '9')
-                PN_FAIL(PN_ERR_FORMAT, "%s: line %lld field %d is not an integer", path, (long long)count, k);
+            if (s >= e || *s < '0' || *s > '9') {
+                r.err = PE_FIELD;
+                r.field = k;
+                return r;
+            }
             int64_t val = 0;
             while (s < e && *s >= '0' && *s <= '9') val = val * 10 + (*s++ - '0');
             if (neg) val = -val;
-            if (cap > 0 && count < cap) {
+            if (keep) {
                 if (k < L)
-                    ids[count * L + k] = (int32_t)val;
+                    ids[slot * L + k] = (int32_t)val;
                 else
-                    codes[count * L + (k - L)] = (uint8_t)val;
+                    codes[slot * L + (k - L)] = (uint8_t)val;
             }
             if (k + 1 < 2 * L) {
-                if (s >= e || *s != ',')
-                    PN_FAIL(PN_ERR_FORMAT, "%s: line %lld has fewer than %d fields", path, (long long)count, 2 * L);
+                if (s >= e || *s != ',') {
+                    r.err = PE_FEWER;
+                    return r;
+                }
                 s++;
             }
         }
-        if (s >= e || *s != ']' || s + 1 >= e || s[1] != '\n')
-            PN_FAIL(PN_ERR_FORMAT, "%s: line %lld does not end with \"]\\n\" after %d fields", path, (long long)count,
-                    2 * L);
+        if (s >= e || *s != ']' || s + 1 >= e || s[1] != '\n') {
+            r.err = PE_END;
+            return r;
+        }
         s += 2;
-        count++;
+        r.lines++;
+    }
+    return r;
+}
+
+// read-only view of a file through the page cache (no copy); an empty file maps to an empty view
+struct MappedFile {
+    const char *data = nullptr;
+    size_t size = 0;
+    bool open(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0) {
+            const int e = errno;
+            ::close(fd);
+            errno = e;
+            return false;
+        }
+        if (st.st_size > 0) {
+            void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                const int e = errno;
+                ::close(fd);
+                errno = e;
+                return false;
+            }
+            data = static_cast<const char *>(m);
+            size = (size_t)st.st_size;
+        }
+        ::close(fd);
+        return true;
+    }
+    ~MappedFile() {
+        if (data) ::munmap(const_cast<char *>(data), size);
+    }
+};
+
+int64_t count_newlines(const char *s, const char *e) {
+    int64_t n = 0;
+    while (s < e) {
+        const char *q = static_cast<const char *>(std::memchr(s, '\n', (size_t)(e - s)));
+        if (!q) break;
+        n++;
+        s = q + 1;
+    }
+    return n;
+}
+}  // namespace
+
+extern "C" {
+
+// The file is cut into one byte range per host thread at line ends; a first pass counts the lines of each range (so
+// that every range knows its first slot), the second parses the ranges concurrently.  A malformed line is reported
+// exactly as a sequential scan would: the first one in file order, by its line number.
+int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) {
+    if (!path || L < 1 || !npaths) PN_FAIL(PN_ERR_ARG, "pn_paths_read_text: bad argument");
+    if (cap > 0 && (!ids || !codes)) PN_FAIL(PN_ERR_ARG, "pn_paths_read_text: cap > 0 needs ids and codes");
+    MappedFile txt;
+    if (!txt.open(path)) PN_FAIL(PN_ERR_IO, "cannot read path file %s: %s", path, std::strerror(errno));
+    const char *s = txt.data, *e = s + txt.size;
+    const int T = host_threads((int64_t)txt.size, 1 << 20);
+    std::vector<const char *> cut((size_t)T + 1, e);
+    cut[0] = s;
+    for (int i = 1; i < T; i++) {
+        const char *c = std::max(cut[i - 1], s + txt.size / T * i);
+        const char *q = c < e ? static_cast<const char *>(std::memchr(c, '\n', (size_t)(e - c))) : nullptr;
+        cut[i] = q ? q + 1 : e;
+    }
+    std::vector<int64_t> first((size_t)T + 1, 0);
+    run_threads(T, [&](int i) { first[i + 1] = count_newlines(cut[i], cut[i + 1]); });
+    for (int i = 0; i < T; i++) first[i + 1] += first[i];
+    if (cap == 0 && (txt.size == 0 || e[-1] == '\n')) {
+        // sizing call on a file that ends in a line end: its lines are validated by the filling call
+        *npaths = first[T];
+        return PN_OK;
+    }
+    std::vector<ParseResult> res((size_t)T);
+    run_threads(T, [&](int i) { res[i] = parse_lines(cut[i], cut[i + 1], L, ids, codes, cap, first[i]); });
+    int64_t count = 0;
+    for (int i = 0; i < T; i++) {
+        // (a range without error holds exactly the lines its newline count promised, so `line` is the file's line number)
+        const long long line = (long long)(first[i] + res[i].lines);
+        switch (res[i].err) {
+            case PE_NONE: break;
+            case PE_START: PN_FAIL(PN_ERR_FORMAT, "%s: line %lld does not start with '['", path, line);
+            case PE_FIELD: PN_FAIL(PN_ERR_FORMAT, "%s: line %lld field %d is not an integer", path, line, res[i].field);
+            case PE_FEWER: PN_FAIL(PN_ERR_FORMAT, "%s: line %lld has fewer than %d fields", path, line, 2 * L);
+            case PE_END:
+                PN_FAIL(PN_ERR_FORMAT, "%s: line %lld does not end with \"]\\n\" after %d fields", path, line, 2 * L);
+        }
+        count += res[i].lines;
     }
     *npaths = count;
     if (cap > 0 && count > cap)

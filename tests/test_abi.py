@@ -86,6 +86,48 @@ def test_path_file_errors(tmp_path):
     assert pathfile.read_paths(f, 4)[0].shape == (0, 4)
 
 
+def test_path_file_threaded_equals_single_thread(tmp_path, monkeypatch):
+    """The text writer / reader split the work over host threads (ranges of paths / of file bytes): same bytes,
+    same arrays, same error line as one thread, including negative ids, ragged digit counts and append mode."""
+    rng = np.random.default_rng(5)
+    n, L = 150_001, 5
+    ids = rng.integers(-3, 10 ** rng.integers(1, 10, (n, 1)), (n, L)).astype(np.int32)
+    codes = rng.integers(0, 256, (n, L)).astype(np.uint8)
+    files = {}
+    for threads in ("1", "7"):
+        monkeypatch.setenv("PN_HOST_THREADS", threads)
+        f = os.path.join(tmp_path, "p%s.txt" % threads)
+        pathfile.write_paths(f, ids[:1000], codes[:1000])
+        pathfile.write_paths(f, ids[1000:], codes[1000:], append=True)
+        files[threads] = f
+    blob = open(files["1"], "rb").read()
+    assert blob == open(files["7"], "rb").read()
+    assert blob[:2000] == merw.format_text(ids[None, :1000], codes[None, :1000])[:2000]
+    for threads in ("1", "7"):
+        monkeypatch.setenv("PN_HOST_THREADS", threads)
+        i2, c2 = pathfile.read_paths(files["7"], L)
+        assert (i2 == ids).all() and (c2 == codes).all()
+    # a malformed line deep inside the file: first error in file order, numbered like a sequential scan
+    lines = blob.split(b"\n")
+    bad_at = 123_456
+    lines[bad_at] = lines[bad_at].replace(b", ", b"; ", 1)
+    lines[bad_at + 5000] = b"oops"
+    fbad = os.path.join(tmp_path, "bad.txt")
+    open(fbad, "wb").write(b"\n".join(lines))
+    msgs = []
+    for threads in ("1", "7"):
+        monkeypatch.setenv("PN_HOST_THREADS", threads)
+        with pytest.raises(_lib.PnError) as e:
+            pathfile.read_paths(fbad, L)
+        assert e.value.code == _lib.PN_ERR_FORMAT
+        msgs.append(str(e.value))
+    assert msgs[0] == msgs[1] and "line %d " % bad_at in msgs[0]
+    # no final line end: the reference reader's line[1:-2] slice would eat a digit; refused, with the line number
+    open(fbad, "wb").write(blob[:-1])
+    with pytest.raises(_lib.PnError, match="line %d does not end" % (n - 1)):
+        pathfile.read_paths(fbad, L)
+
+
 def test_edge_file_reader(tmp_path):
     g = golden("sampler_synthetic97_12_5.npz")
     f = os.path.join(tmp_path, "g.in")
