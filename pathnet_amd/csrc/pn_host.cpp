@@ -111,6 +111,170 @@ GlibcState glibc_seed_state(uint32_t seed) {
 
 using namespace pn;
 
+// Host threads for the host-side loops (PN_HOST_THREADS overrides; never more than one per `grain` items).
+static int host_threads(int64_t items, int64_t grain) {
+    const char *e = std::getenv("PN_HOST_THREADS");
+    const int env = e ? std::atoi(e) : 0;
+    int64_t t = env > 0 ? env : (int64_t)std::thread::hardware_concurrency();
+    t = std::max<int64_t>(1, std::min<int64_t>(t, 32));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(t, items / std::max<int64_t>(grain, 1)));
+}
+
+// fn(0..T-1) on T threads (the caller is thread 0); a thread that cannot be created runs inline.
+template <class F>
+static void run_threads(int T, F &&fn) {
+    std::vector<std::thread> pool;
+    pool.reserve(T > 1 ? T - 1 : 0);
+    for (int i = 1; i < T; i++) {
+        try {
+            pool.emplace_back([&fn, i] { fn(i); });
+        } catch (const std::system_error &) {
+            fn(i);
+        }
+    }
+    fn(0);
+    for (auto &th : pool) th.join();
+}
+
+// read-only view of a file through the page cache (no copy); an empty file maps to an empty view
+struct MappedFile {
+    const char *data = nullptr;
+    size_t size = 0;
+    bool open(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0) {
+            const int e = errno;
+            ::close(fd);
+            errno = e;
+            return false;
+        }
+        if (st.st_size > 0) {
+            void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                const int e = errno;
+                ::close(fd);
+                errno = e;
+                return false;
+            }
+            data = static_cast<const char *>(m);
+            size = (size_t)st.st_size;
+        }
+        ::close(fd);
+        return true;
+    }
+    ~MappedFile() {
+        if (data) ::munmap(const_cast<char *>(data), size);
+    }
+};
+
+// ---- whitespace-delimited number files (edge_input/<name>.in) on all host threads ---------------------------------
+// The reference reads them with scanf("%d%d%lf") (gen_merw.cpp:162-172), i.e. as a stream of tokens.  The fast
+// path cuts the mapped file into byte ranges at token boundaries, counts the tokens of each range, and parses the
+// ranges concurrently (token k is field k % NF of row k / NF).  Anything it does not expect -- a token that is not
+// entirely one number, too few tokens -- makes it give up, and the sequential scanf-equivalent reader below decides
+// (and words the error), so results and failures are those of the sequential reader.
+static inline bool is_ws(unsigned char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+
+static int64_t count_tokens(const char *s, const char *e) {
+    int64_t n = 0;
+    bool in = false;
+    for (; s < e; s++) {
+        const bool w = is_ws((unsigned char)*s);
+        n += (!w && !in);
+        in = !w;
+    }
+    return n;
+}
+
+static bool parse_int_token(const char *t, const char *e, int64_t *out) {
+    bool neg = false;
+    if (t < e && (*t == '-' || *t == '+')) neg = *t++ == '-';
+    if (t >= e || e - t > 18) return false;
+    int64_t val = 0;
+    for (; t < e; t++) {
+        if (*t < '0' || *t > '9') return false;
+        val = val * 10 + (*t - '0');
+    }
+    *out = neg ? -val : val;
+    return true;
+}
+
+// tokens of [s, e); the first one has global index k0.  NF = 3: int int double rows, NF = 2: int int rows.
+template <int NF>
+static bool parse_number_rows(const char *s, const char *e, int64_t k0, int64_t rows, int32_t *u, int32_t *v, double *p) {
+    int64_t k = k0;
+    const int64_t kend = rows * NF;
+    while (k < kend) {
+        while (s < e && is_ws((unsigned char)*s)) s++;
+        if (s >= e) break;
+        const char *t = s;
+        while (s < e && !is_ws((unsigned char)*s)) s++;
+        const int f = (int)(k % NF);
+        const int64_t row = k / NF;
+        if (NF == 3 && f == 2) {
+            char tmp[64];
+            const size_t len = (size_t)(s - t);
+            if (len >= sizeof tmp) return false;
+            std::memcpy(tmp, t, len);
+            tmp[len] = 0;
+            char *end = nullptr;
+            const double d = std::strtod(tmp, &end);     // same conversion scanf("%lf") performs
+            if (end != tmp + len) return false;
+            p[row] = d;
+        } else {
+            int64_t val;
+            if (!parse_int_token(t, s, &val)) return false;
+            (f == 0 ? u : v)[row] = (int32_t)val;
+        }
+        k++;
+    }
+    return true;
+}
+
+// -> 1 header parsed (n, m set; rows filled when cap > 0), 0 give up (caller runs the sequential reader)
+template <int NF>
+static int read_number_file_fast(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, double *p, int64_t cap) {
+    MappedFile f;
+    if (!f.open(path)) return 0;
+    const char *s = f.data, *e = s + f.size;
+    int64_t hdr[2];
+    for (int h = 0; h < 2; h++) {
+        while (s < e && is_ws((unsigned char)*s)) s++;
+        const char *t = s;
+        while (s < e && !is_ws((unsigned char)*s)) s++;
+        if (!parse_int_token(t, s, &hdr[h]) || hdr[h] < 0) return 0;
+    }
+    if (hdr[0] > 2147483647LL) return 0;
+    if (cap == 0) {
+        *n = (int32_t)hdr[0];
+        *m = hdr[1];
+        return 1;
+    }
+    if (cap < hdr[1] || !u || !v || (NF == 3 && !p)) return 0;
+    const int T = host_threads(e - s, 1 << 20);
+    std::vector<const char *> cut((size_t)T + 1, e);
+    cut[0] = s;
+    for (int i = 1; i < T; i++) {
+        const char *c = std::max(cut[i - 1], s + (e - s) / T * i);
+        while (c < e && !is_ws((unsigned char)*c)) c++;
+        cut[i] = c;
+    }
+    std::vector<int64_t> first((size_t)T + 1, 0);
+    run_threads(T, [&](int i) { first[i + 1] = count_tokens(cut[i], cut[i + 1]); });
+    for (int i = 0; i < T; i++) first[i + 1] += first[i];
+    if (first[T] < hdr[1] * NF) return 0;      // truncated: the sequential reader names the row
+    std::atomic<bool> ok(true);
+    run_threads(T, [&](int i) {
+        if (!parse_number_rows<NF>(cut[i], cut[i + 1], first[i], hdr[1], u, v, p)) ok = false;
+    });
+    if (!ok) return 0;
+    *n = (int32_t)hdr[0];
+    *m = hdr[1];
+    return 1;
+}
+
 extern "C" {
 
 int pn_abi_version(void) { return PN_ABI_VERSION; }
@@ -133,6 +297,7 @@ static bool slurp(const char *path, std::string &out) {
 
 int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, double *p, int64_t cap) {
     if (!path || !n || !m) PN_FAIL(PN_ERR_ARG, "pn_edges_read_text: null argument");
+    if (read_number_file_fast<3>(path, n, m, u, v, p, cap)) return PN_OK;
     std::string txt;
     if (!slurp(path, txt)) PN_FAIL(PN_ERR_IO, "cannot read edge file %s: %s", path, std::strerror(errno));
     const char *s = txt.c_str();
@@ -171,6 +336,7 @@ int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int
 // ------------------------------------------------------------------------------------------------
 int pn_pairs_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, int64_t cap) {
     if (!path || !n || !m) PN_FAIL(PN_ERR_ARG, "pn_pairs_read_text: null argument");
+    if (read_number_file_fast<2>(path, n, m, u, v, nullptr, cap)) return PN_OK;
     std::string txt;
     if (!slurp(path, txt)) PN_FAIL(PN_ERR_IO, "cannot read pair file %s: %s", path, std::strerror(errno));
     const char *s = txt.c_str();
@@ -289,19 +455,8 @@ int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, con
         nbr[(size_t)at] = v[e];
         prob[(size_t)at] = p[e];
     }
-    int64_t count = 0;
-    auto emit = [&](int32_t a, int32_t b, double s) {
-        if (count < cap) {
-            if (A) A[count] = a;
-            if (B) B[count] = b;
-            if (S) S[count] = s;
-            if (thr) thr[count] = draw_threshold(s);
-        }
-        count++;
-    };
-    std::deque<Pending> heavy, light;
-    for (int32_t node = 0; node < n; node++) {
-        off[node] = count;
+    // AliasTable::init of one node (gen_merw.cpp:23-79); emit(a, b, s) receives its triples in order
+    auto node_table = [&](int32_t node, std::deque<Pending> &heavy, std::deque<Pending> &light, auto &&emit) {
         const int64_t k = start[(size_t)node + 1] - start[node];
         heavy.clear();
         light.clear();
@@ -324,11 +479,43 @@ int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, con
         }
         for (; !heavy.empty(); heavy.pop_front()) emit(heavy.front().id, heavy.front().id, 1.0);
         for (; !light.empty(); light.pop_front()) emit(light.front().id, light.front().id, 1.0);
+    };
+    // the nodes' tables are independent: blocks of nodes per host thread, first to count the triples of every node
+    // (their number depends on the masses), then -- offsets known -- to write them
+    const int T = host_threads(m + n, 1 << 16);
+    auto node_lo = [&](int ti) { return (int32_t)((int64_t)n * ti / T); };
+    run_threads(T, [&](int ti) {
+        std::deque<Pending> heavy, light;
+        for (int32_t node = node_lo(ti); node < node_lo(ti + 1); node++) {
+            int64_t c = 0;
+            node_table(node, heavy, light, [&](int32_t, int32_t, double) { c++; });
+            off[node] = c;
+        }
+    });
+    int64_t count = 0;
+    for (int32_t node = 0; node < n; node++) {
+        const int64_t c = off[node];
+        off[node] = count;
+        count += c;
     }
     off[n] = count;
     *total = count;
-    if (cap != 0 && cap < count)
+    if (cap == 0) return PN_OK;
+    if (cap < count)
         PN_FAIL(PN_ERR_CAPACITY, "alias buffers hold %lld triples, need %lld", (long long)cap, (long long)count);
+    run_threads(T, [&](int ti) {
+        std::deque<Pending> heavy, light;
+        for (int32_t node = node_lo(ti); node < node_lo(ti + 1); node++) {
+            int64_t at = off[node];
+            node_table(node, heavy, light, [&](int32_t a, int32_t b, double s) {
+                if (A) A[at] = a;
+                if (B) B[at] = b;
+                if (S) S[at] = s;
+                if (thr) thr[at] = draw_threshold(s);
+                at++;
+            });
+        }
+    });
     return PN_OK;
 }
 
@@ -357,21 +544,31 @@ int pn_csr_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32
     std::vector<int64_t> cursor(start.begin(), start.end() - 1);
     std::vector<int32_t> raw((size_t)m);
     for (int64_t e = 0; e < m; e++) raw[(size_t)cursor[src[e]]++] = dst[e];
+    // per-node sort + unique in place (blocks of nodes per host thread), then the compaction to the output
+    const int T = host_threads(m + n, 1 << 16);
+    auto node_lo = [&](int ti) { return (int32_t)((int64_t)n * ti / T); };
+    run_threads(T, [&](int ti) {
+        for (int32_t i = node_lo(ti); i < node_lo(ti + 1); i++) {
+            int32_t *b = raw.data() + start[i], *e = raw.data() + start[(size_t)i + 1];
+            std::sort(b, e);
+            off[i] = std::unique(b, e) - b;
+        }
+    });
     int64_t total = 0;
     for (int32_t i = 0; i < n; i++) {
-        int32_t *b = raw.data() + start[i], *e = raw.data() + start[(size_t)i + 1];
-        std::sort(b, e);
-        e = std::unique(b, e);
+        const int64_t c = off[i];
         off[i] = total;
-        for (int32_t *q = b; q < e; q++) {
-            if (total < cap && adj) adj[total] = *q;
-            total++;
-        }
+        total += c;
     }
     off[n] = total;
     *count = total;
     if (cap != 0 && cap < total)
         PN_FAIL(PN_ERR_CAPACITY, "adjacency buffer holds %lld entries, need %lld", (long long)cap, (long long)total);
+    if (cap != 0 && adj)
+        run_threads(T, [&](int ti) {
+            for (int32_t i = node_lo(ti); i < node_lo(ti + 1); i++)
+                std::copy(raw.data() + start[i], raw.data() + start[i] + (off[(size_t)i + 1] - off[i]), adj + off[i]);
+        });
     return PN_OK;
 }
 
@@ -405,26 +602,31 @@ int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int3
     std::vector<int64_t> cursor(start.begin(), start.end() - 1);
     std::vector<int32_t> nbr((size_t)m);
     for (int64_t e = 0; e < m; e++) nbr[(size_t)cursor[u[e]]++] = v[e];
-    std::memset(dis, 0, (size_t)n * (size_t)n);
-    std::vector<int32_t> frontier, next;
-    for (int32_t src = 0; src < n; src++) {
-        uint8_t *row = dis + (size_t)src * (size_t)n;
-        row[src] = 1;
-        frontier.assign(1, src);
-        // a walk of seq_len nodes reaches at most seq_len-1 hops: label levels 1..seq_len
-        for (int32_t level = 1; level < seq_len && !frontier.empty(); level++) {
-            next.clear();
-            for (int32_t x : frontier)
-                for (int64_t j = start[x]; j < start[(size_t)x + 1]; j++) {
-                    int32_t y = nbr[(size_t)j];
-                    if (row[y] == 0) {
-                        row[y] = (uint8_t)(level + 1);
-                        next.push_back(y);
+    // every source's BFS is independent and owns one row of dis: contiguous blocks of sources per host thread
+    const int T = host_threads(n, 64);
+    run_threads(T, [&](int ti) {
+        const int32_t lo = (int32_t)((int64_t)n * ti / T), hi = (int32_t)((int64_t)n * (ti + 1) / T);
+        std::vector<int32_t> frontier, next;
+        for (int32_t src = lo; src < hi; src++) {
+            uint8_t *row = dis + (size_t)src * (size_t)n;
+            std::memset(row, 0, (size_t)n);
+            row[src] = 1;
+            frontier.assign(1, src);
+            // a walk of seq_len nodes reaches at most seq_len-1 hops: label levels 1..seq_len
+            for (int32_t level = 1; level < seq_len && !frontier.empty(); level++) {
+                next.clear();
+                for (int32_t x : frontier)
+                    for (int64_t j = start[x]; j < start[(size_t)x + 1]; j++) {
+                        int32_t y = nbr[(size_t)j];
+                        if (row[y] == 0) {
+                            row[y] = (uint8_t)(level + 1);
+                            next.push_back(y);
+                        }
                     }
-                }
-            frontier.swap(next);
+                frontier.swap(next);
+            }
         }
-    }
+    });
     return PN_OK;
 }
 
@@ -432,31 +634,6 @@ int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int3
 // path file
 // ------------------------------------------------------------------------------------------------
 }  // extern "C"
-
-// Host threads for the text formatter / parser (PN_HOST_THREADS overrides; never more than one per `grain` items).
-static int host_threads(int64_t items, int64_t grain) {
-    const char *e = std::getenv("PN_HOST_THREADS");
-    const int env = e ? std::atoi(e) : 0;
-    int64_t t = env > 0 ? env : (int64_t)std::thread::hardware_concurrency();
-    t = std::max<int64_t>(1, std::min<int64_t>(t, 32));
-    return (int)std::max<int64_t>(1, std::min<int64_t>(t, items / std::max<int64_t>(grain, 1)));
-}
-
-// fn(0..T-1) on T threads (the caller is thread 0); a thread that cannot be created runs inline.
-template <class F>
-static void run_threads(int T, F &&fn) {
-    std::vector<std::thread> pool;
-    pool.reserve(T > 1 ? T - 1 : 0);
-    for (int i = 1; i < T; i++) {
-        try {
-            pool.emplace_back([&fn, i] { fn(i); });
-        } catch (const std::system_error &) {
-            fn(i);
-        }
-    }
-    fn(0);
-    for (auto &th : pool) th.join();
-}
 
 static inline char *put_uint(char *w, uint32_t x) {
     char tmp[12];
@@ -630,39 +807,6 @@ ParseResult parse_lines(const char *s, const char *e, int32_t L, int32_t *ids, u
     }
     return r;
 }
-
-// read-only view of a file through the page cache (no copy); an empty file maps to an empty view
-struct MappedFile {
-    const char *data = nullptr;
-    size_t size = 0;
-    bool open(const char *path) {
-        const int fd = ::open(path, O_RDONLY);
-        if (fd < 0) return false;
-        struct stat st;
-        if (::fstat(fd, &st) != 0) {
-            const int e = errno;
-            ::close(fd);
-            errno = e;
-            return false;
-        }
-        if (st.st_size > 0) {
-            void *m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m == MAP_FAILED) {
-                const int e = errno;
-                ::close(fd);
-                errno = e;
-                return false;
-            }
-            data = static_cast<const char *>(m);
-            size = (size_t)st.st_size;
-        }
-        ::close(fd);
-        return true;
-    }
-    ~MappedFile() {
-        if (data) ::munmap(const_cast<char *>(data), size);
-    }
-};
 
 int64_t count_newlines(const char *s, const char *e) {
     int64_t n = 0;

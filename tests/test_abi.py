@@ -128,6 +128,41 @@ def test_path_file_threaded_equals_single_thread(tmp_path, monkeypatch):
         pathfile.read_paths(fbad, L)
 
 
+def test_host_setup_threaded_equals_single_thread(tmp_path, monkeypatch):
+    """Edge-file reader, alias tables, CSR lists and the dense hop table run on all host threads; every output is
+    identical to the single-thread run (and the reader to the values written)."""
+    rng = np.random.default_rng(11)
+    n, m_und = 6000, 60000
+    a, b = rng.integers(0, n, m_und), rng.integers(0, n, m_und)
+    u = np.concatenate([a, b, np.arange(n)]).astype(np.int32)
+    v = np.concatenate([b, a, np.arange(n)]).astype(np.int32)
+    order = rng.permutation(len(u))                      # file order is not sorted by source
+    u, v = u[order], v[order]
+    deg = np.bincount(u, minlength=n)
+    p = rng.random(len(u)) * 2.0 / deg[u]                # unnormalised masses: heavy and light entries
+    f = os.path.join(tmp_path, "g.in")
+    merw.write_edge_file(f, n, u, v, p)
+    assert os.path.getsize(f) > 2 << 20                  # several byte ranges
+    out = {}
+    for threads in ("1", "6"):
+        monkeypatch.setenv("PN_HOST_THREADS", threads)
+        n2, u2, v2, p2 = sampler.read_edge_file(f)
+        assert n2 == n and (u2 == u).all() and (v2 == v).all() and (p2 == p).all()
+        out[threads] = (sampler.build_alias(n, u, v, p), sampler.csr_build(n, u, v),
+                        sampler.csr_build(n, u, v, reverse=True), sampler.hops_dense(n, u, v, 4))
+    flat = lambda t: [np.asarray(x) for part in t for x in (part if isinstance(part, tuple) else (part,))]
+    for x, y in zip(flat(out["1"]), flat(out["6"])):
+        assert x.shape == y.shape and (x == y).all()
+    # scanf-style oddities fall back to the sequential reader: rows spread over lines, "+" signs, trailing tokens
+    g = os.path.join(tmp_path, "odd.in")
+    open(g, "w").write("3 2\n0\n1 0.25 1\t+2\n5e-1 77 extra\n")
+    n3, u3, v3, p3 = sampler.read_edge_file(g)
+    assert n3 == 3 and u3.tolist() == [0, 1] and v3.tolist() == [1, 2] and p3.tolist() == [0.25, 0.5]
+    open(g, "w").write("3 2\n0 1 0.25\n1 2\n")
+    with pytest.raises(_lib.PnError, match="row 1 truncated"):
+        sampler.read_edge_file(g)
+
+
 def test_edge_file_reader(tmp_path):
     g = golden("sampler_synthetic97_12_5.npz")
     f = os.path.join(tmp_path, "g.in")
