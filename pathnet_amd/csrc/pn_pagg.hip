@@ -1568,6 +1568,38 @@ int check_shape(const pn_pagg_shape &s) {
     return PN_OK;
 }
 
+#ifndef PN_BWD_OVERLAP
+#define PN_BWD_OVERLAP 1
+#endif
+// Second stream of the backward: the recurrent weight-gradient GEMM (one 8-wave workgroup per CU, 104 KB of LDS)
+// leaves registers and LDS for the small node-level GEMMs that follow the BPTT, which do not depend on it.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+int side_stream(SideStream **out) {
+    static SideStream tab[64];      // per device; one host thread per device drives the library
+    int dev = 0;
+    PN_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) PN_FAIL(PN_ERR_ARG, "device ordinal %d", dev);
+    SideStream &x = tab[dev];
+    if (!x.s) {
+        PN_CHECK_HIP(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
+        PN_CHECK_HIP(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
+        PN_CHECK_HIP(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
+    }
+    *out = &x;
+    return PN_OK;
+}
+// makes `stream` wait for the side stream's work on every way out of the caller
+struct JoinGuard {
+    hipStream_t stream;
+    SideStream *side = nullptr;
+    ~JoinGuard() {
+        if (side) (void)hipStreamWaitEvent(stream, side->join, 0);
+    }
+};
+
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
     constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;      // H = 256: one row group already fills the LDS
@@ -1919,7 +1951,17 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     }
 
     // recurrent weight / bias gradients: [g_W_ih | g_W_hh] = dG^T . XH, g_b = colsum(dG)
+    JoinGuard joiner{stream};
     if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
+        hipStream_t wstream = stream;
+        const bool overlap = PN_BWD_OVERLAP && !profiling_every_stage();   // (per-stage timings are taken serially)
+        if (overlap) {
+            SideStream *ss = nullptr;
+            if (int rc = side_stream(&ss)) return rc;
+            PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
+            PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+            wstream = ss->s;
+        }
         WgradParams wp{};
         wp.dG = dG;
         wp.xh = reinterpret_cast<const float *>(ws + w.xh);
@@ -1939,17 +1981,23 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         wp.part_w = reinterpret_cast<float *>(ws + w.wpart);
         wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
         {
-            StageTimer tm(ST_WGRAD, stream);
+            StageTimer tm(ST_WGRAD, wstream);
             static const hipError_t lds_attr = hipFuncSetAttribute(
                 reinterpret_cast<const void *>(wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
             PN_CHECK_HIP(lds_attr);
             hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
-                               dim3(WG_THREADS), W3_LDS_BYTES, stream, wp);
+                               dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
             PN_CHECK_HIP(hipGetLastError());
             const int64_t nred = (int64_t)GH * 2 * H + GH;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, stream,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
                                wp.part_w, wp.part_b, nz_used, GH, H, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
             PN_CHECK_HIP(hipGetLastError());
+        }
+        if (overlap) {
+            SideStream *ss = nullptr;
+            if (int rc = side_stream(&ss)) return rc;
+            PN_CHECK_HIP(hipEventRecord(ss->join, ss->s));
+            joiner.side = ss;       // `stream` waits for the weight gradients when this function returns
         }
     }
     // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh

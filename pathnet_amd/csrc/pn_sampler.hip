@@ -361,6 +361,7 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
 namespace pn {
 // ---- per-stage HIP-event timing -------------------------------------------------------------------
 static int g_prof_mode = 0, g_prof_stage = -1;
+bool profiling_every_stage() { return g_prof_mode == 1; }
 struct ProfRec {
     int stage;
     hipEvent_t a, b;

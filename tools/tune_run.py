@@ -37,7 +37,17 @@ _lib.check(lib.pn_profile_configure(1, -1))
 for _ in range(%d): step()
 torch.cuda.synchronize()
 prof = bench.read_profile(lib, names)
-print("RESULT " + json.dumps({k: round(v[0] / v[1], 4) for k, v in prof.items()}))
+_lib.check(lib.pn_profile_configure(0, -1))
+for _ in range(5): step()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(50): step()
+e1.record()
+torch.cuda.synchronize()
+res = {k: round(v[0] / v[1], 4) for k, v in prof.items()}
+res["_wall_fwd_bwd"] = round(e0.elapsed_time(e1) / 50, 4)
+print("RESULT " + json.dumps(res))
 '''
 
 
@@ -51,7 +61,9 @@ def main():
         if res:
             d = json.loads(res[0][7:])
             print("%-60s fwd %.3f bwd %.3f wgrad %.3f | total %.3f" % (spec, d.get("seq_fwd", -1), d.get("seq_bwd", -1),
-                                                                      d.get("wgrad", -1), sum(d.values())))
+                                                                      d.get("wgrad", -1),
+                                                                      sum(v for k, v in d.items() if k[0] != "_")) +
+                  " | wall fwd+bwd %.3f" % d.get("_wall_fwd_bwd", -1))
             if os.environ.get("PN_TUNE_ALL"):
                 print("    " + " ".join("%s %.3f" % kv for kv in d.items()))
         else:
