@@ -1587,6 +1587,9 @@ int side_stream(SideStream **out) {
         PN_CHECK_HIP(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
         PN_CHECK_HIP(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
         PN_CHECK_HIP(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
+        // the runtime builds a stream's hardware queue at its first launch (milliseconds): pay that here
+        hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, x.s, ZeroList{});
+        PN_CHECK_HIP(hipGetLastError());
     }
     *out = &x;
     return PN_OK;
@@ -1955,9 +1958,10 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
         hipStream_t wstream = stream;
         const bool overlap = PN_BWD_OVERLAP && !profiling_every_stage();   // (per-stage timings are taken serially)
-        if (overlap) {
-            SideStream *ss = nullptr;
+        SideStream *ss = nullptr;
+        if (PN_BWD_OVERLAP)     // created by the first backward on this device, whichever mode it runs in
             if (int rc = side_stream(&ss)) return rc;
+        if (overlap) {
             PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
             PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
             wstream = ss->s;
@@ -1994,8 +1998,6 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
             PN_CHECK_HIP(hipGetLastError());
         }
         if (overlap) {
-            SideStream *ss = nullptr;
-            if (int rc = side_stream(&ss)) return rc;
             PN_CHECK_HIP(hipEventRecord(ss->join, ss->s));
             joiner.side = ss;       // `stream` waits for the weight gradients when this function returns
         }
