@@ -1571,6 +1571,9 @@ int check_shape(const pn_pagg_shape &s) {
 #ifndef PN_BWD_OVERLAP
 #define PN_BWD_OVERLAP 1
 #endif
+#ifndef PN_SIDE_SMALL
+#define PN_SIDE_SMALL 1
+#endif
 // Second stream of the backward: the recurrent weight-gradient GEMM (one 8-wave workgroup per CU, 104 KB of LDS)
 // leaves registers and LDS for the small node-level GEMMs that follow the BPTT, which do not depend on it.
 struct SideStream {
@@ -1738,6 +1741,31 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
     const int P = s.S * s.W;
     const int homo = s.variant == PN_VARIANT_HOMO;
 
+    // the index plan and the weight packing do not depend on fc0 / bank: second stream, joined before the recurrence
+    JoinGuard joiner{stream};
+    hipStream_t pstream = stream;
+    SideStream *ss = nullptr;
+    if (PN_SIDE_SMALL)
+        if (int rc = side_stream(&ss)) return rc;
+    if (PN_SIDE_SMALL && !profiling_every_stage()) {
+        PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
+        PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+        pstream = ss->s;
+    }
+    {
+        StageTimer tm(ST_PLAN_PACK, pstream);
+        const int64_t n = (int64_t)P * L;
+        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pstream, s.variant, a->ids,
+                           a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
+        PN_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((G * H * H / 4 + 255) / 256)), dim3(256), 0, pstream, a->w_ih,
+                           a->w_hh, a->b_ih, a->b_hh, H, G, reinterpret_cast<u32x4 *>(Wp), biasc);
+        PN_CHECK_HIP(hipGetLastError());
+    }
+    if (pstream != stream) {
+        PN_CHECK_HIP(hipEventRecord(ss->join, ss->s));
+        joiner.side = ss;
+    }
     // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
     if (!a->Xh_in) {
         StageTimer tm(ST_FC0, stream);
@@ -1753,15 +1781,9 @@ int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
                                  H, homo, GEMM_STORE, 1))
             return rc;
     }
-    {
-        StageTimer tm(ST_PLAN_PACK, stream);
-        const int64_t n = (int64_t)P * L;
-        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, s.variant, a->ids,
-                           a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
-        PN_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((G * H * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
-                           a->w_hh, a->b_ih, a->b_hh, H, G, reinterpret_cast<u32x4 *>(Wp), biasc);
-        PN_CHECK_HIP(hipGetLastError());
+    if (joiner.side) {       // the recurrence needs the plan and the packed weights
+        PN_CHECK_HIP(hipStreamWaitEvent(stream, joiner.side->join, 0));
+        joiner.side = nullptr;
     }
     SeqFwdParams sp{};
     sp.Z = Z;
@@ -1887,16 +1909,30 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     }
     if (int rc = flush_zero()) return rc;
 
-    // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out)
-    auto tm_fc2 = std::make_unique<StageTimer>(ST_FC2_GRAD, stream);
+    // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out) -- nothing below reads them: second stream
+    JoinGuard joiner{stream};
+    SideStream *ss = nullptr;
+    if (PN_BWD_OVERLAP || PN_SIDE_SMALL)     // created by the first backward on this device, whichever mode it runs in
+        if (int rc = side_stream(&ss)) return rc;
+    hipStream_t cstream = stream;
+    if (PN_SIDE_SMALL && !profiling_every_stage()) {
+        PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
+        PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
+        cstream = ss->s;
+    }
+    auto tm_fc2 = std::make_unique<StageTimer>(ST_FC2_GRAD, cstream);
     if (a->g_fc2_w) {        // g_fc2_b = row sums of the A operand (g_out^T)
-        if (int rc = launch_gemm(stream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
+        if (int rc = launch_gemm(cstream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
                                  2 * H, s.S, 0, GEMM_ATOMIC, (s.S + 127) / 128, a->g_fc2_b))
             return rc;
     } else if (a->g_fc2_b) {
-        if (int rc = launch_colsum(stream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
+        if (int rc = launch_colsum(cstream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
     }
     tm_fc2.reset();
+    if (cstream != stream) {
+        PN_CHECK_HIP(hipEventRecord(ss->join, ss->s));
+        joiner.side = ss;
+    }
 
     // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
     {
@@ -1954,13 +1990,9 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
     }
 
     // recurrent weight / bias gradients: [g_W_ih | g_W_hh] = dG^T . XH, g_b = colsum(dG)
-    JoinGuard joiner{stream};
     if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
         hipStream_t wstream = stream;
         const bool overlap = PN_BWD_OVERLAP && !profiling_every_stage();   // (per-stage timings are taken serially)
-        SideStream *ss = nullptr;
-        if (PN_BWD_OVERLAP)     // created by the first backward on this device, whichever mode it runs in
-            if (int rc = side_stream(&ss)) return rc;
         if (overlap) {
             PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
             PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
