@@ -15,7 +15,11 @@
  *     retains a pointer past the call.  "dev" in a comment = device (HBM) pointer, "host" = host.
  *   - device work is enqueued on the hipStream_t passed as `stream` (void* here so the header
  *     needs no HIP include; pass torch.cuda.current_stream().cuda_stream).  Device entry points
- *     are asynchronous with respect to the host.
+ *     are asynchronous with respect to the host.  pn_pagg_forward/backward fork a few independent
+ *     launches onto one internal second stream per device and join them back (events) before
+ *     they return: all their work is ordered before whatever the caller enqueues on `stream` next.
+ *   - one host thread per device drives the device entry points (process-per-GPU model); the
+ *     host-only entry points (files, tables) are re-entrant and use up to PN_HOST_THREADS threads.
  *   - sizes: n nodes, m edge rows, W walks per node (path_num), L path length, S masked nodes,
  *     P = S*W paths, H hidden size, F input features, C classes.
  */
