@@ -385,6 +385,7 @@ def main():
         print(json.dumps(result))
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()              # rank 0's untimed extras run a little longer: leave together
         dist.destroy_process_group()
 
 
