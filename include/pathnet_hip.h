@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 2 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step */
+#define PN_ABI_VERSION 3 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -248,6 +248,15 @@ int pn_pagg_gather(const pn_pagg_shape *shape, const float *table /* [N, L, H] *
  * be 1.  bias may be NULL; relu != 0 applies max(0, .). */
 int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_t sBn, int64_t sBk, float *C,
                 int64_t ldc, const float *bias, int32_t M, int32_t N, int32_t K, int32_t relu, void *stream);
+
+/* Y [rows, out_f] = act(X [rows, in_f] . W^T + b): nn.Linear (+ReLU when relu != 0), fc0 of the path for a block of
+ * rows (PathNet_run.py:175 / :242) -- what a rank computes before the all-gather of the node-sharded path.  With a
+ * device workspace of at least PN_LINEAR_SPLIT_MAX * rows * out_f * 4 bytes the reduction dimension is split over
+ * workgroups (deterministic: chunk sums + a fixed-order finish), which is what fills the GPU when rows * out_f is
+ * small; workspace may be NULL (one workgroup per output tile). */
+#define PN_LINEAR_SPLIT_MAX 8
+int pn_linear_forward(const float *X, const float *W, const float *b, int32_t rows, int32_t in_f, int32_t out_f,
+                      int32_t relu, float *Y, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Backward of Y = act(X . W^T + b) for `rows` rows (nn.Linear, fc0 of the path: PathNet_run.py:175 / :242):
  * dY [rows, out_f] is gated by [gate > 0] when gate != NULL (ReLU backward, gate = Y), then

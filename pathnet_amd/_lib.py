@@ -14,6 +14,7 @@ PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOM
     -1, -2, -3, -4, -5, -6, -7)
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
+LINEAR_SPLIT_MAX = 8          # PN_LINEAR_SPLIT_MAX: workspace floats per output element of pn_linear_forward
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -99,6 +100,8 @@ SIGNATURES = {
     "pn_profile_stage_count": (ctypes.c_int, []),
     "pn_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int32]),
     "pn_profile_read": (ctypes.c_int, [c_f64p, c_i64p]),
+    "pn_linear_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp,
+                                         vp, ctypes.c_int64, vp]),
     "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp,
                                           vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
@@ -126,7 +129,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if lib.pn_abi_version() != 2:
+        if lib.pn_abi_version() != 3:
             raise ImportError("libpathnet_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1650,20 +1650,43 @@ int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_
                        GEMM_STORE, 1);
 }
 
+int pn_linear_forward(const float *X, const float *W, const float *b, int32_t rows, int32_t in_f, int32_t out_f,
+                      int32_t relu, float *Y, void *workspace, int64_t workspace_bytes, void *stream_) {
+    static_assert(PN_LINEAR_SPLIT_MAX == GEMM_MAX_SPLIT, "header and kernel agree on the split bound");
+    if (!X || !W || !Y || rows < 0 || in_f < 1 || out_f < 1) PN_FAIL(PN_ERR_ARG, "pn_linear_forward: bad argument");
+    if (rows == 0) return PN_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool split = workspace && workspace_bytes >= (int64_t)GEMM_MAX_SPLIT * rows * out_f * (int64_t)sizeof(float);
+    StageTimer tm(ST_FC0, stream);
+    return launch_gemm_split(stream, X, in_f, 1, nullptr, W, in_f, 1, Y, out_f, b, rows, out_f, in_f, relu, GEMM_STORE,
+                             split ? reinterpret_cast<float *>(workspace) : nullptr);
+}
+
 int pn_linear_backward(const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
                        int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!dY || rows < 0 || in_f < 1 || out_f < 1) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: bad argument");
     StageTimer tm(ST_FC0_BWD, stream);
-    if (g_W) {
-        if (!X) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: g_W needs X");
-        PN_CHECK_HIP(hipMemsetAsync(g_W, 0, (size_t)out_f * in_f * sizeof(float), stream));
-        if (int rc = launch_gemm(stream, dY, 1, out_f, gate, X, 1, in_f, g_W, in_f, nullptr, out_f, in_f, rows, 0,
-                                 GEMM_ATOMIC, (rows + 255) / 256))
-            return rc;
+    if (g_W && !X) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: g_W needs X");
+    if (g_W || g_b) {       // both are accumulated with atomics: one zero-fill launch for the two
+        ZeroList zl{};
+        if (g_W) {
+            zl.ptr[zl.n] = g_W;
+            zl.count[zl.n++] = (unsigned long long)out_f * in_f;
+        }
+        if (g_b) {
+            zl.ptr[zl.n] = g_b;
+            zl.count[zl.n++] = (unsigned long long)out_f;
+        }
+        hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, stream, zl);
+        PN_CHECK_HIP(hipGetLastError());
     }
-    if (g_b) {
-        PN_CHECK_HIP(hipMemsetAsync(g_b, 0, (size_t)out_f * sizeof(float), stream));
+    if (rows == 0) return PN_OK;
+    if (g_W) {              // g_b rides along as the row sums of the (gated) A operand dY^T
+        if (int rc = launch_gemm(stream, dY, 1, out_f, gate, X, 1, in_f, g_W, in_f, nullptr, out_f, in_f, rows, 0,
+                                 GEMM_ATOMIC, (rows + 255) / 256, g_b))
+            return rc;
+    } else if (g_b) {
         if (int rc = launch_colsum(stream, dY, gate, out_f, rows, out_f, g_b)) return rc;
     }
     if (g_X) {

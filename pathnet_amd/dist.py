@@ -38,11 +38,13 @@ class HipOps:
     def project(self, variant, X_loc, w, b):
         lib = _lib.load()
         X_loc = X_loc.contiguous()
-        out = torch.empty((X_loc.shape[0], w.shape[0]), dtype=torch.float32, device=X_loc.device)
+        rows, out_f = X_loc.shape[0], w.shape[0]
+        out = torch.empty((rows, out_f), dtype=torch.float32, device=X_loc.device)
+        ws = torch.empty(max(_lib.LINEAR_SPLIT_MAX * rows * out_f, 1), dtype=torch.float32, device=X_loc.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(X_loc.device).cuda_stream)
-        _lib.check(lib.pn_gemm_f32(X_loc.data_ptr(), X_loc.shape[1], 1, w.data_ptr(), w.shape[1], 1, out.data_ptr(),
-                                   w.shape[0], b.data_ptr(), X_loc.shape[0], w.shape[0], X_loc.shape[1],
-                                   1 if variant == "homo" else 0, stream))
+        _lib.check(lib.pn_linear_forward(X_loc.data_ptr(), w.data_ptr(), b.data_ptr(), rows, X_loc.shape[1], out_f,
+                                         1 if variant == "homo" else 0, out.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                         stream))
         return out
 
     def _args(self, cfg, Xh, ids, codes, sel, p):

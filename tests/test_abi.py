@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.pn_abi_version() == 2
+    assert lib.pn_abi_version() == 3
 
 
 @pytest.mark.parametrize("name", golden_files("sampler_*.npz"))

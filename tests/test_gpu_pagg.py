@@ -50,6 +50,40 @@ def test_gemm_f32_matches_torch():
         assert (C - ref).abs().max().item() < 1e-4 * max(1.0, K ** 0.5 / 8), (M, N, K, "T")
 
 
+def test_linear_forward_and_backward_match_torch():
+    """pn_linear_forward (with and without the split-K workspace: same values) and pn_linear_backward (one zero-fill
+    launch, bias gradient as row sums of the weight-gradient GEMM) against torch's nn.Linear (+ReLU)."""
+    from pathnet_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    for (rows, in_f, out_f, relu) in [(2708, 1433, 128, 1), (300, 77, 64, 0), (5, 16, 32, 1)]:
+        X = torch.randn(rows, in_f, device="cuda")
+        W = torch.randn(out_f, in_f, device="cuda") / in_f ** 0.5
+        b = torch.randn(out_f, device="cuda")
+        Y0, Y1 = torch.empty(rows, out_f, device="cuda"), torch.empty(rows, out_f, device="cuda")
+        ws = torch.empty(_lib.LINEAR_SPLIT_MAX * rows * out_f, device="cuda")
+        _lib.check(lib.pn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), rows, in_f, out_f, relu,
+                                         Y0.data_ptr(), None, 0, None))
+        _lib.check(lib.pn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), rows, in_f, out_f, relu,
+                                         Y1.data_ptr(), ws.data_ptr(), ws.numel() * 4, None))
+        ref = X.double() @ W.double().t() + b.double()
+        ref = (torch.relu(ref) if relu else ref).float()
+        assert (Y0 - ref).abs().max().item() < 2e-5 and (Y1 - ref).abs().max().item() < 2e-5
+        dY = torch.randn(rows, out_f, device="cuda")
+        gW, gb, gX = torch.full_like(W, 7.0), torch.full_like(b, 7.0), torch.empty_like(X)
+        _lib.check(lib.pn_linear_backward(dY.data_ptr(), Y1.data_ptr() if relu else None, X.data_ptr(), W.data_ptr(),
+                                          rows, in_f, out_f, gW.data_ptr(), gb.data_ptr(), gX.data_ptr(), None))
+        d = (dY * (ref > 0)).double() if relu else dY.double()
+        scale = max(1.0, rows ** 0.5 / 8)
+        assert (gW - (d.t() @ X.double()).float()).abs().max().item() < 1e-4 * scale
+        assert (gb - d.sum(0).float()).abs().max().item() < 1e-4 * scale
+        assert (gX - (d @ W.double()).float()).abs().max().item() < 1e-4
+        gb2 = torch.full_like(b, 7.0)       # bias gradient alone
+        _lib.check(lib.pn_linear_backward(dY.data_ptr(), Y1.data_ptr() if relu else None, None, None, rows, in_f, out_f,
+                                          None, gb2.data_ptr(), None, None))
+        assert (gb2 - d.sum(0).float()).abs().max().item() < 1e-4 * scale
+
+
 def test_gemm_detects_transposes():
     from pathnet_amd import _lib
     lib = _lib.load()
