@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
+#include <mutex>
+#include <new>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -120,20 +123,45 @@ static int host_threads(int64_t items, int64_t grain) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(t, items / std::max<int64_t>(grain, 1)));
 }
 
-// fn(0..T-1) on T threads (the caller is thread 0); a thread that cannot be created runs inline.
+// fn(0..T-1) on T threads (the caller is thread 0); a thread that cannot be created runs inline.  An exception in
+// any of them (std::bad_alloc, in practice) is re-thrown here once all have finished.
 template <class F>
 static void run_threads(int T, F &&fn) {
+    std::exception_ptr failure;
+    std::mutex mu;
+    auto guarded = [&](int i) {
+        try {
+            fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!failure) failure = std::current_exception();
+        }
+    };
     std::vector<std::thread> pool;
     pool.reserve(T > 1 ? T - 1 : 0);
     for (int i = 1; i < T; i++) {
         try {
-            pool.emplace_back([&fn, i] { fn(i); });
+            pool.emplace_back([&guarded, i] { guarded(i); });
         } catch (const std::system_error &) {
-            fn(i);
+            guarded(i);
         }
     }
-    fn(0);
+    guarded(0);
     for (auto &th : pool) th.join();
+    if (failure) std::rethrow_exception(failure);
+}
+
+// No exception crosses the C boundary: every entry point below is a function-try-block ending here.
+static int host_exception(const char *where) {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        PN_FAIL(PN_ERR_NOMEM, "%s: out of host memory", where);
+    } catch (const std::exception &e) {
+        PN_FAIL(PN_ERR_IO, "%s: %s", where, e.what());
+    } catch (...) {
+        PN_FAIL(PN_ERR_IO, "%s: unknown failure", where);
+    }
 }
 
 // read-only view of a file through the page cache (no copy); an empty file maps to an empty view
@@ -295,7 +323,7 @@ static bool slurp(const char *path, std::string &out) {
     return got == out.size();
 }
 
-int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, double *p, int64_t cap) {
+int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, double *p, int64_t cap) try {
     if (!path || !n || !m) PN_FAIL(PN_ERR_ARG, "pn_edges_read_text: null argument");
     if (read_number_file_fast<3>(path, n, m, u, v, p, cap)) return PN_OK;
     std::string txt;
@@ -329,12 +357,14 @@ int pn_edges_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int
         p[i] = pr;
     }
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_edges_read_text");
 }
 
 // ------------------------------------------------------------------------------------------------
 // the uniform random-walk sampler's input and graph (gen.cpp:80-94, gen_epoch.cpp)
 // ------------------------------------------------------------------------------------------------
-int pn_pairs_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, int64_t cap) {
+int pn_pairs_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int32_t *v, int64_t cap) try {
     if (!path || !n || !m) PN_FAIL(PN_ERR_ARG, "pn_pairs_read_text: null argument");
     if (read_number_file_fast<2>(path, n, m, u, v, nullptr, cap)) return PN_OK;
     std::string txt;
@@ -364,10 +394,12 @@ int pn_pairs_read_text(const char *path, int32_t *n, int64_t *m, int32_t *u, int
         v[i] = (int32_t)b;
     }
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_pairs_read_text");
 }
 
 int pn_uniform_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int64_t *off, int32_t *packed,
-                     int32_t *src, int32_t *nbr, int64_t cap, int64_t *total) {
+                     int32_t *src, int32_t *nbr, int64_t cap, int64_t *total) try {
     if (n < 0 || m < 0 || (m > 0 && (!u || !v)) || !total) PN_FAIL(PN_ERR_ARG, "pn_uniform_build: bad argument");
     std::vector<int64_t> at((size_t)n + 1, 0);
     for (int32_t i = 0; i < n; i++) at[i] = 1;                       // link(i, i), gen.cpp:83-84
@@ -408,6 +440,8 @@ int pn_uniform_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, i
         put(v[i], u[i]);
     }
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_uniform_build");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -437,7 +471,7 @@ struct Pending {
 }  // namespace
 
 int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, const double *p, int64_t *off,
-                   int32_t *A, int32_t *B, double *S, uint32_t *thr, int64_t cap, int64_t *total) {
+                   int32_t *A, int32_t *B, double *S, uint32_t *thr, int64_t cap, int64_t *total) try {
     if (n < 0 || m < 0 || !off || !total || (m > 0 && (!u || !v || !p)))
         PN_FAIL(PN_ERR_ARG, "pn_alias_build: bad argument");
     // bucket the rows per source node, keeping file order (link(), gen_merw.cpp:95-99)
@@ -517,9 +551,11 @@ int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, con
         }
     });
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_alias_build");
 }
 
-int pn_alias_pack(int64_t total, const int32_t *A, const int32_t *B, const uint32_t *thr, int32_t *dst) {
+int pn_alias_pack(int64_t total, const int32_t *A, const int32_t *B, const uint32_t *thr, int32_t *dst) try {
     if (total < 0 || (total > 0 && (!A || !B || !thr || !dst))) PN_FAIL(PN_ERR_ARG, "pn_alias_pack: bad argument");
     for (int64_t i = 0; i < total; i++) {
         dst[4 * i + 0] = A[i];
@@ -528,10 +564,12 @@ int pn_alias_pack(int64_t total, const int32_t *A, const int32_t *B, const uint3
         dst[4 * i + 3] = 0;
     }
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_alias_pack");
 }
 
 int pn_csr_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t reverse, int64_t *off,
-                 int32_t *adj, int64_t cap, int64_t *count) {
+                 int32_t *adj, int64_t cap, int64_t *count) try {
     if (n < 0 || m < 0 || !off || !count || (m > 0 && (!u || !v))) PN_FAIL(PN_ERR_ARG, "pn_csr_build: bad argument");
     const int32_t *src = reverse ? v : u, *dst = reverse ? u : v;
     std::vector<int64_t> start((size_t)n + 1, 0);
@@ -570,9 +608,11 @@ int pn_csr_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32
                 std::copy(raw.data() + start[i], raw.data() + start[i] + (off[(size_t)i + 1] - off[i]), adj + off[i]);
         });
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_csr_build");
 }
 
-int pn_glibc_draws(uint32_t seed, uint64_t first, int64_t count, int32_t *out) {
+int pn_glibc_draws(uint32_t seed, uint64_t first, int64_t count, int32_t *out) try {
     if (count < 0 || (count > 0 && !out)) PN_FAIL(PN_ERR_ARG, "pn_glibc_draws: bad argument");
     GlibcState st = glibc_apply(glibc_poly_xpow(first), glibc_seed_state(seed));
     uint32_t ring[31];
@@ -584,12 +624,14 @@ int pn_glibc_draws(uint32_t seed, uint64_t first, int64_t count, int32_t *out) {
         ring[at] = ring[at] + ring[(at + 28) % 31];
     }
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_glibc_draws");
 }
 
 // ------------------------------------------------------------------------------------------------
 // hop table
 // ------------------------------------------------------------------------------------------------
-int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t seq_len, uint8_t *dis) {
+int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int32_t seq_len, uint8_t *dis) try {
     if (n < 0 || m < 0 || seq_len < 1 || seq_len > 254 || !dis || (m > 0 && (!u || !v)))
         PN_FAIL(PN_ERR_ARG, "pn_hops_dense: bad argument");
     std::vector<int64_t> start((size_t)n + 1, 0);
@@ -628,6 +670,8 @@ int pn_hops_dense(int32_t n, int64_t m, const int32_t *u, const int32_t *v, int3
         }
     });
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_hops_dense");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -709,18 +753,21 @@ extern "C" {
 // counting only), the prefix sum gives each range its file offset, the second pass formats the range block by block
 // and writes the blocks in place -- no serial section, two thread spawns per call.
 int pn_paths_write_text(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L,
-                        int32_t append) {
+                        int32_t append) try {
     if (!path || npaths < 0 || L < 1 || (npaths > 0 && (!ids || !codes)))
         PN_FAIL(PN_ERR_ARG, "pn_paths_write_text: bad argument");
     const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666);
     if (fd < 0) PN_FAIL(PN_ERR_IO, "cannot open %s for writing: %s", path, std::strerror(errno));
+    struct FdGuard {        // closes on every early way out (errors, exceptions)
+        int fd;
+        ~FdGuard() {
+            if (fd >= 0) ::close(fd);
+        }
+    } guard{fd};
     int64_t at = 0;
     if (append) {
         at = (int64_t)::lseek(fd, 0, SEEK_END);
-        if (at < 0) {
-            ::close(fd);
-            PN_FAIL(PN_ERR_IO, "cannot seek in %s: %s", path, std::strerror(errno));
-        }
+        if (at < 0) PN_FAIL(PN_ERR_IO, "cannot seek in %s: %s", path, std::strerror(errno));
     }
     const int T = host_threads(npaths, 1 << 14);
     std::vector<int64_t> lo((size_t)T + 1), off((size_t)T + 1, 0);
@@ -741,9 +788,12 @@ int pn_paths_write_text(const char *path, const int32_t *ids, const uint8_t *cod
             cursor += (int64_t)len;
         }
     });
+    guard.fd = -1;
     if (::close(fd) != 0 && !failed_errno) failed_errno = errno ? errno : EIO;
     if (failed_errno) PN_FAIL(PN_ERR_IO, "short write to %s: %s", path, std::strerror(failed_errno));
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_paths_write_text");
 }
 
 }  // extern "C"
@@ -825,7 +875,7 @@ extern "C" {
 // The file is cut into one byte range per host thread at line ends; a first pass counts the lines of each range (so
 // that every range knows its first slot), the second parses the ranges concurrently.  A malformed line is reported
 // exactly as a sequential scan would: the first one in file order, by its line number.
-int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) {
+int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) try {
     if (!path || L < 1 || !npaths) PN_FAIL(PN_ERR_ARG, "pn_paths_read_text: bad argument");
     if (cap > 0 && (!ids || !codes)) PN_FAIL(PN_ERR_ARG, "pn_paths_read_text: cap > 0 needs ids and codes");
     MappedFile txt;
@@ -867,6 +917,8 @@ int pn_paths_read_text(const char *path, int32_t L, int32_t *ids, uint8_t *codes
     if (cap > 0 && count > cap)
         PN_FAIL(PN_ERR_CAPACITY, "path buffers hold %lld paths, file has %lld", (long long)cap, (long long)count);
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_paths_read_text");
 }
 
 namespace {
@@ -881,7 +933,7 @@ static_assert(sizeof(BinHeader) == 32, "header is 32 bytes");
 const char kBinMagic[8] = {'P', 'N', 'P', 'A', 'T', 'H', 'S', '1'};
 }  // namespace
 
-int pn_paths_write_bin(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L) {
+int pn_paths_write_bin(const char *path, const int32_t *ids, const uint8_t *codes, int64_t npaths, int32_t L) try {
     if (!path || npaths < 0 || L < 1 || (npaths > 0 && (!ids || !codes)))
         PN_FAIL(PN_ERR_ARG, "pn_paths_write_bin: bad argument");
     FILE *f = std::fopen(path, "wb");
@@ -897,9 +949,11 @@ int pn_paths_write_bin(const char *path, const int32_t *ids, const uint8_t *code
     ok = (std::fclose(f) == 0) && ok;
     if (!ok) PN_FAIL(PN_ERR_IO, "short write to %s", path);
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_paths_write_bin");
 }
 
-int pn_paths_read_bin(const char *path, int32_t *L_out, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) {
+int pn_paths_read_bin(const char *path, int32_t *L_out, int32_t *ids, uint8_t *codes, int64_t cap, int64_t *npaths) try {
     if (!path || !npaths || !L_out) PN_FAIL(PN_ERR_ARG, "pn_paths_read_bin: bad argument");
     FILE *f = std::fopen(path, "rb");
     if (!f) PN_FAIL(PN_ERR_IO, "cannot read path file %s: %s", path, std::strerror(errno));
@@ -923,6 +977,8 @@ int pn_paths_read_bin(const char *path, int32_t *L_out, int32_t *ids, uint8_t *c
     std::fclose(f);
     if (!ok) PN_FAIL(PN_ERR_FORMAT, "%s is truncated", path);
     return PN_OK;
+} catch (...) {
+    return host_exception("pn_paths_read_bin");
 }
 
 }  // extern "C"

@@ -163,6 +163,35 @@ def test_host_setup_threaded_equals_single_thread(tmp_path, monkeypatch):
         sampler.read_edge_file(g)
 
 
+def test_host_out_of_memory_is_an_error_code_not_an_abort():
+    """No exception crosses the C boundary: with the address space capped, a table build that cannot allocate returns
+    PN_ERR_NOMEM and the process lives on (worker threads hand their exceptions to the calling thread the same way)."""
+    import subprocess
+    import sys
+    code = r"""
+import resource, sys
+sys.path.insert(0, %r)
+import numpy as np
+from pathnet_amd import _lib, sampler
+_lib.load()
+n, m = 2000, 40_000_000
+u = np.zeros(m, np.int32); v = np.zeros(m, np.int32)
+vm = [int(l.split()[1]) * 1024 for l in open("/proc/self/status") if l.startswith("VmSize")][0]
+resource.setrlimit(resource.RLIMIT_AS, (vm + (64 << 20), vm + (64 << 20)))     # the 160 MB bucket array cannot be had
+try:
+    sampler.csr_build(n, u, v)
+    print("NO ERROR")
+except _lib.PnError as e:
+    print("CODE", e.code, str(e))
+except MemoryError:
+    print("PYTHON MemoryError")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    out = r.stdout.strip().splitlines()[-1]
+    assert out.startswith("CODE %d" % _lib.PN_ERR_NOMEM) and "out of host memory" in out, out
+
+
 def test_edge_file_reader(tmp_path):
     g = golden("sampler_synthetic97_12_5.npz")
     f = os.path.join(tmp_path, "g.in")
