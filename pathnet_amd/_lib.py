@@ -13,6 +13,7 @@ PN_OK = 0
 PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
+ABI_VERSION = 3               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
 LINEAR_SPLIT_MAX = 8          # PN_LINEAR_SPLIT_MAX: workspace floats per output element of pn_linear_forward
 
@@ -129,7 +130,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError here = header and library disagree
             fn.restype = res
             fn.argtypes = args
-        if lib.pn_abi_version() != 3:
+        if lib.pn_abi_version() != ABI_VERSION:
             raise ImportError("libpathnet_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.pn_abi_version() == 3
+    txt = open(os.path.join(ROOT, "include", "pathnet_hip.h")).read()
+    declared = int(re.search(r"#define PN_ABI_VERSION (\d+)", txt).group(1))
+    assert lib.pn_abi_version() == declared == _lib.ABI_VERSION
 
 
 @pytest.mark.parametrize("name", golden_files("sampler_*.npz"))
