@@ -1,6 +1,5 @@
 """CPU-side checks of the C-ABI library: it loads, exports every symbol include/pathnet_hip.h declares,
 and its host-only entry points (no GPU needed) agree with the oracle."""
-import ctypes
 import os
 import re
 

@@ -1,5 +1,4 @@
 """Loss and optimizer launches (pn_cross_entropy, pn_adam_step) against torch's own implementations."""
-import numpy as np
 import pytest
 import torch
 
