@@ -82,12 +82,76 @@ def stage_names(lib):
     return [lib.pn_profile_stage_name(i).decode() for i in range(lib.pn_profile_stage_count())]
 
 
-def read_profile(lib, names):
+def read_profile(lib, names, ctx=None):
+    from pathnet_amd import _lib
     ms = (ctypes.c_double * len(names))()
     cnt = (ctypes.c_int64 * len(names))()
-    from pathnet_amd import _lib
-    _lib.check(lib.pn_profile_read(ms, cnt))
+    _lib.check(lib.pn_profile_read(ctx if ctx is not None else _lib.context("cuda"), ms, cnt))
     return {names[i]: (ms[i], cnt[i]) for i in range(len(names)) if cnt[i]}
+
+
+def source_hash():
+    """Hash of the library's sources: PMC traffic figures under profiles/ are only quoted for the build they were
+    taken on (tools/pmc_passes.sh stamps them with the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pathnet_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def clock_mhz(lib, dev):
+    from pathnet_amd import _lib
+    v = ctypes.c_double(0.0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pn_clock_probe(ctypes.byref(v), _lib.stream_ptr(dev)))
+    return round(v.value, 1)
+
+
+def seq_flops(P, L, H, G=4):
+    """Flops of one recurrent GEMM kernel over P paths.  SURVEY.md §8d charges L*16*H^2 per path ([x;h] (2H) x 4H gate
+    columns per step); the math needs (2L-1)/(2L) of it: h_{-1} = 0, so the W_hh product of step 0 (seq_fwd), the
+    dh_{-1} product (seq_bwd) and the W_hh gradient of the t = 0 rows (wgrad) do not exist."""
+    survey = 2.0 * P * L * (2 * H) * (G * H)
+    return survey * (2 * L - 1) / (2 * L), survey
+
+
+def roofline_block(dominant, dom_ms, launches, P, L, H, traffic):
+    alg, survey = seq_flops(P, L, H)
+    if dominant in ("seq_fwd", "seq_bwd", "wgrad"):
+        achieved = alg / (dom_ms * 1e-3) / 1e12
+        return {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
+                "peak": round(F32_ON_BF16_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+                "frac": round(achieved / F32_ON_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+                "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(launches),
+                "algorithmic_flops_per_launch": alg,
+                "survey_8d_flops_per_launch": survey,
+                "frac_with_survey_8d_flops": round(survey / (dom_ms * 1e-3) / 1e12 / F32_ON_BF16_PEAK_TFLOPS, 4),
+                "mfma_flops_issued_per_launch": 6 * alg,
+                "ceilings_TFLOPs": {"bf16_pipe_over_6": round(F32_ON_BF16_PEAK_TFLOPS, 1), "f32_input_mfma": 157.3},
+                "frac_of_f32_input_mfma_peak": round(achieved / 157.3, 4),
+                "note": "fp32 results (1e-5 parity; measured 3e-7 against float64) from the bf16 matrix pipe: fp32 = 3 "
+                        "bf16 planes, 6 MFMAs per product, fp32 accumulate; peak = 2.5 PFLOP/s dense bf16 / 6.  achieved "
+                        "counts ALGORITHMIC fp32 flops = (2L-1)*8*H^2 per path, i.e. 7/8 (L=4) of SURVEY.md 8d's "
+                        "L*16*H^2 (the step-0 products with h_{-1} = 0 are not charged); frac_with_survey_8d_flops "
+                        "charges all of it"}
+    return {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": None, "traffic": traffic, "avg_launch_ms": round(dom_ms, 4)}
+
+
+def pmc_traffic(kernel, key):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ -- only when they were
+    taken on this very build (source hash) and workload (key); otherwise None: no stale figure is ever quoted."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tr.get("source_hash") == source_hash() and kernel in tr.get(key, {}):
+            return tr[key][kernel], tr.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None, None
 
 
 def cpu_baseline(wl, seconds_budget=20.0):
@@ -156,12 +220,250 @@ def cpu_baseline_sampler(seconds_budget=20.0):
                       % (n, 1000 * n * 40, dt)}
 
 
+def pubmed_workload(seed=3):
+    """BASELINE.json configs[2] shapes (SURVEY.md §8: Pubmed N=19717, F=500, C=3, 9464 masked nodes, W=40, L=4, hid=128);
+    pubmed.in is absent from the reference mount, so graph, features and labels are synthetic of that size."""
+    n, F, C, H, W, L = 19717, 500, 3, 128, 40, 4
+    g = synthetic_graph(n, seed, avg_und_deg=4.5)             # Pubmed: 44 324 undirected edges
+    rng = np.random.default_rng(seed + 1)
+    X = (rng.random((n, F)) < 0.1).astype(np.float32) * rng.random((n, F)).astype(np.float32)    # TF-IDF-like
+    X /= np.maximum(X.sum(1, keepdims=True), 1e-6)
+    Y = rng.integers(0, C, n)
+    mask = np.zeros(n, bool)
+    mask[rng.permutation(n)[:9464]] = True
+    return dict(n=n, n_loc=n, F=F, C=C, H=H, W=W, L=L, graph=g, X=X, Y=Y, mask=mask)
+
+
+class StepRunner:
+    """One training step of the reference loop on a workload, everything resident on the GPU."""
+
+    def __init__(self, wl, dev, rank, world, sharded, timing_comm=False, hops="auto"):
+        import pathnet_amd
+        self.wl, self.dev, self.world = wl, dev, world
+        n, F, C, H, W, L = wl["n"], wl["F"], wl["C"], wl["H"], wl["W"], wl["L"]
+        gn, u, v, p = wl["graph"]
+        self.smp = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev, hops=hops)
+        torch.manual_seed(0)
+        self.model = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.7).to(dev)
+        self.opt = pathnet_amd.Adam(self.model.parameters(), lr=0.005, weight_decay=0.0005)  # torch.optim.Adam's update, one launch
+        self.lossf = pathnet_amd.CrossEntropyLoss()                                          # torch.nn.CrossEntropyLoss(), one launch
+        Y = torch.from_numpy(wl["Y"]).to(dev)
+        self.runner = None
+        if not sharded:
+            self.X = torch.from_numpy(wl["X"]).to(dev)
+            self.sel = torch.from_numpy(np.flatnonzero(wl["mask"]).astype(np.int64)).to(dev)
+            self.sel32 = self.sel.to(torch.int32)
+            self.node_begin, self.node_count = 0, n
+            self.loss_scale = 1.0
+        else:
+            from pathnet_amd import dist as pdist
+            n_loc = wl["n_loc"]
+            self.node_begin, self.node_count = rank * n_loc, n_loc
+            self.X = torch.from_numpy(wl["X"][self.node_begin:self.node_begin + n_loc]).to(dev)   # this rank's rows only
+            loc_mask = wl["mask"][self.node_begin:self.node_begin + n_loc]
+            self.sel = torch.from_numpy(np.flatnonzero(loc_mask).astype(np.int64)).to(dev)        # local row ids
+            self.sel32 = (self.sel + self.node_begin).to(torch.int32)                             # global node ids
+            self.comm = pdist.Comm(timing=timing_comm)
+            self.runner = pdist.ShardedAggregator(self.model, n_total=n, row_begin=self.node_begin, row_count=n_loc,
+                                                  comm=self.comm)
+            # the mask is fixed: every rank knows every rank's count (no per-step exchange of counts)
+            counts = [int(wl["mask"][r * n_loc:(r + 1) * n_loc].sum()) for r in range(world)]
+            self.runner.set_batch_counts(counts)
+            self.loss_scale = world * counts[rank] / max(sum(counts), 1)      # mean over the WHOLE batch (dist.py)
+        self.S = int(self.sel.numel())
+        self.Ysel = Y[self.sel + (self.node_begin if sharded else 0)]
+        self.ids_buf = torch.empty((1, self.node_count, W, L), dtype=torch.int32, device=dev)
+        self.codes_buf = torch.empty((1, self.node_count, W, L), dtype=torch.uint8, device=dev)
+
+    def step(self, epoch):
+        import pathnet_amd
+        wl = self.wl
+        W, L = wl["W"], wl["L"]
+        self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, node_begin=self.node_begin,
+                        node_count=self.node_count, draw_source=pathnet_amd.DRAW_PHILOX, check=False,
+                        out=(self.ids_buf, self.codes_buf))
+        ids = self.ids_buf[0].index_select(0, self.sel)
+        codes = self.codes_buf[0].index_select(0, self.sel)
+        self.model.train()
+        if self.runner is None:
+            out = self.model(self.X, ids, W, L, self.sel32, codes, None)
+        else:
+            out = self.runner(self.X, ids, W, L, self.sel32, codes)
+        loss = self.lossf(out, self.Ysel)
+        if self.loss_scale != 1.0:
+            loss = loss * self.loss_scale
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.runner is not None:
+            self.runner.allreduce_grads(average=True)
+        self.opt.step()
+        return loss
+
+
+def measure(sr, lib, ctx, names, steps, warmup, barrier):
+    """warm-up with every stage bracketed (finds the dominant kernel) -> exactly `steps` timed steps with only the
+    dominant kernel carrying an event pair -> per-stage breakdown.  Returns a dict."""
+    from pathnet_amd import _lib
+    _lib.check(lib.pn_profile_configure(ctx, 1, -1))
+    for e in range(max(1, warmup)):
+        sr.step(e)
+    torch.cuda.synchronize()
+    prof = read_profile(lib, names, ctx)
+    kernel_stages = {k: v[0] / v[1] for k, v in prof.items()}
+    dominant = max(kernel_stages, key=kernel_stages.get)
+    _lib.check(lib.pn_profile_configure(ctx, 2, names.index(dominant)))
+    for e in range(2):          # two more untimed steps in exactly the timed configuration
+        sr.step(500 + e)
+    barrier()
+    read_profile(lib, names, ctx)    # (drop their event pairs)
+    t0 = time.perf_counter()
+    for e in range(steps):
+        sr.step(1000 + e)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom = read_profile(lib, names, ctx)[dominant]
+    _lib.check(lib.pn_profile_configure(ctx, 1, -1))
+    for e in range(min(10, steps)):
+        sr.step(5000 + e)
+    torch.cuda.synchronize()
+    prof = read_profile(lib, names, ctx)
+    _lib.check(lib.pn_profile_configure(ctx, 0, -1))
+    return {"elapsed": elapsed, "dominant": dominant, "dom_ms": dom[0] / dom[1], "dom_launches": dom[1],
+            "stages_ms": {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
+
+
+def time_launches(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) * 1e-3 / reps
+
+
+def extras_single_gpu(lib, ctx, names, dev, sr, args):
+    """Untimed extras of the N = 1 report: the other single-GPU configurations and the HBM-side microbenchmarks."""
+    import pathnet_amd
+    from pathnet_amd import _lib
+    out = {}
+    wl = sr.wl
+    W, L, H = wl["W"], wl["L"], wl["H"]
+    # ---- sampler alone, bench graph (7 MB hop table: cache resident -- a rate, not a roofline) ----------------------
+    big_e = 16
+    ids_big = torch.empty((big_e, wl["n"], W, L), dtype=torch.int32, device=dev)
+    codes_big = torch.empty((big_e, wl["n"], W, L), dtype=torch.uint8, device=dev)
+    cnt = [0]
+
+    def smp_cora():
+        cnt[0] += 1
+        sr.smp.sample(W, 99, epoch_begin=cnt[0] * big_e, epoch_count=big_e, check=False, out=(ids_big, codes_big))
+    dt = time_launches(smp_cora, 50)
+    paths = big_e * wl["n"] * W
+    out["sampler"] = {"value": paths / dt, "unit": "sampled paths/s", "draws": "philox", "paths_per_launch": paths,
+                      "ms_per_launch": dt * 1e3, "hop_table": "dense %d^2 B (cache resident)" % wl["n"]}
+    del ids_big, codes_big
+
+    # ---- configs[2]: Pubmed-scale full training step (on-GPU MERW sampler + PAGG fwd/bwd + Adam) ---------------------
+    pw = pubmed_workload()
+    t0 = time.time()
+    psr = StepRunner(pw, dev, 0, 1, sharded=False, hops="dense")
+    setup_s = time.time() - t0
+    m = measure(psr, lib, ctx, names, max(5, args.steps // 2), 3, torch.cuda.synchronize)
+    steps_p = max(5, args.steps // 2)
+    Pp = psr.S * W
+    tr, tr_src = pmc_traffic(m["dominant"], "pubmed_hbm_bytes_per_launch")
+    rb = roofline_block(m["dominant"], m["dom_ms"], m["dom_launches"], Pp, L, H, tr)
+    if tr_src:
+        rb["traffic_source"] = tr_src
+    out["pubmed_scale_step"] = {
+        "config": "configs[2] shapes, synthetic: N=%d F=%d C=%d hid=%d W=%d L=%d, %d masked nodes = %d paths/step, "
+                  "PathNet_homo, dropout 0.7, Adam; dense hop table %d MB in HBM" %
+                  (pw["n"], pw["F"], pw["C"], H, W, L, psr.S, Pp, pw["n"] ** 2 >> 20),
+        "value": Pp / (m["elapsed"] / steps_p), "unit": "paths/s", "ms_per_step": m["elapsed"] / steps_p * 1e3,
+        "steps": steps_p, "roofline": rb, "stages_ms": m["stages_ms"], "sampler_setup_s": round(setup_s, 2)}
+    # sampler at Pubmed size: dense 389 MB table (beyond the Infinity Cache) and exact on-the-fly hop codes
+    ids_p = torch.empty((4, pw["n"], W, L), dtype=torch.int32, device=dev)
+    codes_p = torch.empty((4, pw["n"], W, L), dtype=torch.uint8, device=dev)
+
+    def smp_pub(s):
+        def f():
+            cnt[0] += 1
+            s.sample(W, 7, epoch_begin=cnt[0] * 4, epoch_count=4, check=False, out=(ids_p, codes_p))
+        return f
+    dt = time_launches(smp_pub(psr.smp), 20)
+    paths = 4 * pw["n"] * W
+    # SURVEY.md 8d: per path L x (16 B triple + 1 B code) random reads + L x 5 B written; a random read costs a
+    # 64 B sector at least
+    out["sampler_pubmed_dense"] = {"value": paths / dt, "unit": "sampled paths/s", "ms_per_launch": dt * 1e3,
+                                   "hop_table_MB": pw["n"] ** 2 >> 20,
+                                   "algorithmic_GBs": paths * (L * 17 + L * 5) / dt / 1e9,
+                                   "sector_GBs": paths * (L * 2 * 64 + L * 5) / dt / 1e9,
+                                   "frac_of_hbm_peak_at_sector_granularity": paths * (L * 2 * 64 + L * 5) / dt / 1e9 / HBM_PEAK_GBS}
+    gn, u, v, p = pw["graph"]
+    otf = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev, hops="otf")
+    dt = time_launches(smp_pub(otf), 10)
+    out["sampler_pubmed_otf"] = {"value": paths / dt, "unit": "sampled paths/s", "ms_per_launch": dt * 1e3,
+                                 "note": "exact hop codes from CSR lists (no n^2 table): what graphs beyond the "
+                                         "reference's n = 100050 cap use"}
+    del ids_p, codes_p, otf, psr
+
+    # ---- the path-feature gather against HBM: a table that cannot sit in the 256 MB Infinity Cache -------------------
+    Ng, Sg = 1 << 20, 9464                      # Z table [2^20, L, H] fp32 = 2 GB; Pubmed's path count
+    table = torch.randn(Ng, L, H, device=dev)
+    gi = torch.randint(0, Ng, (Sg, W, L), dtype=torch.int32, device=dev)
+    gc = torch.randint(0, L, (Sg, W, L), dtype=torch.uint8, device=dev)
+    rows = torch.empty((Sg * W, L, H), device=dev)
+    sh = _lib.PaggShape(_lib.VARIANT_HOMO, Ng, 1, H, 1, Sg, W, L, 0, 0, 0)
+
+    def gather():
+        _lib.check(lib.pn_pagg_gather(ctx, ctypes.byref(sh), table.data_ptr(), gi.data_ptr(), gc.data_ptr(),
+                                      rows.data_ptr(), _lib.stream_ptr(dev)))
+    dt = time_launches(gather, 20)
+    read_b = Sg * W * (L * H * 4 + L * 5)                  # SURVEY.md §8d: 2068 B/path at L=4, H=128
+    out["gather_hbm_table"] = {"paths": Sg * W, "table_MB": Ng * L * H * 4 >> 20, "ms": dt * 1e3,
+                               "read_GBs": read_b / dt / 1e9, "read_frac_of_hbm_peak": read_b / dt / 1e9 / HBM_PEAK_GBS,
+                               "read_plus_write_GBs": (read_b + Sg * W * L * H * 4) / dt / 1e9,
+                               "read_plus_write_frac_of_hbm_peak": (read_b + Sg * W * L * H * 4) / dt / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_read_bytes_per_path": L * H * 4 + L * 5,
+                               "note": "stand-alone pn_pagg_gather stage: 512-byte rows at random from a 2 GB table (HBM, "
+                                       "not the Infinity Cache), gathered rows written back to HBM"}
+    del rows
+    # the same gather where the product does it: fused into the recurrent forward (rows go HBM -> LDS tile, never back)
+    Nf, Ff = Ng, 16
+    mdl = pathnet_amd.PathNet_homo(Ff, H, 3, L).to(dev).eval()
+    Xf = torch.rand(Nf, Ff, device=dev)
+    self32 = gi[:, 0, 0].contiguous()
+    _lib.check(lib.pn_profile_configure(ctx, 1, -1))
+    with torch.no_grad():
+        for _ in range(6):
+            mdl(Xf, gi, W, L, self32, gc, None)
+    torch.cuda.synchronize()
+    prof = read_profile(lib, names, ctx)
+    _lib.check(lib.pn_profile_configure(ctx, 0, -1))
+    ms = prof["seq_fwd"][0] / prof["seq_fwd"][1]
+    out["fused_gather_hbm_table"] = {"paths": Sg * W, "table_MB": Nf * L * H * 4 >> 20, "seq_fwd_ms": ms,
+                                     "gather_read_GBs": read_b / (ms * 1e-3) / 1e9,
+                                     "gather_read_frac_of_hbm_peak": read_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "inference forward of PathNet_homo on 2^20 nodes: seq_fwd3_kernel gathers the "
+                                             "same rows straight into its LDS tile; the kernel is bound by its MFMA / "
+                                             "weight-fragment stream, not by this read"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline configuration only")
+    ap.add_argument("--workload", choices=["cora", "pubmed"], default="cora",
+                    help="cora = BASELINE.json configs[1], what `value` is quoted on; pubmed = configs[2] as the timed "
+                         "workload (profiling runs: tools/pmc_passes.sh)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,59 +478,21 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    import pathnet_amd
+    import pathnet_amd      # noqa: F401
     from pathnet_amd import _lib
     lib = _lib.load()
+    ctx = _lib.context(dev)
     names = stage_names(lib)
+    info = _lib.DeviceInfo()
+    _lib.check(lib.pn_device_query(ctypes.byref(info)))
 
-    wl = workload(rank, world)
+    if args.workload == "pubmed" and world > 1:
+        raise SystemExit("--workload pubmed is a single-GPU profiling aid")
+    wl = workload(rank, world) if args.workload == "cora" else pubmed_workload()
     n, F, C, H, W, L = wl["n"], wl["F"], wl["C"], wl["H"], wl["W"], wl["L"]
-    gn, u, v, p = wl["graph"]
-    smp = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev)
-    torch.manual_seed(0)
-    model = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.7).to(dev)
-    opt = pathnet_amd.Adam(model.parameters(), lr=0.005, weight_decay=0.0005)   # torch.optim.Adam's update, one launch
-    lossf = pathnet_amd.CrossEntropyLoss()                                      # torch.nn.CrossEntropyLoss(), one launch
-    Y = torch.from_numpy(wl["Y"]).to(dev)
-
     sharded = world > 1 or os.environ.get("PN_BENCH_FORCE_SHARDED") == "1"   # the env hook exercises the N>1 code path on one GPU
-    if not sharded:
-        X = torch.from_numpy(wl["X"]).to(dev)
-        sel = torch.from_numpy(np.flatnonzero(wl["mask"]).astype(np.int64)).to(dev)
-        sel32 = sel.to(torch.int32)
-        node_begin, node_count = 0, n
-        runner = None
-    else:
-        from pathnet_amd import dist as pdist
-        n_loc = wl["n_loc"]
-        node_begin, node_count = rank * n_loc, n_loc
-        X = torch.from_numpy(wl["X"][node_begin:node_begin + n_loc]).to(dev)      # this rank's rows only
-        loc_mask = wl["mask"][node_begin:node_begin + n_loc]
-        sel = torch.from_numpy(np.flatnonzero(loc_mask).astype(np.int64)).to(dev)          # local row ids
-        sel32 = (sel + node_begin).to(torch.int32)                                         # global node ids
-        runner = pdist.ShardedAggregator(model, n_total=n, row_begin=node_begin, row_count=n_loc)
-    S = int(sel.numel())
-    Ysel = Y[sel + (node_begin if sharded else 0)]
-    ids_buf = torch.empty((1, node_count, W, L), dtype=torch.int32, device=dev)
-    codes_buf = torch.empty((1, node_count, W, L), dtype=torch.uint8, device=dev)
-
-    def step(epoch):
-        smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, node_begin=node_begin, node_count=node_count,
-                   draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(ids_buf, codes_buf))
-        ids = ids_buf[0].index_select(0, sel)
-        codes = codes_buf[0].index_select(0, sel)
-        model.train()
-        if runner is None:
-            out = model(X, ids, W, L, sel32, codes, None)
-        else:
-            out = runner(X, ids, W, L, sel32, codes)
-        loss = lossf(out, Ysel)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        if runner is not None:
-            runner.allreduce_grads()
-        opt.step()
-        return loss
+    sr = StepRunner(wl, dev, rank, world, sharded)
+    S = sr.S
 
     def barrier():
         if world > 1:
@@ -236,27 +500,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up, with every stage bracketed by HIP events to find the dominant kernel ----------------
-    _lib.check(lib.pn_profile_configure(1, -1))
-    for e in range(max(1, args.warmup)):
-        step(e)
-    torch.cuda.synchronize()
-    prof = read_profile(lib, names)
-    kernel_stages = {k: v[0] / v[1] for k, v in prof.items()}
-    dominant = max(kernel_stages, key=kernel_stages.get)
-    # ---- timed region: exactly K steps; only the dominant kernel carries an event pair ----------------
-    _lib.check(lib.pn_profile_configure(2, names.index(dominant)))
-    for e in range(2):          # two more untimed steps in exactly the timed configuration
-        step(500 + e)
-    barrier()
-    read_profile(lib, names)    # (drop their event pairs)
-    t0 = time.perf_counter()
-    for e in range(args.steps):
-        step(1000 + e)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dom = read_profile(lib, names)[dominant]
-    dom_ms = dom[0] / dom[1]
+    clk0 = clock_mhz(lib, dev)
+    m = measure(sr, lib, ctx, names, args.steps, args.warmup, barrier)
+    clk1 = clock_mhz(lib, dev)
+    elapsed, dominant, dom_ms = m["elapsed"], m["dominant"], m["dom_ms"]
+    collectives = None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -265,101 +513,35 @@ def main():
         s_tot = torch.tensor([S], dtype=torch.int64, device=dev)
         dist.all_reduce(s_tot)
         S_total = int(s_tot.item())
+        # untimed: a few steps with every collective bracketed by device synchronisation, per rank
+        sr.comm.timing = True
+        k = min(10, args.steps)
+        for e in range(k):
+            sr.step(7000 + e)
+        sr.comm.timing = False
+        mine = {kk: round(v / k * 1e3, 4) for kk, v in sr.comm.seconds.items()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        collectives = {"ms_per_step_by_rank": gathered,
+                       "note": "each collective bracketed by torch.cuda.synchronize (serialised: an upper bound on what "
+                               "the overlapped step pays)",
+                       "bytes_per_step": {"all_gather_Xh": n * H * 4, "reduce_scatter_dXh": n * H * 4,
+                                          "all_reduce_grads": sum(q.numel() for q in sr.model.parameters()) * 4}}
     else:
         S_total = S
     ms_per_step = elapsed / args.steps * 1e3
     value = S_total * W / (elapsed / args.steps)
 
-    # ---- untimed extras on rank 0: per-stage breakdown, sampler-only rate, gather microbenchmark ------
-    _lib.check(lib.pn_profile_configure(1, -1))
-    for e in range(min(10, args.steps)):
-        step(5000 + e)
-    torch.cuda.synchronize()
-    prof = read_profile(lib, names)
-    stages_ms = {k: round(v[0] / v[1], 4) for k, v in prof.items()}
-    _lib.check(lib.pn_profile_configure(0, -1))
-
     P = S * W
-    G4 = 4
-    # LSTM = L*16*H^2 flops per path ([x;h] (2H) x 4H gate columns per step).  The kernels are
-    # charged only what the math requires: h_{-1} = 0, so the W_hh product of step 0 (seq_fwd), the dh_{-1}
-    # product (seq_bwd) and the W_hh gradient of the t = 0 rows (wgrad) are not algorithmic work:
-    # (2L-1)/(2L) of that figure = (2L-1)*8*H^2 = 0.918 MFLOP per path and kernel at L=4, H=128.
-    flops_seq = 2.0 * P * L * (2 * H) * (G4 * H) * (2 * L - 1) / (2 * L)
-    algo = {"seq_fwd": flops_seq, "seq_bwd": flops_seq, "wgrad": flops_seq}
-    if dominant in algo:
-        achieved = algo[dominant] / (dom_ms * 1e-3) / 1e12
-        roofline = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
-                    "peak": round(F32_ON_BF16_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / F32_ON_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                    "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(dom[1]),
-                    "algorithmic_flops_per_launch": algo[dominant],
-                    "mfma_flops_issued_per_launch": 6 * algo[dominant],
-                    "frac_of_bf16_pipe": round(6 * achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                    "frac_of_f32_input_mfma_peak": round(achieved / 157.3, 4),
-                    "note": "fp32 results (1e-5 parity; measured 3e-7 against float64) from the bf16 matrix pipe: "
-                            "fp32 = 3 bf16 planes, 6 MFMAs per product, fp32 accumulate; peak = 2.5 PFLOP/s dense "
-                            "bf16 / 6.  achieved counts ALGORITHMIC fp32 flops = (2L-1)*8*H^2 per path = SURVEY.md "
-                            "§8d's L*16*H^2 minus the step-0 products with h_{-1} = 0"}
-    else:
-        roofline = {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": None, "traffic": None, "avg_launch_ms": round(dom_ms, 4)}
-
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the figure is the
-    # one measured on this workload and committed under profiles/ (null when that file is absent or stale)
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if world == 1 and dominant in tr["hbm_bytes_per_launch"]:
-            roofline["traffic"] = tr["hbm_bytes_per_launch"][dominant]
-            roofline["traffic_source"] = tr["source"]
-    except (OSError, ValueError, KeyError):
-        pass
+    tr, tr_src = pmc_traffic(dominant, "hbm_bytes_per_launch" if args.workload == "cora" else
+                             "pubmed_hbm_bytes_per_launch") if world == 1 else (None, None)
+    roofline = roofline_block(dominant, dom_ms, m["dom_launches"], P, L, H, tr)
+    if tr_src:
+        roofline["traffic_source"] = tr_src
 
     extras = {}
-    if rank == 0:
-        # sampler alone: one epoch of all local nodes per launch
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 50
-        big_e = 16
-        ids_big = torch.empty((big_e, node_count, W, L), dtype=torch.int32, device=dev)
-        codes_big = torch.empty((big_e, node_count, W, L), dtype=torch.uint8, device=dev)
-        smp.sample(W, 99, epoch_count=big_e, node_begin=node_begin, node_count=node_count, out=(ids_big, codes_big))
-        ev0.record()
-        for r in range(reps):
-            smp.sample(W, 99, epoch_begin=r * big_e, epoch_count=big_e, node_begin=node_begin, node_count=node_count,
-                       check=False, out=(ids_big, codes_big))
-        ev1.record()
-        torch.cuda.synchronize()
-        dt = ev0.elapsed_time(ev1) * 1e-3 / reps
-        paths = big_e * node_count * W
-        extras["sampler"] = {"value": paths / dt, "unit": "sampled paths/s", "draws": "philox",
-                             "paths_per_launch": paths, "ms_per_launch": dt * 1e3,
-                             "algorithmic_bytes_per_path": L * (16 + 1) + L * 5,
-                             "achieved_GBs": paths * (L * 17 + L * 5) / dt / 1e9}
-        # the [P, L, H] path-feature gather alone, at Pubmed scale (north_star's HBM-roofline target)
-        Ng, Sg = 19717, 9464
-        table = torch.randn(Ng, L, H, device=dev)
-        gi = torch.randint(0, Ng, (Sg, W, L), dtype=torch.int32, device=dev)
-        gc = torch.randint(0, L, (Sg, W, L), dtype=torch.uint8, device=dev)
-        rows = torch.empty((Sg * W, L, H), device=dev)
-        sh = _lib.PaggShape(_lib.VARIANT_HOMO, Ng, 1, H, 1, Sg, W, L)
-        for _ in range(3):
-            _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), gi.data_ptr(), gc.data_ptr(),
-                                          rows.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        ev0.record()
-        for _ in range(20):
-            _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), gi.data_ptr(), gc.data_ptr(),
-                                          rows.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        ev1.record()
-        torch.cuda.synchronize()
-        dt = ev0.elapsed_time(ev1) * 1e-3 / 20
-        read_b = Sg * W * (L * H * 4 + L * 5)                  # 2068 B/path at L=4, H=128
-        extras["gather_pubmed_scale"] = {"paths": Sg * W, "ms": dt * 1e3, "read_GBs": read_b / dt / 1e9,
-                                         "read_frac_of_hbm_peak": read_b / dt / 1e9 / HBM_PEAK_GBS,
-                                         "read_plus_write_GBs": (read_b + Sg * W * L * H * 4) / dt / 1e9,
-                                         "algorithmic_read_bytes_per_path": L * H * 4 + L * 5,
-                                         "note": "table (40 MB) is cache resident; rows (775 MB) are written to HBM"}
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = extras_single_gpu(lib, ctx, names, dev, sr, args)
 
     result = {
         "metric": "paths aggregated/sec (PAGG fwd+bwd, one training step incl. on-GPU MERW sampling + Adam)",
@@ -368,13 +550,22 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "dtype_note": "fp32 in, fp32 out, fp32 accumulation; the recurrent GEMM products run as 3-plane bf16 splits "
                       "(6 bf16 MFMAs per fp32 product), everything else in fp32",
-        "config": {"workload": "Cora-shaped synthetic (configs[1]): N=%d F=%d C=%d hid=%d path_num=%d path_len=%d, "
+        "config": {"workload": ("Cora-shaped synthetic (configs[1])" if args.workload == "cora" else
+                                "Pubmed-shaped synthetic (configs[2])") + ": N=%d F=%d C=%d hid=%d path_num=%d path_len=%d, "
                                "%d masked nodes = %d paths/step, PathNet_homo, dropout 0.7, Adam" %
                                (n, F, C, H, W, L, S_total, S_total * W),
                    "nodes": n, "paths_per_step": S_total * W, "parallelism": "node-shard x%d" % world},
         "roofline": roofline,
-        "stages_ms": stages_ms,
+        "stages_ms": m["stages_ms"],
+        "device": {"name": info.name.decode(errors="replace"), "arch": info.arch.decode(errors="replace"),
+                   "compute_units": info.compute_units, "max_clock_mhz": info.clock_khz / 1e3,
+                   "shader_clock_mhz_probe": {"before": clk0, "after": clk1},
+                   "note": "probe = shader cycles per 100 MHz wall tick of a one-wave kernel right before / after the "
+                           "timed region (light load: the clock under the MFMA kernels is lower)"},
+        "library_source_hash": source_hash(),
     }
+    if collectives:
+        result["collectives"] = collectives
     result.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(wl)

@@ -15,11 +15,15 @@
  *     retains a pointer past the call.  "dev" in a comment = device (HBM) pointer, "host" = host.
  *   - device work is enqueued on the hipStream_t passed as `stream` (void* here so the header
  *     needs no HIP include; pass torch.cuda.current_stream().cuda_stream).  Device entry points
- *     are asynchronous with respect to the host.  pn_pagg_forward/backward fork a few independent
- *     launches onto one internal second stream per device and join them back (events) before
- *     they return: all their work is ordered before whatever the caller enqueues on `stream` next.
- *   - one host thread per device drives the device entry points (process-per-GPU model); the
- *     host-only entry points (files, tables) are re-entrant and use up to PN_HOST_THREADS threads.
+ *     are asynchronous with respect to the host.
+ *   - the library has NO process-global state.  What outlives a call -- the second stream
+ *     pn_pagg_forward/backward fork a few independent launches onto (joined back with events before
+ *     they return, so all their work is ordered before whatever the caller enqueues on `stream`
+ *     next) and the per-stage timing records -- lives in an opaque pn_context the caller creates for
+ *     one device and destroys when done.  A context serialises nothing: two host threads may drive
+ *     the same device through two contexts; one context must not be used by two threads at once.
+ *     Every device entry point accepts ctx = NULL: everything then runs on `stream` alone, untimed.
+ *   - the host-only entry points (files, tables) are re-entrant and use up to PN_HOST_THREADS threads.
  *   - sizes: n nodes, m edge rows, W walks per node (path_num), L path length, S masked nodes,
  *     P = S*W paths, H hidden size, F input features, C classes.
  */
@@ -32,7 +36,10 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 3 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step */
+#define PN_ABI_VERSION 4 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
+                          * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
+                          *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
+                          *    offsets throughout; pn_clock_probe */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -56,6 +63,18 @@ typedef struct pn_device_info {
     int32_t clock_khz;
 } pn_device_info;
 int pn_device_query(pn_device_info *out);
+
+/* Per-device, per-caller state: one internal non-blocking stream with its fork/join events and the records of
+ * pn_profile_*.  Created on the current HIP device; every call that is handed the context must run with that
+ * device current (checked).  pn_context_destroy waits for the context's own stream and releases it. */
+typedef struct pn_context pn_context;
+int pn_context_create(pn_context **out);
+int pn_context_destroy(pn_context *ctx);
+
+/* Shader clock the device sustains right now (MHz), measured by a short kernel that reads the shader-cycle counter
+ * (s_memtime) against the 100 MHz wall clock -- bench reports carry it so that box-to-box differences can be told
+ * from code differences.  Synchronises `stream`. */
+int pn_clock_probe(double *mhz, void *stream);
 
 /* ================================================================================================
  * Sampler, host side.  Replaces the set-up half of preprocess/gen_merw.cpp main() (:162-179).
@@ -147,7 +166,7 @@ int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t
  * roll of each walk is drawn and discarded (:195-196).
  * status_flag (dev int32, may be NULL) is set to PN_ERR_EMPTY_TABLE if any walk reaches a node with
  * an empty table (the reference exits there). */
-int pn_sample_paths(const pn_sampler_tables *tables, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
+int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tables, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
                     int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
                     uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag, void *stream);
 
@@ -179,8 +198,22 @@ int pn_paths_read_bin(const char *path, int32_t *L_out, int32_t *ids, uint8_t *c
 
 typedef struct pn_pagg_shape {
     int32_t variant;
-    int32_t N, F, H, C; /* nodes, input features, hidden, classes */
-    int32_t S, W, L;    /* masked nodes, paths per node, path length */
+    int32_t N, F, H, C; /* nodes, input features, hidden (a multiple of 32, <= 256), classes */
+    int32_t S, W, L;    /* masked nodes this call aggregates (rows of out), paths per node, path length */
+    /* A call may aggregate a slice of a larger batch: S_total masked nodes in the batch (0 means S), of which this
+     * call computes the pooling groups [group_begin, group_begin + S).  ids / codes / sel / the explicit masks always
+     * describe the WHOLE batch ([S_total, ...]); out / g_out are the S rows of the slice.  For HOMO / PAGG a group
+     * only reads its own rows; HETERO's [W, S] re-view (PathNet_run.py:196-197) makes group g read paths of other
+     * masked nodes of the batch -- with the whole batch's index arrays at hand a slice is still exactly the rows the
+     * reference computes for the whole batch.  This is what node sharding across GPUs (pathnet_amd/dist.py) and the
+     * micro-batches below rely on.  Dropout counters are functions of the position in the whole batch. */
+    int32_t S_total, group_begin;
+    /* > 0: the library walks the S groups in micro-batches of at most batch_groups groups, so that the per-path
+     * tensors of the workspace are sized by batch_groups * W paths instead of S * W (configs with more paths than
+     * HBM holds saved tensors for).  With more than one micro-batch the forward keeps no per-path tensors and the
+     * backward re-runs each micro-batch's recurrence before its BPTT (same seed, same masks); gradients accumulate
+     * across micro-batches and the node-level backward (bank, fc0) runs once at the end.  0: one batch. */
+    int32_t batch_groups;
 } pn_pagg_shape;
 
 /* All pointers are device pointers.  Weights use the reference state_dict layout
@@ -228,19 +261,28 @@ typedef struct pn_pagg_args {
     /* inference: non-zero skips writing the saved-for-backward tensors (gates, cell states, [x|h] rows --
      * ~3.6 KB per path step); pn_pagg_backward must not follow such a forward. */
     int32_t no_save;
+    /* non-zero: Xh and Z = bank(Xh) of the previous pn_pagg_forward on this workspace are still valid (same X, same
+     * fc0 / bank weights, same N, H, L): skip fc0 and the bank.  The validation and test forwards of an epoch
+     * (PathNet_run.py:362, :378) share them this way.  The caller vouches for the precondition. */
+    int32_t reuse_tables;
+    /* non-zero: ids / codes / sel hold only the rows of this call's slice ([S, W, L] / [S]: rows group_begin ..
+     * group_begin + S of the batch) instead of the whole batch.  HOMO / PAGG only (a group reads nothing but its own
+     * rows there); positions in the batch -- dropout counters, explicit masks -- stay batch-wide.  This is what a rank
+     * of the node-sharded path passes: its own paths, no exchange of index arrays. */
+    int32_t index_rows_local;
 } pn_pagg_args;
 
 int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes);
 /* out = forward(...).  Leaves what backward needs in the workspace. */
-int pn_pagg_forward(const pn_pagg_args *args, void *stream);
+int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 /* Gradients of sum(out * g_out) w.r.t. every parameter (overwritten, not accumulated) and X.
  * Must follow a pn_pagg_forward on the same args/workspace. */
-int pn_pagg_backward(const pn_pagg_args *args, void *stream);
+int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 
 /* Stand-alone stages of the same path, exposed for measurement and tests. */
 /* rows[q, t, :] = table[(node(q,t) * L + code(q,t)), :] for the variant's index plan: the
  * [P, L, H] path-feature gather with the distance code fused in (PathNet_run.py:179 / :246). */
-int pn_pagg_gather(const pn_pagg_shape *shape, const float *table /* [N, L, H] */, const int32_t *ids,
+int pn_pagg_gather(pn_context *ctx, const pn_pagg_shape *shape, const float *table /* [N, L, H] */, const int32_t *ids,
                    const uint8_t *codes, float *rows /* [P, L, H] */, void *stream);
 
 /* C[m*ldc + n] = act( sum_k A[m*sAm + k*sAk] * B[n*sBn + k*sBk] + bias[n] ): the fp32 MFMA GEMM
@@ -255,13 +297,13 @@ int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_
  * workgroups (deterministic: chunk sums + a fixed-order finish), which is what fills the GPU when rows * out_f is
  * small; workspace may be NULL (one workgroup per output tile). */
 #define PN_LINEAR_SPLIT_MAX 8
-int pn_linear_forward(const float *X, const float *W, const float *b, int32_t rows, int32_t in_f, int32_t out_f,
+int pn_linear_forward(pn_context *ctx, const float *X, const float *W, const float *b, int32_t rows, int32_t in_f, int32_t out_f,
                       int32_t relu, float *Y, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* Backward of Y = act(X . W^T + b) for `rows` rows (nn.Linear, fc0 of the path: PathNet_run.py:175 / :242):
  * dY [rows, out_f] is gated by [gate > 0] when gate != NULL (ReLU backward, gate = Y), then
  * g_W [out_f, in_f] = dY^T . X,  g_b [out_f] = colsum(dY),  g_X [rows, in_f] = dY . W.  Any output may be NULL. */
-int pn_linear_backward(const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
+int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
                        int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream);
 
 /* ---- the MERW transition probabilities: what writes edge_input/<name>.in ----------------------
@@ -303,15 +345,15 @@ int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, flo
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]);
 
 /* ================================================================================================
- * Per-stage timing with HIP events recorded on the caller's stream (measurement only).
+ * Per-stage timing with HIP events recorded on the caller's stream (measurement only; state in the context).
  * mode 0: off (default).  mode 1: bracket every stage.  mode 2: bracket only stage `stage`.
  * pn_profile_read waits for the recorded events, adds the elapsed times into ms_sum[i] / count[i]
  * (arrays of pn_profile_stage_count() entries) and clears the recording.
  * ============================================================================================== */
-int pn_profile_configure(int32_t mode, int32_t stage);
+int pn_profile_configure(pn_context *ctx, int32_t mode, int32_t stage);
 int pn_profile_stage_count(void);
 const char *pn_profile_stage_name(int32_t stage);
-int pn_profile_read(double *ms_sum, int64_t *count);
+int pn_profile_read(pn_context *ctx, double *ms_sum, int64_t *count);
 
 #ifdef __cplusplus
 }

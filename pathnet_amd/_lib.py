@@ -13,7 +13,7 @@ PN_OK = 0
 PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
-ABI_VERSION = 3               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
+ABI_VERSION = 4               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
 LINEAR_SPLIT_MAX = 8          # PN_LINEAR_SPLIT_MAX: workspace floats per output element of pn_linear_forward
 
@@ -42,8 +42,11 @@ class SamplerTables(ctypes.Structure):
 
 
 class PaggShape(ctypes.Structure):
+    """struct pn_pagg_shape.  S_total / group_begin: this call computes the pooling groups [group_begin, +S) of a
+    batch of S_total masked nodes (0 = S); batch_groups > 0: internal micro-batches of that many groups."""
     _fields_ = [("variant", ctypes.c_int32), ("N", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
-                ("C", ctypes.c_int32), ("S", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32)]
+                ("C", ctypes.c_int32), ("S", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32),
+                ("S_total", ctypes.c_int32), ("group_begin", ctypes.c_int32), ("batch_groups", ctypes.c_int32)]
 
 
 class PaggArgs(ctypes.Structure):
@@ -55,7 +58,8 @@ class PaggArgs(ctypes.Structure):
                  ("g_out", vp), ("g_X", vp)] +
                 [("g_" + k, vp) for k in ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w",
                                           "att_b", "fc2_w", "fc2_b")] +
-                [("Xh_in", vp), ("g_Xh", vp), ("no_save", ctypes.c_int32)])
+                [("Xh_in", vp), ("g_Xh", vp), ("no_save", ctypes.c_int32), ("reuse_tables", ctypes.c_int32),
+                 ("index_rows_local", ctypes.c_int32)])
 
 
 # name -> (restype, argtypes): every symbol include/pathnet_hip.h declares
@@ -69,6 +73,9 @@ SIGNATURES = {
     "pn_abi_version": (ctypes.c_int, []),
     "pn_last_error": (ctypes.c_char_p, []),
     "pn_device_query": (ctypes.c_int, [ctypes.POINTER(DeviceInfo)]),
+    "pn_context_create": (ctypes.c_int, [ctypes.POINTER(vp)]),
+    "pn_context_destroy": (ctypes.c_int, [vp]),
+    "pn_clock_probe": (ctypes.c_int, [c_f64p, vp]),
     "pn_edges_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, c_f64p, ctypes.c_int64]),
     "pn_pairs_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, ctypes.c_int64]),
     "pn_uniform_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, c_i64p, c_i32p, c_i32p, c_i32p,
@@ -82,7 +89,7 @@ SIGNATURES = {
     "pn_glibc_draws": (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64, c_i32p]),
     "pn_sample_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                                  ctypes.c_int32, c_i64p]),
-    "pn_sample_paths": (ctypes.c_int, [ctypes.POINTER(SamplerTables), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+    "pn_sample_paths": (ctypes.c_int, [vp, ctypes.POINTER(SamplerTables), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                        vp, vp, vp, ctypes.c_int64, vp, vp]),
     "pn_paths_write_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32,
@@ -91,20 +98,20 @@ SIGNATURES = {
     "pn_paths_write_bin": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32]),
     "pn_paths_read_bin": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i32p, c_u8p, ctypes.c_int64, c_i64p]),
     "pn_pagg_workspace_bytes": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
-    "pn_pagg_forward": (ctypes.c_int, [ctypes.POINTER(PaggArgs), vp]),
-    "pn_pagg_backward": (ctypes.c_int, [ctypes.POINTER(PaggArgs), vp]),
-    "pn_pagg_gather": (ctypes.c_int, [ctypes.POINTER(PaggShape), vp, vp, vp, vp, vp]),
+    "pn_pagg_forward": (ctypes.c_int, [vp, ctypes.POINTER(PaggArgs), vp]),
+    "pn_pagg_backward": (ctypes.c_int, [vp, ctypes.POINTER(PaggArgs), vp]),
+    "pn_pagg_gather": (ctypes.c_int, [vp, ctypes.POINTER(PaggShape), vp, vp, vp, vp, vp]),
     "pn_gemm_f32": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp,
                                    ctypes.c_int64, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                    vp]),
-    "pn_profile_configure": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32]),
+    "pn_profile_configure": (ctypes.c_int, [vp, ctypes.c_int32, ctypes.c_int32]),
     "pn_profile_stage_count": (ctypes.c_int, []),
     "pn_profile_stage_name": (ctypes.c_char_p, [ctypes.c_int32]),
-    "pn_profile_read": (ctypes.c_int, [c_f64p, c_i64p]),
-    "pn_linear_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp,
+    "pn_profile_read": (ctypes.c_int, [vp, c_f64p, c_i64p]),
+    "pn_linear_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp,
                                          vp, ctypes.c_int64, vp]),
-    "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp,
-                                          vp]),
+    "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp,
+                                          vp, vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
     "pn_merw_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, c_i64p]),
     "pn_merw_probabilities": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, vp, vp, vp, vp, vp, c_f64p, ctypes.c_int32,
@@ -134,6 +141,45 @@ def load():
             raise ImportError("libpathnet_hip.so ABI version mismatch")
         _lib = lib
     return _lib
+
+
+_contexts = {}
+
+
+def context(device):
+    """This process's pn_context for a CUDA device (created at first use with that device current, destroyed at
+    interpreter exit).  The context owns the library's second stream and the pn_profile_* records; pass it to every
+    device entry point, inside ``with torch.cuda.device(device)``."""
+    import torch
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    ctx = _contexts.get(idx)
+    if ctx is None:
+        lib = load()
+        h = vp()
+        with torch.cuda.device(idx):
+            check(lib.pn_context_create(ctypes.byref(h)))
+        ctx = _contexts[idx] = vp(h.value)
+        if len(_contexts) == 1:
+            import atexit
+            atexit.register(_destroy_contexts)
+    return ctx
+
+
+def _destroy_contexts():
+    if _lib is None:
+        return
+    for h in _contexts.values():
+        try:
+            _lib.pn_context_destroy(h)
+        except Exception:       # interpreter shutdown: the HIP runtime may already be gone
+            pass
+    _contexts.clear()
+
+
+def stream_ptr(device):
+    import torch
+    return vp(torch.cuda.current_stream(device).cuda_stream)
 
 
 def check(rc):

@@ -478,6 +478,8 @@ int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, con
     std::vector<int64_t> start((size_t)n + 1, 0);
     for (int64_t e = 0; e < m; e++) {
         if (u[e] < 0 || u[e] >= n) PN_FAIL(PN_ERR_ARG, "edge row %lld: source %d out of range", (long long)e, u[e]);
+        // the targets become the A / B entries the walker uses as node ids: same bound
+        if (v[e] < 0 || v[e] >= n) PN_FAIL(PN_ERR_ARG, "edge row %lld: target %d out of range", (long long)e, v[e]);
         start[(size_t)u[e] + 1]++;
     }
     for (int32_t i = 0; i < n; i++) start[(size_t)i + 1] += start[i];
@@ -777,7 +779,8 @@ int pn_paths_write_text(const char *path, const int32_t *ids, const uint8_t *cod
     for (int i = 0; i < T; i++) off[i + 1] += off[i];
     std::atomic<int> failed_errno(0);
     run_threads(T, [&](int i) {
-        const size_t line_max = (size_t)L * (12 + 5) + 4;
+        // per path node at most "-2147483648, " (13) for the id and "255, " (5) for the code, plus "[" and "]\n"
+        const size_t line_max = (size_t)L * (13 + 5) + 4;
         const int64_t block = 1 << 14;
         std::vector<char> buf(line_max * (size_t)std::min<int64_t>(block, std::max<int64_t>(lo[i + 1] - lo[i], 1)));
         int64_t cursor = off[i];

@@ -39,17 +39,25 @@ GlibcState glibc_apply(const GlibcPoly &p, const GlibcState &st);
 // state whose s[0] >> 1 is the first rand() after srand(seed)
 GlibcState glibc_seed_state(uint32_t seed);
 
-// ---- per-stage HIP-event timing (pn_profile_*) -------------------------------------------------------
+// ---- pn_context: the only state that outlives a call (pn_context.hip) ------------------------------------
 enum Stage {
     ST_SAMPLER_FILL = 0, ST_SAMPLER_WALK, ST_GATHER, ST_FC0, ST_BANK, ST_PLAN_PACK, ST_SEQ_FWD, ST_POOL_FWD,
     ST_FC2_GRAD, ST_POOL_BWD, ST_SEQ_BWD, ST_WGRAD, ST_BIAS_GRAD, ST_BANK_BWD, ST_FC0_BWD, ST_COUNT
 };
-// true while pn_profile_configure(1, ...) brackets every stage: stages then run back to back on one stream
-bool profiling_every_stage();
-// RAII bracket: records a start event now and a stop event at scope exit when profiling selects `stage`
+// true while pn_profile_configure(ctx, 1, ...) brackets every stage: stages then run back to back on one stream
+bool profiling_every_stage(const pn_context *ctx);
+// ctx == nullptr is fine everywhere: no timing, no second stream.  Fails when the context belongs to another device.
+int context_check_device(const pn_context *ctx);
+// the context's second stream, forked from `stream` (event) -- nullptr when there is no context
+void *context_fork(pn_context *ctx, void *stream);
+// records the join event on the second stream; context_join makes `stream` wait for it
+int context_record_join(pn_context *ctx);
+int context_join(pn_context *ctx, void *stream);
+// RAII bracket: records a start event now and a stop event at scope exit when the context's profiling selects `stage`
 struct StageTimer {
-    StageTimer(int stage, void *stream);
+    StageTimer(pn_context *ctx, int stage, void *stream);
     ~StageTimer();
+    pn_context *ctx;
     int slot;
     void *stream;
 };

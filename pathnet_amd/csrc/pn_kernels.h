@@ -134,6 +134,25 @@ __device__ __forceinline__ void wait_frag(f32x4 (&b)[G]) {
     else wait_vm<N>(b[0], b[1], b[2], b[3]);
 }
 
+// element at `bytes` (32-bit, zero-extended) past a wave-uniform 64-bit base: the form hipcc turns into
+// global_load/store with an SGPR base and ONE offset VGPR (a 64-bit index would cost an address pair per access)
+template <class T>
+__device__ __forceinline__ T &at_bytes(T *base, uint32_t bytes) {
+    return *reinterpret_cast<T *>(reinterpret_cast<unsigned char *>(base) + bytes);
+}
+template <class T>
+__device__ __forceinline__ const T &at_bytes(const T *base, uint32_t bytes) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const unsigned char *>(base) + bytes);
+}
+
+// the lane id (0..63) recomputed from the hardware, never common-subexpression'd: per-step address arithmetic derived
+// from it does not become a set of loop invariants living (and spilling) across the MFMA loops
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -250,30 +250,6 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(const float *__restric
         *dst = v;
 }
 
-// max K chunks of a split GEMM (sizes the partial buffer)
-constexpr int GEMM_MAX_SPLIT = 8;
-
-int launch_gemm_split(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
-                      int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
-                      int mode, float *partial) {
-    const int tiles = ((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
-    int nz = tiles > 0 ? (512 + tiles - 1) / tiles : 1;                // aim at ~2 workgroups per CU
-    if (nz > GEMM_MAX_SPLIT) nz = GEMM_MAX_SPLIT;
-    if (nz > K / (2 * GEMM_KT)) nz = K / (2 * GEMM_KT);                // at least two K tiles per chunk
-    if (nz <= 1 || !partial || M <= 0 || N <= 0)
-        return launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 1);
-    int kchunk = (K + nz - 1) / nz;
-    kchunk = (kchunk + GEMM_KT - 1) / GEMM_KT * GEMM_KT;
-    nz = (K + kchunk - 1) / kchunk;
-    if (int rc = launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, partial, N, nullptr, M, N, K, 0, GEMM_PARTIAL, nz))
-        return rc;
-    const int64_t n = (int64_t)M * N;
-    hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, nz, M, N,
-                       bias, relu, mode, C, ldc);
-    PN_CHECK_HIP(hipGetLastError());
-    return PN_OK;
-}
-
 // out[n] (+)= sum_m A[m*ld + n] * [gate[m*ld+n] > 0]      (bias gradients)
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, const float *__restrict__ gate,
                                                      int64_t ld, int M, int N, int rows_per_block,
@@ -304,38 +280,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A
 //                            HETERO    r = q*L + t, node ids[r % P, L-1 - r / P]  (flip + reshape, :182-183)
 //   and always the code codes[q, t] (:184 / :248).
 // ================================================================================================
-__device__ __forceinline__ void plan_entry(int variant, const int32_t *ids, const uint8_t *codes, int S, int W, int L,
-                                           int slot, int t, int &q, int &node, int &code) {
-    const int P = S * W;
+// A call may cover a slice of the batch (pn_pagg_shape: S_total, group_begin): `slot` below is the position in the WHOLE
+// batch's slot' order, (group_begin + local group) * W + member; ids / codes are the whole batch's arrays.
+struct PlanDims {
+    int S_total, W, L, N;
+    int64_t P_total;          // S_total * W
+    int64_t row_base;         // batch position of row 0 of ids / codes (non-zero: the arrays hold a slice; HOMO / PAGG)
+};
+__device__ __forceinline__ void plan_entry(int variant, const int32_t *ids, const uint8_t *codes, const PlanDims &d,
+                                           int64_t slot, int t, int64_t &q, int &node, int &code) {
     if (variant == PN_VARIANT_HETERO) {
-        const int g = slot / W, mem = slot - g * W;
-        q = mem * S + g;
-        const int64_t r = (int64_t)q * L + t;
-        node = ids[(r % P) * L + (L - 1 - (int)(r / P))];
+        const int64_t g = slot / d.W, mem = slot - g * d.W;
+        q = mem * d.S_total + g;
+        const int64_t r = q * d.L + t;
+        node = ids[(r % d.P_total) * d.L + (d.L - 1 - (int)(r / d.P_total))];
     } else {
         q = slot;
-        node = ids[(int64_t)q * L + t];
+        node = ids[(q - d.row_base) * d.L + t];
     }
-    code = codes[(int64_t)q * L + t];
+    code = codes[(q - d.row_base) * d.L + t];
 }
 
-__global__ void plan_kernel(int variant, const int32_t *__restrict__ ids, const uint8_t *__restrict__ codes, int S,
-                            int W, int L, int N, int32_t *__restrict__ rowidx, int32_t *__restrict__ egoidx,
-                            int32_t *__restrict__ slotof) {
+// slots [slot_begin, slot_begin + count) of the batch -> rowidx / egoidx / slotof of the local slots 0 .. count-1
+__global__ void plan_kernel(int variant, const int32_t *__restrict__ ids, const uint8_t *__restrict__ codes, PlanDims d,
+                            int64_t slot_begin, int64_t count, int32_t *__restrict__ rowidx,
+                            int32_t *__restrict__ egoidx, int32_t *__restrict__ slotof) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t P = (int64_t)S * W;
-    if (i >= P * L) return;
-    const int slot = (int)(i / L), t = (int)(i - (int64_t)slot * L);
-    int q, node, code;
-    plan_entry(variant, ids, codes, S, W, L, slot, t, q, node, code);
-    node = min(max(node, 0), N - 1);
-    code = min(code, L - 1);
-    rowidx[i] = node * L + code;
+    if (i >= count * d.L) return;
+    const int64_t ls = i / d.L;
+    const int t = (int)(i - ls * d.L);
+    int64_t q;
+    int node, code;
+    plan_entry(variant, ids, codes, d, slot_begin + ls, t, q, node, code);
+    node = min(max(node, 0), d.N - 1);
+    code = min(code, d.L - 1);
+    rowidx[i] = node * d.L + code;
     if (t == 0) {
-        slotof[slot] = q;
+        slotof[ls] = (int32_t)q;      // position in the whole batch: what the dropout counters / explicit masks index
         // attention ego: HOMO uses the transformed row of (q, step 0) (ego_full, :259-260);
         // HETERO uses the untransformed Xh row of path q's first node (neis[0], :199)
-        egoidx[slot] = variant == PN_VARIANT_HETERO ? min(max(ids[(int64_t)q * L], 0), N - 1) : node * L + code;
+        egoidx[ls] = variant == PN_VARIANT_HETERO ? min(max(ids[(q - d.row_base) * d.L], 0), d.N - 1) : node * d.L + code;
     }
 }
 
@@ -343,19 +327,21 @@ __global__ void plan_kernel(int variant, const int32_t *__restrict__ ids, const 
 template <int VEC>
 __global__ __launch_bounds__(256) void gather_kernel(int variant, const float *__restrict__ table,
                                                      const int32_t *__restrict__ ids,
-                                                     const uint8_t *__restrict__ codes, int S, int W, int L, int N,
-                                                     int H, float *__restrict__ rows) {
+                                                     const uint8_t *__restrict__ codes, PlanDims d, int64_t slot_begin,
+                                                     int64_t count, int H, float *__restrict__ rows) {
     const int hv = H / VEC;
-    const int64_t total = (int64_t)S * W * L * hv;
+    const int64_t total = count * d.L * hv;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / hv;
         const int c = (int)(i - row * hv);
-        const int slot = (int)(row / L), t = (int)(row - (int64_t)slot * L);
-        int q, node, code;
-        plan_entry(variant, ids, codes, S, W, L, slot, t, q, node, code);
-        node = min(max(node, 0), N - 1);
-        code = min(code, L - 1);
-        const int64_t src = ((int64_t)node * L + code) * hv + c;
+        const int64_t ls = row / d.L;
+        const int t = (int)(row - ls * d.L);
+        int64_t q;
+        int node, code;
+        plan_entry(variant, ids, codes, d, slot_begin + ls, t, q, node, code);
+        node = min(max(node, 0), d.N - 1);
+        code = min(code, d.L - 1);
+        const int64_t src = ((int64_t)node * d.L + code) * hv + c;
         if (VEC == 4)
             reinterpret_cast<float4 *>(rows)[i] = reinterpret_cast<const float4 *>(table)[src];
         else
@@ -375,10 +361,11 @@ struct SeqFwdParams {
                             //                the weight-gradient GEMM of the backward reads them back; may be null
     uint8_t *keep;          // [P, L, H/4]    built-in dropout: keep bits of columns 4c .. 4c+3 in bits 0-3 (the backward
                             //                reads them instead of re-drawing the Philox stream); may be null
-    int P, L;
+    int P, L;               // slots of this launch (one micro-batch), path length
+    int64_t Pmask;          // slots of the WHOLE batch: the dropout counters / the explicit mask are [L, Pmask, H]
     float p_drop;
     uint64_t seed;
-    const float *mask;      // [L, P, H] explicit mask (reference order: original slot q) or null
+    const float *mask;      // [L, Pmask, H] explicit mask (reference order: original slot q) or null
 };
 
 // ================================================================================================
@@ -424,7 +411,7 @@ __global__ void pack_fwd3_kernel(const float *__restrict__ w_ih, const float *__
 // waves per SIMD the forward kernel is compiled for: H = 256 fills the LDS with one workgroup of 8 waves, H = 32 is
 // a single wave per workgroup (no register cap: a spill next to the asm loads would be a hazard)
 template <int H, int RG>
-constexpr int fwd_waves() { return H == 32 && RG == 1 ? 1 : (H >= 256 || RG > 1) ? 2 : PN_FWD_WAVES; }
+constexpr int fwd_waves() { return H == 32 && RG == 1 ? 1 : (H > 128 || RG > 1) ? 2 : PN_FWD_WAVES; }
 
 template <int H, int G, int RG>
 __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fwd3_kernel(SeqFwdParams p) {
@@ -440,10 +427,11 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);  // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
     const int ws = wave % NW, r0 = 32 * (wave / NW);            // column slice / first tile row of this wave
     const int q0 = blockIdx.x * MT;
     const int col = 32 * ws + li;
+    const int ws_u = __builtin_amdgcn_readfirstlane(ws);        // the wave's column slice as a scalar (weight stream base)
 
     for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = q0 + i / p.L < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
     for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
@@ -453,6 +441,14 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     for (int r = 0; r < 16; r++) cst[r] = 0.0f;
     const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     const bool builtin_drop = !p.mask && p.p_drop > 0.0f;
+    // per-path tensors are addressed as a 64-bit tile base (wave-uniform: SGPRs) + a 32-bit offset inside the tile,
+    // so no tensor size is bounded by 2^32 elements
+    const size_t tile_row = (size_t)q0 * (size_t)p.L;                       // first [P, L] row of this tile
+    uint8_t *keep_t = p.keep ? p.keep + tile_row * (H / 4) : nullptr;
+    float4 *xh4_t = p.xh ? reinterpret_cast<float4 *>(p.xh) + tile_row * (2 * H / 4) : nullptr;
+    float *xh_t = p.xh ? p.xh + tile_row * (2 * H) : nullptr;
+    float *saved_t = p.saved ? p.saved + tile_row * (SV * H) : nullptr;
+    float *hn_t = p.hn + (size_t)q0 * H;
     __syncthreads();
 
     // ---- coalesced row gather of x_{t+1} (H*4 bytes per row).  With PREFETCH_X (two workgroups per CU) the loads
@@ -463,7 +459,8 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     constexpr int NLD = 4;        // float4 per thread = MT * (H/4) / NT
     f32x4 xr[NLD];
     uint32_t keepbits = 0;        // 4 bits per row of this thread
-    int tid_g = tid;              // opaque copy, refreshed per step: the per-row offsets derived from it would
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int tid_g = tid;              // re-derived per step (fresh_lane): the per-row offsets derived from it would
                                   // otherwise live (and spill) across the MFMA loop as loop invariants
     auto gather_issue = [&](int t) {
 #pragma unroll
@@ -478,7 +475,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             for (int i = 0; i < NLD; i++) {
                 const int idx = tid_g + NT * i;
                 const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-                const float4 m = dropout4(p.seed, ((uint64_t)t * p.P + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
+                const float4 m = dropout4(p.seed, ((uint64_t)t * p.Pmask + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
                 bits |= ((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) |
                          (m.w != 0.f ? 8u : 0u)) << (4 * i);
             }
@@ -498,7 +495,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             if (p.mask) {
                 if (q < p.P) {
                     const float4 m = reinterpret_cast<const float4 *>(
-                        p.mask)[((int64_t)t * p.P + s_slotof[row]) * (H / 4) + c4];
+                        p.mask)[((int64_t)t * p.Pmask + s_slotof[row]) * (H / 4) + c4];
                     v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
                 }
             } else if (builtin_drop) {
@@ -507,7 +504,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
                 v.y = b & 2u ? v.y * keep_scale : 0.0f;
                 v.z = b & 4u ? v.z * keep_scale : 0.0f;
                 v.w = b & 8u ? v.w * keep_scale : 0.0f;
-                if (p.keep && q < p.P) p.keep[((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(H / 4) + c4] = (uint8_t)(b & 15u);
+                if (keep_t && q < p.P) keep_t[((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(H / 4) + c4] = (uint8_t)(b & 15u);
             }
             uint32_t a0, a1, a2, b0, b1, b2;
             split3(v.x, v.y, a0, a1, a2);
@@ -516,12 +513,10 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             *reinterpret_cast<uint2 *>(d) = make_uint2(a0, b0);
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
             *reinterpret_cast<uint2 *>(d + 2 * PLANE) = make_uint2(a2, b2);
-            if (p.xh && q < p.P) {
-                // 32-bit element offsets (check_shape bounds every tensor below 2^32 elements)
-                float4 *xo4 = reinterpret_cast<float4 *>(p.xh);
-                const uint32_t xo = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4;
-                xo4[xo] = v;
-                if (t == 0) xo4[xo + H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xh4_t && q < p.P) {
+                float4 *xo = &at_bytes(xh4_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4) * 16u);
+                xo[0] = v;
+                if (t == 0) xo[H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -531,7 +526,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
 
     for (int t = 0; t < p.L; t++) {
         PN_STAMP(4 * t + 0);
-        asm volatile("" : "+v"(tid_g));
+        tid_g = wave_u * 64 + fresh_lane();
         if (PREFETCH_X && t + 1 < p.L) gather_issue(t + 1);
         PN_STAMP(4 * t + 1);
 
@@ -551,10 +546,10 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
         {
             const int nsteps = t == 0 ? KX : KS;
             // wave-uniform stream base in SGPRs, one VGPR of lane offset (pn_kernels.h: async_load_frags)
-            const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.Wp) +
-                                      (size_t)__builtin_amdgcn_readfirstlane(ws) * (KS * 3 * G * 1024);
-            const uint32_t voff = lane * 16;
-            const unsigned char *arow = ldsb + (r0 + li) * PB + 16 * hk;
+            const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.Wp) + (size_t)ws_u * (KS * 3 * G * 1024);
+            const int lane_k = fresh_lane();
+            const uint32_t voff = lane_k * 16;
+            const unsigned char *arow = ldsb + (r0 + (lane_k & 31)) * PB + 16 * (lane_k >> 5);
             u32x4 P0a[G], P0b[G], P1[G], P2[G];
             auto load = [&](u32x4 (&B)[G], int s, int pl) {
                 async_load_frags<G>(B, wb + (size_t)(s * 3 + pl) * (G * 1024), voff);
@@ -618,11 +613,11 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
 
         // ---- cell update in registers; h_t goes back to LDS (split) for the next step ----------------------
         float hv[16];
+        const int lane_o = fresh_lane();    // row offsets are re-derived in every step: hoisted out of the t loop they spill
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int row = r0 + acc_row(r, lane);
-            int q = q0 + row;
-            asm volatile("" : "+v"(q));     // recompute the row offsets here: hoisted out of the t loop they spill
+            const int row = r0 + acc_row(r, lane_o);
+            const int q = q0 + row;
             float h;
             if (G == 4) {
                 const float ig = sigmoidf_(acc[0][r]);
@@ -632,21 +627,21 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
                 const float c = fg * cst[r] + ig * gg;
                 cst[r] = c;
                 h = og * tanhf_(c);
-                if (p.saved && q < p.P) {
-                    const uint32_t so = ((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
-                    p.saved[so] = ig; p.saved[so + H] = fg; p.saved[so + 2 * H] = gg; p.saved[so + 3 * H] = og;
-                    p.saved[so + 4 * H] = c;
+                if (saved_t && q < p.P) {
+                    // (constant displacements on top of base + zext(offset) fold into the instructions' immediates)
+                    float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
+                    sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
                 }
             } else {
                 h = tanhf_(acc[0][r]);
-                if (p.saved && q < p.P) p.saved[((uint32_t)q * (uint32_t)p.L + t) * (uint32_t)H + col] = h;
+                if (saved_t && q < p.P) at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)H + col) * 4u) = h;
             }
             hv[r] = h;
             if (q < p.P) {
                 if (t == p.L - 1)
-                    p.hn[(uint32_t)q * (uint32_t)H + col] = h;
-                else if (p.xh)
-                    p.xh[((uint32_t)q * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col] = h;
+                    at_bytes(hn_t, ((uint32_t)row * (uint32_t)H + col) * 4u) = h;
+                else if (xh_t)
+                    at_bytes(xh_t, (((uint32_t)row * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col) * 4u) = h;
             }
         }
         if (t + 1 < p.L) {
@@ -654,7 +649,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
                 uint32_t h0, h1, h2;
                 split3(hv[r], hv[r + 1], h0, h1, h2);
-                unsigned char *d = ldsb + (r0 + acc_row(r, lane)) * PB + 2 * (H + col);
+                unsigned char *d = ldsb + (r0 + acc_row(r, lane_o)) * PB + 2 * (H + col);
                 *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
                 *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
                 *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
@@ -662,7 +657,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
                 *reinterpret_cast<uint16_t *>(d + 2 * PLANE) = (uint16_t)h2;
                 *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(h2 >> 16);
             }
-            asm volatile("" : "+v"(tid_g));
+            tid_g = wave_u * 64 + fresh_lane();
             if (!PREFETCH_X) gather_issue(t + 1);
             gather_commit(t + 1);     // (every wave is past its reads of x_t)
             __syncthreads();
@@ -676,6 +671,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
 // ================================================================================================
 struct PoolParams {
     int variant, S, W, H, C;
+    int64_t goff;           // position of local group 0 in the whole batch (dropout counters / explicit mask rows)
     const float *hn;        // [P, H] in slot' order
     const float *ego_tab;   // Z (HOMO) or Xh (HETERO)
     const int32_t *egoidx;  // [P] row of ego_tab
@@ -773,12 +769,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
 #pragma unroll 8
         for (int mem = 0; mem < p.W; mem++) acc += sc[mem] * p.hn[((int64_t)g * p.W + mem) * H + j];
         float a = ego[j], b = acc * inv_w;
+        const uint64_t gg = (uint64_t)(p.goff + g);
         if (p.mask) {
-            a *= p.mask[(int64_t)g * 2 * H + j];
-            b *= p.mask[(int64_t)g * 2 * H + H + j];
+            a *= p.mask[gg * 2 * H + j];
+            b *= p.mask[gg * 2 * H + H + j];
         } else if (p.p_drop > 0.0f) {
-            const float4 m0 = dropout4(p.seed, ((uint64_t)g * 2 * H + j) >> 2, 2u, p.p_drop);
-            const float4 m1 = dropout4(p.seed, ((uint64_t)g * 2 * H + H + j) >> 2, 2u, p.p_drop);
+            const float4 m0 = dropout4(p.seed, (gg * 2 * H + j) >> 2, 2u, p.p_drop);
+            const float4 m1 = dropout4(p.seed, (gg * 2 * H + H + j) >> 2, 2u, p.p_drop);
             const int e0 = j & 3;
             a *= e0 == 0 ? m0.x : e0 == 1 ? m0.y : e0 == 2 ? m0.z : m0.w;
             b *= e0 == 0 ? m1.x : e0 == 1 ? m1.y : e0 == 2 ? m1.z : m1.w;
@@ -803,6 +800,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
 // ---- pooling / attention / classifier backward: one wavefront per group -------------------------
 struct PoolBwdParams {
     int variant, S, W, H, C;
+    int64_t goff;
     const float *hn, *ego_tab;
     const int32_t *egoidx, *sel;
     const float *att_w, *fc2_w, *g_out, *coef, *rawsc;
@@ -845,12 +843,13 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 a += go * p.fc2_w[(int64_t)c * 2 * H + j];
                 b += go * p.fc2_w[(int64_t)c * 2 * H + H + j];
             }
+            const uint64_t gg = (uint64_t)(p.goff + g);
             if (p.mask) {
-                a *= p.mask[(int64_t)g * 2 * H + j];
-                b *= p.mask[(int64_t)g * 2 * H + H + j];
+                a *= p.mask[gg * 2 * H + j];
+                b *= p.mask[gg * 2 * H + H + j];
             } else if (p.p_drop > 0.0f) {
-                a *= dropout1(p.seed, (uint64_t)g * 2 * H + j, 2u, p.p_drop);
-                b *= dropout1(p.seed, (uint64_t)g * 2 * H + H + j, 2u, p.p_drop);
+                a *= dropout1(p.seed, gg * 2 * H + j, 2u, p.p_drop);
+                b *= dropout1(p.seed, gg * 2 * H + H + j, 2u, p.p_drop);
             }
             atomicAdd(&p.dXh[(int64_t)p.sel[g] * H + j], a);
             dp[j] = b * inv_w;
@@ -952,6 +951,7 @@ struct SeqBwdParams {
     float *dG;              // [P, L, G*H] pre-activation gate gradients (input of the weight-gradient GEMM)
     float *dZ;              // [N*L, H]    += d x_t   (atomic scatter: the backward of the row gather)
     int P, L;
+    int64_t Pmask;          // slots of the whole batch (explicit mask [L, Pmask, H])
     float p_drop;
     uint64_t seed;
     const float *mask;
@@ -1012,6 +1012,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
     // are the ones still in the 256 MB Infinity Cache when the backward starts
     const int q0 = (PN_BWD_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * MT;
     const int col = 32 * ws + li;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave), ws_u = __builtin_amdgcn_readfirstlane(ws);
 
     for (int i = tid; i < MT * p.L; i += NT) {
         const int q = q0 + i / p.L;
@@ -1020,15 +1021,22 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
     for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
 
     const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
+    // 64-bit tile bases (wave-uniform) + 32-bit offsets inside the tile; rows past P read the tile's clamped last row
+    const size_t tile_row = (size_t)q0 * (size_t)p.L;
+    const float *saved_t = p.saved + tile_row * (SV * H);
+    float *dG_t = p.dG + tile_row * GH;
+    const uint8_t *keep_t = p.keep ? p.keep + tile_row * (H / 4) : nullptr;
+    const float *dhn_t = p.dhn + (size_t)q0 * H;
+    const int rows_here = min(MT, p.P - q0);            // >= 1
     f32x16 dh, dc, cnext;   // cnext: c_t of the step processed next (= c_{t-1} now)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-        const int q = q0 + r0 + acc_row(r, lane);
-        const int qc = min(q, p.P - 1);
-        const float dh0 = p.dhn[(uint32_t)qc * (uint32_t)H + col];     // unconditional load, select afterwards
-        dh[r] = q < p.P ? dh0 : 0.0f;
+        const int row = r0 + acc_row(r, lane);
+        const int rc = min(row, rows_here - 1);
+        const float dh0 = at_bytes(dhn_t, ((uint32_t)rc * (uint32_t)H + col) * 4u);     // unconditional load, select afterwards
+        dh[r] = row < rows_here ? dh0 : 0.0f;
         dc[r] = 0.0f;
-        cnext[r] = G == 4 && CARRY_C ? p.saved[(((uint32_t)qc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col] : 0.0f;
+        cnext[r] = G == 4 && CARRY_C ? at_bytes(saved_t, ((((uint32_t)rc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col) * 4u) : 0.0f;
     }
 
     // the bf16 planes of two tile rows (accumulator registers r, r+1) of gate slot gs (0 or 1) of the resident pair
@@ -1048,16 +1056,14 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
         PN_STAMP(4 * (p.L - 1 - t) + 0);
         // (row numbers are re-derived from an opaque copy of the lane id in every step: as loop invariants the
         //  per-row offsets would occupy ~40 registers across the MFMA loops and spill)
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
+        const int lane_t = fresh_lane();
         if (p.keep) {      // this step's keep bytes (MT rows x H/4) -> LDS, read by the scatter phase below
-            int tid_t = tid;
-            asm volatile("" : "+v"(tid_t));    // (offsets re-derived per step, see lane_t)
+            const int tid_t = wave_u * 64 + lane_t;    // (offsets re-derived per step, see lane_t)
             for (int i = tid_t; i < MT * (H / 16); i += NT) {
                 const int row = i / (H / 16), w = i - row * (H / 16);
-                const uint32_t q = (uint32_t)min(q0 + row, p.P - 1);
+                const uint32_t rc = (uint32_t)min(row, rows_here - 1);
                 reinterpret_cast<uint32_t *>(s_keep + (t & 1) * MT * (H / 4))[i] =
-                    reinterpret_cast<const uint32_t *>(p.keep + (q * (uint32_t)p.L + t) * (uint32_t)(H / 4))[w];
+                    at_bytes(reinterpret_cast<const uint32_t *>(keep_t), (rc * (uint32_t)p.L + t) * (uint32_t)(H / 4) + 4u * w);
             }
         }
         // ---- cell backward.  All loads of a batch of NB accumulator elements are issued together (unconditionally, padded rows read a
@@ -1069,24 +1075,24 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
 #pragma unroll
             for (int e = 0; e < NB; e++) {
                 const int r = half * NB + e;
-                const int qc = min(q0 + r0 + acc_row(r, lane_t), p.P - 1);
-                const uint32_t so = ((uint32_t)qc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col;
+                const int rc = min(r0 + acc_row(r, lane_t), rows_here - 1);
+                const float *sv = &at_bytes(saved_t, (((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
                 if (G == 4) {
-                    vi[e] = p.saved[so]; vf[e] = p.saved[so + H]; vg[e] = p.saved[so + 2 * H];
-                    vo[e] = p.saved[so + 3 * H];
-                    vc[e] = t > 0 ? p.saved[so - H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
-                    vn[e] = CARRY_C ? cnext[r] : p.saved[so + 4 * H];        // c_t
+                    vi[e] = sv[0]; vf[e] = sv[H]; vg[e] = sv[2 * H];
+                    vo[e] = sv[3 * H];
+                    vc[e] = t > 0 ? sv[-H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
+                    vn[e] = CARRY_C ? cnext[r] : sv[4 * H];         // c_t
                 } else {
-                    vi[e] = p.saved[so];                                      // h_t
+                    vi[e] = sv[0];                                   // h_t
                 }
             }
             float ai[NB], af[NB];
 #pragma unroll
             for (int e = 0; e < NB; e++) {
                 const int r = half * NB + e;
-                const int q = q0 + r0 + acc_row(r, lane_t);
-                const bool ok = q < p.P;
-                float *d = p.dG + (((uint32_t)min(q, p.P - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col);
+                const int row = r0 + acc_row(r, lane_t);
+                const bool ok = row < rows_here;
+                float *d = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col) * 4u);
                 if (G == 4) {
                     const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
                     const float tc = tanhf_(vn[e]);
@@ -1126,10 +1132,9 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
         for (int nt = 0; nt < 2; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
-        const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.WpT) +
-                                  (size_t)__builtin_amdgcn_readfirstlane(ws) * (NU * 12 * 1024);
-        const uint32_t voff = lane * 16;
-        const unsigned char *arow = ldsb + (r0 + li) * PB + 16 * hk;
+        const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.WpT) + (size_t)ws_u * (NU * 12 * 1024);
+        const uint32_t voff = lane_t * 16;
+        const unsigned char *arow = ldsb + (r0 + (lane_t & 31)) * PB + 16 * (lane_t >> 5);
         // The weight stream runs through both passes without a break: the last unit of the (i, f) pass prefetches the
         // first unit of the (g, o) pass, whose fragments are then in flight across the two barriers in between.  Same
         // fragment pipeline as seq_fwd3_kernel: vmcnt (in order) sees [P0(u) P1(u) P2(u) P0(u+1)] at the top of unit u.
@@ -1223,10 +1228,10 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
             if (q0 + row < p.P) {
                 float dx = acc[0][r];
                 if (p.mask)
-                    dx *= p.mask[((uint64_t)t * p.P + s_slotof[row]) * H + col];
+                    dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col];
                 else if (p.keep)
                     dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col >> 2)] >> (col & 3)) & 1 ? dx * keep_scale : 0.0f;
-                atomicAdd(&p.dZ[(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col], dx);
+                atomicAdd(p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col), dx);
             }
             dh[r] = acc[1][r];
         }
@@ -1404,9 +1409,11 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
 }
 
 // sums the split partials and scatters them into the reference layouts g_W_ih [GH,H], g_W_hh [GH,H], g_b_*
+// (accumulate != 0: added to what the previous micro-batches left there)
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const float *__restrict__ part_b, int nsplit,
-                                    int GH, int H, float *__restrict__ g_w_ih, float *__restrict__ g_w_hh,
-                                    float *__restrict__ g_b_ih, float *__restrict__ g_b_hh) {
+                                    int GH, int H, int accumulate, float *__restrict__ g_w_ih,
+                                    float *__restrict__ g_w_hh, float *__restrict__ g_b_ih,
+                                    float *__restrict__ g_b_hh) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nw = (int64_t)GH * 2 * H;
     if (i < nw) {
@@ -1414,16 +1421,16 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const floa
         for (int z = 0; z < nsplit; z++) s += part_w[(int64_t)z * nw + i];
         const int m = (int)(i / (2 * H)), n = (int)(i - (int64_t)m * 2 * H);
         if (n < H) {
-            if (g_w_ih) g_w_ih[(int64_t)m * H + n] = s;
+            if (g_w_ih) g_w_ih[(int64_t)m * H + n] = accumulate ? g_w_ih[(int64_t)m * H + n] + s : s;
         } else if (g_w_hh) {
-            g_w_hh[(int64_t)m * H + (n - H)] = s;
+            g_w_hh[(int64_t)m * H + (n - H)] = accumulate ? g_w_hh[(int64_t)m * H + (n - H)] + s : s;
         }
     } else if (i < nw + GH) {
         const int m = (int)(i - nw);
         float s = 0.0f;
         for (int z = 0; z < nsplit; z++) s += part_b[(int64_t)z * GH + m];
-        if (g_b_ih) g_b_ih[m] = s;
-        if (g_b_hh) g_b_hh[m] = s;
+        if (g_b_ih) g_b_ih[m] = accumulate ? g_b_ih[m] + s : s;
+        if (g_b_hh) g_b_hh[m] = accumulate ? g_b_hh[m] + s : s;
     }
 }
 
@@ -1479,132 +1486,18 @@ int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
 
 template <int G>
 int dispatch_seq_bwd(hipStream_t stream, int H, const SeqBwdParams &sp) {
-    switch (H) {
+    switch (H) {      // every multiple of 32 up to 256 (the LDS tile of H = 256 is 98 KB)
         case 32: return launch_seq_bwd<32, G>(stream, sp);
         case 64: return launch_seq_bwd<64, G>(stream, sp);
+        case 96: return launch_seq_bwd<96, G>(stream, sp);
         case 128: return launch_seq_bwd<128, G>(stream, sp);
+        case 160: return launch_seq_bwd<160, G>(stream, sp);
+        case 192: return launch_seq_bwd<192, G>(stream, sp);
+        case 224: return launch_seq_bwd<224, G>(stream, sp);
         case 256: return launch_seq_bwd<256, G>(stream, sp);
     }
     PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
 }
-
-// ================================================================================================
-// workspace layout
-// ================================================================================================
-struct WsLayout {
-    size_t Xh, Z, rowidx, egoidx, slotof, Wp, biasc, hn, saved, coef, rawsc, layer1;  // forward
-    size_t xh, keep;                                                                  // forward (saved)
-    size_t WpT, dG, dZ, dXh, dhn, dl1, wpart;                                         // backward
-    size_t gpart;                                                                     // split-K partial sums of the node GEMMs
-    int wgrad_split;
-    size_t total;
-};
-
-inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-
-WsLayout ws_layout(const pn_pagg_shape &s) {
-    WsLayout w{};
-    const size_t N = s.N, H = s.H, L = s.L, P = (size_t)s.S * s.W, S = s.S;
-    const size_t G = s.variant == PN_VARIANT_PAGG ? 1 : 4, SV = G == 4 ? 5 : 1;
-    size_t at = 0;
-    auto take = [&](size_t bytes) {
-        size_t o = at;
-        at = align256(at + bytes);
-        return o;
-    };
-    w.Xh = take(N * H * 4);
-    w.Z = take(N * L * H * 4);
-    w.rowidx = take(P * L * 4);
-    w.egoidx = take(P * 4);
-    w.slotof = take(P * 4);
-    w.Wp = take(G * H * 3 * H * 4);
-    w.biasc = take(G * H * 4);
-    w.hn = take(P * H * 4);
-    w.saved = take(P * L * SV * H * 4);
-    w.coef = take(P * 4);
-    w.rawsc = take(P * 4);
-    w.layer1 = take(S * 2 * H * 4);
-    w.WpT = take(G * H * 3 * H * 4);
-    w.dG = take(P * L * G * H * 4);
-    w.dZ = take(N * L * H * 4);
-    w.dXh = take(N * H * 4);
-    w.dhn = take(P * H * 4);
-    w.dl1 = take(S * 2 * H * 4);
-    w.xh = take(P * L * 2 * H * 4);
-    w.keep = take(P * L * (H / 4));
-    {
-        // split of the P*L rows of the weight-gradient GEMM: enough workgroups to fill 256 CUs ~3x
-        const size_t rows = P * L, tiles = ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN);
-        size_t nz = (256 + tiles - 1) / tiles;     // one 8-wave workgroup per CU
-        const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
-        if (nz > max_nz) nz = max_nz;
-        if (nz < 1) nz = 1;
-        w.wgrad_split = (int)nz;
-        w.wpart = take(nz * (G * H * 2 * H + G * H) * 4);
-    }
-    w.gpart = take((size_t)GEMM_MAX_SPLIT * N * H * 4);
-    w.total = at;
-    return w;
-}
-
-int check_shape(const pn_pagg_shape &s) {
-    if (s.variant < 0 || s.variant > 2) PN_FAIL(PN_ERR_ARG, "unknown variant %d", s.variant);
-    if (s.H != 32 && s.H != 64 && s.H != 128 && s.H != 256)
-        PN_FAIL(PN_ERR_ARG, "hidden size %d not supported (32, 64, 128, 256)", s.H);
-    if (s.N < 1 || s.F < 1 || s.C < 1 || s.S < 0 || s.W < 1 || s.L < 1 || s.L > 64)
-        PN_FAIL(PN_ERR_ARG, "bad aggregator shape N=%d F=%d C=%d S=%d W=%d L=%d", s.N, s.F, s.C, s.S, s.W, s.L);
-    // the pooling kernels keep per-walk scores, coefficients and ego rows of four nodes in LDS (64 W + 48 H bytes)
-    if (64 * (int64_t)s.W + 48 * s.H > 64 * 1024)
-        PN_FAIL(PN_ERR_ARG, "W=%d walks per node exceed the pooling kernels' LDS budget (W <= %d at H=%d)", s.W,
-                (64 * 1024 - 48 * s.H) / 64, s.H);
-    if (s.variant == PN_VARIANT_PAGG && s.L != 4)
-        PN_FAIL(PN_ERR_ARG, "PAGG has exactly four distance layers nei0..nei3 (copy.py:310-313); L=%d", s.L);
-    if ((int64_t)s.S * s.W * s.L > 2000000000LL || (int64_t)s.N * s.L > 2000000000LL)
-        PN_FAIL(PN_ERR_ARG, "index space exceeds int32; split the node set");
-    // the recurrent kernels address their per-path tensors with 32-bit element offsets
-    if ((int64_t)s.S * s.W * s.L * 5 * s.H >= (1LL << 32) || (int64_t)s.N * s.L * s.H >= (1LL << 32))
-        PN_FAIL(PN_ERR_ARG, "S*W*L*5*H = %lld elements exceeds 2^32: aggregate the masked nodes in batches",
-                (long long)s.S * s.W * s.L * 5 * s.H);
-    return PN_OK;
-}
-
-#ifndef PN_BWD_OVERLAP
-#define PN_BWD_OVERLAP 1
-#endif
-#ifndef PN_SIDE_SMALL
-#define PN_SIDE_SMALL 1
-#endif
-// Second stream of the backward: the recurrent weight-gradient GEMM (one 8-wave workgroup per CU, 104 KB of LDS)
-// leaves registers and LDS for the small node-level GEMMs that follow the BPTT, which do not depend on it.
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-int side_stream(SideStream **out) {
-    static SideStream tab[64];      // per device; one host thread per device drives the library
-    int dev = 0;
-    PN_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64) PN_FAIL(PN_ERR_ARG, "device ordinal %d", dev);
-    SideStream &x = tab[dev];
-    if (!x.s) {
-        PN_CHECK_HIP(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
-        PN_CHECK_HIP(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
-        PN_CHECK_HIP(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
-        // the runtime builds a stream's hardware queue at its first launch (milliseconds): pay that here
-        hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, x.s, ZeroList{});
-        PN_CHECK_HIP(hipGetLastError());
-    }
-    *out = &x;
-    return PN_OK;
-}
-// makes `stream` wait for the side stream's work on every way out of the caller
-struct JoinGuard {
-    hipStream_t stream;
-    SideStream *side = nullptr;
-    ~JoinGuard() {
-        if (side) (void)hipStreamWaitEvent(stream, side->join, 0);
-    }
-};
 
 template <int H, int G>
 int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
@@ -1625,10 +1518,289 @@ int dispatch_seq_fwd(hipStream_t stream, int H, const SeqFwdParams &sp) {
     switch (H) {
         case 32: return launch_seq_fwd<32, G>(stream, sp);
         case 64: return launch_seq_fwd<64, G>(stream, sp);
+        case 96: return launch_seq_fwd<96, G>(stream, sp);
         case 128: return launch_seq_fwd<128, G>(stream, sp);
+        case 160: return launch_seq_fwd<160, G>(stream, sp);
+        case 192: return launch_seq_fwd<192, G>(stream, sp);
+        case 224: return launch_seq_fwd<224, G>(stream, sp);
         case 256: return launch_seq_fwd<256, G>(stream, sp);
     }
     PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
+}
+
+
+// ================================================================================================
+// shape bookkeeping and workspace layout
+// ================================================================================================
+struct Dims {
+    int variant, N, F, H, C, S, W, L, G, SV;
+    int S_total, group_begin;
+    int Sb;             // pooling groups per micro-batch
+    int nb;             // micro-batches of this call
+    int64_t P_total;    // paths of the whole batch
+};
+
+// K chunks a split node-level GEMM is cut into (1 = not split): aim at ~2 workgroups per CU, at least two K tiles each
+constexpr int GEMM_MAX_SPLIT = 8;
+int gemm_split_count(int M, int N, int K) {
+    const int64_t tiles = (int64_t)((M + GEMM_BM - 1) / GEMM_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
+    int64_t nz = tiles > 0 ? (512 + tiles - 1) / tiles : 1;
+    if (nz > GEMM_MAX_SPLIT) nz = GEMM_MAX_SPLIT;
+    if (nz > K / (2 * GEMM_KT)) nz = K / (2 * GEMM_KT);
+    return nz < 1 ? 1 : (int)nz;
+}
+
+int launch_gemm_split(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
+                      int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
+                      int mode, float *partial) {
+    int nz = gemm_split_count(M, N, K);
+    if (nz <= 1 || !partial || M <= 0 || N <= 0)
+        return launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 1);
+    int kchunk = (K + nz - 1) / nz;
+    kchunk = (kchunk + GEMM_KT - 1) / GEMM_KT * GEMM_KT;
+    nz = (K + kchunk - 1) / kchunk;
+    if (int rc = launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, partial, N, nullptr, M, N, K, 0, GEMM_PARTIAL, nz))
+        return rc;
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, nz, M, N,
+                       bias, relu, mode, C, ldc);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+int make_dims(const pn_pagg_shape &s, Dims &d) {
+    if (s.variant < 0 || s.variant > 2) PN_FAIL(PN_ERR_ARG, "unknown variant %d", s.variant);
+    if (s.H < 32 || s.H > 256 || s.H % 32 != 0)
+        PN_FAIL(PN_ERR_ARG, "hidden size %d not supported (multiples of 32 up to 256)", s.H);
+    if (s.N < 1 || s.F < 1 || s.C < 1 || s.S < 0 || s.W < 1 || s.L < 1 || s.L > 64)
+        PN_FAIL(PN_ERR_ARG, "bad aggregator shape N=%d F=%d C=%d S=%d W=%d L=%d", s.N, s.F, s.C, s.S, s.W, s.L);
+    // the pooling kernels keep per-walk scores, coefficients and ego rows of four nodes in LDS (64 W + 48 H bytes)
+    if (64 * (int64_t)s.W + 48 * s.H > 64 * 1024)
+        PN_FAIL(PN_ERR_ARG, "W=%d walks per node exceed the pooling kernels' LDS budget (W <= %d at H=%d)", s.W,
+                (64 * 1024 - 48 * s.H) / 64, s.H);
+    if (s.variant == PN_VARIANT_PAGG && s.L != 4)
+        PN_FAIL(PN_ERR_ARG, "PAGG has exactly four distance layers nei0..nei3 (copy.py:310-313); L=%d", s.L);
+    const int S_total = s.S_total > 0 ? s.S_total : s.S;
+    if (s.group_begin < 0 || (int64_t)s.group_begin + s.S > S_total || s.batch_groups < 0)
+        PN_FAIL(PN_ERR_ARG, "bad slice: groups [%d, +%d) of a batch of %d, batch_groups=%d", s.group_begin, s.S,
+                S_total, s.batch_groups);
+    // int32 indices: a node's table row (node * L + code) and a path's position in the batch
+    if ((int64_t)S_total * s.W > 2000000000LL || (int64_t)s.N * s.L > 2000000000LL)
+        PN_FAIL(PN_ERR_ARG, "index space exceeds int32 (S_total*W = %lld paths, N*L = %lld rows)",
+                (long long)S_total * s.W, (long long)s.N * s.L);
+    d.variant = s.variant;
+    d.N = s.N, d.F = s.F, d.H = s.H, d.C = s.C, d.S = s.S, d.W = s.W, d.L = s.L;
+    d.G = s.variant == PN_VARIANT_PAGG ? 1 : 4;
+    d.SV = d.G == 4 ? 5 : 1;
+    d.S_total = S_total;
+    d.group_begin = s.group_begin;
+    d.Sb = (s.batch_groups > 0 && s.batch_groups < s.S) ? s.batch_groups : s.S;
+    d.nb = d.Sb > 0 ? (s.S + d.Sb - 1) / d.Sb : 1;
+    d.P_total = (int64_t)S_total * s.W;
+    // rows of one micro-batch's [Pb * L, .] tensors are counted in int32 inside the kernels
+    if ((int64_t)d.Sb * s.W * s.L > 2000000000LL)
+        PN_FAIL(PN_ERR_ARG, "%lld path steps in one micro-batch exceed int32: set batch_groups", (long long)d.Sb * s.W * s.L);
+    return PN_OK;
+}
+
+struct WsLayout {
+    size_t Xh, Z;                                                        // node tables (first: reuse_tables relies on it)
+    size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
+    size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
+    size_t xh, keep, dG, dhn, dl1;                                       // per micro-batch, saved / backward
+    int wgrad_split;
+    size_t total;
+};
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+WsLayout ws_layout(const Dims &d) {
+    WsLayout w{};
+    const size_t N = d.N, H = d.H, L = d.L, G = d.G, SV = d.SV, Sb = d.Sb, Pb = (size_t)d.Sb * d.W;
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = at;
+        at = align256(at + bytes);
+        return o;
+    };
+    w.Xh = take(N * H * 4);
+    w.Z = take(N * L * H * 4);
+    w.Wp = take(G * H * 3 * H * 4);
+    w.biasc = take(G * H * 4);
+    w.WpT = take(G * H * 3 * H * 4);
+    {
+        // split of the Pb*L rows of the weight-gradient GEMM: one 8-wave workgroup per CU
+        const size_t rows = Pb * L, tiles = ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN);
+        size_t nz = (256 + tiles - 1) / tiles;
+        const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
+        if (nz > max_nz) nz = max_nz;
+        if (nz < 1) nz = 1;
+        w.wgrad_split = (int)nz;
+        w.wpart = take(nz * (G * H * 2 * H + G * H) * 4);
+    }
+    {
+        const int nz = std::max(gemm_split_count(d.N, d.H, d.F), gemm_split_count(d.N, d.H, d.L * d.H));
+        w.gpart = take(nz > 1 ? (size_t)nz * N * H * 4 : 0);
+    }
+    w.dZ = take(N * L * H * 4);
+    w.dXh = take(N * H * 4);
+    w.rowidx = take(Pb * L * 4);
+    w.egoidx = take(Pb * 4);
+    w.slotof = take(Pb * 4);
+    w.hn = take(Pb * H * 4);
+    w.saved = take(Pb * L * SV * H * 4);
+    w.coef = take(Pb * 4);
+    w.rawsc = take(Pb * 4);
+    w.layer1 = take(Sb * 2 * H * 4);
+    w.outb = take(Sb * (size_t)d.C * 4);
+    w.xh = take(Pb * L * 2 * H * 4);
+    w.keep = take(Pb * L * (H / 4));
+    w.dG = take(Pb * L * G * H * 4);
+    w.dhn = take(Pb * H * 4);
+    w.dl1 = take(Sb * 2 * H * 4 + 1024);
+    w.total = at;
+    return w;
+}
+
+#ifndef PN_BWD_OVERLAP
+#define PN_BWD_OVERLAP 1
+#endif
+#ifndef PN_SIDE_SMALL
+#define PN_SIDE_SMALL 1
+#endif
+// Independent launches go to the context's second stream (pn_context.hip): the index plan and the weight packing beside
+// fc0 / bank in the forward; in the backward the classifier's weight gradient beside the pooling backward and the
+// BPTT, and the recurrent weight-gradient GEMM (one 8-wave workgroup per CU, 104 KB of LDS) beside the node-level
+// GEMMs that follow the BPTT.  The guard makes `stream` wait for whatever was forked on every way out.
+struct JoinGuard {
+    pn_context *ctx;
+    hipStream_t stream;
+    bool pending = false;
+    int mark() {                        // the forked work is complete up to here on the second stream
+        if (int rc = context_record_join(ctx)) return rc;
+        pending = true;
+        return PN_OK;
+    }
+    int join() {
+        if (!pending) return PN_OK;
+        pending = false;
+        return context_join(ctx, stream);
+    }
+    ~JoinGuard() { (void)join(); }
+};
+
+
+// ---- one aggregator call, resolved: shapes, workspace pointers, and the stages that run once per micro-batch ---------
+struct Call {
+    pn_context *ctx;
+    hipStream_t stream;
+    const pn_pagg_args *a;
+    Dims d;
+    WsLayout w;
+    char *ws;
+    const float *Xh;
+    float *Z;
+    template <class T>
+    T *at(size_t off) const { return reinterpret_cast<T *>(ws + off); }
+    int groups(int b) const { return std::min(d.Sb, d.S - b * d.Sb); }                 // pooling groups of micro-batch b
+    int64_t group0(int b) const { return (int64_t)d.group_begin + (int64_t)b * d.Sb; }  // its first group, batch-wide
+    const int32_t *sel(int b) const { return a->sel + (a->index_rows_local ? (int64_t)b * d.Sb : group0(b)); }
+};
+
+int resolve_call(Call &c, pn_context *ctx, const pn_pagg_args *a, hipStream_t stream, const char *who) {
+    if (!a) PN_FAIL(PN_ERR_ARG, "%s: null args", who);
+    if (int rc = context_check_device(ctx)) return rc;
+    if (int rc = make_dims(a->shape, c.d)) return rc;
+    c.ctx = ctx;
+    c.stream = stream;
+    c.a = a;
+    c.w = ws_layout(c.d);
+    if (!a->workspace) PN_FAIL(PN_ERR_ARG, "%s: null workspace", who);
+    if (a->workspace_bytes < (int64_t)c.w.total)
+        PN_FAIL(PN_ERR_CAPACITY, "aggregator workspace holds %lld bytes, need %lld", (long long)a->workspace_bytes,
+                (long long)c.w.total);
+    c.ws = reinterpret_cast<char *>(a->workspace);
+    c.Xh = a->Xh_in ? a->Xh_in : c.at<const float>(c.w.Xh);
+    c.Z = c.at<float>(c.w.Z);
+    if (a->index_rows_local && c.d.variant == PN_VARIANT_HETERO && (c.d.group_begin != 0 || c.d.S != c.d.S_total))
+        PN_FAIL(PN_ERR_ARG, "%s: the hetero class reads paths of the whole batch (PathNet_run.py:196-197): "
+                "index_rows_local needs the whole batch's ids / codes", who);
+    return PN_OK;
+}
+
+int run_plan(const Call &c, hipStream_t s, int b) {
+    const Dims &d = c.d;
+    const int64_t count = (int64_t)c.groups(b) * d.W, n = count * d.L;
+    const PlanDims pd{d.S_total, d.W, d.L, d.N, d.P_total, c.a->index_rows_local ? (int64_t)d.group_begin * d.W : 0};
+    hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d.variant, c.a->ids, c.a->codes,
+                       pd, c.group0(b) * d.W, count, c.at<int32_t>(c.w.rowidx), c.at<int32_t>(c.w.egoidx),
+                       c.at<int32_t>(c.w.slotof));
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+int run_pack_fwd(const Call &c, hipStream_t s) {
+    const Dims &d = c.d;
+    hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((d.G * d.H * d.H / 4 + 255) / 256)), dim3(256), 0, s, c.a->w_ih,
+                       c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, c.at<u32x4>(c.w.Wp), c.at<float>(c.w.biasc));
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+int run_seq_fwd(const Call &c, int b, bool save) {
+    const Dims &d = c.d;
+    const pn_pagg_args *a = c.a;
+    SeqFwdParams sp{};
+    sp.Z = c.Z;
+    sp.rowidx = c.at<int32_t>(c.w.rowidx);
+    sp.slotof = c.at<int32_t>(c.w.slotof);
+    sp.Wp = c.at<float>(c.w.Wp);
+    sp.biasc = c.at<float>(c.w.biasc);
+    sp.hn = c.at<float>(c.w.hn);
+    sp.saved = save ? c.at<float>(c.w.saved) : nullptr;
+    sp.xh = save ? c.at<float>(c.w.xh) : nullptr;
+    sp.keep = (!save || a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : c.at<uint8_t>(c.w.keep);
+    sp.P = c.groups(b) * d.W;
+    sp.L = d.L;
+    sp.Pmask = d.P_total;
+    sp.p_drop = a->p_seq;
+    sp.seed = a->seed;
+    sp.mask = a->mask_seq;
+    StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
+    return d.G == 4 ? dispatch_seq_fwd<4>(c.stream, d.H, sp) : dispatch_seq_fwd<1>(c.stream, d.H, sp);
+}
+
+int run_pool_fwd(const Call &c, int b, float *out) {
+    const Dims &d = c.d;
+    const pn_pagg_args *a = c.a;
+    const int homo = d.variant == PN_VARIANT_HOMO;
+    PoolParams pp{};
+    pp.variant = d.variant;
+    pp.S = c.groups(b);
+    pp.W = d.W;
+    pp.H = d.H;
+    pp.C = d.C;
+    pp.goff = c.group0(b);
+    pp.hn = c.at<float>(c.w.hn);
+    pp.ego_tab = homo ? c.Z : c.Xh;
+    pp.egoidx = c.at<int32_t>(c.w.egoidx);
+    pp.Xh = c.Xh;
+    pp.sel = c.sel(b);
+    pp.att_w = a->att_w;
+    pp.att_b = a->att_b;
+    pp.fc2_w = a->fc2_w;
+    pp.fc2_b = a->fc2_b;
+    pp.p_drop = a->p_cls;
+    pp.seed = a->seed;
+    pp.mask = a->mask_cls;
+    pp.coef = c.at<float>(c.w.coef);
+    pp.rawsc = c.at<float>(c.w.rawsc);
+    pp.layer1 = c.at<float>(c.w.layer1);
+    pp.out = out;
+    StageTimer tm(c.ctx, ST_POOL_FWD, c.stream);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3((pp.S + 3) / 4), dim3(256), (size_t)8 * d.W * sizeof(float), c.stream, pp);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
 }
 
 }  // namespace
@@ -1637,8 +1809,9 @@ extern "C" {
 
 int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes) {
     if (!shape || !bytes) PN_FAIL(PN_ERR_ARG, "pn_pagg_workspace_bytes: null");
-    if (int rc = check_shape(*shape)) return rc;
-    *bytes = (int64_t)ws_layout(*shape).total;
+    Dims d;
+    if (int rc = make_dims(*shape, d)) return rc;
+    *bytes = (int64_t)ws_layout(d).total;
     return PN_OK;
 }
 
@@ -1650,23 +1823,25 @@ int pn_gemm_f32(const float *A, int64_t sAm, int64_t sAk, const float *B, int64_
                        GEMM_STORE, 1);
 }
 
-int pn_linear_forward(const float *X, const float *W, const float *b, int32_t rows, int32_t in_f, int32_t out_f,
-                      int32_t relu, float *Y, void *workspace, int64_t workspace_bytes, void *stream_) {
+int pn_linear_forward(pn_context *ctx, const float *X, const float *W, const float *b, int32_t rows, int32_t in_f,
+                      int32_t out_f, int32_t relu, float *Y, void *workspace, int64_t workspace_bytes, void *stream_) {
     static_assert(PN_LINEAR_SPLIT_MAX == GEMM_MAX_SPLIT, "header and kernel agree on the split bound");
     if (!X || !W || !Y || rows < 0 || in_f < 1 || out_f < 1) PN_FAIL(PN_ERR_ARG, "pn_linear_forward: bad argument");
+    if (int rc = context_check_device(ctx)) return rc;
     if (rows == 0) return PN_OK;
     hipStream_t stream = (hipStream_t)stream_;
     const bool split = workspace && workspace_bytes >= (int64_t)GEMM_MAX_SPLIT * rows * out_f * (int64_t)sizeof(float);
-    StageTimer tm(ST_FC0, stream);
+    StageTimer tm(ctx, ST_FC0, stream);
     return launch_gemm_split(stream, X, in_f, 1, nullptr, W, in_f, 1, Y, out_f, b, rows, out_f, in_f, relu, GEMM_STORE,
                              split ? reinterpret_cast<float *>(workspace) : nullptr);
 }
 
-int pn_linear_backward(const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
-                       int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream_) {
+int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, const float *X, const float *W, int32_t rows,
+                       int32_t in_f, int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!dY || rows < 0 || in_f < 1 || out_f < 1) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: bad argument");
-    StageTimer tm(ST_FC0_BWD, stream);
+    if (int rc = context_check_device(ctx)) return rc;
+    StageTimer tm(ctx, ST_FC0_BWD, stream);
     if (g_W && !X) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: g_W needs X");
     if (g_W || g_b) {       // both are accumulated with atomics: one zero-fill launch for the two
         ZeroList zl{};
@@ -1699,6 +1874,7 @@ int pn_linear_backward(const float *dY, const float *gate, const float *X, const
 }
 
 #if PN_TRACE_PHASES
+// tuning builds only (-DPN_TRACE_PHASES=1, tools/trace_phases.py): not part of the ABI, absent from the shipped library
 int pn_debug_set_trace(long long *dev_buf) {
     PN_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &dev_buf, sizeof dev_buf));
     return PN_OK;
@@ -1707,8 +1883,9 @@ int pn_debug_set_trace(long long *dev_buf) {
 
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
     if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_debug_offsets: null");
-    if (int rc = check_shape(*shape)) return rc;
-    const WsLayout w = ws_layout(*shape);
+    Dims d;
+    if (int rc = make_dims(*shape, d)) return rc;
+    const WsLayout w = ws_layout(d);
     out[0] = (int64_t)w.Xh;
     out[1] = (int64_t)w.Z;
     out[2] = (int64_t)w.hn;
@@ -1716,177 +1893,107 @@ int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
     return PN_OK;
 }
 
-int pn_pagg_gather(const pn_pagg_shape *shape, const float *table, const int32_t *ids, const uint8_t *codes,
-                   float *rows, void *stream_) {
+int pn_pagg_gather(pn_context *ctx, const pn_pagg_shape *shape, const float *table, const int32_t *ids,
+                   const uint8_t *codes, float *rows, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!shape || !table || !ids || !codes || !rows) PN_FAIL(PN_ERR_ARG, "pn_pagg_gather: null");
+    if (int rc = context_check_device(ctx)) return rc;
     const pn_pagg_shape &s = *shape;
     if (s.S < 0 || s.W < 1 || s.L < 1 || s.H < 1 || s.N < 1) PN_FAIL(PN_ERR_ARG, "pn_pagg_gather: bad shape");
-    const int64_t rowsn = (int64_t)s.S * s.W * s.L;
+    const int S_total = s.S_total > 0 ? s.S_total : s.S;
+    if (s.group_begin < 0 || (int64_t)s.group_begin + s.S > S_total) PN_FAIL(PN_ERR_ARG, "pn_pagg_gather: bad slice");
+    const int64_t count = (int64_t)s.S * s.W, rowsn = count * s.L;
     if (rowsn == 0) return PN_OK;
     const bool vec = (s.H % 4 == 0) && ((reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(rows)) % 16 == 0);
     const int64_t work = rowsn * (vec ? s.H / 4 : s.H);
     const int blocks = (int)std::min<int64_t>((work + 255) / 256, 256 * 32);
-    StageTimer tm(ST_GATHER, stream);
+    const PlanDims pd{S_total, s.W, s.L, s.N, (int64_t)S_total * s.W, 0};
+    const int64_t slot_begin = (int64_t)s.group_begin * s.W;
+    StageTimer tm(ctx, ST_GATHER, stream);
     if (vec)
-        hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, stream, s.variant, table, ids, codes, s.S, s.W,
-                           s.L, s.N, s.H, rows);
+        hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, stream, s.variant, table, ids, codes, pd,
+                           slot_begin, count, s.H, rows);
     else
-        hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, s.variant, table, ids, codes, s.S, s.W,
-                           s.L, s.N, s.H, rows);
+        hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, stream, s.variant, table, ids, codes, pd,
+                           slot_begin, count, s.H, rows);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
 
-int pn_pagg_forward(const pn_pagg_args *a, void *stream_) {
+int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!a) PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null args");
-    const pn_pagg_shape &s = a->shape;
-    if (int rc = check_shape(s)) return rc;
+    Call c;
+    if (int rc = resolve_call(c, ctx, a, stream, "pn_pagg_forward")) return rc;
+    const Dims &d = c.d;
     if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->bank_b || !a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh ||
-        !a->fc2_w || !a->fc2_b || !a->out || !a->workspace)
+        !a->fc2_w || !a->fc2_b || !a->out)
         PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null tensor");
-    if (!a->Xh_in && (!a->X || !a->fc0_w || !a->fc0_b)) PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: X / fc0 missing");
-    if (s.variant != PN_VARIANT_PAGG && (!a->att_w || !a->att_b)) PN_FAIL(PN_ERR_ARG, "attention weights missing");
-    const WsLayout w = ws_layout(s);
-    if (a->workspace_bytes < (int64_t)w.total)
-        PN_FAIL(PN_ERR_CAPACITY, "aggregator workspace holds %lld bytes, need %lld", (long long)a->workspace_bytes,
-                (long long)w.total);
-    if (s.S == 0) return PN_OK;
-    char *ws = reinterpret_cast<char *>(a->workspace);
-    const float *Xh = a->Xh_in ? a->Xh_in : reinterpret_cast<const float *>(ws + w.Xh);
-    float *Z = reinterpret_cast<float *>(ws + w.Z);
-    int32_t *rowidx = reinterpret_cast<int32_t *>(ws + w.rowidx), *egoidx = reinterpret_cast<int32_t *>(ws + w.egoidx),
-            *slotof = reinterpret_cast<int32_t *>(ws + w.slotof);
-    float *Wp = reinterpret_cast<float *>(ws + w.Wp), *biasc = reinterpret_cast<float *>(ws + w.biasc);
-    float *hn = reinterpret_cast<float *>(ws + w.hn), *saved = reinterpret_cast<float *>(ws + w.saved);
-    const int H = s.H, L = s.L, G = s.variant == PN_VARIANT_PAGG ? 1 : 4;
-    const int P = s.S * s.W;
-    const int homo = s.variant == PN_VARIANT_HOMO;
+    if (!a->Xh_in && !a->reuse_tables && (!a->X || !a->fc0_w || !a->fc0_b))
+        PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: X / fc0 missing");
+    if (d.variant != PN_VARIANT_PAGG && (!a->att_w || !a->att_b)) PN_FAIL(PN_ERR_ARG, "attention weights missing");
+    if (d.S == 0) return PN_OK;
+    const int H = d.H, L = d.L;
+    const int homo = d.variant == PN_VARIANT_HOMO;
 
-    // the index plan and the weight packing do not depend on fc0 / bank: second stream, joined before the recurrence
-    JoinGuard joiner{stream};
+    // the index plan (of the first micro-batch) and the weight packing do not depend on fc0 / bank: second stream,
+    // joined before the recurrence
+    JoinGuard joiner{ctx, stream};
     hipStream_t pstream = stream;
-    SideStream *ss = nullptr;
-    if (PN_SIDE_SMALL)
-        if (int rc = side_stream(&ss)) return rc;
-    if (PN_SIDE_SMALL && !profiling_every_stage()) {
-        PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
-        PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
-        pstream = ss->s;
-    }
+    if (PN_SIDE_SMALL && !profiling_every_stage(ctx))
+        if (void *side = context_fork(ctx, stream)) pstream = (hipStream_t)side;
     {
-        StageTimer tm(ST_PLAN_PACK, pstream);
-        const int64_t n = (int64_t)P * L;
-        hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, pstream, s.variant, a->ids,
-                           a->codes, s.S, s.W, L, s.N, rowidx, egoidx, slotof);
-        PN_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((G * H * H / 4 + 255) / 256)), dim3(256), 0, pstream, a->w_ih,
-                           a->w_hh, a->b_ih, a->b_hh, H, G, reinterpret_cast<u32x4 *>(Wp), biasc);
-        PN_CHECK_HIP(hipGetLastError());
+        StageTimer tm(ctx, ST_PLAN_PACK, pstream);
+        if (int rc = run_plan(c, pstream, 0)) return rc;
+        if (int rc = run_pack_fwd(c, pstream)) return rc;
     }
-    if (pstream != stream) {
-        PN_CHECK_HIP(hipEventRecord(ss->join, ss->s));
-        joiner.side = ss;
-    }
-    // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
-    if (!a->Xh_in) {
-        StageTimer tm(ST_FC0, stream);
-        if (int rc = launch_gemm_split(stream, a->X, s.F, 1, nullptr, a->fc0_w, s.F, 1,
-                                       reinterpret_cast<float *>(ws + w.Xh), H, a->fc0_b, s.N, H, s.F, homo, GEMM_STORE,
-                                       reinterpret_cast<float *>(ws + w.gpart)))
+    if (pstream != stream)
+        if (int rc = joiner.mark()) return rc;
+    if (!a->reuse_tables) {
+        // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
+        if (!a->Xh_in) {
+            StageTimer tm(ctx, ST_FC0, stream);
+            if (int rc = launch_gemm_split(stream, a->X, d.F, 1, nullptr, a->fc0_w, d.F, 1, c.at<float>(c.w.Xh), H,
+                                           a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart)))
+                return rc;
+        }
+        // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
+        StageTimer tm(ctx, ST_BANK, stream);
+        if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
+                                 L * H, H, homo, GEMM_STORE, 1))
             return rc;
     }
-    // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
-    {
-        StageTimer tm(ST_BANK, stream);
-        if (int rc = launch_gemm(stream, Xh, H, 1, nullptr, a->bank_w, H, 1, Z, (int64_t)L * H, a->bank_b, s.N, L * H,
-                                 H, homo, GEMM_STORE, 1))
-            return rc;
+    if (int rc = joiner.join()) return rc;       // the recurrence needs the plan and the packed weights
+    const bool save = d.nb == 1 && !a->no_save;  // several micro-batches: the backward re-runs each one's recurrence
+    for (int b = 0; b < d.nb; b++) {
+        if (b > 0) {
+            StageTimer tm(ctx, ST_PLAN_PACK, stream);
+            if (int rc = run_plan(c, stream, b)) return rc;
+        }
+        if (int rc = run_seq_fwd(c, b, save)) return rc;
+        if (int rc = run_pool_fwd(c, b, a->out + (size_t)b * d.Sb * d.C)) return rc;
     }
-    if (joiner.side) {       // the recurrence needs the plan and the packed weights
-        PN_CHECK_HIP(hipStreamWaitEvent(stream, joiner.side->join, 0));
-        joiner.side = nullptr;
-    }
-    SeqFwdParams sp{};
-    sp.Z = Z;
-    sp.rowidx = rowidx;
-    sp.slotof = slotof;
-    sp.Wp = Wp;
-    sp.biasc = biasc;
-    sp.hn = hn;
-    sp.saved = a->no_save ? nullptr : saved;
-    sp.xh = a->no_save ? nullptr : reinterpret_cast<float *>(ws + w.xh);
-    sp.keep = (a->no_save || a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : reinterpret_cast<uint8_t *>(ws + w.keep);
-    sp.P = P;
-    sp.L = L;
-    sp.p_drop = a->p_seq;
-    sp.seed = a->seed;
-    sp.mask = a->mask_seq;
-    {
-        StageTimer tm(ST_SEQ_FWD, stream);
-        if (int rc = (G == 4 ? dispatch_seq_fwd<4>(stream, H, sp) : dispatch_seq_fwd<1>(stream, H, sp))) return rc;
-    }
-
-    PoolParams pp{};
-    pp.variant = s.variant;
-    pp.S = s.S;
-    pp.W = s.W;
-    pp.H = H;
-    pp.C = s.C;
-    pp.hn = hn;
-    pp.ego_tab = homo ? Z : Xh;
-    pp.egoidx = egoidx;
-    pp.Xh = Xh;
-    pp.sel = a->sel;
-    pp.att_w = a->att_w;
-    pp.att_b = a->att_b;
-    pp.fc2_w = a->fc2_w;
-    pp.fc2_b = a->fc2_b;
-    pp.p_drop = a->p_cls;
-    pp.seed = a->seed;
-    pp.mask = a->mask_cls;
-    pp.coef = reinterpret_cast<float *>(ws + w.coef);
-    pp.rawsc = reinterpret_cast<float *>(ws + w.rawsc);
-    pp.layer1 = reinterpret_cast<float *>(ws + w.layer1);
-    pp.out = a->out;
-    {
-        StageTimer tm(ST_POOL_FWD, stream);
-        hipLaunchKernelGGL(pool_fwd_kernel, dim3((s.S + 3) / 4), dim3(256), (size_t)8 * s.W * sizeof(float), stream,
-                           pp);
-    }
-    PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
 
-int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
+int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!a) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null args");
-    const pn_pagg_shape &s = a->shape;
-    if (int rc = check_shape(s)) return rc;
-    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->w_ih || !a->w_hh || !a->fc2_w || !a->g_out || !a->workspace)
+    Call c;
+    if (int rc = resolve_call(c, ctx, a, stream, "pn_pagg_backward")) return rc;
+    const Dims &d = c.d;
+    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->w_ih || !a->w_hh || !a->fc2_w || !a->g_out)
         PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null tensor");
     if (!a->Xh_in && (!a->X || !a->fc0_w)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: X / fc0 missing");
     if (a->Xh_in && !a->g_Xh) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: g_Xh is required with Xh_in");
-    const WsLayout w = ws_layout(s);
-    if (a->workspace_bytes < (int64_t)w.total)
-        PN_FAIL(PN_ERR_CAPACITY, "aggregator workspace holds %lld bytes, need %lld", (long long)a->workspace_bytes,
-                (long long)w.total);
-    const int H = s.H, L = s.L, G = s.variant == PN_VARIANT_PAGG ? 1 : 4, GH = G * H;
-    const int P = s.S * s.W;
-    const int homo = s.variant == PN_VARIANT_HOMO;
-    const bool has_att = s.variant != PN_VARIANT_PAGG;
-    char *ws = reinterpret_cast<char *>(a->workspace);
-    const float *Xh = a->Xh_in ? a->Xh_in : reinterpret_cast<const float *>(ws + w.Xh);
-    float *Z = reinterpret_cast<float *>(ws + w.Z);
-    int32_t *rowidx = reinterpret_cast<int32_t *>(ws + w.rowidx), *egoidx = reinterpret_cast<int32_t *>(ws + w.egoidx),
-            *slotof = reinterpret_cast<int32_t *>(ws + w.slotof);
-    float *hn = reinterpret_cast<float *>(ws + w.hn), *saved = reinterpret_cast<float *>(ws + w.saved);
-    float *coef = reinterpret_cast<float *>(ws + w.coef), *rawsc = reinterpret_cast<float *>(ws + w.rawsc);
-    float *layer1 = reinterpret_cast<float *>(ws + w.layer1), *WpT = reinterpret_cast<float *>(ws + w.WpT);
-    float *dG = reinterpret_cast<float *>(ws + w.dG), *dZ = reinterpret_cast<float *>(ws + w.dZ);
-    float *dXh = a->Xh_in ? a->g_Xh : reinterpret_cast<float *>(ws + w.dXh);
-    float *dhn = reinterpret_cast<float *>(ws + w.dhn);
+    if (d.nb > 1 && (!a->b_ih || !a->b_hh || !a->fc2_b || (d.variant != PN_VARIANT_PAGG && !a->att_b)))
+        PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: micro-batches re-run the forward and need every forward tensor");
+    const int H = d.H, L = d.L, G = d.G, GH = G * H;
+    const int homo = d.variant == PN_VARIANT_HOMO;
+    const bool has_att = d.variant != PN_VARIANT_PAGG;
+    const float *Xh = c.Xh;
+    float *Z = c.Z;
+    float *dZ = c.at<float>(c.w.dZ);
+    float *dXh = a->Xh_in ? a->g_Xh : c.at<float>(c.w.dXh);
+    float *dhn = c.at<float>(c.w.dhn), *dG = c.at<float>(c.w.dG);
     // every buffer the kernels below accumulate into (atomics / += / split-K) is cleared by ONE launch
     ZeroList zl{};
     auto zero = [&](float *ptr, size_t count) -> int {
@@ -1906,185 +2013,196 @@ int pn_pagg_backward(const pn_pagg_args *a, void *stream_) {
         }
         return PN_OK;
     };
-    float *scratch = reinterpret_cast<float *>(ws + w.dl1);
-    if (int rc = zero(dZ, (size_t)s.N * L * H)) return rc;
-    if (int rc = zero(dXh, (size_t)s.N * H)) return rc;
+    float *scratch = c.at<float>(c.w.dl1);
+    if (int rc = zero(dZ, (size_t)d.N * L * H)) return rc;
+    if (int rc = zero(dXh, (size_t)d.N * H)) return rc;
     if (int rc = zero(a->g_att_w, has_att ? (size_t)2 * H : 0)) return rc;
     if (int rc = zero(a->g_att_b, has_att ? 1 : 0)) return rc;
     if (has_att && (!a->g_att_w || !a->g_att_b))
         if (int rc = zero(scratch, (size_t)2 * H + 1)) return rc;
-    if (int rc = zero(a->g_fc2_b, (size_t)s.C)) return rc;
-    if (int rc = zero(a->g_fc2_w, (size_t)s.C * 2 * H)) return rc;
+    if (int rc = zero(a->g_fc2_b, (size_t)d.C)) return rc;
+    if (int rc = zero(a->g_fc2_w, (size_t)d.C * 2 * H)) return rc;
     if (int rc = zero(a->g_bank_w, (size_t)L * H * H)) return rc;
     if (int rc = zero(a->g_bank_b, (size_t)L * H)) return rc;
     if (!a->Xh_in) {
-        if (int rc = zero(a->g_fc0_w, (size_t)H * s.F)) return rc;
+        if (int rc = zero(a->g_fc0_w, (size_t)H * d.F)) return rc;
         if (int rc = zero(a->g_fc0_b, (size_t)H)) return rc;
     }
-    if (s.S == 0) {
+    if (d.S == 0) {
         if (int rc = flush_zero()) return rc;
         if (int rc = zero(a->g_w_ih, (size_t)GH * H)) return rc;
         if (int rc = zero(a->g_w_hh, (size_t)GH * H)) return rc;
         if (int rc = zero(a->g_b_ih, (size_t)GH)) return rc;
         if (int rc = zero(a->g_b_hh, (size_t)GH)) return rc;
-        if (int rc = zero(a->g_X, (size_t)s.N * s.F)) return rc;
+        if (int rc = zero(a->g_X, (size_t)d.N * d.F)) return rc;
         return flush_zero();
     }
     if (int rc = flush_zero()) return rc;
 
-    // classifier: g_fc2_w = g_out^T . layer1, g_fc2_b = colsum(g_out) -- nothing below reads them: second stream
-    JoinGuard joiner{stream};
-    SideStream *ss = nullptr;
-    if (PN_BWD_OVERLAP || PN_SIDE_SMALL)     // created by the first backward on this device, whichever mode it runs in
-        if (int rc = side_stream(&ss)) return rc;
-    hipStream_t cstream = stream;
-    if (PN_SIDE_SMALL && !profiling_every_stage()) {
-        PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
-        PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
-        cstream = ss->s;
-    }
-    auto tm_fc2 = std::make_unique<StageTimer>(ST_FC2_GRAD, cstream);
-    if (a->g_fc2_w) {        // g_fc2_b = row sums of the A operand (g_out^T)
-        if (int rc = launch_gemm(cstream, a->g_out, 1, s.C, nullptr, layer1, 1, 2 * H, a->g_fc2_w, 2 * H, nullptr, s.C,
-                                 2 * H, s.S, 0, GEMM_ATOMIC, (s.S + 127) / 128, a->g_fc2_b))
-            return rc;
-    } else if (a->g_fc2_b) {
-        if (int rc = launch_colsum(cstream, a->g_out, nullptr, s.C, s.S, s.C, a->g_fc2_b)) return rc;
-    }
-    tm_fc2.reset();
-    if (cstream != stream) {
-        PN_CHECK_HIP(hipEventRecord(ss->join, ss->s));
-        joiner.side = ss;
-    }
-
-    // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
+    JoinGuard joiner{ctx, stream};
+    const bool side_ok = !profiling_every_stage(ctx);     // (per-stage timings are taken serially)
     {
-        PoolBwdParams pp{};
-        pp.variant = s.variant;
-        pp.S = s.S;
-        pp.W = s.W;
-        pp.H = H;
-        pp.C = s.C;
-        pp.hn = hn;
-        pp.ego_tab = homo ? Z : Xh;
-        pp.egoidx = egoidx;
-        pp.sel = a->sel;
-        pp.att_w = a->att_w;
-        pp.fc2_w = a->fc2_w;
-        pp.g_out = a->g_out;
-        pp.coef = coef;
-        pp.rawsc = rawsc;
-        pp.p_drop = a->p_cls;
-        pp.seed = a->seed;
-        pp.mask = a->mask_cls;
-        pp.dhn = dhn;
-        pp.dXh = dXh;
-        pp.dego = homo ? dZ : dXh;
-        // attention gradients are optional outputs: fall back to scratch so the kernel needs no branches
-        pp.g_att_w = a->g_att_w ? a->g_att_w : scratch;
-        pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
-        const size_t lds_bytes = (size_t)(4 * (2 * s.W + H) + 8 * H + 8 * s.W) * sizeof(float);
-        StageTimer tm(ST_POOL_BWD, stream);
-        hipLaunchKernelGGL(pool_bwd_kernel, dim3((s.S + 3) / 4), dim3(256), lds_bytes, stream, pp);
-        PN_CHECK_HIP(hipGetLastError());
-    }
-
-    // BPTT + gather-backward scatter
-    {
-        StageTimer tm(ST_SEQ_BWD, stream);
+        StageTimer tm(ctx, ST_SEQ_BWD, stream);
         hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
-                           a->w_hh, H, G, reinterpret_cast<u32x4 *>(WpT));
+                           a->w_hh, H, G, c.at<u32x4>(c.w.WpT));
         PN_CHECK_HIP(hipGetLastError());
-        SeqBwdParams sp{};
-        sp.saved = saved;
-        sp.keep = (a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : reinterpret_cast<const uint8_t *>(ws + w.keep);
-        sp.dhn = dhn;
-        sp.rowidx = rowidx;
-        sp.slotof = slotof;
-        sp.WpT = WpT;
-        sp.dG = dG;
-        sp.dZ = dZ;
-        sp.P = P;
-        sp.L = L;
-        sp.p_drop = a->p_seq;
-        sp.seed = a->seed;
-        sp.mask = a->mask_seq;
-        if (int rc = (G == 4 ? dispatch_seq_bwd<4>(stream, H, sp) : dispatch_seq_bwd<1>(stream, H, sp))) return rc;
     }
-
-    // recurrent weight / bias gradients: [g_W_ih | g_W_hh] = dG^T . XH, g_b = colsum(dG)
-    if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
-        hipStream_t wstream = stream;
-        const bool overlap = PN_BWD_OVERLAP && !profiling_every_stage();   // (per-stage timings are taken serially)
-        if (overlap) {
-            PN_CHECK_HIP(hipEventRecord(ss->fork, stream));
-            PN_CHECK_HIP(hipStreamWaitEvent(ss->s, ss->fork, 0));
-            wstream = ss->s;
+    for (int b = 0; b < d.nb; b++) {
+        const int Sb = c.groups(b);
+        const int64_t Pb = (int64_t)Sb * d.W;
+        const float *g_out = a->g_out + (size_t)b * d.Sb * d.C;
+        if (d.nb > 1) {
+            // this micro-batch's recurrence again (same seed and positions in the batch -> same dropout masks), now
+            // keeping what the BPTT needs
+            {
+                StageTimer tm(ctx, ST_PLAN_PACK, stream);
+                if (int rc = run_plan(c, stream, b)) return rc;
+            }
+            if (int rc = run_seq_fwd(c, b, true)) return rc;
+            if (int rc = run_pool_fwd(c, b, c.at<float>(c.w.outb))) return rc;
         }
-        WgradParams wp{};
-        wp.dG = dG;
-        wp.xh = reinterpret_cast<const float *>(ws + w.xh);
-        wp.R = (int64_t)P * L;
-        wp.GH = GH;
-        wp.H2 = 2 * H;
-        const int nz = w.wgrad_split;
-        int64_t rps = (wp.R + nz - 1) / nz;
-        rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
-        wp.rows_per_split = rps;
-#if PN_WGRAD_STRIDED
-        const int64_t ntiles = (wp.R + WG_KT - 1) / WG_KT;
-        const int nz_used = (int)(ntiles < nz ? ntiles : nz);
-#else
-        const int nz_used = (int)((wp.R + rps - 1) / rps);
-#endif
-        wp.part_w = reinterpret_cast<float *>(ws + w.wpart);
-        wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
+        // classifier: g_fc2_w += g_out^T . layer1, g_fc2_b += colsum(g_out) -- nothing below reads them: second stream
+        hipStream_t cstream = stream;
+        if (PN_SIDE_SMALL && side_ok)
+            if (void *side = context_fork(ctx, stream)) cstream = (hipStream_t)side;
         {
-            StageTimer tm(ST_WGRAD, wstream);
-            static const hipError_t lds_attr = hipFuncSetAttribute(
-                reinterpret_cast<const void *>(wgrad3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
-            PN_CHECK_HIP(lds_attr);
-            hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
-                               dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
-            PN_CHECK_HIP(hipGetLastError());
-            const int64_t nred = (int64_t)GH * 2 * H + GH;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
-                               wp.part_w, wp.part_b, nz_used, GH, H, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
+            StageTimer tm(ctx, ST_FC2_GRAD, cstream);
+            if (a->g_fc2_w) {        // g_fc2_b = row sums of the A operand (g_out^T)
+                if (int rc = launch_gemm(cstream, g_out, 1, d.C, nullptr, c.at<float>(c.w.layer1), 1, 2 * H, a->g_fc2_w,
+                                         2 * H, nullptr, d.C, 2 * H, Sb, 0, GEMM_ATOMIC, (Sb + 127) / 128, a->g_fc2_b))
+                    return rc;
+            } else if (a->g_fc2_b) {
+                if (int rc = launch_colsum(cstream, g_out, nullptr, d.C, Sb, d.C, a->g_fc2_b)) return rc;
+            }
+        }
+        if (cstream != stream)
+            if (int rc = joiner.mark()) return rc;
+
+        // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
+        {
+            PoolBwdParams pp{};
+            pp.variant = d.variant;
+            pp.S = Sb;
+            pp.W = d.W;
+            pp.H = H;
+            pp.C = d.C;
+            pp.goff = c.group0(b);
+            pp.hn = c.at<float>(c.w.hn);
+            pp.ego_tab = homo ? Z : Xh;
+            pp.egoidx = c.at<int32_t>(c.w.egoidx);
+            pp.sel = c.sel(b);
+            pp.att_w = a->att_w;
+            pp.fc2_w = a->fc2_w;
+            pp.g_out = g_out;
+            pp.coef = c.at<float>(c.w.coef);
+            pp.rawsc = c.at<float>(c.w.rawsc);
+            pp.p_drop = a->p_cls;
+            pp.seed = a->seed;
+            pp.mask = a->mask_cls;
+            pp.dhn = dhn;
+            pp.dXh = dXh;
+            pp.dego = homo ? dZ : dXh;
+            // attention gradients are optional outputs: fall back to scratch so the kernel needs no branches
+            pp.g_att_w = a->g_att_w ? a->g_att_w : scratch;
+            pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
+            const size_t lds_bytes = (size_t)(4 * (2 * d.W + H) + 8 * H + 8 * d.W) * sizeof(float);
+            StageTimer tm(ctx, ST_POOL_BWD, stream);
+            hipLaunchKernelGGL(pool_bwd_kernel, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
             PN_CHECK_HIP(hipGetLastError());
         }
-        if (overlap) {
-            PN_CHECK_HIP(hipEventRecord(ss->join, ss->s));
-            joiner.side = ss;       // `stream` waits for the weight gradients when this function returns
+
+        // BPTT + gather-backward scatter
+        {
+            StageTimer tm(ctx, ST_SEQ_BWD, stream);
+            SeqBwdParams sp{};
+            sp.saved = c.at<float>(c.w.saved);
+            sp.keep = (a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : c.at<const uint8_t>(c.w.keep);
+            sp.dhn = dhn;
+            sp.rowidx = c.at<int32_t>(c.w.rowidx);
+            sp.slotof = c.at<int32_t>(c.w.slotof);
+            sp.WpT = c.at<float>(c.w.WpT);
+            sp.dG = dG;
+            sp.dZ = dZ;
+            sp.P = (int)Pb;
+            sp.L = L;
+            sp.Pmask = d.P_total;
+            sp.p_drop = a->p_seq;
+            sp.seed = a->seed;
+            sp.mask = a->mask_seq;
+            if (int rc = (G == 4 ? dispatch_seq_bwd<4>(stream, H, sp) : dispatch_seq_bwd<1>(stream, H, sp))) return rc;
         }
+
+        // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG)
+        if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
+            hipStream_t wstream = stream;
+            if (PN_BWD_OVERLAP && side_ok)
+                if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;
+            WgradParams wp{};
+            wp.dG = dG;
+            wp.xh = c.at<const float>(c.w.xh);
+            wp.R = Pb * L;
+            wp.GH = GH;
+            wp.H2 = 2 * H;
+            const int nz = c.w.wgrad_split;
+            int64_t rps = (wp.R + nz - 1) / nz;
+            rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
+            wp.rows_per_split = rps;
+#if PN_WGRAD_STRIDED
+            const int64_t ntiles = (wp.R + WG_KT - 1) / WG_KT;
+            const int nz_used = (int)(ntiles < nz ? ntiles : nz);
+#else
+            const int nz_used = (int)((wp.R + rps - 1) / rps);
+#endif
+            wp.part_w = c.at<float>(c.w.wpart);
+            wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
+            {
+                StageTimer tm(ctx, ST_WGRAD, wstream);
+                PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES));
+                hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
+                                   dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
+                PN_CHECK_HIP(hipGetLastError());
+                const int64_t nred = (int64_t)GH * 2 * H + GH;
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
+                                   wp.part_w, wp.part_b, nz_used, GH, H, b > 0 ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih,
+                                   a->g_b_hh);
+                PN_CHECK_HIP(hipGetLastError());
+            }
+            if (wstream != stream)
+                if (int rc = joiner.mark()) return rc;   // `stream` waits for the weight gradients on the way out
+        }
+        // the next micro-batch rewrites the [x|h] rows and dG the weight-gradient GEMM is reading
+        if (b + 1 < d.nb)
+            if (int rc = joiner.join()) return rc;
     }
     // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh
     const float *zgate = homo ? Z : nullptr;
-    auto tm_bank = std::make_unique<StageTimer>(ST_BANK_BWD, stream);
-    if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, s.N, H, L * H,
-                                   0, GEMM_ADD, reinterpret_cast<float *>(ws + w.gpart)))
+    auto tm_bank = std::make_unique<StageTimer>(ctx, ST_BANK_BWD, stream);
+    if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, d.N, H, L * H,
+                                   0, GEMM_ADD, c.at<float>(c.w.gpart)))
         return rc;
     if (a->g_bank_w) {       // g_bank_b rides along as the row sums of the same (gated) A operand
-        if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, s.N,
-                                 0, GEMM_ATOMIC, (s.N + 255) / 256, a->g_bank_b))
+        if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, d.N,
+                                 0, GEMM_ATOMIC, (d.N + 255) / 256, a->g_bank_b))
             return rc;
     } else if (a->g_bank_b) {
-        if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, s.N, L * H, a->g_bank_b)) return rc;
+        if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, d.N, L * H, a->g_bank_b)) return rc;
     }
 
     tm_bank.reset();
     if (a->Xh_in) return PN_OK;   // the caller finishes fc0 after the reduce-scatter of g_Xh
     // fc0 backward (ReLU gate for HOMO)
     const float *xgate = homo ? Xh : nullptr;
-    StageTimer tm_fc0(ST_FC0_BWD, stream);
+    StageTimer tm_fc0(ctx, ST_FC0_BWD, stream);
     if (a->g_fc0_w) {
-        if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, s.F, a->g_fc0_w, s.F, nullptr, H, s.F, s.N, 0,
-                                 GEMM_ATOMIC, (s.N + 255) / 256, a->g_fc0_b))
+        if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, d.F, a->g_fc0_w, d.F, nullptr, H, d.F, d.N, 0,
+                                 GEMM_ATOMIC, (d.N + 255) / 256, a->g_fc0_b))
             return rc;
     } else if (a->g_fc0_b) {
-        if (int rc = launch_colsum(stream, dXh, xgate, H, s.N, H, a->g_fc0_b)) return rc;
+        if (int rc = launch_colsum(stream, dXh, xgate, H, d.N, H, a->g_fc0_b)) return rc;
     }
     if (a->g_X)
-        if (int rc = launch_gemm(stream, dXh, H, 1, xgate, a->fc0_w, 1, s.F, a->g_X, s.F, nullptr, s.N, s.F, H, 0,
+        if (int rc = launch_gemm(stream, dXh, H, 1, xgate, a->fc0_w, 1, d.F, a->g_X, d.F, nullptr, d.N, d.F, H, 0,
                                  GEMM_STORE, 1))
             return rc;
     return PN_OK;

@@ -358,84 +358,7 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
 
 }  // namespace
 
-namespace pn {
-// ---- per-stage HIP-event timing -------------------------------------------------------------------
-static int g_prof_mode = 0, g_prof_stage = -1;
-bool profiling_every_stage() { return g_prof_mode == 1; }
-struct ProfRec {
-    int stage;
-    hipEvent_t a, b;
-};
-static std::vector<ProfRec> g_prof_recs;
-static std::vector<hipEvent_t> g_prof_free;
-
-static hipEvent_t prof_event() {
-    if (!g_prof_free.empty()) {
-        hipEvent_t e = g_prof_free.back();
-        g_prof_free.pop_back();
-        return e;
-    }
-    hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
-    return e;
-}
-
-StageTimer::StageTimer(int stage, void *stream_) : slot(-1), stream(stream_) {
-    if (g_prof_mode == 0 || (g_prof_mode == 2 && stage != g_prof_stage)) return;
-    ProfRec r{stage, prof_event(), prof_event()};
-    (void)hipEventRecord(r.a, (hipStream_t)stream);
-    slot = (int)g_prof_recs.size();
-    g_prof_recs.push_back(r);
-}
-StageTimer::~StageTimer() {
-    if (slot >= 0) (void)hipEventRecord(g_prof_recs[(size_t)slot].b, (hipStream_t)stream);
-}
-}  // namespace pn
-
 extern "C" {
-
-int pn_profile_configure(int32_t mode, int32_t stage) {
-    if (mode < 0 || mode > 2) PN_FAIL(PN_ERR_ARG, "profile mode %d", mode);
-    pn::g_prof_mode = mode;
-    pn::g_prof_stage = stage;
-    return PN_OK;
-}
-int pn_profile_stage_count(void) { return pn::ST_COUNT; }
-const char *pn_profile_stage_name(int32_t stage) {
-    static const char *names[pn::ST_COUNT] = {"sampler_glibc_fill", "sampler_walk", "gather",   "fc0",      "bank",
-                                              "plan_pack",          "seq_fwd",      "pool_fwd", "fc2_grad", "pool_bwd",
-                                              "seq_bwd",            "wgrad",        "bias_grad", "bank_bwd", "fc0_bwd"};
-    return (stage >= 0 && stage < pn::ST_COUNT) ? names[stage] : "?";
-}
-int pn_profile_read(double *ms_sum, int64_t *count) {
-    if (!ms_sum || !count) PN_FAIL(PN_ERR_ARG, "pn_profile_read: null");
-    for (auto &r : pn::g_prof_recs) {
-        PN_CHECK_HIP(hipEventSynchronize(r.b));
-        float ms = 0.0f;
-        PN_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-        ms_sum[r.stage] += ms;
-        count[r.stage] += 1;
-        pn::g_prof_free.push_back(r.a);
-        pn::g_prof_free.push_back(r.b);
-    }
-    pn::g_prof_recs.clear();
-    return PN_OK;
-}
-
-int pn_device_query(pn_device_info *out) {
-    if (!out) PN_FAIL(PN_ERR_ARG, "pn_device_query: null");
-    int dev = 0;
-    PN_CHECK_HIP(hipGetDevice(&dev));
-    hipDeviceProp_t prop;
-    PN_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-    std::snprintf(out->name, sizeof out->name, "%s", prop.name);
-    std::snprintf(out->arch, sizeof out->arch, "%s", prop.gcnArchName);
-    out->compute_units = prop.multiProcessorCount;
-    out->lds_bytes_per_block = (int32_t)prop.sharedMemPerBlock;
-    out->hbm_bytes = (int64_t)prop.totalGlobalMem;
-    out->clock_khz = prop.clockRate;
-    return PN_OK;
-}
 
 static int64_t fill_blocks(int64_t seg_len) { return (seg_len + kDrawsPerBlock - 1) / kDrawsPerBlock; }
 
@@ -453,10 +376,11 @@ int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t
     return PN_OK;
 }
 
-int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
+int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
                     int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
                     uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = pn::context_check_device(ctx)) return rc;
     if (!tb || !tb->off || !tb->triples || !ids || !codes) PN_FAIL(PN_ERR_ARG, "pn_sample_paths: null table or output");
     const bool otf = tb->dis == nullptr;
     if (otf && (!tb->adj_off || !tb->adj || !tb->radj_off || !tb->radj))
@@ -533,14 +457,14 @@ int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t d
         PN_CHECK_HIP(hipStreamSynchronize(stream));  // `host` dies at scope exit (parity mode, not the fast path)
         dim3 grid((unsigned)nblk, (unsigned)epoch_count);
         {
-        pn::StageTimer tm(pn::ST_SAMPLER_FILL, stream);
+        pn::StageTimer tm(ctx, pn::ST_SAMPLER_FILL, stream);
         hipLaunchKernelGGL(glibc_fill_kernel, grid, dim3(kFillThreads), 0, stream, d_tables,
                            d_tables + (size_t)epoch_count * 31, d_tables + (size_t)(epoch_count + nblk) * 31, seg_len,
                            d_draws);
         }
         PN_CHECK_HIP(hipGetLastError());
         wp.draws = d_draws;
-        pn::StageTimer tm(pn::ST_SAMPLER_WALK, stream);
+        pn::StageTimer tm(ctx, pn::ST_SAMPLER_WALK, stream);
         if (otf) {
             OtfParams op{wp, tb->adj_off, tb->adj, tb->radj_off, tb->radj};
             hipLaunchKernelGGL(merw_walk_otf_kernel<PN_DRAW_GLIBC_REPLAY>, dim3((node_count + kOtfWaves - 1) / kOtfWaves),
@@ -551,7 +475,7 @@ int pn_sample_paths(const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t d
         }
         PN_CHECK_HIP(hipGetLastError());
     } else if (draw_source == PN_DRAW_PHILOX) {
-        pn::StageTimer tm(pn::ST_SAMPLER_WALK, stream);
+        pn::StageTimer tm(ctx, pn::ST_SAMPLER_WALK, stream);
         if (otf) {
             OtfParams op{wp, tb->adj_off, tb->adj, tb->radj_off, tb->radj};
             hipLaunchKernelGGL(merw_walk_otf_kernel<PN_DRAW_PHILOX>, dim3((node_count + kOtfWaves - 1) / kOtfWaves),

@@ -10,20 +10,32 @@ The reference is single-process; this is the multi-GPU desig
     every rank the table its path gather reads;
   * backward: d loss / d Xh comes out of the aggregator backward for all N rows; ONE reduce-scatter
     returns each row block to its owner, which finishes fc0's backward on its rows;
-  * parameter gradients: ONE flat all-reduce (a single bucket: the model has ~0.4 M parameters).
+  * parameter gradients: ONE all-reduce of a persistent flat buffer the .grad tensors are views of.
 
-No other data moves between GPUs: path sampling and aggregation of a node are independent of every
-other node's.  Exact for the homo / PAGG classes.  For the hetero class (PathNet) the reference's
-[W, S] re-view of the hidden states mixes paths of different masked nodes *within a batch*
-(PathNet_run.py:196-197), so its output depends on how the masked nodes are batched; sharding
-changes the batch and therefore (by the reference's own definition) the result -- each shard is
-exactly what the reference computes when given that shard as its batch.
+The step's batch is the concatenation of the ranks' masked-node lists in rank order; rank r computes
+the pooling groups [offset_r, offset_r + S_r) of it (pn_pagg_shape.S_total / group_begin).  One tiny
+all-gather of the S_r tells every rank its offset; dropout counters are positions in that batch, so the
+masks of different ranks are independent draws of one stream, as in a single process.
+
+homo / PAGG: a group reads only its own paths -- no other exchange, result identical to one process.
+hetero (PathNet): the reference's [W, S] re-view of the hidden states (PathNet_run.py:196-197) makes
+group g read paths of OTHER masked nodes of the batch.  The ranks therefore all-gather the batch's index
+arrays (ids / codes / sel: 5 bytes per path step, 1 MB at Cora size per rank) and each computes its
+groups from the whole batch's paths: every output row is exactly what a single process computes for
+the whole batch.  (The alternative, an all-to-all of the [P, H] hidden states, moves 100x the bytes.)
+
+What is replicated: the distance bank Z = bank(Xh) over all N rows and its backward run on every rank
+(2*N*L*H^2 flops each way).  Sharding them would replace the all-gather of Xh by one of Z -- L times
+the bytes over xGMI -- for GEMMs that take 0.06 ms at 8 x 2708 nodes and ~25 ms at 10^7 nodes against
+~90 ms for moving 30 GB of Z at 7 x 50 GB/s: replication is cheaper at every size.
 
 The compute backend is an object with four methods (project / forward / backward /
 linear_backward).  The product backend is HipOps (libpathnet_hip.so); CPU tests plug in a checker
-backend to exercise the sharding and the collectives with gloo.
+backend to exercise the sharding and the collectives with gloo.  Collectives go through a Comm object
+(torch.distributed by default) so tests can stage device tensors through the host for gloo.
 """
 import ctypes
+import time
 
 import torch
 import torch.distributed as dist
@@ -32,43 +44,116 @@ from . import _lib
 from . import modules as M
 
 
+class Comm:
+    """The four collectives of a step over a torch.distributed group; seconds spent are accumulated per kind
+    (device-synchronised only when timing is switched on)."""
+
+    def __init__(self, group=None, timing=False):
+        self.group = group
+        self.timing = timing
+        self.seconds = {"all_gather_Xh": 0.0, "reduce_scatter_dXh": 0.0, "all_reduce_grads": 0.0, "all_gather_index": 0.0}
+
+    def world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def rank(self):
+        return dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+
+    def _timed(self, kind, fn, tensor):
+        if not self.timing:
+            return fn()
+        if tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+        t0 = time.perf_counter()
+        out = fn()
+        if tensor.is_cuda:
+            torch.cuda.synchronize(tensor.device)
+        self.seconds[kind] += time.perf_counter() - t0
+        return out
+
+    # -- primitives (overridden by the host-staging test double) ---------------------------------------------------
+    def _all_gather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def _reduce_scatter(self, out, inp):
+        dist.reduce_scatter_tensor(out, inp, group=self.group)
+
+    def _all_reduce(self, t):
+        dist.all_reduce(t, group=self.group)
+
+    # -- what a step uses ----------------------------------------------------------------------------------------------
+    def all_gather_rows(self, t, kind="all_gather_Xh"):
+        """[rows, ...] per rank (equal rows) -> [world*rows, ...]"""
+        t = t.contiguous()
+        out = torch.empty((t.shape[0] * self.world(),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self._timed(kind, lambda: self._all_gather(out, t), t)
+        return out
+
+    def reduce_scatter_rows(self, t, rows):
+        t = t.contiguous()
+        out = torch.empty((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self._timed("reduce_scatter_dXh", lambda: self._reduce_scatter(out, t), t)
+        return out
+
+    def all_reduce(self, t):
+        self._timed("all_reduce_grads", lambda: self._all_reduce(t), t)
+
+    def counts(self, n, device):
+        """every rank's n -> list of ints"""
+        mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
+        return [int(v) for v in self.all_gather_rows(mine, kind="all_gather_index").tolist()]
+
+    def all_gather_ragged(self, t, counts):
+        """[n_r, ...] per rank -> [sum n_r, ...] in rank order (padded to the largest n_r on the wire)"""
+        cap = max(counts)
+        pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        full = self.all_gather_rows(pad, kind="all_gather_index")
+        return torch.cat([full[r * cap: r * cap + counts[r]] for r in range(len(counts))])
+
+
 class HipOps:
     """The HIP kernels behind the sharded aggregator."""
 
     def project(self, variant, X_loc, w, b):
         lib = _lib.load()
         X_loc = X_loc.contiguous()
+        dev = X_loc.device
         rows, out_f = X_loc.shape[0], w.shape[0]
-        out = torch.empty((rows, out_f), dtype=torch.float32, device=X_loc.device)
-        ws = torch.empty(max(_lib.LINEAR_SPLIT_MAX * rows * out_f, 1), dtype=torch.float32, device=X_loc.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(X_loc.device).cuda_stream)
-        _lib.check(lib.pn_linear_forward(X_loc.data_ptr(), w.data_ptr(), b.data_ptr(), rows, X_loc.shape[1], out_f,
-                                         1 if variant == "homo" else 0, out.data_ptr(), ws.data_ptr(), ws.numel() * 4,
-                                         stream))
+        with torch.cuda.device(dev):
+            out = torch.empty((rows, out_f), dtype=torch.float32, device=dev)
+            ws = torch.empty(max(_lib.LINEAR_SPLIT_MAX * rows * out_f, 1), dtype=torch.float32, device=dev)
+            _lib.check(lib.pn_linear_forward(_lib.context(dev), X_loc.data_ptr(), w.data_ptr(), b.data_ptr(), rows,
+                                             X_loc.shape[1], out_f, 1 if variant == "homo" else 0, out.data_ptr(),
+                                             ws.data_ptr(), ws.numel() * 4, _lib.stream_ptr(dev)))
         return out
 
     def _args(self, cfg, Xh, ids, codes, sel, p):
         a = _lib.PaggArgs()
-        a.shape = M._shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
+        a.shape = M._cfg_shape(cfg)
         a.Xh_in = Xh.data_ptr()
         a.ids, a.codes, a.sel = ids.data_ptr(), codes.data_ptr(), sel.data_ptr()
+        a.index_rows_local = 1 if cfg.get("index_rows_local") else 0
         for k in M._HEAD_PARAMS[2:]:
             setattr(a, k, p[k].data_ptr() if p.get(k) is not None else None)
         a.bank_w, a.bank_b = cfg["bank_w"].data_ptr(), cfg["bank_b"].data_ptr()
         a.p_seq, a.p_cls, a.seed = cfg["p_seq"], cfg["p_cls"], cfg["seed"]
+        ms, mc = cfg.get("mask_seq"), cfg.get("mask_cls")
+        a.mask_seq = ms.data_ptr() if ms is not None else None
+        a.mask_cls = mc.data_ptr() if mc is not None else None
         return a
 
     def forward(self, cfg, Xh, ids, codes, sel, p):
         lib = _lib.load()
         dev = Xh.device
-        out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
-        ws = torch.empty(max(M.workspace_bytes(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"],
-                                               cfg["W"], cfg["L"]), 1), dtype=torch.uint8, device=dev)
-        a = self._args(cfg, Xh, ids, codes, sel, p)
-        a.out = out.data_ptr()
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        if cfg["S"] > 0:
-            _lib.check(lib.pn_pagg_forward(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        with torch.cuda.device(dev):
+            out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
+            ws = torch.empty(max(M._cfg_workspace_bytes(cfg), 1), dtype=torch.uint8, device=dev)
+            a = self._args(cfg, Xh, ids, codes, sel, p)
+            a.out = out.data_ptr()
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            if cfg["S"] > 0:
+                _lib.check(lib.pn_pagg_forward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
         return out, (cfg, Xh, ids, codes, sel, p, ws)
 
     def backward(self, state, g_out):
@@ -77,35 +162,34 @@ class HipOps:
         lib = _lib.load()
         cfg, Xh, ids, codes, sel, p, ws = state
         dev = Xh.device
-        a = self._args(cfg, Xh, ids, codes, sel, p)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        g_out = g_out.contiguous().float()
-        a.g_out = g_out.data_ptr()
-        g_Xh = torch.empty_like(Xh)
-        a.g_Xh = g_Xh.data_ptr()
-        grads = {"bank_w": torch.empty_like(cfg["bank_w"]), "bank_b": torch.empty_like(cfg["bank_b"])}
-        a.g_bank_w, a.g_bank_b = grads["bank_w"].data_ptr(), grads["bank_b"].data_ptr()
-        for k in M._HEAD_PARAMS[2:]:
-            if p.get(k) is None:
-                continue
-            grads[k] = torch.empty_like(p[k])
-            setattr(a, "g_" + k, grads[k].data_ptr())
-        if cfg["S"] > 0:
-            _lib.check(lib.pn_pagg_backward(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        else:
-            g_Xh.zero_()
-            for g in grads.values():
-                g.zero_()
+        with torch.cuda.device(dev):
+            a = self._args(cfg, Xh, ids, codes, sel, p)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            g_out = g_out.contiguous().float()
+            a.g_out = g_out.data_ptr()
+            g_Xh = torch.empty_like(Xh)
+            a.g_Xh = g_Xh.data_ptr()
+            grads = {"bank_w": torch.empty_like(cfg["bank_w"]), "bank_b": torch.empty_like(cfg["bank_b"])}
+            a.g_bank_w, a.g_bank_b = grads["bank_w"].data_ptr(), grads["bank_b"].data_ptr()
+            for k in M._HEAD_PARAMS[2:]:
+                if p.get(k) is None:
+                    continue
+                grads[k] = torch.empty_like(p[k])
+                setattr(a, "g_" + k, grads[k].data_ptr())
+            # (S == 0: the library zero-fills every gradient it was given)
+            _lib.check(lib.pn_pagg_backward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
         return g_Xh, grads
 
     def linear_backward(self, variant, dXh_loc, Xh_loc, X_loc, w):
         lib = _lib.load()
-        dXh_loc = dXh_loc.contiguous()
-        g_w, g_b = torch.empty_like(w), torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
-        gate = Xh_loc.data_ptr() if variant == "homo" else None
-        stream = ctypes.c_void_p(torch.cuda.current_stream(w.device).cuda_stream)
-        _lib.check(lib.pn_linear_backward(dXh_loc.data_ptr(), gate, X_loc.data_ptr(), w.data_ptr(), X_loc.shape[0],
-                                          w.shape[1], w.shape[0], g_w.data_ptr(), g_b.data_ptr(), None, stream))
+        dev = w.device
+        with torch.cuda.device(dev):
+            dXh_loc = dXh_loc.contiguous()
+            g_w, g_b = torch.empty_like(w), torch.empty(w.shape[0], dtype=torch.float32, device=dev)
+            gate = Xh_loc.data_ptr() if variant == "homo" else None
+            _lib.check(lib.pn_linear_backward(_lib.context(dev), dXh_loc.data_ptr(), gate, X_loc.data_ptr(), w.data_ptr(),
+                                              X_loc.shape[0], w.shape[1], w.shape[0], g_w.data_ptr(), g_b.data_ptr(),
+                                              None, _lib.stream_ptr(dev)))
         return g_w, g_b
 
 
@@ -113,14 +197,10 @@ class _ShardedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, cfg, X_loc, ids, codes, sel, *params):
         p = M._split_params(params, cfg["L"])
-        ops, group = runner.ops, runner.group
+        ops, comm = runner.ops, runner.comm
         Xh_loc = ops.project(cfg["variant"], X_loc, p["fc0_w"], p["fc0_b"])
-        world = dist.get_world_size(group) if runner.distributed else 1
-        if world > 1:
-            Xh = torch.empty((cfg["N"], cfg["H"]), dtype=Xh_loc.dtype, device=Xh_loc.device)
-            dist.all_gather_into_tensor(Xh, Xh_loc.contiguous(), group=group)     # the one forward collective
-        else:
-            Xh = Xh_loc
+        world = comm.world()
+        Xh = comm.all_gather_rows(Xh_loc) if world > 1 else Xh_loc          # the one forward collective
         out, state = ops.forward(cfg, Xh, ids, codes, sel, p)
         ctx.runner, ctx.state, ctx.cfg = runner, state, cfg
         ctx.save_for_backward(X_loc, Xh_loc, p["fc0_w"])
@@ -130,15 +210,10 @@ class _ShardedFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         runner, cfg = ctx.runner, ctx.cfg
-        ops, group = runner.ops, runner.group
+        ops, comm = runner.ops, runner.comm
         X_loc, Xh_loc, fc0_w = ctx.saved_tensors
         g_Xh, grads = ops.backward(ctx.state, g_out)
-        world = dist.get_world_size(group) if runner.distributed else 1
-        if world > 1:
-            g_loc = torch.empty_like(Xh_loc)
-            dist.reduce_scatter_tensor(g_loc, g_Xh.contiguous(), group=group)     # the one backward collective
-        else:
-            g_loc = g_Xh
+        g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0]) if comm.world() > 1 else g_Xh   # the one backward collective
         grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w)
         L = cfg["L"]
         head = tuple(grads.get(k) if pres else None for k, pres in zip(M._HEAD_PARAMS, ctx.present[:10]))
@@ -153,44 +228,114 @@ class ShardedAggregator:
     n_total     : nodes in the whole graph;  row_begin/row_count: this rank's block (equal on every rank)
     """
 
-    def __init__(self, module, n_total, row_begin, row_count, group=None, ops=None):
+    def __init__(self, module, n_total, row_begin, row_count, group=None, ops=None, comm=None, dropout_seed=0):
         self.module, self.n_total, self.row_begin, self.row_count = module, int(n_total), int(row_begin), int(row_count)
-        self.group = group
+        self.comm = comm if comm is not None else Comm(group)
+        self.group = self.comm.group
         self.ops = ops if ops is not None else HipOps()
-        self.distributed = dist.is_available() and dist.is_initialized()
-        world = dist.get_world_size(group) if self.distributed else 1
-        if self.row_count * world != self.n_total:
+        self.distributed = self.comm.world() > 1
+        if self.row_count * self.comm.world() != self.n_total:
             raise ValueError("node blocks must be equal: %d rows x %d ranks != %d nodes (pad the graph)"
-                             % (self.row_count, world, self.n_total))
-        self._flat = None
+                             % (self.row_count, self.comm.world(), self.n_total))
+        self._flat = None           # persistent flat gradient buffer (see flat_grads)
+        self._flat_ids = None
+        self.batch_counts = None    # masked nodes per rank of the last call
+        self._fixed_counts = None
+        # every rank draws the step's dropout seed from its own copy of the same generator: equal seeds, no traffic
+        self._seed_gen = torch.Generator()
+        self._seed_gen.manual_seed(int(dropout_seed))
+        self.mask_seq = self.mask_cls = None    # test hook: explicit dropout masks of the WHOLE batch
 
     def __call__(self, X_loc, neis, num_w, walk_len, sel_global, layer_type):
         """X_loc [row_count, F]; sel_global: global node ids of this rank's masked nodes (inside its block);
         neis / layer_type: their paths [S, W*L] / [S, W, L] with GLOBAL node ids.  -> logits [S, C]."""
         m = self.module
         dev = X_loc.device
-        ids, codes, sel, S = M._as_index_tensors(neis, layer_type, sel_global, num_w, walk_len, dev)
+        ids, codes, sel, S = M._as_index_tensors(neis, layer_type, sel_global, num_w, walk_len, dev, n_nodes=self.n_total)
         fw, fb, params = m._param_inputs()
         p = m.dropout_p() if m.training else 0.0
+        comm = self.comm
+        world = comm.world()
+        if world == 1:
+            counts = [S]
+        elif self._fixed_counts is not None:
+            counts = self._fixed_counts
+            if counts[comm.rank()] != S:
+                raise ValueError("set_batch_counts said %d masked nodes for this rank, the call has %d"
+                                 % (counts[comm.rank()], S))
+        else:
+            counts = comm.counts(S, dev)        # (a host round trip: see set_batch_counts)
+        self.batch_counts = counts
+        S_total, begin = sum(counts), sum(counts[:comm.rank()])
+        local_rows = True
+        if world > 1 and m.variant == "hetero":
+            # the [W, S] re-view reads other ranks' paths: every rank gets the whole batch's index arrays
+            ids, codes, sel = (comm.all_gather_ragged(t, counts) for t in (ids, codes, sel))
+            local_rows = False
+        # one seed per step for all ranks (positions in the batch separate their masks)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=self._seed_gen).item()) if p > 0 else 0
         cfg = dict(variant=m.variant, N=self.n_total, F=X_loc.shape[1], H=m.hidden_size, C=m.out_size, S=S,
-                   W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb,
-                   seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
+                   W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb, seed=seed,
+                   S_total=S_total, group_begin=begin, index_rows_local=local_rows and world > 1,
+                   mask_seq=None, mask_cls=None)
+        if world == 1:
+            cfg["S_total"], cfg["group_begin"] = 0, 0
+        if m.training and (self.mask_seq is not None or self.mask_cls is not None):
+            cfg["mask_seq"], cfg["mask_cls"] = self.mask_seq, self.mask_cls
+            cfg["p_seq"] = cfg["p_cls"] = 0.0
+        cfg["batch_groups"] = M.pick_batch_groups(m.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
+                                                  cfg["L"], m.workspace_budget) if isinstance(self.ops, HipOps) else 0
         return _ShardedFn.apply(self, cfg, X_loc.contiguous().float(), ids, codes, sel, *params)
 
-    def allreduce_grads(self, average=True):
-        """One flat all-reduce of every parameter gradient (single bucket)."""
-        if not self.distributed or dist.get_world_size(self.group) == 1:
-            return
+    def set_batch_counts(self, counts):
+        """Masked nodes per rank, when they are the same every step (a fixed train mask): spares the per-step
+        all-gather of the counts and its host round trip.  None returns to asking every step."""
+        self._fixed_counts = None if counts is None else [int(c) for c in counts]
+
+    # ---- loss over the whole batch ------------------------------------------------------------------------------------
+    def loss_scale(self):
+        """Factor for this rank's MEAN loss over its own S_r masked nodes so that the summed gradients are those of
+        the mean over the whole batch (PathNet_run.py:297, :346): S_r / S_total.  Use with allreduce_grads(average=False);
+        with equal S_r on every rank it equals 1/world, i.e. average=True."""
+        counts = self.batch_counts or [1]
+        tot = sum(counts)
+        return counts[self.comm.rank()] / tot if tot else 0.0
+
+    # ---- parameter gradients: one persistent flat buffer, .grad tensors are views of it ------------------------------
+    def flat_grads(self):
         ps = [q for q in self.module.parameters() if q.requires_grad]
-        for q in ps:
-            if q.grad is None:
-                q.grad = torch.zeros_like(q)
-        flat = torch.cat([q.grad.reshape(-1) for q in ps])
-        dist.all_reduce(flat, group=self.group)
-        if average:
-            flat /= dist.get_world_size(self.group)
+        key = tuple((id(q), q.data_ptr()) for q in ps)
+        if self._flat is None or self._flat_ids != key:
+            n = sum(q.numel() for q in ps)
+            self._flat = torch.zeros(n, dtype=ps[0].dtype, device=ps[0].device)
+            self._flat_ids = key
         at = 0
+        views = []
         for q in ps:
-            n = q.numel()
-            q.grad.copy_(flat[at:at + n].view_as(q))
-            at += n
+            v = self._flat[at:at + q.numel()].view_as(q)
+            at += q.numel()
+            views.append((q, v))
+        return views
+
+    def allreduce_grads(self, average=True):
+        """One all-reduce of every parameter gradient (single bucket): the gradients autograd produced this step are
+        copied into the persistent flat buffer by one multi-tensor launch, the buffer is all-reduced in place and
+        every .grad becomes a view of it (use optimizer.zero_grad(set_to_none=True)).  average=True divides by the world size:
+        right when every rank's loss is a mean over equally many masked nodes; otherwise scale the local loss
+        by loss_scale() and pass average=False."""
+        if not self.distributed:
+            return
+        views = self.flat_grads()
+        src, dst = [], []
+        for q, v in views:
+            if q.grad is None:
+                v.zero_()
+            elif q.grad.data_ptr() != v.data_ptr():      # autograd handed out a fresh tensor this step
+                src.append(q.grad)
+                dst.append(v)
+            q.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)                # one multi-tensor launch into the flat buffer
+        self.comm.all_reduce(self._flat)
+        if average:
+            self._flat /= self.comm.world()

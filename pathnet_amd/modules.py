@@ -26,15 +26,41 @@ _VARIANT = {"hetero": _lib.VARIANT_HETERO, "homo": _lib.VARIANT_HOMO, "pagg": _l
 _HEAD_PARAMS = ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b")
 
 
-def _shape(variant, N, F, H, C, S, W, L):
-    return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L)
+# Per-path tensors of one aggregator call (saved gates, [x|h] rows, gate gradients: ~6 KB per path step) are kept
+# below this many bytes: a batch with more paths is walked in micro-batches inside the library (pn_pagg_shape
+# .batch_groups), the backward re-running each micro-batch's recurrence.  Cora / Pubmed-size batches fit in one.
+WORKSPACE_BUDGET_BYTES = 48 << 30
 
 
-def workspace_bytes(variant, N, F, H, C, S, W, L):
+def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0):
+    return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L, S_total, group_begin, batch_groups)
+
+
+def _cfg_shape(cfg):
+    return _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
+                  cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0))
+
+
+def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0):
     n = ctypes.c_int64(0)
-    sh = _shape(variant, N, F, H, C, S, W, L)
+    sh = _shape(variant, N, F, H, C, S, W, L, S_total, group_begin, batch_groups)
     _lib.check(_lib.load().pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(n)))
     return n.value
+
+
+def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None):
+    """0 when the whole batch fits the workspace budget, else the largest micro-batch (in masked nodes) that does."""
+    budget = WORKSPACE_BUDGET_BYTES if budget is None else int(budget)
+    if S <= 1 or workspace_bytes(variant, N, F, H, C, S, W, L) <= budget:
+        return 0
+    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L)
+    per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L) - fixed) // 1024, 1)
+    return int(max(1, min(S, (budget - fixed) // per_group if budget > fixed else 1)))
+
+
+def _cfg_workspace_bytes(cfg):
+    return workspace_bytes(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
+                           cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0))
 
 
 def _split_params(params, L):
@@ -53,7 +79,7 @@ class _PaggFunction(torch.autograd.Function):
     @staticmethod
     def _args(cfg, X, ids, codes, sel, p):
         a = _lib.PaggArgs()
-        a.shape = _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
+        a.shape = _cfg_shape(cfg)
         a.X, a.ids, a.codes, a.sel = X.data_ptr(), ids.data_ptr(), codes.data_ptr(), sel.data_ptr()
         for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b"):
             setattr(a, k, p[k].data_ptr() if p[k] is not None else None)
@@ -69,17 +95,19 @@ class _PaggFunction(torch.autograd.Function):
         lib = _lib.load()
         p = _split_params(params, cfg["L"])
         dev = X.device
-        out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
-        nbytes = workspace_bytes(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"])
+        nbytes = _cfg_workspace_bytes(cfg)
         ws = cfg.get("workspace")
-        if ws is None or ws.numel() < nbytes or ws.device != dev:
-            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
-        a.out = out.data_ptr()
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-        a.no_save = 0 if cfg.get("grad", True) else 1       # torch.no_grad() forwards skip the saved tensors
-        if cfg["S"] > 0:
-            _lib.check(lib.pn_pagg_forward(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        with torch.cuda.device(dev):        # the library launches on the current device
+            out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
+            if ws is None or ws.numel() < nbytes or ws.device != dev:
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
+            a.out = out.data_ptr()
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            a.no_save = 0 if cfg.get("grad", True) else 1       # torch.no_grad() forwards skip the saved tensors
+            a.reuse_tables = 1 if cfg.get("reuse_tables") else 0
+            if cfg["S"] > 0:
+                _lib.check(lib.pn_pagg_forward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
         ctx.cfg, ctx.ws = cfg, ws
         ctx.present = [t is not None for t in params]
         ctx.save_for_backward(X, ids, codes, sel, *[t for t in params if t is not None])
@@ -95,44 +123,63 @@ class _PaggFunction(torch.autograd.Function):
         params = [next(it) if pres else None for pres in ctx.present]
         L = cfg["L"]
         p = _split_params(params, L)
-        g_out = g_out.contiguous().float()
-        a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
-        grads = {}
-        for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b"):
-            if p[k] is not None:
-                grads[k] = torch.empty_like(p[k])
-                setattr(a, "g_" + k, grads[k].data_ptr())
-        g_bank_w, g_bank_b = torch.empty_like(cfg["bank_w"]), torch.empty_like(cfg["bank_b"])
-        a.g_bank_w, a.g_bank_b = g_bank_w.data_ptr(), g_bank_b.data_ptr()
-        gX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
-        a.g_X = gX.data_ptr() if gX is not None else None
-        a.workspace, a.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
-        a.g_out = g_out.data_ptr()
-        if cfg["S"] > 0:
-            _lib.check(lib.pn_pagg_backward(ctypes.byref(a),
-                                            ctypes.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)))
-        else:
-            for g in list(grads.values()) + [g_bank_w, g_bank_b]:
-                g.zero_()
-            if gX is not None:
-                gX.zero_()
+        dev = X.device
+        with torch.cuda.device(dev):
+            g_out = g_out.contiguous().float()
+            a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
+            grads = {}
+            for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b"):
+                if p[k] is not None:
+                    grads[k] = torch.empty_like(p[k])
+                    setattr(a, "g_" + k, grads[k].data_ptr())
+            g_bank_w, g_bank_b = torch.empty_like(cfg["bank_w"]), torch.empty_like(cfg["bank_b"])
+            a.g_bank_w, a.g_bank_b = g_bank_w.data_ptr(), g_bank_b.data_ptr()
+            gX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
+            a.g_X = gX.data_ptr() if gX is not None else None
+            a.workspace, a.workspace_bytes = ctx.ws.data_ptr(), ctx.ws.numel()
+            a.g_out = g_out.data_ptr()
+            if cfg["S"] > 0:
+                _lib.check(lib.pn_pagg_backward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
+            else:
+                for g in list(grads.values()) + [g_bank_w, g_bank_b]:
+                    g.zero_()
+                if gX is not None:
+                    gX.zero_()
         head = tuple(grads.get(k) for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b",
                                             "fc2_w", "fc2_b"))
         return (None, gX, None, None, None) + head + tuple(g_bank_w[d] for d in range(L)) + tuple(
             g_bank_b[d] for d in range(L))
 
 
-def _as_index_tensors(neis, layer_type, indices, num_w, walk_len, device):
-    """Reference argument conventions -> device int32 ids [S,W,L], uint8 codes, int32 sel [S]."""
+def _as_index_tensors(neis, layer_type, indices, num_w, walk_len, device, n_nodes=None):
+    """Reference argument conventions -> device int32 ids [S,W,L], uint8 codes, int32 sel [S].
+    `indices`: a bool mask over the nodes (numpy or torch: the reference's two conventions) or the node ids
+    themselves (any integer dtype, numpy or torch)."""
     if isinstance(indices, np.ndarray):
-        sel = torch.from_numpy(np.flatnonzero(indices).astype(np.int32))
+        if indices.dtype == np.bool_:
+            sel = torch.from_numpy(np.flatnonzero(indices).astype(np.int32))
+        elif np.issubdtype(indices.dtype, np.integer):
+            sel = torch.from_numpy(np.ascontiguousarray(indices).reshape(-1).astype(np.int32))
+        else:
+            raise TypeError("indices: bool mask or integer node ids expected, got numpy %s" % indices.dtype)
     else:
         idx = torch.as_tensor(indices)
-        sel = (torch.nonzero(idx, as_tuple=False).flatten() if idx.dtype == torch.bool else idx.flatten()).to(
-            torch.int32)
+        if idx.dtype == torch.bool:
+            sel = torch.nonzero(idx, as_tuple=False).flatten().to(torch.int32)
+        elif not idx.dtype.is_floating_point and not idx.dtype.is_complex:
+            sel = idx.flatten().to(torch.int32)
+        else:
+            raise TypeError("indices: bool mask or integer node ids expected, got %s" % idx.dtype)
     S = int(sel.numel())
     ids = torch.as_tensor(neis)
     codes = torch.as_tensor(layer_type)
+    if ids.numel() != S * num_w * walk_len or codes.numel() != S * num_w * walk_len:
+        raise ValueError("neis / layer_type hold %d / %d entries, %d masked nodes x %d paths x %d steps = %d expected"
+                         % (ids.numel(), codes.numel(), S, num_w, walk_len, S * num_w * walk_len))
+    if n_nodes is not None and S and sel.device.type == "cpu":      # (device-resident ids: the kernels clamp)
+        lo, hi = int(sel.min()), int(sel.max())
+        if lo < 0 or hi >= n_nodes:
+            raise IndexError("indices name node %d, the feature matrix has %d rows" % (lo if lo < 0 else hi, n_nodes))
     if ids.dtype != torch.int32:
         ids = ids.to(torch.int32)
     if codes.dtype != torch.uint8:
@@ -150,6 +197,8 @@ class _Aggregator(nn.Module):
         self.feature_length, self.hidden_size, self.out_size = feature_length, hidden_size, out_size
         self._dropout = dropout_p
         self._ws_eval = None
+        self._ws_tables = None            # (X address, shape, L) whose tables sit in _ws_eval
+        self.workspace_budget = None      # bytes; None = modules.WORKSPACE_BUDGET_BYTES (see pick_batch_groups)
         self._mask_seq = None     # test hook: explicit dropout masks (reference order)
         self._mask_cls = None
         self._bank_flat = (None, None)
@@ -197,29 +246,51 @@ class _Aggregator(nn.Module):
                 self.fc2.weight, self.fc2.bias)
         return fw, fb, head + tuple(ws) + tuple(bs)
 
-    def forward(self, X, neis, num_w, walk_len, indices, layer_type, indxx=None):
+    def forward(self, X, neis, num_w, walk_len, indices, layer_type, indxx=None, reuse_tables=False, group_slice=None):
+        """reuse_tables (extension, inference only): X and the weights are those of the previous no-grad forward of this
+        module -- the validation and the test forward of an epoch (PathNet_run.py:362, :378) -- so the projected
+        feature matrix and the distance bank still sitting in the module's workspace are used again.
+        group_slice=(begin, count) (extension): neis / indices / layer_type describe the whole batch as always, but only
+        the logits of its masked nodes [begin, begin + count) are computed and returned -- exactly those rows of the
+        whole-batch result, also for the hetero class whose rows read paths of other masked nodes of the batch."""
         dev = X.device
         if dev.type != "cuda":
             raise RuntimeError("pathnet_amd aggregators run on the GPU only (X is on %s); no CPU fallback" % dev)
         X = X.contiguous().float()
-        ids, codes, sel, S = _as_index_tensors(neis, layer_type, indices, num_w, walk_len, dev)
+        ids, codes, sel, S = _as_index_tensors(neis, layer_type, indices, num_w, walk_len, dev, n_nodes=X.shape[0])
         fw, fb, params = self._param_inputs()
         training = self.training
         p = self.dropout_p() if training else 0.0
         cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=self.hidden_size, C=self.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
                    seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
+        if group_slice is not None:
+            begin, count = int(group_slice[0]), int(group_slice[1])
+            if begin < 0 or count < 0 or begin + count > S:
+                raise ValueError("group_slice (%d, %d) outside the batch of %d masked nodes" % (begin, count, S))
+            cfg["S_total"], cfg["group_begin"], cfg["S"] = S, begin, count
+            S = count
         if len(params) != 10 + 2 * cfg["L"]:
             raise ValueError("walk_len=%d but the module has %d distance layers" % (cfg["L"], (len(params) - 10) // 2))
         if training and (self._mask_seq is not None or self._mask_cls is not None):
             cfg["mask_seq"], cfg["mask_cls"] = self._mask_seq, self._mask_cls
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["grad"] = torch.is_grad_enabled()
+        cfg["batch_groups"] = pick_batch_groups(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
+                                                cfg["L"], self.workspace_budget)
         if not cfg["grad"]:
-            need = workspace_bytes(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"], cfg["L"])
-            if self._ws_eval is None or self._ws_eval.numel() < need or self._ws_eval.device != dev:
-                self._ws_eval = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+            need = _cfg_workspace_bytes(cfg)
+            fits = self._ws_eval is not None and self._ws_eval.numel() >= need and self._ws_eval.device == dev
+            if reuse_tables and not (fits and self._ws_tables == (X.data_ptr(), X.shape, cfg["L"])):
+                reuse_tables = False        # nothing (valid) to reuse: compute the tables as usual
+            if not fits:
+                with torch.cuda.device(dev):
+                    self._ws_eval = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
             cfg["workspace"] = self._ws_eval
+            cfg["reuse_tables"] = bool(reuse_tables)
+            self._ws_tables = (X.data_ptr(), X.shape, cfg["L"])
+        elif reuse_tables:
+            raise RuntimeError("reuse_tables is for no-grad (inference) forwards")
         return _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
 
 

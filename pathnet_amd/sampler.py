@@ -142,6 +142,8 @@ class MerwSampler:
         list (eu -> ev): the dense table or the two CSR lists."""
         self.n, self.L = int(n), int(seq_len)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         if hops == "auto":
             hops = "dense" if self.n * self.n <= self.DENSE_LIMIT_BYTES else "otf"
         if hops not in ("dense", "otf"):
@@ -175,26 +177,33 @@ class MerwSampler:
         if node_count is None:
             node_count = self.n - node_begin
         L = self.L
+        shape = (epoch_count, node_count, W, L)
         if out is None:
-            ids = torch.empty((epoch_count, node_count, W, L), dtype=torch.int32, device=self.device)
-            codes = torch.empty((epoch_count, node_count, W, L), dtype=torch.uint8, device=self.device)
+            ids = torch.empty(shape, dtype=torch.int32, device=self.device)
+            codes = torch.empty(shape, dtype=torch.uint8, device=self.device)
         else:
             ids, codes = out
+            for t, dt in ((ids, torch.int32), (codes, torch.uint8)):
+                if (tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device.type != "cuda" or
+                        (self.device.index is not None and t.device != self.device)):
+                    raise ValueError("sample(out=...): contiguous %s tensor of shape %s on %s expected, got %s %s on %s"
+                                     % (dt, shape, self.device, t.dtype, tuple(t.shape), t.device))
         need = ctypes.c_int64(0)
         _lib.check(lib.pn_sample_workspace_bytes(W, L, draw_source, epoch_count, node_count, ctypes.byref(need)))
-        if need.value and (self._ws is None or self._ws.numel() < need.value):
-            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
         dp = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
         tb = _lib.SamplerTables(self.n, self.total, self.d_off.data_ptr(), self.d_triples.data_ptr(), dp(self.d_dis),
                                 dp(self.d_adj_off), dp(self.d_adj), dp(self.d_radj_off), dp(self.d_radj),
                                 self.draws_per_step)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        if check:
-            self._status.zero_()
-        _lib.check(lib.pn_sample_paths(ctypes.byref(tb), W, L, draw_source, seed & 0xFFFFFFFFFFFFFFFF, epoch_begin,
-                                       epoch_count, node_begin, node_count, _lib.ptr(ids), _lib.ptr(codes),
-                                       _lib.ptr(self._ws) if need.value else None, need.value,
-                                       _lib.ptr(self._status), ctypes.c_void_p(stream)))
+        dev = ids.device
+        with torch.cuda.device(dev):        # the library launches on the current device
+            if need.value and (self._ws is None or self._ws.numel() < need.value):
+                self._ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
+            if check:
+                self._status.zero_()
+            _lib.check(lib.pn_sample_paths(_lib.context(dev), ctypes.byref(tb), W, L, draw_source,
+                                           seed & 0xFFFFFFFFFFFFFFFF, epoch_begin, epoch_count, node_begin, node_count,
+                                           _lib.ptr(ids), _lib.ptr(codes), _lib.ptr(self._ws) if need.value else None,
+                                           need.value, _lib.ptr(self._status), _lib.stream_ptr(dev)))
         if check and int(self._status.item()) != 0:
             # the reference prints this and exits (gen_merw.cpp:84-87)
             raise _lib.PnError(int(self._status.item()), "ERROR:: A.size() == 0 in Alias Table")

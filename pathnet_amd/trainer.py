@@ -88,12 +88,14 @@ def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices
         with torch.no_grad():
             model.eval()
             pred = model(X, ids.index_select(0, va), num_w, walk_len, va32, codes.index_select(0, va), None).argmax(1)
-            val_acc = float((pred == Y[va]).double().mean())
+            val_acc = float((pred == Y[va]).double().mean())      # the one host round trip of an epoch
             if best_val < val_acc:
                 best_val = val_acc
                 torch.save(model.state_dict(), ckpt)
+                # same X, same weights as the validation forward just above: its projected features and distance
+                # bank are still in the module's workspace (PathNet_run.py:362 and :378 recompute them)
                 pred = model(X, ids.index_select(0, te), num_w, walk_len, te32, codes.index_select(0, te),
-                             None).argmax(1)
+                             None, reuse_tables=True).argmax(1)
                 result = classification_metrics(Y[te], pred, num_classes)
         if verbose and (epoch % 50 == 0 or epoch == epochs - 1):
             print("epoch %d loss %.4f val_acc %.4f test_acc %.4f" % (epoch, float(loss), val_acc, result[4]))

@@ -64,3 +64,7 @@ if __name__ == "__main__":
         make(variant, "h64w40", N=61, F=33, H=64, C=5, W=40, L=4, S=23, seed=12)
     for variant in ("hetero", "homo"):
         make(variant, "h32l6", N=45, F=12, H=32, C=4, W=8, L=6, S=17, seed=13)
+    # the headline shape: hid = 128, 40 paths, Cornell's N = 183 / S_train = 87 (PathNet_run.py:178); F reduced from
+    # 1703 to 160 to keep the fixture small (fc0 is a plain Linear; its width is covered by the oracle tests)
+    for variant in ("hetero", "homo", "pagg"):
+        make(variant, "h128w40cornell", N=183, F=160, H=128, C=5, W=40, L=4, S=87, seed=14)

@@ -82,6 +82,10 @@ if __name__ == "__main__":
     one("cornell_40_4", os.path.join(REF_EDGE, "cornell.in"), 40, 4, 1, 2, full_md5=True)
     one("cornell_7_6", os.path.join(REF_EDGE, "cornell.in"), 7, 6, 20220722, 3)
     one("nba_5_4", os.path.join(REF_EDGE, "Nba.in"), 5, 4, 3, 2)
+    # the shipped graphs with pathological rows (disconnected: negative and > 1 "probabilities", row sums -92 .. +35,
+    # SURVEY.md 8a-1): the alias builder's re-queue paths and the walker see them through the reference binary's output
+    one("cora_40_4", os.path.join(REF_EDGE, "cora.in"), 40, 4, 7, 1)
+    one("citeseer_10_4", os.path.join(REF_EDGE, "citeseer.in"), 10, 4, 11, 2)
     syn = "/tmp/pn_syn_edges.in"
     synthetic_edge_file(syn, 97, 5)
     one("synthetic97_12_5", syn, 12, 5, 42, 4)

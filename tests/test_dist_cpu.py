@@ -55,8 +55,24 @@ class OracleOps:
             params["attw.weight"] = leaf["att_w"].reshape(1, -1)
             params["attw.bias"] = leaf["att_b"]
         Xh = Xh.detach().clone().requires_grad_(True)
-        out = po.forward(cfg["variant"], params, None, ids.numpy(), codes.numpy(), sel.numpy(), cfg["W"], cfg["L"],
-                         Xh=Xh)
+        # a rank computes the pooling groups [group_begin, +S) of the step's batch (pn_pagg_shape.S_total / group_begin).
+        # homo / PAGG ranks hold their own rows only (index_rows_local); a hetero rank holds the whole batch's index
+        # arrays: by definition its rows are those rows of the whole-batch forward
+        drop_seq, drop_cls = cfg.get("mask_seq"), cfg.get("mask_cls")
+        W = cfg["W"]
+        S, S_total, begin = cfg["S"], cfg.get("S_total") or cfg["S"], cfg.get("group_begin", 0)
+        if cfg.get("index_rows_local") and S_total != S:
+            assert cfg["variant"] != "hetero" and len(sel) == S
+            if drop_seq is not None:
+                drop_seq = drop_seq[:, begin * W:(begin + S) * W]
+            if drop_cls is not None:
+                drop_cls = drop_cls[begin:begin + S]
+            out = po.forward(cfg["variant"], params, None, ids.numpy(), codes.numpy(), sel.numpy(), W, cfg["L"],
+                             Xh=Xh, drop_seq=drop_seq, drop_cls=drop_cls)
+        else:
+            assert len(sel) == S_total
+            out = po.forward(cfg["variant"], params, None, ids.numpy(), codes.numpy(), sel.numpy(), W, cfg["L"],
+                             Xh=Xh, drop_seq=drop_seq, drop_cls=drop_cls)[begin:begin + S]
         return out.detach(), (out, Xh, leaf)
 
     def backward(self, state, g_out):
@@ -70,18 +86,23 @@ class OracleOps:
         return g.t() @ X_loc, g.sum(0)
 
 
-def make_case(variant, seed=0):
+def make_case(variant, seed=0, uneven=False):
     rng = np.random.default_rng(seed)
     N, F, H, C, W, L = 24, 10, 32, 3, 5, 4
     X = torch.as_tensor(rng.random((N, F), dtype=np.float32))
     mask = np.zeros(N, bool)
-    mask[rng.permutation(N)[:14]] = True
+    if uneven:                      # 9 masked nodes in the first row block, 3 in the second
+        mask[rng.permutation(N // 2)[:9]] = True
+        mask[N // 2 + rng.permutation(N // 2)[:3]] = True
+    else:
+        mask[rng.permutation(N)[:14]] = True
     sel = np.flatnonzero(mask)
     ids = rng.integers(0, N, (len(sel), W, L))
     ids[:, :, 0] = sel[:, None]
     codes = np.minimum(rng.integers(0, L, (len(sel), W, L)), np.arange(L)[None, None, :])
     G = torch.as_tensor(rng.standard_normal((len(sel), C)).astype(np.float32))
-    return dict(N=N, F=F, H=H, C=C, W=W, L=L, X=X, sel=sel, ids=ids, codes=codes, G=G)
+    Y = torch.as_tensor(rng.integers(0, C, len(sel)))
+    return dict(N=N, F=F, H=H, C=C, W=W, L=L, X=X, sel=sel, ids=ids, codes=codes, G=G, Y=Y)
 
 
 def build_module(variant, case):
@@ -92,22 +113,39 @@ def build_module(variant, case):
     return m.eval()
 
 
-def worker(rank, world, port, variant, ret):
+def worker(rank, world, port, variant, ret, mode="sum"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pathnet_amd import dist as pdist
-        case = make_case(variant)
+        case = make_case(variant, uneven=(mode == "mean_uneven"))
         m = build_module(variant, case)
         n_loc = case["N"] // world
         lo = rank * n_loc
         mine = (case["sel"] >= lo) & (case["sel"] < lo + n_loc)
         runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, ops=OracleOps(variant, case["L"]))
+        if mode == "masks":             # training mode, explicit masks of the WHOLE batch
+            S, W, H = len(case["sel"]), case["W"], case["H"]
+            g = torch.Generator().manual_seed(9)
+            runner.mask_seq = (torch.rand(case["L"], S * W, H, generator=g) >= 0.5).float() / 0.5
+            runner.mask_cls = (torch.rand(S, 2 * H, generator=g) >= 0.5).float() / 0.5
+            m.train()
+        # the sel argument as a NUMPY integer array of node ids (round 1 mistook that for a bool mask)
         out = runner(case["X"][lo:lo + n_loc], torch.as_tensor(case["ids"][mine].reshape(mine.sum(), -1)), case["W"],
-                     case["L"], torch.as_tensor(case["sel"][mine].astype(np.int32)),
-                     torch.as_tensor(case["codes"][mine]))
-        (out * case["G"][mine]).sum().backward()
+                     case["L"], case["sel"][mine].astype(np.int64), torch.as_tensor(case["codes"][mine]))
+        assert runner.batch_counts == [int(((case["sel"] >= r * n_loc) & (case["sel"] < (r + 1) * n_loc)).sum())
+                                       for r in range(world)]
+        if mode == "mean_uneven":
+            # every rank's loss is the MEAN over its own masked nodes (PathNet_run.py:346); scaled by S_r / S_total the
+            # summed gradients are those of the mean over the whole batch
+            loss = torch.nn.functional.cross_entropy(out, case["Y"][mine]) * runner.loss_scale()
+            loss.backward()
+        else:
+            (out * case["G"][mine]).sum().backward()
         runner.allreduce_grads(average=False)
+        flat = runner._flat
+        assert all(v.grad.data_ptr() >= flat.data_ptr() and
+                   v.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4 for v in m.parameters())   # views of one buffer
         ret[rank] = (out.detach().numpy(), {k: v.grad.numpy().copy() for k, v in m.named_parameters()},
                      np.flatnonzero(mine))
     finally:
@@ -122,17 +160,31 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("variant", ["homo", "pagg"])
-def test_two_rank_sharding_matches_single_process(variant):
+@pytest.mark.parametrize("variant,mode", [("homo", "sum"), ("pagg", "sum"), ("hetero", "sum"), ("hetero", "masks"),
+                                          ("homo", "masks"), ("homo", "mean_uneven"), ("hetero", "mean_uneven")])
+def test_two_rank_sharding_matches_single_process(variant, mode):
+    """Two ranks = one process on the concatenated batch -- for the hetero class too: its [W, S] re-view
+    (PathNet_run.py:196-197) makes a rank's rows read the other rank's paths, which is why the ranks exchange the
+    batch's index arrays and compute slices of the WHOLE batch (pn_pagg_shape.S_total / group_begin)."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(world, free_port(), variant, ret), nprocs=world, join=True)
-    case = make_case(variant)
+    mp.spawn(worker, args=(world, free_port(), variant, ret, mode), nprocs=world, join=True)
+    case = make_case(variant, uneven=(mode == "mean_uneven"))
     m = build_module(variant, case)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    want = po.forward(variant, params, case["X"], case["ids"], case["codes"], case["sel"], case["W"], case["L"])
-    (want * case["G"]).sum().backward()
+    drop_seq = drop_cls = None
+    if mode == "masks":
+        S, W, H = len(case["sel"]), case["W"], case["H"]
+        g = torch.Generator().manual_seed(9)
+        drop_seq = (torch.rand(case["L"], S * W, H, generator=g) >= 0.5).float() / 0.5
+        drop_cls = (torch.rand(S, 2 * H, generator=g) >= 0.5).float() / 0.5
+    want = po.forward(variant, params, case["X"], case["ids"], case["codes"], case["sel"], case["W"], case["L"],
+                      drop_seq=drop_seq, drop_cls=drop_cls)
+    if mode == "mean_uneven":
+        torch.nn.functional.cross_entropy(want, case["Y"]).backward()
+    else:
+        (want * case["G"]).sum().backward()
     for rank in range(world):
         out, grads, rows = ret[rank]
         assert np.abs(out - want.detach().numpy()[rows]).max() < 1e-5
@@ -154,3 +206,27 @@ def test_single_process_runner_without_process_group():
     assert (out - want).abs().max().item() < 1e-5
     with pytest.raises(ValueError):
         pdist.ShardedAggregator(m, case["N"] + 1, 0, case["N"], ops=OracleOps("homo", case["L"]))
+
+
+def test_index_argument_conventions():
+    """`indices` is a bool mask (numpy or torch: the reference's two conventions) or the node ids
+    themselves in any integer dtype -- a numpy integer array is NOT a mask."""
+    from pathnet_amd import modules as M
+    N, W, L = 10, 2, 3
+    ids_all = np.arange(N)
+    mask = np.zeros(N, bool)
+    mask[[0, 3, 7]] = True
+    neis = np.zeros((3, W * L), np.int64)
+    lt = np.zeros((3, W, L), np.int64)
+    for idx in (mask, torch.as_tensor(mask), np.array([0, 3, 7]), np.array([0, 3, 7], np.int32),
+                torch.tensor([0, 3, 7]), torch.tensor([0, 3, 7], dtype=torch.int32)):
+        ids, codes, sel, S = M._as_index_tensors(neis, lt, idx, W, L, "cpu", n_nodes=N)
+        assert S == 3 and sel.dtype == torch.int32 and sel.tolist() == [0, 3, 7], type(idx)
+        assert ids.shape == (3, W, L) and ids.dtype == torch.int32 and codes.dtype == torch.uint8
+    with pytest.raises(IndexError):
+        M._as_index_tensors(neis, lt, np.array([0, 3, 10]), W, L, "cpu", n_nodes=N)
+    with pytest.raises(ValueError):
+        M._as_index_tensors(neis[:2], lt, np.array([0, 3, 7]), W, L, "cpu", n_nodes=N)
+    with pytest.raises(TypeError):
+        M._as_index_tensors(neis, lt, np.array([0.0, 3.0, 7.0]), W, L, "cpu", n_nodes=N)
+    assert ids_all.sum() == 45

@@ -1,0 +1,367 @@
+"""Round-2 surface of the aggregator (through the C ABI): micro-batches, slices of a batch, hidden sizes that are any
+multiple of 32, shapes beyond 2^32 elements (BASELINE.json configs[4]), the shared projected tables of the
+validation / test forwards, contexts, and an end-to-end training trajectory against the CPU oracle."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pagg_oracle as po
+from test_gpu_pagg import TOL_OUT, build_module, grad_tol, run_module
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(rng, N, S, W, L):
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    return mask, sel, ids, codes
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+@pytest.mark.parametrize("mode", ["eval", "masks", "philox"])
+def test_micro_batches_equal_one_batch(variant, mode, monkeypatch):
+    """pn_pagg_shape.batch_groups: the library walks the masked nodes in micro-batches (forward keeps nothing, backward
+    re-runs each micro-batch's recurrence).  Logits and every gradient must equal the one-batch run -- with explicit
+    masks, and with the built-in Philox masks, whose counters are positions in the whole batch."""
+    from pathnet_amd import modules
+    torch.manual_seed(61)
+    rng = np.random.default_rng(61)
+    N, F, H, C, W, L, S = 90, 24, 64, 4, 12, 4, 53
+    m = build_module(variant, F, H, C, L, N, None)
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F).cuda()
+    G = torch.randn(S, C).cuda()
+    if mode == "eval":
+        m.eval()
+    else:
+        m.train()
+        m.set_dropout(0.5)
+        if mode == "masks":
+            m._mask_seq = ((torch.rand(L, S * W, H) >= 0.5).float() / 0.5).cuda()
+            m._mask_cls = ((torch.rand(S, 2 * H) >= 0.5).float() / 0.5).cuda()
+
+    def run(batch_groups):
+        monkeypatch.setattr(modules, "pick_batch_groups", lambda *a, **k: batch_groups)
+        m.zero_grad()
+        Xd = X.clone().requires_grad_(True)
+        torch.manual_seed(5)                    # same dropout seed
+        out = run_module(m, Xd, ids, codes, mask, W, L)
+        (out * G).sum().backward()
+        return out.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()}, Xd.grad.clone()
+
+    out1, g1, gx1 = run(0)
+    for bg in (7, 20, 52):                      # 8, 3 and 2 micro-batches, ragged tails
+        outb, gb, gxb = run(bg)
+        assert (outb - out1).abs().max().item() < 2e-6, (bg, "out")
+        for k in g1:
+            tol = 2e-5 * max(1.0, g1[k].abs().max().item())
+            assert (gb[k] - g1[k]).abs().max().item() < tol, (bg, k)
+        assert (gxb - gx1).abs().max().item() < 2e-5 * max(1.0, gx1.abs().max().item()), (bg, "X")
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+def test_slice_of_a_batch_is_rows_of_the_whole_batch(variant):
+    """pn_pagg_shape.S_total / group_begin (modules: group_slice): for the hetero class a row reads paths of OTHER
+    masked nodes of the batch (PathNet_run.py:196-197); computed from the whole batch's index arrays a slice is still
+    bit-for-bit the rows of the whole-batch result -- what node sharding across GPUs relies on."""
+    torch.manual_seed(62)
+    rng = np.random.default_rng(62)
+    N, F, H, C, W, L, S = 70, 20, 64, 3, 9, 4, 41
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F).cuda()
+    neis = torch.as_tensor(ids.reshape(S, W * L).astype(np.int64))
+    lt = torch.as_tensor(codes.astype(np.int64))
+    with torch.no_grad():
+        whole = m(X, neis, W, L, mask, lt, None)
+        for begin, count in ((0, 13), (13, 20), (33, 8), (5, 0)):
+            part = m(X, neis, W, L, mask, lt, None, group_slice=(begin, count))
+            assert part.shape == (count, C)
+            assert torch.equal(part, whole[begin:begin + count]), (begin, count)
+    # gradients of the slices add up to the gradient of the whole batch
+    G = torch.randn(S, C).cuda()
+    m.zero_grad()
+    (m(X, neis, W, L, mask, lt, None) * G).sum().backward()
+    want = {k: v.grad.clone() for k, v in m.named_parameters()}
+    m.zero_grad()
+    for begin, count in ((0, 17), (17, 24)):
+        (m(X, neis, W, L, mask, lt, None, group_slice=(begin, count)) * G[begin:begin + count]).sum().backward()
+    for k, v in m.named_parameters():
+        assert (v.grad - want[k]).abs().max().item() < 2e-5 * max(1.0, want[k].abs().max().item()), k
+    with pytest.raises(ValueError):
+        m(X, neis, W, L, mask, lt, None, group_slice=(30, 20))
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+@pytest.mark.parametrize("H", [96, 160, 192, 224])
+def test_hidden_sizes_that_are_multiples_of_32(variant, H):
+    """The reference's -hid is any integer (PathNet_run.py:52); the recurrent kernels are instantiated for every
+    multiple of 32 up to 256 (3, 5, 6, 7 waves per workgroup besides the powers of two)."""
+    torch.manual_seed(63)
+    rng = np.random.default_rng(63)
+    N, F, C, W, L, S = 60, 18, 4, 11, 4, 27
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith("bias"):
+                v.uniform_(-0.3, 0.3)
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F)
+    G = torch.randn(S, C)
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    (out * G.cuda()).sum().backward()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Xo = X.clone().requires_grad_(True)
+    want = po.forward(variant, pr, Xo, ids, codes, sel, W, L)
+    (want * G).sum().backward()
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT
+    bad = {}
+    for k, v in m.named_parameters():
+        ref = pr[k].grad.numpy()
+        err = np.abs(v.grad.cpu().numpy() - ref).max()
+        if not err < grad_tol(ref):
+            bad[k] = (err, grad_tol(ref))
+    assert not bad, bad
+    assert (Xd.grad.cpu() - Xo.grad).abs().max().item() < grad_tol(Xo.grad.numpy())
+
+
+def test_unsupported_hidden_sizes_fail_loudly():
+    from pathnet_amd import _lib
+    for H in (48, 288, 512):
+        m = build_module("homo", 8, H, 3, 4, 20, None).eval()
+        with pytest.raises(_lib.PnError):
+            run_module(m, torch.rand(20, 8).cuda(), np.zeros((2, 3, 4), np.int64), np.zeros((2, 3, 4), np.int64),
+                       np.arange(20) < 2, 3, 4)
+
+
+@pytest.mark.parametrize("variant", ["homo", "hetero"])
+def test_configs4_shape_beyond_2_pow_32_elements(variant):
+    """BASELINE.json configs[4] on one GPU, scaled to what a test can afford: N = 6 M nodes, hid = F = 128, L = 6, so
+    that the node tables Z / dZ [N, L, H] hold 4.6e9 elements (> 2^32: round 1 refused the shape), the masked nodes
+    walked in micro-batches.  Checked against the CPU oracle on the COMPACTED graph (only the visited nodes, renumbered:
+    a node's logits depend on nothing else), including table rows beyond the 2^32-element offset."""
+    from pathnet_amd import modules
+    torch.manual_seed(64)
+    rng = np.random.default_rng(64)
+    N, F, H, C, W, L, S = 6_000_000, 128, 128, 4, 40, 6, 600
+    assert N * L * H > 2 ** 32
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    m.workspace_budget = modules.workspace_bytes(variant, N, F, H, C, 128, W, L) + 1       # -> micro-batches of <= 128 nodes
+    sel = np.sort(rng.choice(N, S, replace=False))
+    sel[-50:] = np.sort(rng.choice(np.arange(N - 100_000, N), 50, replace=False))    # high rows: offsets > 2^32 elements
+    sel = np.unique(sel)
+    S = len(sel)
+    near = rng.integers(0, N, 5000)                     # paths revisit a pool of nodes (and the top of the table)
+    near[:500] = rng.integers(N - 1000, N, 500)
+    ids = near[rng.integers(0, len(near), (S, W, L))]
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    used = np.unique(np.concatenate([ids.reshape(-1), sel]))
+    Xs = torch.rand(len(used), F)                       # features of the visited nodes; everything else is zero
+    X = torch.zeros(N, F, device="cuda")
+    X[torch.as_tensor(used).cuda()] = Xs.cuda()
+    assert modules.pick_batch_groups(variant, N, F, H, C, S, W, L, m.workspace_budget) <= 128
+    G = torch.randn(S, C)
+    d_ids, d_codes = torch.as_tensor(ids.astype(np.int32)).cuda(), torch.as_tensor(codes.astype(np.uint8)).cuda()
+    out = m(X, d_ids, W, L, torch.as_tensor(sel.astype(np.int32)).cuda(), d_codes, None)
+    (out * G.cuda()).sum().backward()
+    # oracle on the compacted graph
+    remap = np.full(N, -1, np.int64)
+    remap[used] = np.arange(len(used))
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = po.forward(variant, pr, Xs, remap[ids], codes, remap[sel], W, L)
+    (want * G).sum().backward()
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT
+    bad = {}
+    for k, v in m.named_parameters():
+        ref = pr[k].grad.numpy()
+        err = np.abs(v.grad.cpu().numpy() - ref).max()
+        # the bias gradients of fc0 / the bank sum over all N rows on the GPU and over the visited rows in the
+        # oracle: rows nobody visits have zero upstream gradient, so they are the same numbers
+        if not err < grad_tol(ref):
+            bad[k] = (err, grad_tol(ref))
+    assert not bad, bad
+
+
+def test_validation_and_test_forwards_share_the_projected_tables():
+    """pn_pagg_args.reuse_tables: the test forward of an epoch reuses Xh / Z of the validation forward
+    (PathNet_run.py:362, :378 recompute fc0 and the bank) -- same logits, bit for bit."""
+    torch.manual_seed(65)
+    rng = np.random.default_rng(65)
+    N, F, H, C, W, L = 200, 64, 128, 5, 40, 4
+    m = build_module("homo", F, H, C, L, N, None).eval()
+    X = torch.rand(N, F).cuda()
+    mv, sv, iv, cv = random_case(rng, N, 50, W, L)
+    mt, st, it, ct = random_case(rng, N, 90, W, L)          # larger batch: the workspace is re-allocated
+    mt2, st2, it2, ct2 = random_case(rng, N, 30, W, L)
+    with torch.no_grad():
+        want_t = run_module(m, X, it, ct, mt, W, L).clone()
+        want_t2 = run_module(m, X, it2, ct2, mt2, W, L).clone()
+        run_module(m, X, iv, cv, mv, W, L)                  # "validation"
+        S = 30
+        got_t2 = m(X, torch.as_tensor(it2.reshape(S, -1)), W, L, mt2, torch.as_tensor(ct2), None, reuse_tables=True)
+        assert torch.equal(got_t2, want_t2)
+        # a forward whose workspace does not hold the tables falls back to computing them
+        S = 90
+        got_t = m(X, torch.as_tensor(it.reshape(S, -1)), W, L, mt, torch.as_tensor(ct), None, reuse_tables=True)
+        assert torch.equal(got_t, want_t)
+        # and the flag really skips the work: with the tables poisoned the result changes
+        run_module(m, X, iv, cv, mv, W, L)
+        m._ws_eval[:N * H * 4].zero_()
+        S = 30
+        poisoned = m(X, torch.as_tensor(it2.reshape(S, -1)), W, L, mt2, torch.as_tensor(ct2), None, reuse_tables=True)
+        assert not torch.equal(poisoned, want_t2)
+    with pytest.raises(RuntimeError):
+        m(X, torch.as_tensor(it2.reshape(30, -1)), W, L, mt2, torch.as_tensor(ct2), None, reuse_tables=True)
+
+
+def test_two_contexts_two_host_threads_one_device():
+    """No process-global state: two host threads drive the same GPU through two pn_context handles on
+    two streams at the same time; a NULL context works too (single stream); a context of another device is refused."""
+    import ctypes
+    from pathnet_amd import _lib, modules
+    lib = _lib.load()
+    torch.manual_seed(66)
+    rng = np.random.default_rng(66)
+    N, F, H, C, W, L, S = 120, 32, 128, 4, 40, 4, 60
+    m = build_module("homo", F, H, C, L, N, None).eval()
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F).cuda()
+    with torch.no_grad():
+        want = run_module(m, X, ids, codes, mask, W, L).clone()
+    d_ids, d_codes = torch.as_tensor(ids.astype(np.int32)).cuda(), torch.as_tensor(codes.astype(np.uint8)).cuda()
+    d_sel = torch.as_tensor(sel.astype(np.int32)).cuda()
+    fw, fb, params = m._param_inputs()
+    p = modules._split_params(params, L)
+    nbytes = modules.workspace_bytes("homo", N, F, H, C, S, W, L)
+    results, errors = {}, []
+
+    def worker(tag, use_ctx):
+        try:
+            torch.cuda.set_device(0)
+            ctx = ctypes.c_void_p()
+            if use_ctx:
+                _lib.check(lib.pn_context_create(ctypes.byref(ctx)))
+            stream = torch.cuda.Stream()
+            out = torch.empty(S, C, device="cuda")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            cfg = dict(variant="homo", N=N, F=F, H=H, C=C, S=S, W=W, L=L, p_seq=0.0, p_cls=0.0, seed=0, bank_w=fw,
+                       bank_b=fb)
+            a = modules._PaggFunction._args(cfg, X, d_ids, d_codes, d_sel, p)
+            a.out, a.workspace, a.workspace_bytes, a.no_save = out.data_ptr(), ws.data_ptr(), ws.numel(), 1
+            stream.wait_stream(torch.cuda.default_stream())
+            for _ in range(20):
+                _lib.check(lib.pn_pagg_forward(ctx if use_ctx else None, ctypes.byref(a),
+                                               ctypes.c_void_p(stream.cuda_stream)))
+            stream.synchronize()
+            results[tag] = out.clone()
+            if use_ctx:
+                _lib.check(lib.pn_context_destroy(ctx))
+        except Exception as e:      # noqa: BLE001
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=("a", True)), threading.Thread(target=worker, args=("b", True)),
+               threading.Thread(target=worker, args=("null", False))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tag in ("a", "b", "null"):
+        assert torch.equal(results[tag], want), tag
+    assert lib.pn_context_destroy(None) == 0
+    assert lib.pn_profile_configure(None, 1, -1) != 0           # profiling state lives in a context
+
+
+def test_module_on_a_non_current_device_index():
+    """launches must go to the device of the tensors, not to whatever device is current.  With one GPU this
+    can only check that an explicit cuda:0 works while the calls are wrapped in torch.cuda.device()."""
+    torch.manual_seed(67)
+    rng = np.random.default_rng(67)
+    N, F, H, C, W, L, S = 50, 16, 64, 3, 8, 4, 20
+    m = build_module("homo", F, H, C, L, N, None).eval().to("cuda:0")
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F)
+    with torch.no_grad():
+        out = run_module(m, X.to("cuda:0"), ids, codes, mask, W, L).cpu()
+    want = po.forward("homo", {k: v.cpu() for k, v in m.state_dict().items()}, X, ids, codes, sel, W, L)
+    assert (out - want).abs().max().item() < TOL_OUT
+
+
+def test_sampler_rejects_wrong_output_tensors():
+    """sample(out=...) validates shape / dtype / device before handing raw pointers to the kernel."""
+    import pathnet_amd
+    import bench
+    n, u, v, p = bench.synthetic_graph(300, 1)
+    smp = pathnet_amd.MerwSampler(n, u, v, p, 4, device="cuda")
+    good = (torch.empty((1, n, 5, 4), dtype=torch.int32, device="cuda"),
+            torch.empty((1, n, 5, 4), dtype=torch.uint8, device="cuda"))
+    smp.sample(5, 1, out=good)
+    for bad in ((torch.empty((1, n, 5, 3), dtype=torch.int32, device="cuda"), good[1]),
+                (good[0].to(torch.int64), good[1]),
+                (good[0], torch.empty((1, n, 5, 4), dtype=torch.uint8)),
+                (good[0].transpose(2, 3), good[1])):
+        with pytest.raises(ValueError):
+            smp.sample(5, 1, out=bad)
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo"])
+def test_training_trajectory_matches_the_oracle(variant):
+    """End-to-end substitute for the Cornell accuracy check (splits.zip is absent from the reference mount): the
+    reference recipe -- Adam(lr 0.005, wd 5e-4) + CrossEntropyLoss, dropout 0.7, fresh paths every epoch
+    (PathNet_run.py:336-352) -- run for 25 epochs with the SAME dropout masks on the HIP path (fused loss / Adam
+    launches included) and on the CPU oracle (torch autograd + torch.optim.Adam): the loss trajectories agree to 1e-4
+    and the predictions of all masked nodes are identical at the end."""
+    import pathnet_amd
+    torch.manual_seed(68)
+    rng = np.random.default_rng(68)
+    N, F, H, C, W, L, S, E = 120, 32, 64, 4, 20, 4, 60, 25
+    pdrop = 0.7
+    m = build_module(variant, F, H, C, L, N, None)
+    m.set_dropout(pdrop)
+    Y = torch.as_tensor(rng.integers(0, C, N))
+    X = torch.rand(N, F) + torch.nn.functional.one_hot(Y, F).float() * 1.5
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt_o = torch.optim.Adam(list(pr.values()), lr=0.005, weight_decay=0.0005)
+    opt_h = pathnet_amd.Adam(m.parameters(), lr=0.005, weight_decay=0.0005)
+    lossf_h = pathnet_amd.CrossEntropyLoss()
+    Xd, Yd = X.cuda(), Y[mask].cuda()
+    worst = 0.0
+    for epoch in range(E):
+        ids = rng.integers(0, N, (S, W, L))
+        ids[:, :, 0] = sel[:, None]
+        codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+        mseq = (torch.rand(L, S * W, H) >= pdrop).float() / (1 - pdrop)
+        mcls = (torch.rand(S, 2 * H) >= pdrop).float() / (1 - pdrop)
+        m.train()
+        m._mask_seq, m._mask_cls = mseq.cuda(), mcls.cuda()
+        loss_h = lossf_h(run_module(m, Xd, ids, codes, mask, W, L), Yd)
+        opt_h.zero_grad(set_to_none=True)
+        loss_h.backward()
+        opt_h.step()
+        loss_o = torch.nn.functional.cross_entropy(po.forward(variant, pr, X, ids, codes, sel, W, L, drop_seq=mseq,
+                                                              drop_cls=mcls), Y[mask])
+        opt_o.zero_grad()
+        loss_o.backward()
+        opt_o.step()
+        worst = max(worst, abs(loss_h.item() - loss_o.item()))
+        assert worst < 1e-4, (epoch, loss_h.item(), loss_o.item())
+    m.eval()
+    with torch.no_grad():
+        pred_h = run_module(m, Xd, ids, codes, mask, W, L).argmax(1).cpu()
+        out_o = po.forward(variant, pr, X, ids, codes, sel, W, L)
+    top2 = out_o.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3            # (ties within rounding are not predictions)
+    assert torch.equal(pred_h[clear], out_o.argmax(1)[clear]) and clear.float().mean() > 0.9
+    for k, v in m.state_dict().items():
+        assert (v.cpu() - pr[k].detach()).abs().max().item() < 1e-3, k

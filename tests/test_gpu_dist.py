@@ -1,0 +1,121 @@
+"""The node-sharded path with the PRODUCT arithmetic at world size 2 on one GPU: two processes share cuda:0, the
+collectives of pathnet_amd/dist.py run over gloo with the device tensors staged through the host (RCCL refuses two
+ranks on one device), the kernels are libpathnet_hip.so's (HipOps).  Expected: the single-process HIP module on the
+concatenated batch -- logits of every masked node and, after the flat all-reduce, every parameter gradient."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(seed=0):
+    rng = np.random.default_rng(seed)
+    N, F, H, C, W, L = 160, 48, 128, 5, 40, 4
+    X = torch.as_tensor(rng.random((N, F), dtype=np.float32))
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N // 2)[:37]] = True                   # uneven: 37 masked nodes in block 0, 21 in block 1
+    mask[N // 2 + rng.permutation(N // 2)[:21]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (len(sel), W, L))
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (len(sel), W, L)), np.arange(L)[None, None, :])
+    G = torch.as_tensor(rng.standard_normal((len(sel), C)).astype(np.float32))
+    return dict(N=N, F=F, H=H, C=C, W=W, L=L, X=X, sel=sel, ids=ids, codes=codes, G=G)
+
+
+def build(variant, case):
+    import pathnet_amd
+    torch.manual_seed(321)
+    cls = {"homo": pathnet_amd.PathNet_homo, "pagg": pathnet_amd.PAGG, "hetero": pathnet_amd.PathNet}[variant]
+    return cls(case["F"], case["H"], case["C"], case["L"] if variant != "pagg" else case["N"]).cuda()
+
+
+def masks(case, p=0.5):
+    S, W, H, L = len(case["sel"]), case["W"], case["H"], case["L"]
+    g = torch.Generator().manual_seed(17)
+    return ((torch.rand(L, S * W, H, generator=g) >= p).float() / (1 - p),
+            (torch.rand(S, 2 * H, generator=g) >= p).float() / (1 - p))
+
+
+def worker(rank, world, port, variant, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pathnet_amd import dist as pdist
+
+        class HostStagedComm(pdist.Comm):
+            """gloo moves host memory: stage the device tensors through it"""
+
+            def _all_gather(self, out, inp):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+                out.copy_(o)
+
+            def _reduce_scatter(self, out, inp):
+                o = torch.empty(out.shape, dtype=out.dtype)
+                dist.reduce_scatter_tensor(o, inp.cpu(), group=self.group)
+                out.copy_(o)
+
+            def _all_reduce(self, t):
+                h = t.cpu()
+                dist.all_reduce(h, group=self.group)
+                t.copy_(h)
+
+        case = make_case()
+        m = build(variant, case).train()
+        n_loc = case["N"] // world
+        lo = rank * n_loc
+        mine = (case["sel"] >= lo) & (case["sel"] < lo + n_loc)
+        runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, comm=HostStagedComm())      # ops = HipOps (default)
+        assert isinstance(runner.ops, pdist.HipOps) and runner.distributed
+        ms, mc = masks(case)
+        runner.mask_seq, runner.mask_cls = ms.cuda(), mc.cuda()         # the whole batch's masks
+        out = runner(case["X"][lo:lo + n_loc].cuda(), torch.as_tensor(case["ids"][mine].reshape(mine.sum(), -1)),
+                     case["W"], case["L"], torch.as_tensor(case["sel"][mine].astype(np.int32)),
+                     torch.as_tensor(case["codes"][mine]))
+        (out * case["G"][mine].cuda()).sum().backward()
+        runner.allreduce_grads(average=False)
+        torch.cuda.synchronize()
+        ret[rank] = (out.detach().cpu().numpy(), {k: v.grad.cpu().numpy().copy() for k, v in m.named_parameters()},
+                     np.flatnonzero(mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("variant", ["homo", "hetero", "pagg"])
+def test_two_ranks_hip_ops_match_the_single_process_module(variant):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, free_port(), variant, ret), nprocs=world, join=True)
+    case = make_case()
+    m = build(variant, case).train()
+    ms, mc = masks(case)
+    m._mask_seq, m._mask_cls = ms.cuda(), mc.cuda()
+    S = len(case["sel"])
+    mask = np.zeros(case["N"], bool)
+    mask[case["sel"]] = True
+    out = m(case["X"].cuda(), torch.as_tensor(case["ids"].reshape(S, -1)), case["W"], case["L"], mask,
+            torch.as_tensor(case["codes"]), None)
+    (out * case["G"].cuda()).sum().backward()
+    want = out.detach().cpu().numpy()
+    for rank in range(world):
+        got, grads, rows = ret[rank]
+        assert np.abs(got - want[rows]).max() < 2e-6, rank
+        for k, v in m.named_parameters():
+            ref = v.grad.cpu().numpy()
+            assert np.abs(grads[k] - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), (rank, k)

@@ -62,16 +62,16 @@ def test_linear_forward_and_backward_match_torch():
         b = torch.randn(out_f, device="cuda")
         Y0, Y1 = torch.empty(rows, out_f, device="cuda"), torch.empty(rows, out_f, device="cuda")
         ws = torch.empty(_lib.LINEAR_SPLIT_MAX * rows * out_f, device="cuda")
-        _lib.check(lib.pn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), rows, in_f, out_f, relu,
+        _lib.check(lib.pn_linear_forward(_lib.context("cuda"), X.data_ptr(), W.data_ptr(), b.data_ptr(), rows, in_f, out_f, relu,
                                          Y0.data_ptr(), None, 0, None))
-        _lib.check(lib.pn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), rows, in_f, out_f, relu,
+        _lib.check(lib.pn_linear_forward(_lib.context("cuda"), X.data_ptr(), W.data_ptr(), b.data_ptr(), rows, in_f, out_f, relu,
                                          Y1.data_ptr(), ws.data_ptr(), ws.numel() * 4, None))
         ref = X.double() @ W.double().t() + b.double()
         ref = (torch.relu(ref) if relu else ref).float()
         assert (Y0 - ref).abs().max().item() < 2e-5 and (Y1 - ref).abs().max().item() < 2e-5
         dY = torch.randn(rows, out_f, device="cuda")
         gW, gb, gX = torch.full_like(W, 7.0), torch.full_like(b, 7.0), torch.empty_like(X)
-        _lib.check(lib.pn_linear_backward(dY.data_ptr(), Y1.data_ptr() if relu else None, X.data_ptr(), W.data_ptr(),
+        _lib.check(lib.pn_linear_backward(_lib.context("cuda"), dY.data_ptr(), Y1.data_ptr() if relu else None, X.data_ptr(), W.data_ptr(),
                                           rows, in_f, out_f, gW.data_ptr(), gb.data_ptr(), gX.data_ptr(), None))
         d = (dY * (ref > 0)).double() if relu else dY.double()
         scale = max(1.0, rows ** 0.5 / 8)
@@ -79,7 +79,7 @@ def test_linear_forward_and_backward_match_torch():
         assert (gb - d.sum(0).float()).abs().max().item() < 1e-4 * scale
         assert (gX - (d @ W.double()).float()).abs().max().item() < 1e-4
         gb2 = torch.full_like(b, 7.0)       # bias gradient alone
-        _lib.check(lib.pn_linear_backward(dY.data_ptr(), Y1.data_ptr() if relu else None, None, None, rows, in_f, out_f,
+        _lib.check(lib.pn_linear_backward(_lib.context("cuda"), dY.data_ptr(), Y1.data_ptr() if relu else None, None, None, rows, in_f, out_f,
                                           None, gb2.data_ptr(), None, None))
         assert (gb2 - d.sum(0).float()).abs().max().item() < 1e-4 * scale
 
@@ -107,7 +107,7 @@ def test_gather_stage_matches_plan(variant):
     rows = torch.empty(S * W, L, H, device="cuda")
     sh = _lib.PaggShape({"hetero": 0, "homo": 1, "pagg": 2}[variant], N, 1, H, 1, S, W, L)
     d_ids, d_codes = torch.as_tensor(ids).cuda(), torch.as_tensor(codes).cuda()      # keep alive across the call
-    _lib.check(lib.pn_pagg_gather(ctypes.byref(sh), table.data_ptr(), d_ids.data_ptr(), d_codes.data_ptr(),
+    _lib.check(lib.pn_pagg_gather(_lib.context("cuda"), ctypes.byref(sh), table.data_ptr(), d_ids.data_ptr(), d_codes.data_ptr(),
                                   rows.data_ptr(), None))
     torch.cuda.synchronize()
     node, code, group, member, ego = po.plan(variant, ids, codes, S, W, L)
@@ -489,10 +489,17 @@ def test_pubmed_scale_batch_invariance_and_oracle_subset(variant):
         assert (v.grad - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item()), k
 
 
-def test_rejects_batches_beyond_32bit_offsets():
+def test_large_batches_are_sized_not_rejected():
+    """Round 1 refused S*W*L*5*H >= 2^32 elements; the kernels now address every per-path tensor as a 64-bit tile
+    base + a 32-bit in-tile offset, and a batch beyond the workspace budget is walked in micro-batches."""
     from pathnet_amd import _lib, modules
+    full = modules.workspace_bytes("homo", 1000, 16, 128, 3, 50000, 40, 4)      # S*W*L*5*H = 5.1e9 elements
+    assert full > 50000 * 40 * 4 * 5 * 128 * 4
+    bg = modules.pick_batch_groups("homo", 1000, 16, 128, 3, 50000, 40, 4, budget=8 << 30)
+    assert 0 < bg < 50000
+    assert modules.workspace_bytes("homo", 1000, 16, 128, 3, 50000, 40, 4, batch_groups=bg) <= 8 << 30
     with pytest.raises(_lib.PnError):
-        modules.workspace_bytes("homo", 1000, 16, 128, 3, 50000, 40, 4)      # S*W*L*5*H >= 2^32
+        modules.workspace_bytes("homo", 1000, 16, 128, 3, 100, 40, 4, S_total=50, group_begin=0)   # slice > batch
 
 
 def test_cora_config_forward_backward_full_parity():

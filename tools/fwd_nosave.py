@@ -22,9 +22,9 @@ for grad in (True, False):
             return model(X, ids, wl["W"], wl["L"], sel.to(torch.int32), codes, None)
     for _ in range(3): step()
     torch.cuda.synchronize()
-    _lib.check(lib.pn_profile_configure(1, -1))
+    _lib.check(lib.pn_profile_configure(_lib.context("cuda"), 1, -1))
     for _ in range(20): step()
     torch.cuda.synchronize()
     prof = bench.read_profile(lib, names)
-    _lib.check(lib.pn_profile_configure(0, -1))
+    _lib.check(lib.pn_profile_configure(_lib.context("cuda"), 0, -1))
     print("saved tensors written" if grad else "no_save", json.dumps({k: round(v[0] / v[1], 4) for k, v in prof.items()}))

@@ -33,11 +33,11 @@ def step():
     out.backward(G)
 for _ in range(3): step()
 torch.cuda.synchronize()
-_lib.check(lib.pn_profile_configure(1, -1))
+_lib.check(lib.pn_profile_configure(_lib.context("cuda"), 1, -1))
 for _ in range(%d): step()
 torch.cuda.synchronize()
 prof = bench.read_profile(lib, names)
-_lib.check(lib.pn_profile_configure(0, -1))
+_lib.check(lib.pn_profile_configure(_lib.context("cuda"), 0, -1))
 for _ in range(5): step()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()

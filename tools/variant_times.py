@@ -26,10 +26,10 @@ for name, cls, arg in (("homo", pathnet_amd.PathNet_homo, wl["L"]), ("hetero", p
         out.backward(G)
     for _ in range(3): step()
     torch.cuda.synchronize()
-    _lib.check(lib.pn_profile_configure(1, -1))
+    _lib.check(lib.pn_profile_configure(_lib.context("cuda"), 1, -1))
     for _ in range(10): step()
     torch.cuda.synchronize()
     prof = bench.read_profile(lib, names)
-    _lib.check(lib.pn_profile_configure(0, -1))
+    _lib.check(lib.pn_profile_configure(_lib.context("cuda"), 0, -1))
     d = {k: round(v[0] / v[1], 4) for k, v in prof.items()}
     print(name, "total %.3f" % sum(d.values()), json.dumps(d))
