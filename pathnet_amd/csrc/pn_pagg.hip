@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);   // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
     uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_slotof + MT); // [2][MT][H/4] dropout keep bits of step t (t & 1)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
     const int ws = wave % NW, r0 = 32 * (wave / NW);             // column slice / first tile row of this wave
     // PN_BWD_REVERSE: tiles in descending order -- the forward wrote the saved tensors of the last tiles last, they
     // are the ones still in the 256 MB Infinity Cache when the backward starts
