@@ -402,7 +402,8 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
                                    "hop_table_MB": pw["n"] ** 2 >> 20,
                                    "algorithmic_GBs": paths * (L * 17 + L * 5) / dt / 1e9,
                                    "sector_GBs": paths * (L * 2 * 64 + L * 5) / dt / 1e9,
-                                   "frac_of_hbm_peak_at_sector_granularity": paths * (L * 2 * 64 + L * 5) / dt / 1e9 / HBM_PEAK_GBS}
+                                   "note": "random 16 B triple + 1 B hop-code reads: latency / cache bound (L2 + Infinity "
+                                           "Cache serve most of the 64 B sectors), not an HBM streaming roofline"}
     gn, u, v, p = pw["graph"]
     otf = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev, hops="otf")
     dt = time_launches(smp_pub(otf), 10)

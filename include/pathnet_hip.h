@@ -71,6 +71,19 @@ typedef struct pn_context pn_context;
 int pn_context_create(pn_context **out);
 int pn_context_destroy(pn_context *ctx);
 
+/* Per-step values kept in DEVICE memory, so that a whole training step captured into a hipGraph (every launch below is
+ * capturable: no allocation, no synchronisation, the second stream joins the capture through its fork / join events) can
+ * be replayed with fresh values: the sampler's epoch, the dropout seed and Adam's step count are read by the kernels
+ * when they run, not baked into the launch.  pn_step_state_advance (one tiny launch, the first node of the graph) moves
+ * to the next step: epoch += 1, adam_step += 1, seed = splitmix64(seed). */
+typedef struct pn_step_state {
+    int64_t epoch;      /* pn_sample_paths: epoch_begin */
+    uint64_t seed;      /* pn_sample_paths (Philox seed) and pn_pagg_* (dropout seed) */
+    int64_t adam_step;  /* pn_adam_step: the step count (from 1) */
+    int64_t reserved;
+} pn_step_state;
+int pn_step_state_advance(pn_step_state *dev_state, void *stream);
+
 /* Shader clock the device sustains right now (MHz), measured by a short kernel that reads the shader-cycle counter
  * (s_memtime) against the 100 MHz wall clock -- bench reports carry it so that box-to-box differences can be told
  * from code differences.  Synchronises `stream`. */
@@ -168,7 +181,9 @@ int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t
  * an empty table (the reference exits there). */
 int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tables, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
                     int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
-                    uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag, void *stream);
+                    uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag,
+                    const pn_step_state *step_state /* dev or NULL: PN_DRAW_PHILOX only; replaces seed / epoch_begin */,
+                    void *stream);
 
 /* ================================================================================================
  * Path file.  The on-disk interface between sampler and trainer: one line per path,
@@ -270,6 +285,8 @@ typedef struct pn_pagg_args {
      * rows there); positions in the batch -- dropout counters, explicit masks -- stay batch-wide.  This is what a rank
      * of the node-sharded path passes: its own paths, no exchange of index arrays. */
     int32_t index_rows_local;
+    /* dev or NULL: the dropout seed is step_state->seed, read when the kernels run (hipGraph replay), instead of `seed` */
+    const pn_step_state *step_state;
 } pn_pagg_args;
 
 int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes);
@@ -338,7 +355,8 @@ typedef struct pn_adam_tensor {
     int64_t count;
 } pn_adam_tensor;
 int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int64_t step, void *stream);
+                 float weight_decay, int64_t step, const pn_step_state *step_state /* dev or NULL: replaces step */,
+                 void *stream);
 
 /* Byte offsets inside the aggregator workspace of the intermediates tests look at:
  * out[0] Xh [N,H], out[1] Z [N,L,H], out[2] hn [P,H] (pooling-group order), out[3] layer1 [S,2H]. */

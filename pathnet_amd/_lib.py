@@ -59,7 +59,7 @@ class PaggArgs(ctypes.Structure):
                 [("g_" + k, vp) for k in ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w",
                                           "att_b", "fc2_w", "fc2_b")] +
                 [("Xh_in", vp), ("g_Xh", vp), ("no_save", ctypes.c_int32), ("reuse_tables", ctypes.c_int32),
-                 ("index_rows_local", ctypes.c_int32)])
+                 ("index_rows_local", ctypes.c_int32), ("step_state", vp)])
 
 
 # name -> (restype, argtypes): every symbol include/pathnet_hip.h declares
@@ -76,6 +76,7 @@ SIGNATURES = {
     "pn_context_create": (ctypes.c_int, [ctypes.POINTER(vp)]),
     "pn_context_destroy": (ctypes.c_int, [vp]),
     "pn_clock_probe": (ctypes.c_int, [c_f64p, vp]),
+    "pn_step_state_advance": (ctypes.c_int, [vp, vp]),
     "pn_edges_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, c_f64p, ctypes.c_int64]),
     "pn_pairs_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, ctypes.c_int64]),
     "pn_uniform_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, c_i64p, c_i32p, c_i32p, c_i32p,
@@ -91,7 +92,7 @@ SIGNATURES = {
                                                  ctypes.c_int32, c_i64p]),
     "pn_sample_paths": (ctypes.c_int, [vp, ctypes.POINTER(SamplerTables), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
-                                       vp, vp, vp, ctypes.c_int64, vp, vp]),
+                                       vp, vp, vp, ctypes.c_int64, vp, vp, vp]),
     "pn_paths_write_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_int32]),
     "pn_paths_read_text": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, c_i32p, c_u8p, ctypes.c_int64, c_i64p]),
@@ -118,7 +119,7 @@ SIGNATURES = {
                                              ctypes.c_double, c_i32p, vp, ctypes.c_int64, vp]),
     "pn_cross_entropy": (ctypes.c_int, [vp, vp, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]),
     "pn_adam_step": (ctypes.c_int, [ctypes.POINTER(AdamTensor), ctypes.c_int32, ctypes.c_float, ctypes.c_float,
-                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int64, vp]),
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int64, vp, vp]),
 }
 
 _lib = None

@@ -3,6 +3,7 @@
 // an opaque handle").
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <new>
 #include <vector>
 
@@ -19,11 +20,22 @@ struct pn_context {
     };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> free_events;
+    std::map<const void *, int> lds_attr;      // kernel -> dynamic LDS bytes already granted on this device
 };
 
 namespace {
 
 __global__ void warm_kernel() {}
+
+__global__ void step_state_advance_kernel(pn_step_state *s) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    s->epoch += 1;
+    s->adam_step += 1;
+    uint64_t z = (s->seed += 0x9E3779B97F4A7C15ull);       // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    s->seed = z ^ (z >> 31);
+}
 
 // spins for ~`spin_ticks` ticks of the constant 100 MHz wall clock and reports shader cycles against wall ticks
 __global__ void clock_probe_kernel(long long spin_ticks, long long *out) {
@@ -62,6 +74,16 @@ int context_check_device(const pn_context *ctx) {
     PN_CHECK_HIP(hipGetDevice(&dev));
     if (dev != ctx->device)
         PN_FAIL(PN_ERR_ARG, "pn_context belongs to device %d, the current device is %d", ctx->device, dev);
+    return PN_OK;
+}
+
+int ensure_dynamic_lds(pn_context *ctx, const void *kernel, int bytes) {
+    if (ctx) {
+        auto it = ctx->lds_attr.find(kernel);
+        if (it != ctx->lds_attr.end() && it->second >= bytes) return PN_OK;
+    }
+    PN_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (ctx) ctx->lds_attr[kernel] = bytes;
     return PN_OK;
 }
 
@@ -181,6 +203,13 @@ int pn_device_query(pn_device_info *out) {
     out->lds_bytes_per_block = (int32_t)prop.sharedMemPerBlock;
     out->hbm_bytes = (int64_t)prop.totalGlobalMem;
     out->clock_khz = prop.clockRate;
+    return PN_OK;
+}
+
+int pn_step_state_advance(pn_step_state *dev_state, void *stream_) {
+    if (!dev_state) PN_FAIL(PN_ERR_ARG, "pn_step_state_advance: null");
+    hipLaunchKernelGGL(step_state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, dev_state);
+    PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
 

@@ -53,6 +53,9 @@ void *context_fork(pn_context *ctx, void *stream);
 // records the join event on the second stream; context_join makes `stream` wait for it
 int context_record_join(pn_context *ctx);
 int context_join(pn_context *ctx, void *stream);
+// hipFuncSetAttribute(kernel, MaxDynamicSharedMemorySize, bytes), remembered per context (= per device) so that the
+// steady state issues no runtime call besides the launches (a captured step must not)
+int ensure_dynamic_lds(pn_context *ctx, const void *kernel, int bytes);
 // RAII bracket: records a start event now and a stop event at scope exit when the context's profiling selects `stage`
 struct StageTimer {
     StageTimer(pn_context *ctx, int stage, void *stream);

@@ -72,6 +72,11 @@ __device__ __forceinline__ void async_load_b128_s(u32x4 &dst, const void *sbase,
     static_assert(IMM >= 0 && IMM < 4096, "13-bit signed instruction offset");
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
 }
+template <int IMM>
+__device__ __forceinline__ void async_load_b128_s(f32x4 &dst, const void *sbase, uint32_t voff) {
+    static_assert(IMM >= 0 && IMM < 4096, "13-bit signed instruction offset");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
 // G (1, 2 or 4) consecutive 1 KB fragments starting at sbase
 template <int G>
 __device__ __forceinline__ void async_load_frags(u32x4 (&b)[G], const void *sbase, uint32_t voff) {

@@ -365,6 +365,7 @@ struct SeqFwdParams {
     int64_t Pmask;          // slots of the WHOLE batch: the dropout counters / the explicit mask are [L, Pmask, H]
     float p_drop;
     uint64_t seed;
+    const pn_step_state *dyn;   // seed in device memory when set (hipGraph replay)
     const float *mask;      // [L, Pmask, H] explicit mask (reference order: original slot q) or null
 };
 
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     for (int r = 0; r < 16; r++) cst[r] = 0.0f;
     const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     const bool builtin_drop = !p.mask && p.p_drop > 0.0f;
+    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
     // per-path tensors are addressed as a 64-bit tile base (wave-uniform: SGPRs) + a 32-bit offset inside the tile,
     // so no tensor size is bounded by 2^32 elements
     const size_t tile_row = (size_t)q0 * (size_t)p.L;                       // first [P, L] row of this tile
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             for (int i = 0; i < NLD; i++) {
                 const int idx = tid_g + NT * i;
                 const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-                const float4 m = dropout4(p.seed, ((uint64_t)t * p.Pmask + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
+                const float4 m = dropout4(seed, ((uint64_t)t * p.Pmask + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
                 bits |= ((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) |
                          (m.w != 0.f ? 8u : 0u)) << (4 * i);
             }
@@ -680,6 +682,7 @@ struct PoolParams {
     const float *att_w, *att_b, *fc2_w, *fc2_b;
     float p_drop;
     uint64_t seed;
+    const pn_step_state *dyn;
     const float *mask;      // [S, 2H] or null
     float *coef;            // [P] pooling coefficient per slot' (1+att | softmax | 1)
     float *rawsc;           // [P] raw attention score (pre LeakyReLU) per slot'
@@ -774,8 +777,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
             a *= p.mask[gg * 2 * H + j];
             b *= p.mask[gg * 2 * H + H + j];
         } else if (p.p_drop > 0.0f) {
-            const float4 m0 = dropout4(p.seed, (gg * 2 * H + j) >> 2, 2u, p.p_drop);
-            const float4 m1 = dropout4(p.seed, (gg * 2 * H + H + j) >> 2, 2u, p.p_drop);
+            const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+            const float4 m0 = dropout4(seed, (gg * 2 * H + j) >> 2, 2u, p.p_drop);
+            const float4 m1 = dropout4(seed, (gg * 2 * H + H + j) >> 2, 2u, p.p_drop);
             const int e0 = j & 3;
             a *= e0 == 0 ? m0.x : e0 == 1 ? m0.y : e0 == 2 ? m0.z : m0.w;
             b *= e0 == 0 ? m1.x : e0 == 1 ? m1.y : e0 == 2 ? m1.z : m1.w;
@@ -806,6 +810,7 @@ struct PoolBwdParams {
     const float *att_w, *fc2_w, *g_out, *coef, *rawsc;
     float p_drop;
     uint64_t seed;
+    const pn_step_state *dyn;
     const float *mask;
     float *dhn;        // [P, H]
     float *dXh;        // [N, H]  (+= ego of the classifier input; HETERO: += attention ego)
@@ -848,8 +853,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 a *= p.mask[gg * 2 * H + j];
                 b *= p.mask[gg * 2 * H + H + j];
             } else if (p.p_drop > 0.0f) {
-                a *= dropout1(p.seed, gg * 2 * H + j, 2u, p.p_drop);
-                b *= dropout1(p.seed, gg * 2 * H + H + j, 2u, p.p_drop);
+                const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+                a *= dropout1(seed, gg * 2 * H + j, 2u, p.p_drop);
+                b *= dropout1(seed, gg * 2 * H + H + j, 2u, p.p_drop);
             }
             atomicAdd(&p.dXh[(int64_t)p.sel[g] * H + j], a);
             dp[j] = b * inv_w;
@@ -1470,14 +1476,13 @@ int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t
 }
 
 template <int H, int G>
-int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
+int launch_seq_bwd(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;
     constexpr int MT = 32 * RG;
     const size_t lds_bytes = (size_t)3 * MT * (2 * (G == 4 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4 +
                              (size_t)2 * MT * (H / 4);
     auto kern = seq_bwd3_kernel<H, G, RG>;
-    PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes));
+    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
     const int blocks = (sp.P + MT - 1) / MT;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64 * RG), lds_bytes, stream, sp);
     PN_CHECK_HIP(hipGetLastError());
@@ -1485,28 +1490,27 @@ int launch_seq_bwd(hipStream_t stream, const SeqBwdParams &sp) {
 }
 
 template <int G>
-int dispatch_seq_bwd(hipStream_t stream, int H, const SeqBwdParams &sp) {
+int dispatch_seq_bwd(pn_context *ctx, hipStream_t stream, int H, const SeqBwdParams &sp) {
     switch (H) {      // every multiple of 32 up to 256 (the LDS tile of H = 256 is 98 KB)
-        case 32: return launch_seq_bwd<32, G>(stream, sp);
-        case 64: return launch_seq_bwd<64, G>(stream, sp);
-        case 96: return launch_seq_bwd<96, G>(stream, sp);
-        case 128: return launch_seq_bwd<128, G>(stream, sp);
-        case 160: return launch_seq_bwd<160, G>(stream, sp);
-        case 192: return launch_seq_bwd<192, G>(stream, sp);
-        case 224: return launch_seq_bwd<224, G>(stream, sp);
-        case 256: return launch_seq_bwd<256, G>(stream, sp);
+        case 32: return launch_seq_bwd<32, G>(ctx, stream, sp);
+        case 64: return launch_seq_bwd<64, G>(ctx, stream, sp);
+        case 96: return launch_seq_bwd<96, G>(ctx, stream, sp);
+        case 128: return launch_seq_bwd<128, G>(ctx, stream, sp);
+        case 160: return launch_seq_bwd<160, G>(ctx, stream, sp);
+        case 192: return launch_seq_bwd<192, G>(ctx, stream, sp);
+        case 224: return launch_seq_bwd<224, G>(ctx, stream, sp);
+        case 256: return launch_seq_bwd<256, G>(ctx, stream, sp);
     }
     PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
 }
 
 template <int H, int G>
-int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
+int launch_seq_fwd(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
     constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;      // H = 256: one row group already fills the LDS
     constexpr int MT = 32 * RG;
     const size_t lds_bytes = (size_t)3 * MT * (4 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_fwd3_kernel<H, G, RG>;
-    PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds_bytes));
+    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
     const int blocks = (sp.P + MT - 1) / MT;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64 * RG), lds_bytes, stream, sp);
     PN_CHECK_HIP(hipGetLastError());
@@ -1514,16 +1518,16 @@ int launch_seq_fwd(hipStream_t stream, const SeqFwdParams &sp) {
 }
 
 template <int G>
-int dispatch_seq_fwd(hipStream_t stream, int H, const SeqFwdParams &sp) {
+int dispatch_seq_fwd(pn_context *ctx, hipStream_t stream, int H, const SeqFwdParams &sp) {
     switch (H) {
-        case 32: return launch_seq_fwd<32, G>(stream, sp);
-        case 64: return launch_seq_fwd<64, G>(stream, sp);
-        case 96: return launch_seq_fwd<96, G>(stream, sp);
-        case 128: return launch_seq_fwd<128, G>(stream, sp);
-        case 160: return launch_seq_fwd<160, G>(stream, sp);
-        case 192: return launch_seq_fwd<192, G>(stream, sp);
-        case 224: return launch_seq_fwd<224, G>(stream, sp);
-        case 256: return launch_seq_fwd<256, G>(stream, sp);
+        case 32: return launch_seq_fwd<32, G>(ctx, stream, sp);
+        case 64: return launch_seq_fwd<64, G>(ctx, stream, sp);
+        case 96: return launch_seq_fwd<96, G>(ctx, stream, sp);
+        case 128: return launch_seq_fwd<128, G>(ctx, stream, sp);
+        case 160: return launch_seq_fwd<160, G>(ctx, stream, sp);
+        case 192: return launch_seq_fwd<192, G>(ctx, stream, sp);
+        case 224: return launch_seq_fwd<224, G>(ctx, stream, sp);
+        case 256: return launch_seq_fwd<256, G>(ctx, stream, sp);
     }
     PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
 }
@@ -1765,9 +1769,10 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     sp.Pmask = d.P_total;
     sp.p_drop = a->p_seq;
     sp.seed = a->seed;
+    sp.dyn = a->step_state;
     sp.mask = a->mask_seq;
     StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
-    return d.G == 4 ? dispatch_seq_fwd<4>(c.stream, d.H, sp) : dispatch_seq_fwd<1>(c.stream, d.H, sp);
+    return d.G == 4 ? dispatch_seq_fwd<4>(c.ctx, c.stream, d.H, sp) : dispatch_seq_fwd<1>(c.ctx, c.stream, d.H, sp);
 }
 
 int run_pool_fwd(const Call &c, int b, float *out) {
@@ -1792,6 +1797,7 @@ int run_pool_fwd(const Call &c, int b, float *out) {
     pp.fc2_b = a->fc2_b;
     pp.p_drop = a->p_cls;
     pp.seed = a->seed;
+    pp.dyn = a->step_state;
     pp.mask = a->mask_cls;
     pp.coef = c.at<float>(c.w.coef);
     pp.rawsc = c.at<float>(c.w.rawsc);
@@ -2098,6 +2104,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             pp.rawsc = c.at<float>(c.w.rawsc);
             pp.p_drop = a->p_cls;
             pp.seed = a->seed;
+            pp.dyn = a->step_state;
             pp.mask = a->mask_cls;
             pp.dhn = dhn;
             pp.dXh = dXh;
@@ -2129,7 +2136,8 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             sp.p_drop = a->p_seq;
             sp.seed = a->seed;
             sp.mask = a->mask_seq;
-            if (int rc = (G == 4 ? dispatch_seq_bwd<4>(stream, H, sp) : dispatch_seq_bwd<1>(stream, H, sp))) return rc;
+            if (int rc = (G == 4 ? dispatch_seq_bwd<4>(ctx, stream, H, sp) : dispatch_seq_bwd<1>(ctx, stream, H, sp)))
+                return rc;
         }
 
         // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG)
@@ -2157,8 +2165,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
             {
                 StageTimer tm(ctx, ST_WGRAD, wstream);
-                PN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad3_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES));
+                if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(wgrad3_kernel), W3_LDS_BYTES)) return rc;
                 hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
                                    dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
                 PN_CHECK_HIP(hipGetLastError());

@@ -101,6 +101,7 @@ struct WalkParams {
     const int32_t *draws;  // GLIBC only: [epoch_count][node_count*W*dps*L]
     int32_t *status;
     int32_t dps;           // draws per step: 2 = alias roll (gen_merw.cpp:81-91), 1 = uniform rand() % deg (gen.cpp:113-114)
+    const pn_step_state *dyn;   // Philox: seed / epoch_begin read from device memory when set (hipGraph replay)
 };
 
 // The draws of step t of a walk.  Alias roll: draws 2t, 2t+1 of the walk's stream; uniform: draw t.  Philox words
@@ -151,11 +152,13 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     const int64_t rem = g - e_l * per_epoch;
     const int32_t st = p.node_begin + (int32_t)(rem / p.W);
     const int32_t wi = (int32_t)(rem % p.W);
-    const uint64_t walk = ((uint64_t)(p.epoch_begin + e_l) * (uint64_t)p.n + (uint64_t)st) * (uint64_t)p.W + wi;
+    const int64_t epoch_begin = p.dyn ? p.dyn->epoch : p.epoch_begin;
+    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+    const uint64_t walk = ((uint64_t)(epoch_begin + e_l) * (uint64_t)p.n + (uint64_t)st) * (uint64_t)p.W + wi;
 
     rocrand_state_philox4x32_10 rng;
     uint4 word = {0, 0, 0, 0};
-    if (DRAW == PN_DRAW_PHILOX) rocrand_init(p.seed, walk, 0, &rng);
+    if (DRAW == PN_DRAW_PHILOX) rocrand_init(seed, walk, 0, &rng);
     const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * p.dps * (int64_t)p.L : nullptr;
 
     const uint8_t *dis_row = p.dis + (size_t)st * (size_t)p.n;
@@ -292,13 +295,15 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
     __builtin_amdgcn_wave_barrier();
 
     // ---- walks: lane = walk index (loop when W > 64), all epochs of the window -------------------------
+    const int64_t epoch_begin = p.dyn ? p.dyn->epoch : p.epoch_begin;
+    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
     for (int64_t e_l = 0; e_l < p.epoch_count; e_l++) {
         for (int wi = lane; wi < p.W; wi += 64) {
             const int64_t g = (e_l * p.node_count + st_l) * p.W + wi;
-            const uint64_t walk = ((uint64_t)(p.epoch_begin + e_l) * (uint64_t)p.n + (uint64_t)st) * (uint64_t)p.W + wi;
+            const uint64_t walk = ((uint64_t)(epoch_begin + e_l) * (uint64_t)p.n + (uint64_t)st) * (uint64_t)p.W + wi;
             rocrand_state_philox4x32_10 rng;
             uint4 word = {0, 0, 0, 0};
-            if (DRAW == PN_DRAW_PHILOX) rocrand_init(p.seed, walk, 0, &rng);
+            if (DRAW == PN_DRAW_PHILOX) rocrand_init(seed, walk, 0, &rng);
             const int32_t *my_draws = DRAW == PN_DRAW_GLIBC_REPLAY ? p.draws + g * p.dps * (int64_t)p.L : nullptr;
             int32_t *out_ids = p.ids + g * p.L;
             uint8_t *out_codes = p.codes + g * p.L;
@@ -378,8 +383,12 @@ int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t
 
 int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
                     int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
-                    uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag, void *stream_) {
+                    uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag,
+                    const pn_step_state *step_state, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (step_state && draw_source != PN_DRAW_PHILOX)
+        PN_FAIL(PN_ERR_ARG, "pn_sample_paths: a device step state needs PN_DRAW_PHILOX (the glibc replay prepares its "
+                "jump tables on the host)");
     if (int rc = pn::context_check_device(ctx)) return rc;
     if (!tb || !tb->off || !tb->triples || !ids || !codes) PN_FAIL(PN_ERR_ARG, "pn_sample_paths: null table or output");
     const bool otf = tb->dis == nullptr;
@@ -414,6 +423,7 @@ int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int
     if (tb->draws_per_step != 0 && tb->draws_per_step != 1 && tb->draws_per_step != 2)
         PN_FAIL(PN_ERR_ARG, "pn_sample_paths: draws_per_step = %d (0, 1 or 2)", tb->draws_per_step);
     wp.dps = dps;
+    wp.dyn = step_state;
 
     if (draw_source == PN_DRAW_GLIBC_REPLAY) {
         int64_t need = 0;

@@ -49,9 +49,27 @@ struct AdamList {
     int block_begin[PN_ADAM_MAX_TENSORS + 1];
     int n;
     float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay;
+    float lr;
+    const pn_step_state *dyn;     // step count in device memory (hipGraph replay): the bias corrections are formed here
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamList a) {
+    float lr_over_bc1 = a.lr_over_bc1, inv_sqrt_bc2 = a.inv_sqrt_bc2;
+    if (a.dyn) {      // block-uniform: beta^step by squaring (exact enough in double; step < 2^31)
+        long long n = a.dyn->adam_step;
+        double p1 = 1.0, p2 = 1.0, b1 = (double)a.beta1, b2 = (double)a.beta2;
+        while (n > 0) {
+            if (n & 1) {
+                p1 *= b1;
+                p2 *= b2;
+            }
+            b1 *= b1;
+            b2 *= b2;
+            n >>= 1;
+        }
+        lr_over_bc1 = (float)((double)a.lr / (1.0 - p1));
+        inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - p2));
+    }
     int k = 0;
     while (k + 1 < a.n && (int)blockIdx.x >= a.block_begin[k + 1]) k++;      // block-uniform
     const pn_adam_tensor t = a.t[k];
@@ -67,7 +85,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamList a) {
         const float v = a.beta2 * t.exp_avg_sq[e] + (1.0f - a.beta2) * g * g;
         t.exp_avg[e] = m;
         t.exp_avg_sq[e] = v;
-        t.param[e] = p - a.lr_over_bc1 * (m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps));
+        t.param[e] = p - lr_over_bc1 * (m / (sqrtf(v) * inv_sqrt_bc2 + a.eps));
     }
 }
 
@@ -89,8 +107,9 @@ int pn_cross_entropy(const float *logits, const int64_t *target, int32_t rows, i
 }
 
 int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int64_t step, void *stream_) {
+                 float weight_decay, int64_t step, const pn_step_state *step_state, void *stream_) {
     if (n_tensors < 0 || (n_tensors > 0 && !tensors)) PN_FAIL(PN_ERR_ARG, "pn_adam_step: bad tensor list");
+    if (step_state) step = 1;       // (ignored: the kernel reads step_state->adam_step)
     if (step < 1) PN_FAIL(PN_ERR_ARG, "pn_adam_step: step counts from 1 (got %lld)", (long long)step);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
@@ -113,6 +132,8 @@ int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, flo
         a.beta2 = beta2;
         a.eps = eps;
         a.weight_decay = weight_decay;
+        a.lr = lr;
+        a.dyn = step_state;
         if (blocks == 0) continue;
         hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
         PN_CHECK_HIP(hipGetLastError());

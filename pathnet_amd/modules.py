@@ -88,6 +88,8 @@ class _PaggFunction(torch.autograd.Function):
         ms, mc = cfg.get("mask_seq"), cfg.get("mask_cls")
         a.mask_seq = ms.data_ptr() if ms is not None else None
         a.mask_cls = mc.data_ptr() if mc is not None else None
+        st = cfg.get("step_state")
+        a.step_state = st.ptr() if st is not None else None
         return a
 
     @staticmethod
@@ -198,6 +200,7 @@ class _Aggregator(nn.Module):
         self._dropout = dropout_p
         self._ws_eval = None
         self._ws_tables = None            # (X address, shape, L) whose tables sit in _ws_eval
+        self.step_state = None            # pathnet_amd.StepState: dropout seed read from device memory (hipGraph replay)
         self.workspace_budget = None      # bytes; None = modules.WORKSPACE_BUDGET_BYTES (see pick_batch_groups)
         self._mask_seq = None     # test hook: explicit dropout masks (reference order)
         self._mask_cls = None
@@ -263,7 +266,8 @@ class _Aggregator(nn.Module):
         p = self.dropout_p() if training else 0.0
         cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=self.hidden_size, C=self.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
-                   seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0 else 0)
+                   step_state=self.step_state,
+                   seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.step_state is None) else 0)
         if group_slice is not None:
             begin, count = int(group_slice[0]), int(group_slice[1])
             if begin < 0 or count < 0 or begin + count > S:

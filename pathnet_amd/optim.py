@@ -51,10 +51,13 @@ class Adam(torch.optim.Optimizer):
     """Drop-in for ``torch.optim.Adam(params, lr, betas, eps, weight_decay)`` (no amsgrad / maximize): one launch
     per step over all parameters.  State keys match torch's (``step``, ``exp_avg``, ``exp_avg_sq``)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, step_state=None):
+        """step_state (StepState): the step count of the bias corrections is read from device memory when the kernel runs
+        (a step captured in a hipGraph can be replayed); state["step"] then only counts the Python-side calls."""
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("Adam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.step_state = step_state
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -88,5 +91,29 @@ class Adam(torch.optim.Optimizer):
                                              st["exp_avg_sq"].data_ptr(), p.numel())
                 with torch.cuda.device(items[0][0].device):
                     _lib.check(lib.pn_adam_step(arr, len(items), group["lr"], group["betas"][0], group["betas"][1],
-                                                group["eps"], group["weight_decay"], step, _stream()))
+                                                group["eps"], group["weight_decay"], step,
+                                                self.step_state.ptr() if self.step_state is not None else None,
+                                                _stream()))
         return loss
+
+
+class StepState:
+    """struct pn_step_state in device memory: {epoch, seed, adam_step} of the current training step, read by the sampler,
+    the aggregator's dropout and Adam WHEN THEIR KERNELS RUN -- so a whole step (sample -> forward -> loss -> backward ->
+    Adam) captured into a hipGraph (torch.cuda.CUDAGraph) replays with a new epoch / seed / step count each time.
+    ``advance()`` is the first launch of a step: epoch += 1, adam_step += 1, seed = splitmix64(seed)."""
+
+    def __init__(self, device="cuda", seed=0, first_epoch=0):
+        dev = torch.device(device)
+        self.t = torch.tensor([int(first_epoch) - 1, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=dev)
+
+    def ptr(self):
+        return ctypes.c_void_p(self.t.data_ptr())
+
+    def advance(self):
+        with torch.cuda.device(self.t.device):
+            _lib.check(_lib.load().pn_step_state_advance(self.ptr(), _lib.stream_ptr(self.t.device)))
+
+    def values(self):
+        e, s, a, _ = self.t.tolist()
+        return {"epoch": e, "seed": s & 0xFFFFFFFFFFFFFFFF, "adam_step": a}

@@ -171,8 +171,10 @@ class MerwSampler:
         return cls(n, u, v, p, seq_len, device=device, hops=hops)
 
     def sample(self, W, seed, epoch_begin=0, epoch_count=1, node_begin=0, node_count=None,
-               draw_source=DRAW_PHILOX, check=True, out=None):
-        """-> ids int32 [epoch_count, node_count, W, L], codes uint8 [...] on the GPU."""
+               draw_source=DRAW_PHILOX, check=True, out=None, step_state=None):
+        """-> ids int32 [epoch_count, node_count, W, L], codes uint8 [...] on the GPU.
+        step_state (pathnet_amd.StepState, Philox only): seed and epoch_begin are read from device memory when the
+        kernel runs, so the call can be captured in a hipGraph and replayed."""
         lib = _lib.load()
         if node_count is None:
             node_count = self.n - node_begin
@@ -203,7 +205,8 @@ class MerwSampler:
             _lib.check(lib.pn_sample_paths(_lib.context(dev), ctypes.byref(tb), W, L, draw_source,
                                            seed & 0xFFFFFFFFFFFFFFFF, epoch_begin, epoch_count, node_begin, node_count,
                                            _lib.ptr(ids), _lib.ptr(codes), _lib.ptr(self._ws) if need.value else None,
-                                           need.value, _lib.ptr(self._status), _lib.stream_ptr(dev)))
+                                           need.value, _lib.ptr(self._status),
+                                           step_state.ptr() if step_state is not None else None, _lib.stream_ptr(dev)))
         if check and int(self._status.item()) != 0:
             # the reference prints this and exits (gen_merw.cpp:84-87)
             raise _lib.PnError(int(self._status.item()), "ERROR:: A.size() == 0 in Alias Table")

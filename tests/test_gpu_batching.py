@@ -167,7 +167,7 @@ def test_configs4_shape_beyond_2_pow_32_elements(variant):
     Xs = torch.rand(len(used), F)                       # features of the visited nodes; everything else is zero
     X = torch.zeros(N, F, device="cuda")
     X[torch.as_tensor(used).cuda()] = Xs.cuda()
-    assert modules.pick_batch_groups(variant, N, F, H, C, S, W, L, m.workspace_budget) <= 128
+    assert 0 < modules.pick_batch_groups(variant, N, F, H, C, S, W, L, m.workspace_budget) < S / 2     # several micro-batches
     G = torch.randn(S, C)
     d_ids, d_codes = torch.as_tensor(ids.astype(np.int32)).cuda(), torch.as_tensor(codes.astype(np.uint8)).cuda()
     out = m(X, d_ids, W, L, torch.as_tensor(sel.astype(np.int32)).cuda(), d_codes, None)
@@ -365,3 +365,74 @@ def test_training_trajectory_matches_the_oracle(variant):
     assert torch.equal(pred_h[clear], out_o.argmax(1)[clear]) and clear.float().mean() > 0.9
     for k, v in m.state_dict().items():
         assert (v.cpu() - pr[k].detach()).abs().max().item() < 1e-3, k
+
+
+def test_step_captured_in_a_hip_graph_replays_with_fresh_epoch_seed_and_adam_step():
+    """pn_step_state: the sampler's epoch, the dropout seed and Adam's step count live in device memory and are read when
+    the kernels run, so one training step captured into a hipGraph replays as the NEXT step each time (the library's
+    second stream joins the capture through its fork / join events; no runtime call besides launches after warm-up)."""
+    import pathnet_amd
+    import bench
+    n, u, v, p = bench.synthetic_graph(400, 2)
+    rng = np.random.default_rng(70)
+    F, H, C, W, L = 24, 64, 4, 10, 4
+    X = torch.rand(n, F, device="cuda")
+    Y = torch.as_tensor(rng.integers(0, C, n)).cuda()
+    sel = torch.as_tensor(np.sort(rng.permutation(n)[:150])).cuda()
+    sel32 = sel.to(torch.int32)
+
+    def make():
+        torch.manual_seed(7)
+        smp = pathnet_amd.MerwSampler(n, u, v, p, L, device="cuda")
+        m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.5).cuda().train()
+        st = pathnet_amd.StepState("cuda", seed=1234, first_epoch=0)
+        m.step_state = st
+        opt = pathnet_amd.Adam(m.parameters(), lr=0.005, weight_decay=0.0005, step_state=st)
+        lossf = pathnet_amd.CrossEntropyLoss()
+        ids_buf = torch.empty((1, n, W, L), dtype=torch.int32, device="cuda")
+        codes_buf = torch.empty((1, n, W, L), dtype=torch.uint8, device="cuda")
+        loss_out = torch.zeros((), device="cuda")
+
+        def step():
+            st.advance()
+            smp.sample(W, 0, check=False, out=(ids_buf, codes_buf), step_state=st)
+            out = m(X, ids_buf[0].index_select(0, sel), W, L, sel32, codes_buf[0].index_select(0, sel), None)
+            loss = lossf(out, Y[sel])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            loss_out.copy_(loss.detach())
+        return m, st, step, ids_buf, loss_out
+
+    K = 6
+    ma, sta, step_a, ids_a, loss_a = make()
+    losses_a, first_ids = [], []
+    for _ in range(K):
+        step_a()
+        losses_a.append(loss_a.item())
+        first_ids.append(ids_a[0, :, :, 1].clone())
+    assert sta.values()["epoch"] == K - 1 and sta.values()["adam_step"] == K
+    assert not torch.equal(first_ids[0], first_ids[1])                      # a new epoch's walks every step
+
+    mb, stb, step_b, ids_b, loss_b = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step_b()                                                            # warm-up = step 1
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    losses_b = [loss_b.item()]
+    assert torch.equal(ids_b[0, :, :, 1], first_ids[0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step_b()                                                            # captured, not run
+    assert stb.values()["adam_step"] == 1
+    for k in range(1, K):
+        g.replay()
+        torch.cuda.synchronize()
+        losses_b.append(loss_b.item())
+        assert torch.equal(ids_b[0, :, :, 1], first_ids[k]), k             # the replay sampled epoch k
+    assert stb.values() == sta.values()
+    assert max(abs(a - b) for a, b in zip(losses_a, losses_b)) < 1e-4, (losses_a, losses_b)
+    for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert (va - vb).abs().max().item() < 5e-4, k
