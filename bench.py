@@ -272,18 +272,17 @@ class StepRunner:
             self.loss_scale = world * counts[rank] / max(sum(counts), 1)      # mean over the WHOLE batch (dist.py)
         self.S = int(self.sel.numel())
         self.Ysel = Y[self.sel + (self.node_begin if sharded else 0)]
-        self.ids_buf = torch.empty((1, self.node_count, W, L), dtype=torch.int32, device=dev)
-        self.codes_buf = torch.empty((1, self.node_count, W, L), dtype=torch.uint8, device=dev)
+        # the step samples the paths of its masked nodes only (PathNet_run.py:345 picks them out of the epoch's file)
+        self.ids_buf = torch.empty((1, self.S, W, L), dtype=torch.int32, device=dev)
+        self.codes_buf = torch.empty((1, self.S, W, L), dtype=torch.uint8, device=dev)
 
     def step(self, epoch):
         import pathnet_amd
         wl = self.wl
         W, L = wl["W"], wl["L"]
-        self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, node_begin=self.node_begin,
-                        node_count=self.node_count, draw_source=pathnet_amd.DRAW_PHILOX, check=False,
-                        out=(self.ids_buf, self.codes_buf))
-        ids = self.ids_buf[0].index_select(0, self.sel)
-        codes = self.codes_buf[0].index_select(0, self.sel)
+        self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, nodes=self.sel32,
+                        draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(self.ids_buf, self.codes_buf))
+        ids, codes = self.ids_buf[0], self.codes_buf[0]
         self.model.train()
         if self.runner is None:
             out = self.model(self.X, ids, W, L, self.sel32, codes, None)

@@ -161,7 +161,13 @@ typedef struct pn_sampler_tables {
     /* draws per walk step: 0 or 2 = the MERW alias roll (slot draw + probability draw, gen_merw.cpp:81-91);
      * 1 = the uniform sampler's single rand() % deg (gen.cpp:113-114) over tables from pn_uniform_build. */
     int32_t draws_per_step;
+    /* dev [n][2] uint32 {first triple, number of triples} of every node (pn_node_ref_pack), or NULL: with it a roll
+     * fetches a node's table position with ONE 8-byte load instead of two words of off[] (total < 2^32 triples). */
+    const uint32_t *node_ref;
 } pn_sampler_tables;
+
+/* host: off[n+1] -> ref[n][2] = {off[i], off[i+1] - off[i]}.  Fails when the table holds 2^32 triples or more. */
+int pn_node_ref_pack(int32_t n, const int64_t *off, uint32_t *ref);
 
 /* Pack host A/B/thr arrays into the 16-byte device layout (host helper, dst is a host buffer of
  * total*4 int32 that the caller then copies to the device). */
@@ -172,7 +178,10 @@ int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t
                               int64_t *bytes);
 
 /* Sample paths for epochs [epoch_begin, epoch_begin+epoch_count) and source nodes
- * [node_begin, node_begin+node_count).  ids/codes are dev [epoch_count, node_count, W, L]
+ * [node_begin, node_begin+node_count) -- or, with node_list (dev int32 [node_count], PN_DRAW_PHILOX only: a walk's draws
+ * are a function of (epoch, source node, walk index), whatever else is sampled beside it), the listed source nodes in
+ * list order: a training step samples the paths of its masked nodes only (PathNet_run.py:345 indexes them out of the
+ * epoch's file).  ids/codes are dev [epoch_count, node_count, W, L]
  * (int32 node ids, uint8 distance codes = dis - 1), i.e. exactly the numbers the reference prints,
  * in the reference's order.  The draw index of (epoch e, node st, walk i, step t) is
  * 2*(((e*n + st)*W + i)*L + t) (+1 for the probability draw), as in the reference where the last
@@ -183,7 +192,7 @@ int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tables, int32_t W,
                     int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
                     uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag,
                     const pn_step_state *step_state /* dev or NULL: PN_DRAW_PHILOX only; replaces seed / epoch_begin */,
-                    void *stream);
+                    const int32_t *node_list /* dev [node_count] or NULL */, void *stream);
 
 /* ================================================================================================
  * Path file.  The on-disk interface between sampler and trainer: one line per path,

@@ -38,7 +38,8 @@ class DeviceInfo(ctypes.Structure):
 
 class SamplerTables(ctypes.Structure):
     _fields_ = [("n", ctypes.c_int32), ("total", ctypes.c_int64), ("off", vp), ("triples", vp), ("dis", vp),
-                ("adj_off", vp), ("adj", vp), ("radj_off", vp), ("radj", vp), ("draws_per_step", ctypes.c_int32)]
+                ("adj_off", vp), ("adj", vp), ("radj_off", vp), ("radj", vp), ("draws_per_step", ctypes.c_int32),
+                ("node_ref", vp)]
 
 
 class PaggShape(ctypes.Structure):
@@ -84,6 +85,7 @@ SIGNATURES = {
     "pn_alias_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, c_f64p, c_i64p, c_i32p, c_i32p,
                                       c_f64p, c_u32p, ctypes.c_int64, c_i64p]),
     "pn_alias_pack": (ctypes.c_int, [ctypes.c_int64, c_i32p, c_i32p, c_u32p, c_i32p]),
+    "pn_node_ref_pack": (ctypes.c_int, [ctypes.c_int32, c_i64p, c_u32p]),
     "pn_hops_dense": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, ctypes.c_int32, c_u8p]),
     "pn_csr_build": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, c_i32p, c_i32p, ctypes.c_int32, c_i64p, c_i32p,
                                     ctypes.c_int64, c_i64p]),
@@ -92,7 +94,7 @@ SIGNATURES = {
                                                  ctypes.c_int32, c_i64p]),
     "pn_sample_paths": (ctypes.c_int, [vp, ctypes.POINTER(SamplerTables), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                        ctypes.c_uint64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
-                                       vp, vp, vp, ctypes.c_int64, vp, vp, vp]),
+                                       vp, vp, vp, ctypes.c_int64, vp, vp, vp, vp]),
     "pn_paths_write_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_int32]),
     "pn_paths_read_text": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int32, c_i32p, c_u8p, ctypes.c_int64, c_i64p]),

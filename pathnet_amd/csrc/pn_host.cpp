@@ -557,6 +557,17 @@ int pn_alias_build(int32_t n, int64_t m, const int32_t *u, const int32_t *v, con
     return host_exception("pn_alias_build");
 }
 
+int pn_node_ref_pack(int32_t n, const int64_t *off, uint32_t *ref) {
+    if (n < 0 || !off || (n > 0 && !ref)) PN_FAIL(PN_ERR_ARG, "pn_node_ref_pack: bad argument");
+    if (off[n] >= (1LL << 32)) PN_FAIL(PN_ERR_ARG, "pn_node_ref_pack: %lld triples do not fit 32-bit positions", (long long)off[n]);
+    for (int32_t i = 0; i < n; i++) {
+        if (off[i + 1] < off[i]) PN_FAIL(PN_ERR_ARG, "pn_node_ref_pack: off[] is not a prefix sum at node %d", i);
+        ref[2 * (size_t)i] = (uint32_t)off[i];
+        ref[2 * (size_t)i + 1] = (uint32_t)(off[i + 1] - off[i]);
+    }
+    return PN_OK;
+}
+
 int pn_alias_pack(int64_t total, const int32_t *A, const int32_t *B, const uint32_t *thr, int32_t *dst) try {
     if (total < 0 || (total > 0 && (!A || !B || !thr || !dst))) PN_FAIL(PN_ERR_ARG, "pn_alias_pack: bad argument");
     for (int64_t i = 0; i < total; i++) {

@@ -2048,7 +2048,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     JoinGuard joiner{ctx, stream};
     const bool side_ok = !profiling_every_stage(ctx);     // (per-stage timings are taken serially)
     {
-        StageTimer tm(ctx, ST_SEQ_BWD, stream);
+        StageTimer tm(ctx, ST_PLAN_PACK, stream);      // (its own bracket: ST_SEQ_BWD times the BPTT kernel alone)
         hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
                            a->w_hh, H, G, c.at<u32x4>(c.w.WpT));
         PN_CHECK_HIP(hipGetLastError());

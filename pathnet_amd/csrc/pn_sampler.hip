@@ -25,6 +25,7 @@
 #include <rocrand/rocrand_kernel.h>
 
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "pn_internal.h"
@@ -102,7 +103,21 @@ struct WalkParams {
     int32_t *status;
     int32_t dps;           // draws per step: 2 = alias roll (gen_merw.cpp:81-91), 1 = uniform rand() % deg (gen.cpp:113-114)
     const pn_step_state *dyn;   // Philox: seed / epoch_begin read from device memory when set (hipGraph replay)
+    const uint2 *node_ref;      // [n] {first triple, count} (one 8-byte load per roll) or null: two words of off[]
+    const int32_t *node_list;   // source node of window slot i (Philox) or null: node_begin + i
 };
+
+// table position of node x
+__device__ __forceinline__ void node_table(const WalkParams &p, int32_t x, int64_t &o0, int32_t &len) {
+    if (p.node_ref) {
+        const uint2 r = p.node_ref[x];
+        o0 = r.x;
+        len = (int32_t)r.y;
+    } else {
+        o0 = p.off[x];
+        len = (int32_t)(p.off[x + 1] - o0);
+    }
+}
 
 // The draws of step t of a walk.  Alias roll: draws 2t, 2t+1 of the walk's stream; uniform: draw t.  Philox words
 // come four at a time: draw q is word q & 3 of block q >> 2.
@@ -121,7 +136,8 @@ __device__ __forceinline__ void step_draws(const int dps, const int32_t *my_draw
     }
 }
 
-template <int DRAW>
+// L4: path length 4 (the reference's default): ids and codes of a path leave as one 16-byte and one 4-byte store
+template <int DRAW, bool L4>
 __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     __shared__ int4 s_tab[kStageTriples];
     const int64_t per_epoch = (int64_t)p.node_count * p.W;
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     const int64_t e_first = g0 / per_epoch, e_last = g_last / per_epoch;
     int64_t stage_base = 0, stage_cnt = 0;
     int32_t st_lo = 0, st_hi = -1;
-    if (e_first == e_last) {
+    if (e_first == e_last && !p.node_list) {
         st_lo = p.node_begin + (int32_t)((g0 % per_epoch) / p.W);
         st_hi = p.node_begin + (int32_t)((g_last % per_epoch) / p.W);
         stage_base = p.off[st_lo];
@@ -150,7 +166,8 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
 
     const int64_t e_l = g / per_epoch;
     const int64_t rem = g - e_l * per_epoch;
-    const int32_t st = p.node_begin + (int32_t)(rem / p.W);
+    const int32_t st_i = (int32_t)(rem / p.W);
+    const int32_t st = p.node_list ? p.node_list[st_i] : p.node_begin + st_i;
     const int32_t wi = (int32_t)(rem % p.W);
     const int64_t epoch_begin = p.dyn ? p.dyn->epoch : p.epoch_begin;
     const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
@@ -165,28 +182,64 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     int32_t *out_ids = p.ids + g * p.L;
     uint8_t *out_codes = p.codes + g * p.L;
     int32_t x = st;
-    for (int32_t t = 0; t < p.L; t++) {
-        out_ids[t] = x;
-        out_codes[t] = (uint8_t)(dis_row[x] - 1);
-        const int64_t o0 = p.off[x];
-        const int32_t len = (int32_t)(p.off[x + 1] - o0);
-        uint32_t r0, r1;
-        step_draws<DRAW>(p.dps, my_draws, rng, word, t, r0, r1);
-        if (len <= 0) {
-            if (p.status) atomicExch(p.status, PN_ERR_EMPTY_TABLE);
-            for (int32_t k = t + 1; k < p.L; k++) {
-                out_ids[k] = x;
-                out_codes[k] = out_codes[t];
+    int32_t idv[4] = {0, 0, 0, 0};          // L4: the path's ids / codes, stored once at the end
+    uint32_t cdv = 0;
+    int32_t dead = 1 << 30, fill_x = 0;     // first step after an empty alias table, and what fills the rest
+    uint8_t fill_c = 0;
+    const int32_t steps = L4 ? 4 : p.L;
+    // one path node (no lambda: the Philox state must stay in registers); `break`s out of the enclosing loop on an
+    // empty alias table
+#define PN_WALK_STEP(t)                                                                            \
+    {                                                                                              \
+        const uint8_t code = (uint8_t)(dis_row[x] - 1);                                            \
+        if constexpr (L4) {                                                                        \
+            idv[(t) & 3] = x;                                                                      \
+            cdv |= (uint32_t)code << (8 * ((t) & 3));                                              \
+        } else {                                                                                   \
+            out_ids[t] = x;                                                                        \
+            out_codes[t] = code;                                                                   \
+        }                                                                                          \
+        int64_t o0;                                                                                \
+        int32_t len;                                                                               \
+        node_table(p, x, o0, len);                                                                 \
+        uint32_t r0, r1;                                                                           \
+        step_draws<DRAW>(p.dps, my_draws, rng, word, t, r0, r1);                                   \
+        if (len <= 0) {                                                                            \
+            if (p.status) atomicExch(p.status, PN_ERR_EMPTY_TABLE);                                \
+            dead = (t) + 1; /* the rest of the path repeats this node (the reference exits here) */ \
+            fill_x = x;                                                                            \
+            fill_c = code;                                                                         \
+            break;                                                                                 \
+        }                                                                                          \
+        const int64_t slot = o0 + (int64_t)(r0 % (uint32_t)len);                                   \
+        int4 tr;                                                                                   \
+        if ((t) == 0 && st >= st_lo && st <= st_hi)                                                \
+            tr = s_tab[slot - stage_base];                                                         \
+        else                                                                                       \
+            tr = p.triples[slot];                                                                  \
+        x = (r1 >= (uint32_t)tr.z) ? tr.x : tr.y;                                                  \
+    }
+    if constexpr (L4) {
+#pragma unroll
+        for (int32_t t = 0; t < 4; t++) PN_WALK_STEP(t)
+    } else {
+        for (int32_t t = 0; t < steps; t++) PN_WALK_STEP(t)
+    }
+#undef PN_WALK_STEP
+    if constexpr (L4) {
+#pragma unroll
+        for (int k = 1; k < 4; k++)
+            if (k >= dead) {
+                idv[k] = fill_x;
+                cdv |= (uint32_t)fill_c << (8 * k);
             }
-            return;
+        *reinterpret_cast<int4 *>(out_ids) = make_int4(idv[0], idv[1], idv[2], idv[3]);
+        *reinterpret_cast<uint32_t *>(out_codes) = cdv;
+    } else {
+        for (int32_t k = dead; k < steps; k++) {
+            out_ids[k] = fill_x;
+            out_codes[k] = fill_c;
         }
-        const int64_t slot = o0 + (int64_t)(r0 % (uint32_t)len);
-        int4 tr;
-        if (t == 0 && st >= st_lo && st <= st_hi)
-            tr = s_tab[slot - stage_base];
-        else
-            tr = p.triples[slot];
-        x = (r1 >= (uint32_t)tr.z) ? tr.x : tr.y;
     }
 }
 
@@ -253,7 +306,7 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int st_l = blockIdx.x * kOtfWaves + wave;
     if (st_l >= p.node_count) return;                       // wave-uniform; no block barriers below
-    const int32_t st = p.node_begin + st_l;
+    const int32_t st = p.node_list ? p.node_list[st_l] : p.node_begin + st_l;
     uint32_t *tab = s_tab[wave];
 
     // ---- out-ball of st, radius rf (largest of 2, 1, 0 that keeps the table at most half full) ----------
@@ -342,8 +395,9 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
                 out_ids[t] = x;
                 out_codes[t] = (uint8_t)best;
                 // ---- roll (same as the dense-table walker) ------------------------------------------------
-                const int64_t o0 = p.off[x];
-                const int32_t len = (int32_t)(p.off[x + 1] - o0);
+                int64_t o0;
+                int32_t len;
+                node_table(p, x, o0, len);
                 uint32_t r0, r1;
                 step_draws<DRAW>(p.dps, my_draws, rng, word, t, r0, r1);
                 if (len <= 0) {
@@ -384,8 +438,11 @@ int pn_sample_workspace_bytes(int32_t W, int32_t L, int32_t draw_source, int64_t
 int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int32_t L, int32_t draw_source, uint64_t seed,
                     int64_t epoch_begin, int64_t epoch_count, int32_t node_begin, int32_t node_count, int32_t *ids,
                     uint8_t *codes, void *workspace, int64_t workspace_bytes, int32_t *status_flag,
-                    const pn_step_state *step_state, void *stream_) {
+                    const pn_step_state *step_state, const int32_t *node_list, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (node_list && draw_source != PN_DRAW_PHILOX)
+        PN_FAIL(PN_ERR_ARG, "pn_sample_paths: a node list needs PN_DRAW_PHILOX (the glibc replay walks the reference's "
+                "contiguous draw stream)");
     if (step_state && draw_source != PN_DRAW_PHILOX)
         PN_FAIL(PN_ERR_ARG, "pn_sample_paths: a device step state needs PN_DRAW_PHILOX (the glibc replay prepares its "
                 "jump tables on the host)");
@@ -396,8 +453,9 @@ int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int
         PN_FAIL(PN_ERR_ARG, "pn_sample_paths: neither a dense hop table nor the CSR lists for on-the-fly hop codes");
     if (otf && (tb->n >= (1 << 28) || L > 8))
         PN_FAIL(PN_ERR_ARG, "on-the-fly hop codes support n < 2^28 and L <= 8 (n=%d L=%d)", tb->n, L);
+    if (node_list) node_begin = 0;
     if (W < 1 || L < 1 || epoch_begin < 0 || epoch_count < 0 || node_begin < 0 || node_count < 0 ||
-        (int64_t)node_begin + node_count > tb->n)
+        (!node_list && (int64_t)node_begin + node_count > tb->n))
         PN_FAIL(PN_ERR_ARG, "pn_sample_paths: bad window (n=%d W=%d L=%d nodes [%d,+%d))", tb->n, W, L, node_begin,
                 node_count);
     const int64_t total = epoch_count * node_count * W;
@@ -424,6 +482,8 @@ int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int
         PN_FAIL(PN_ERR_ARG, "pn_sample_paths: draws_per_step = %d (0, 1 or 2)", tb->draws_per_step);
     wp.dps = dps;
     wp.dyn = step_state;
+    wp.node_ref = reinterpret_cast<const uint2 *>(tb->node_ref);
+    wp.node_list = node_list;
 
     if (draw_source == PN_DRAW_GLIBC_REPLAY) {
         int64_t need = 0;
@@ -481,7 +541,10 @@ int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int
                                dim3(kOtfWaves * 64), 0, stream, op);
         } else {
             const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
-            hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_GLIBC_REPLAY>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+            if (L == 4)
+                hipLaunchKernelGGL((merw_walk_kernel<PN_DRAW_GLIBC_REPLAY, true>), dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+            else
+                hipLaunchKernelGGL((merw_walk_kernel<PN_DRAW_GLIBC_REPLAY, false>), dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
         }
         PN_CHECK_HIP(hipGetLastError());
     } else if (draw_source == PN_DRAW_PHILOX) {
@@ -492,7 +555,10 @@ int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int
                                dim3(kOtfWaves * 64), 0, stream, op);
         } else {
             const unsigned blocks = (unsigned)((total + kWalkThreads - 1) / kWalkThreads);
-            hipLaunchKernelGGL(merw_walk_kernel<PN_DRAW_PHILOX>, dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+            if (L == 4)
+                hipLaunchKernelGGL((merw_walk_kernel<PN_DRAW_PHILOX, true>), dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
+            else
+                hipLaunchKernelGGL((merw_walk_kernel<PN_DRAW_PHILOX, false>), dim3(blocks), dim3(kWalkThreads), 0, stream, wp);
         }
         PN_CHECK_HIP(hipGetLastError());
     } else {

@@ -151,6 +151,12 @@ class MerwSampler:
         self.hops = hops
         self.d_off = torch.from_numpy(off).to(self.device)
         self.d_triples = torch.from_numpy(packed).to(self.device)
+        self.d_node_ref = None
+        if int(off[-1]) < 2 ** 32:          # {first triple, count} per node: one 8-byte load per roll
+            ref = np.empty(2 * max(int(n), 1), np.uint32)
+            _lib.check(_lib.load().pn_node_ref_pack(int(n), _lib.np_ptr(np.ascontiguousarray(off), ctypes.c_int64),
+                                                    _lib.np_ptr(ref, ctypes.c_uint32)))
+            self.d_node_ref = torch.from_numpy(ref.view(np.int32)).to(self.device)
         self.d_dis = self.d_adj_off = self.d_adj = self.d_radj_off = self.d_radj = None
         if hops == "dense":
             self.d_dis = torch.from_numpy(hops_dense(n, eu, ev, seq_len)).to(self.device)
@@ -171,12 +177,19 @@ class MerwSampler:
         return cls(n, u, v, p, seq_len, device=device, hops=hops)
 
     def sample(self, W, seed, epoch_begin=0, epoch_count=1, node_begin=0, node_count=None,
-               draw_source=DRAW_PHILOX, check=True, out=None, step_state=None):
+               draw_source=DRAW_PHILOX, check=True, out=None, step_state=None, nodes=None):
         """-> ids int32 [epoch_count, node_count, W, L], codes uint8 [...] on the GPU.
+        nodes (int32 device tensor, Philox only): sample the paths of these source nodes (in this order) instead of the
+        range [node_begin, node_begin + node_count) -- e.g. the step's masked nodes; a walk's draws depend on (epoch,
+        source node, walk index) only, so the paths are the ones a full-epoch sample holds for those nodes.
         step_state (pathnet_amd.StepState, Philox only): seed and epoch_begin are read from device memory when the
         kernel runs, so the call can be captured in a hipGraph and replayed."""
         lib = _lib.load()
-        if node_count is None:
+        if nodes is not None:
+            if nodes.dtype != torch.int32 or not nodes.is_cuda or not nodes.is_contiguous() or nodes.dim() != 1:
+                raise ValueError("sample(nodes=...): contiguous 1-D int32 device tensor of node ids expected")
+            node_begin, node_count = 0, int(nodes.numel())
+        elif node_count is None:
             node_count = self.n - node_begin
         L = self.L
         shape = (epoch_count, node_count, W, L)
@@ -195,7 +208,7 @@ class MerwSampler:
         dp = lambda t: t.data_ptr() if t is not None else None      # noqa: E731
         tb = _lib.SamplerTables(self.n, self.total, self.d_off.data_ptr(), self.d_triples.data_ptr(), dp(self.d_dis),
                                 dp(self.d_adj_off), dp(self.d_adj), dp(self.d_radj_off), dp(self.d_radj),
-                                self.draws_per_step)
+                                self.draws_per_step, dp(self.d_node_ref))
         dev = ids.device
         with torch.cuda.device(dev):        # the library launches on the current device
             if need.value and (self._ws is None or self._ws.numel() < need.value):
@@ -206,7 +219,8 @@ class MerwSampler:
                                            seed & 0xFFFFFFFFFFFFFFFF, epoch_begin, epoch_count, node_begin, node_count,
                                            _lib.ptr(ids), _lib.ptr(codes), _lib.ptr(self._ws) if need.value else None,
                                            need.value, _lib.ptr(self._status),
-                                           step_state.ptr() if step_state is not None else None, _lib.stream_ptr(dev)))
+                                           step_state.ptr() if step_state is not None else None,
+                                           _lib.ptr(nodes) if nodes is not None else None, _lib.stream_ptr(dev)))
         if check and int(self._status.item()) != 0:
             # the reference prints this and exits (gen_merw.cpp:84-87)
             raise _lib.PnError(int(self._status.item()), "ERROR:: A.size() == 0 in Alias Table")

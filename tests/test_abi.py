@@ -260,3 +260,16 @@ def test_binary_path_file_is_lossless_and_rejects_garbage(tmp_path):
     with pytest.raises(_lib.PnError) as e:
         pathfile.read_paths_binary(fb)
     assert e.value.code == _lib.PN_ERR_FORMAT
+
+
+def test_node_ref_pack():
+    import ctypes
+    lib = _lib.load()
+    off = np.array([0, 3, 3, 10, 4000000000], np.int64)
+    ref = np.zeros(8, np.uint32)
+    _lib.check(lib.pn_node_ref_pack(4, _lib.np_ptr(off, ctypes.c_int64), _lib.np_ptr(ref, ctypes.c_uint32)))
+    assert ref.reshape(4, 2).tolist() == [[0, 3], [3, 0], [3, 7], [10, 3999999990]]
+    off[-1] = 2 ** 32
+    assert lib.pn_node_ref_pack(4, _lib.np_ptr(off, ctypes.c_int64), _lib.np_ptr(ref, ctypes.c_uint32)) == _lib.PN_ERR_ARG
+    bad = np.array([0, 5, 3], np.int64)
+    assert lib.pn_node_ref_pack(2, _lib.np_ptr(bad, ctypes.c_int64), _lib.np_ptr(ref, ctypes.c_uint32)) == _lib.PN_ERR_ARG

@@ -313,3 +313,41 @@ def test_uniform_cli_output_is_byte_identical_to_reference_program(tmp_path):
     assert r.stdout.split() == [str(n), str(len(g["u"]))]
     cat = b"".join(open(os.path.join(cwd, "syn_%d_%d_%d.txt" % (W, L, e)), "rb").read() for e in range(3))
     assert cat == want[:len(cat)]
+
+
+def test_node_list_window_equals_rows_of_the_full_epoch():
+    import pathnet_amd
+    from pathnet_amd import _lib
+    """pn_sample_paths(node_list): a training step samples the paths of its masked nodes only; a walk's Philox draws are
+    a function of (epoch, source node, walk index), so these are the rows a full-epoch sample holds for those nodes --
+    with the dense hop table and with on-the-fly hop codes, L = 4 (vector stores) and L = 5."""
+    import bench
+    n, u, v, p = bench.synthetic_graph(700, 9)
+    rng = np.random.default_rng(9)
+    for L in (4, 5):
+        for hops in ("dense", "otf"):
+            smp = pathnet_amd.MerwSampler(n, u, v, p, L, device="cuda", hops=hops)
+            full_i, full_c = smp.sample(13, 77, epoch_begin=3, epoch_count=2)
+            nodes = torch.as_tensor(rng.permutation(n)[:123].astype(np.int32)).cuda()       # any order, any subset
+            got_i, got_c = smp.sample(13, 77, epoch_begin=3, epoch_count=2, nodes=nodes)
+            assert got_i.shape == (2, 123, 13, L)
+            assert torch.equal(got_i, full_i[:, nodes.long()]) and torch.equal(got_c, full_c[:, nodes.long()])
+            oi, oc = merw.sample_full(n, u, v, p, 13, L, merw.DRAW_PHILOX, 77, epoch_begin=3, epoch_count=2)
+            assert (full_i.cpu().numpy() == oi).all() and (full_c.cpu().numpy() == oc).all()
+    with pytest.raises(ValueError):
+        smp.sample(13, 77, nodes=nodes.long())
+    with pytest.raises(_lib.PnError):
+        smp.sample(13, 77, nodes=nodes, draw_source=pathnet_amd.DRAW_GLIBC_REPLAY)
+
+
+def test_walker_without_the_packed_node_refs():
+    import pathnet_amd
+    """the 8-byte {first triple, count} word per node is an optimisation of the two-word off[] lookup: same paths"""
+    g = golden("sampler_synthetic97_12_5.npz")
+    n, W, L = int(g["n"]), int(g["W"]), int(g["L"])
+    smp = pathnet_amd.MerwSampler(n, g["u"], g["v"], g["p"], L, device="cuda")
+    assert smp.d_node_ref is not None
+    a = smp.sample(W, int(g["seed"]), epoch_count=int(g["epochs"]), draw_source=pathnet_amd.DRAW_GLIBC_REPLAY)
+    smp.d_node_ref = None
+    b = smp.sample(W, int(g["seed"]), epoch_count=int(g["epochs"]), draw_source=pathnet_amd.DRAW_GLIBC_REPLAY)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and (a[0].cpu().numpy() == g["ids"]).all()
