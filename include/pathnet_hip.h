@@ -238,7 +238,18 @@ typedef struct pn_pagg_shape {
      * backward re-runs each micro-batch's recurrence before its BPTT (same seed, same masks); gradients accumulate
      * across micro-batches and the node-level backward (bank, fc0) runs once at the end.  0: one batch. */
     int32_t batch_groups;
+    /* The path encoder between the distance bank and the pooling.  0: the variant's own (LSTM for PathNet / PathNet_homo,
+     * tanh RNN for PAGG).  The others are the ablation rows of the paper's table ("Changing the PAGG class can deliver
+     * other variants", README.md:118; no code in the reference): GRU = torch.nn.GRU's cell (weights [3H, H], gate order
+     * r, z, n), MEAN / SUM = the mean / the sum of a path's (dropped-out) step rows, no recurrent weights (w_* / b_* NULL). */
+    int32_t cell;
 } pn_pagg_shape;
+#define PN_CELL_DEFAULT 0
+#define PN_CELL_LSTM 1
+#define PN_CELL_RNN 2
+#define PN_CELL_GRU 3
+#define PN_CELL_MEAN 4
+#define PN_CELL_SUM 5
 
 /* All pointers are device pointers.  Weights use the reference state_dict layout
  * (nn.Linear weight [out, in]; LSTM/RNN weight_ih/hh [G*H, H] with torch gate order i,f,g,o).
@@ -253,7 +264,7 @@ typedef struct pn_pagg_args {
     /* parameters */
     const float *fc0_w, *fc0_b;   /* [H, F], [H] */
     const float *bank_w, *bank_b; /* [L, H, H], [L, H]   nets.<d> / nei<d> stacked by d */
-    const float *w_ih, *w_hh;     /* [G*H, H]            G = 4 (LSTM) or 1 (RNN) */
+    const float *w_ih, *w_hh;     /* [G*H, H]            G = 4 (LSTM), 1 (RNN), 3 (GRU); NULL for the mean / sum cells */
     const float *b_ih, *b_hh;     /* [G*H] */
     const float *att_w, *att_b;   /* [2H], [1]           unused for PN_VARIANT_PAGG */
     const float *fc2_w, *fc2_b;   /* [C, 2H], [C] */

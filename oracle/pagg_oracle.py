@@ -67,7 +67,7 @@ def project(variant, fc0_w, fc0_b, X):
 
 
 def forward(variant, params, X, ids, codes, sel, W, L, drop_seq=None, drop_cls=None, dtype=torch.float32,
-            return_intermediates=False, Xh=None):
+            return_intermediates=False, Xh=None, cell=None):
     """Reference forward, restated.
 
     params : dict name -> tensor with the reference state_dict keys (fc0.*, nets.<d>.* or nei<d>.*,
@@ -76,6 +76,10 @@ def forward(variant, params, X, ids, codes, sel, W, L, drop_seq=None, drop_cls=N
     drop_seq : None or multiplicative mask [L, P, H] already scaled by 1/(1-p)  (F.dropout on the
                recurrent input, PathNet_run.py:194 / :264 / copy.py:348)
     drop_cls : None or mask [S, 2H] (F.dropout on the classifier input, :209 / :276 / copy.py:357)
+    cell     : None = the class's own path encoder (nn.LSTM; nn.RNN for PAGG).  "gru" / "mean" / "sum" are the ablation
+               rows of the paper's table, which the reference ships no code for (README.md:118): "gru" is torch.nn.GRU's
+               cell (parameters GRU.*, gate order r, z, n), "mean" / "sum" the mean / sum over the L steps of the
+               dropped-out step rows (no recurrent parameters); "lstm" / "rnn" force those cells for any class.
     """
     g = {k: (v.detach() if not v.requires_grad else v).to(dtype) for k, v in params.items()}
     S = len(sel)
@@ -106,13 +110,29 @@ def forward(variant, params, X, ids, codes, sel, W, L, drop_seq=None, drop_cls=N
         xs = xs * drop_seq.to(dtype)
 
     # recurrent cell over the L steps, zero initial state, only the final h is used
-    if variant == "pagg":
+    cell = cell or ("rnn" if variant == "pagg" else "lstm")
+    if cell in ("mean", "sum"):
+        h = xs.sum(dim=0) if cell == "sum" else xs.mean(dim=0)
+    elif cell == "gru":
+        wih, whh = g["GRU.weight_ih_l0"], g["GRU.weight_hh_l0"]
+        bih, bhh = g["GRU.bias_ih_l0"], g["GRU.bias_hh_l0"]
+        h = torch.zeros(P, H, dtype=dtype)
+        for t in range(L):
+            gi = xs[t] @ wih.t() + bih
+            gh = h @ whh.t() + bhh
+            i_r, i_z, i_n = gi.split(H, dim=1)
+            h_r, h_z, h_n = gh.split(H, dim=1)
+            r = torch.sigmoid(i_r + h_r)
+            z = torch.sigmoid(i_z + h_z)
+            n = torch.tanh(i_n + r * h_n)
+            h = (1.0 - z) * n + z * h
+    elif cell == "rnn":
         wih, whh = g["RNN.weight_ih_l0"], g["RNN.weight_hh_l0"]
         b = g["RNN.bias_ih_l0"] + g["RNN.bias_hh_l0"]
         h = torch.zeros(P, H, dtype=dtype)
         for t in range(L):
             h = torch.tanh(xs[t] @ wih.t() + h @ whh.t() + b)
-    else:
+    elif cell == "lstm":
         wih, whh = g["LSTM.weight_ih_l0"], g["LSTM.weight_hh_l0"]
         b = g["LSTM.bias_ih_l0"] + g["LSTM.bias_hh_l0"]
         h = torch.zeros(P, H, dtype=dtype)
@@ -123,6 +143,8 @@ def forward(variant, params, X, ids, codes, sel, W, L, drop_seq=None, drop_cls=N
             i, f, gg, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)
             c = f * c + i * gg
             h = o * torch.tanh(c)
+    else:
+        raise ValueError("unknown cell %r" % (cell,))
 
     # pooling over the W members of each group
     order = torch.from_numpy(np.argsort(group * W + member, kind="stable"))

@@ -15,6 +15,7 @@ PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOM
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
 ABI_VERSION = 4               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
+CELL_DEFAULT, CELL_LSTM, CELL_RNN, CELL_GRU, CELL_MEAN, CELL_SUM = 0, 1, 2, 3, 4, 5
 LINEAR_SPLIT_MAX = 8          # PN_LINEAR_SPLIT_MAX: workspace floats per output element of pn_linear_forward
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
@@ -47,7 +48,8 @@ class PaggShape(ctypes.Structure):
     batch of S_total masked nodes (0 = S); batch_groups > 0: internal micro-batches of that many groups."""
     _fields_ = [("variant", ctypes.c_int32), ("N", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("C", ctypes.c_int32), ("S", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32),
-                ("S_total", ctypes.c_int32), ("group_begin", ctypes.c_int32), ("batch_groups", ctypes.c_int32)]
+                ("S_total", ctypes.c_int32), ("group_begin", ctypes.c_int32), ("batch_groups", ctypes.c_int32),
+                ("cell", ctypes.c_int32)]
 
 
 class PaggArgs(ctypes.Structure):

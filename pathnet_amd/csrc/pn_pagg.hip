@@ -349,6 +349,60 @@ __global__ __launch_bounds__(256) void gather_kernel(int variant, const float *_
     }
 }
 
+// ---- order-agnostic path encoders of the ablation ("mean" / "sum" instead of the recurrent cell): h_n of a path is the
+//      mean (sum) over its L steps of the dropped-out rows the recurrent kernels would consume.  One thread per (path,
+//      4 columns); the backward scatters scale * mask * d h_n back onto the L table rows.
+struct SeqReduceParams {
+    const float *Z;          // [N*L, H]
+    const int32_t *rowidx;   // [P, L]
+    const int32_t *slotof;   // [P]
+    float *hn;               // [P, H]   forward output
+    const float *dhn;        // [P, H]   backward input
+    float *dZ;               // [N*L, H] backward output (atomic scatter)
+    int P, L, H;
+    int64_t Pmask;
+    float scale;             // 1/L (mean) or 1 (sum)
+    float p_drop;
+    uint64_t seed;
+    const pn_step_state *dyn;
+    const float *mask;       // [L, Pmask, H] or null
+};
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void seq_reduce_kernel(SeqReduceParams p) {
+    const int hv = p.H / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.P * hv) return;
+    const int q = (int)(i / hv), c4 = (int)(i - (int64_t)q * hv);
+    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+    const int64_t slot = p.slotof[q];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BACKWARD) {
+        g = reinterpret_cast<const float4 *>(p.dhn)[i];
+        g.x *= p.scale; g.y *= p.scale; g.z *= p.scale; g.w *= p.scale;
+    }
+    for (int t = 0; t < p.L; t++) {
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p.mask)
+            m = reinterpret_cast<const float4 *>(p.mask)[((int64_t)t * p.Pmask + slot) * hv + c4];
+        else if (p.p_drop > 0.0f)
+            m = dropout4(seed, ((uint64_t)t * p.Pmask + slot) * hv + c4, 1u, p.p_drop);     // the recurrent kernels' counters
+        const size_t row = (size_t)(uint32_t)p.rowidx[(int64_t)q * p.L + t];
+        if (BACKWARD) {
+            float *d = p.dZ + row * p.H + 4 * c4;
+            atomicAdd(d + 0, g.x * m.x); atomicAdd(d + 1, g.y * m.y); atomicAdd(d + 2, g.z * m.z); atomicAdd(d + 3, g.w * m.w);
+        } else {
+            const float4 v = reinterpret_cast<const float4 *>(p.Z)[row * hv + c4];
+            acc.x += v.x * m.x; acc.y += v.y * m.y; acc.z += v.z * m.z; acc.w += v.w * m.w;
+        }
+    }
+    if (!BACKWARD) {
+        acc.x *= p.scale; acc.y *= p.scale; acc.z *= p.scale; acc.w *= p.scale;
+        reinterpret_cast<float4 *>(p.hn)[i] = acc;
+    }
+}
+
 struct SeqFwdParams {
     const float *Z;         // [N*L, H] bank output (post activation)
     const int32_t *rowidx;  // [P, L]
@@ -378,11 +432,24 @@ struct SeqFwdParams {
 //   A operand: LDS holds the three planes of the tile [32][x_t | h_{t-1}] as bf16, row pitch 4H + 16 bytes
 //     (conflict-free ds_read_b128).  x is split when the gathered rows are committed, h in the cell update.
 // ================================================================================================
+// GRU (torch gate order r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn))) rides on the four gate slots of the
+// LSTM kernels: slot 0 = r, 1 = z over [x | h] as usual, slot 2 = "nx" = W_in x + b_in (its h half of the weights is
+// zero), slot 3 = "nh" = W_hn h + b_hn (its x half is zero).  A quarter of the products multiplies zeros; in return
+// the recurrence, its BPTT and the weight-gradient GEMM are the LSTM's kernels with another cell function.
+__device__ __forceinline__ int gru_weight_row(int slot, int j, int H) { return (slot < 2 ? slot : 2) * H + j; }
+
 __global__ void pack_fwd3_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
-                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G,
+                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G, int gru,
                                  u32x4 *__restrict__ Wp, float *__restrict__ biasc) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < G * H) biasc[idx] = b_ih[idx] + b_hh[idx];
+    if (idx < G * H) {
+        if (!gru) {
+            biasc[idx] = b_ih[idx] + b_hh[idx];
+        } else {
+            const int slot = idx / H, j = idx - slot * H, wr = gru_weight_row(slot, j, H);
+            biasc[idx] = slot < 2 ? b_ih[wr] + b_hh[wr] : slot == 2 ? b_ih[wr] : b_hh[wr];
+        }
+    }
     const int KS = H / 8, NW = H / 32;
     if (idx >= NW * KS * G * 64) return;
     const int lane = idx & 63;
@@ -390,9 +457,11 @@ __global__ void pack_fwd3_kernel(const float *__restrict__ w_ih, const float *__
     const int g = rest % G;
     rest /= G;
     const int s = rest % KS, w = rest / KS;
-    const int row = g * H + 32 * w + (lane & 31), k = 16 * s + 8 * (lane >> 5);
+    const int j = 32 * w + (lane & 31), k = 16 * s + 8 * (lane >> 5);
+    const int row = gru ? gru_weight_row(g, j, H) : g * H + j;
     const float *src = k < H ? w_ih + (int64_t)row * H + k : w_hh + (int64_t)row * H + (k - H);
-    const float4 v0 = reinterpret_cast<const float4 *>(src)[0], v1 = reinterpret_cast<const float4 *>(src)[1];
+    float4 v0 = reinterpret_cast<const float4 *>(src)[0], v1 = reinterpret_cast<const float4 *>(src)[1];
+    if (gru && ((g == 2 && k >= H) || (g == 3 && k < H))) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
     u32x4 q0, q1, q2;
     uint32_t x0, x1, x2;
     split3(v0.x, v0.y, x0, x1, x2); q0[0] = x0; q1[0] = x1; q2[0] = x2;
@@ -414,8 +483,11 @@ __global__ void pack_fwd3_kernel(const float *__restrict__ w_ih, const float *__
 template <int H, int RG>
 constexpr int fwd_waves() { return H == 32 && RG == 1 ? 1 : (H > 128 || RG > 1) ? 2 : PN_FWD_WAVES; }
 
-template <int H, int G, int RG>
+// GC: 4 = LSTM, 1 = tanh RNN, 3 = GRU (on the LSTM's four gate slots, see pack_fwd3_kernel)
+template <int H, int GC, int RG>
 __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fwd3_kernel(SeqFwdParams p) {
+    constexpr int G = GC == 3 ? 4 : GC;
+    constexpr bool GRU = GC == 3;
     constexpr int MT = 32 * RG;
     constexpr int NW = H / 32, NT = NW * 64 * RG, SV = (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
@@ -621,7 +693,20 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             const int row = r0 + acc_row(r, lane_o);
             const int q = q0 + row;
             float h;
-            if (G == 4) {
+            if (GRU) {
+                // saved: r, z, n, the pre-activation W_hn h + b_hn, h_{t-1}
+                const float rg = sigmoidf_(acc[0][r]);
+                const float zg = sigmoidf_(acc[G > 1 ? 1 : 0][r]);
+                const float nh = acc[G > 3 ? 3 : 0][r];
+                const float ng = tanhf_(acc[G > 2 ? 2 : 0][r] + rg * nh);
+                const float hp = cst[r];
+                h = (1.0f - zg) * ng + zg * hp;
+                cst[r] = h;
+                if (saved_t && q < p.P) {
+                    float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
+                    sv[0] = rg; sv[H] = zg; sv[2 * H] = ng; sv[3 * H] = nh; sv[4 * H] = hp;
+                }
+            } else if (G == 4) {
                 const float ig = sigmoidf_(acc[0][r]);
                 const float fg = sigmoidf_(acc[G > 1 ? 1 : 0][r]);
                 const float gg = tanhf_(acc[G > 2 ? 2 : 0][r]);
@@ -971,7 +1056,7 @@ struct SeqBwdParams {
 //   A operand: the three bf16 planes of dG_t in LDS.  All four LSTM gates would take 3 x 32 x 4H x 2 B = 96 KB per
 //     workgroup (one workgroup per CU); the tile therefore holds one gate pair at a time -- (i, f) then (g, o), K = 2H
 //     each, 50 KB -- and the k loop runs in two passes with the (g, o) gradients parked in registers meanwhile.
-__global__ void pack_bwd3_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int H, int G,
+__global__ void pack_bwd3_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int H, int G, int gru,
                                  u32x4 *__restrict__ WpT) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int GH = G * H, NU = GH / 32, NW = H / 32;
@@ -981,10 +1066,18 @@ __global__ void pack_bwd3_kernel(const float *__restrict__ w_ih, const float *__
     const int u = rest % NU, w = rest / NU;
     const int kk = f >> 1, nt = f & 1;
     const int k = 32 * u + 16 * kk + 8 * (lane >> 5), n = 32 * w + (lane & 31);
-    const float *src = (nt == 0 ? w_ih : w_hh) + (int64_t)k * H + n;
     float v[8];
+    if (!gru) {
+        const float *src = (nt == 0 ? w_ih : w_hh) + (int64_t)k * H + n;
 #pragma unroll
-    for (int e = 0; e < 8; e++) v[e] = src[(int64_t)e * H];
+        for (int e = 0; e < 8; e++) v[e] = src[(int64_t)e * H];
+    } else {        // k .. k+7 lie inside one gate slot (8 | H)
+        const int slot = k / H, j = k - slot * H;
+        const bool zero = (slot == 2 && nt == 1) || (slot == 3 && nt == 0);
+        const float *src = (nt == 0 ? w_ih : w_hh) + (int64_t)gru_weight_row(slot, j, H) * H + n;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = zero ? 0.0f : src[(int64_t)e * H];
+    }
     u32x4 q0, q1, q2;
 #pragma unroll
     for (int h = 0; h < 4; h++) {
@@ -999,8 +1092,10 @@ __global__ void pack_bwd3_kernel(const float *__restrict__ w_ih, const float *__
 }
 
 // RG row groups per workgroup share the weight stream through L1, as in seq_fwd3_kernel.
-template <int H, int G, int RG>
+template <int H, int GC, int RG>
 __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_WAVES) void seq_bwd3_kernel(SeqBwdParams p) {
+    constexpr int G = GC == 3 ? 4 : GC;         // GC: 4 = LSTM, 1 = tanh RNN, 3 = GRU on the LSTM's four gate slots
+    constexpr bool GRU = GC == 3;
     constexpr int MT = 32 * RG, NW = H / 32;
     constexpr int NT = NW * 64 * RG, GH = G * H, SV = (G == 4 ? 5 : 1);
     constexpr int NPASS = G == 4 ? 2 : 1, KP = GH / NPASS;      // K extent of one pass (one gate pair)
@@ -1083,7 +1178,12 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                 const int r = half * NB + e;
                 const int rc = min(r0 + acc_row(r, lane_t), rows_here - 1);
                 const float *sv = &at_bytes(saved_t, (((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
-                if (G == 4) {
+                if (GRU) {
+                    vi[e] = sv[0]; vf[e] = sv[H]; vg[e] = sv[2 * H];     // r, z, n
+                    vo[e] = sv[3 * H];                                    // W_hn h + b_hn
+                    vc[e] = sv[4 * H];                                    // h_{t-1}
+                    vn[e] = 0.0f;
+                } else if (G == 4) {
                     vi[e] = sv[0]; vf[e] = sv[H]; vg[e] = sv[2 * H];
                     vo[e] = sv[3 * H];
                     vc[e] = t > 0 ? sv[-H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
@@ -1099,7 +1199,23 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                 const int row = r0 + acc_row(r, lane_t);
                 const bool ok = row < rows_here;
                 float *d = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col) * 4u);
-                if (G == 4) {
+                if (GRU) {
+                    // h = (1 - z) n + z h_prev,  n = tanh(nx + r nh):  gradients of the four slots r, z, nx, nh; the direct
+                    // path d h_t / d h_{t-1} = z is carried in dc[] across the GEMM and added to its dh output
+                    const float rg = vi[e], zg = vf[e], ng = vg[e], nh = vo[e], hp = vc[e];
+                    const float dhv = dh[r];
+                    const float dnp = dhv * (1.0f - zg) * (1.0f - ng * ng);
+                    float a_r = dnp * nh * rg * (1.0f - rg);
+                    float a_z = dhv * (hp - ng) * zg * (1.0f - zg);
+                    float a_nx = dnp;
+                    float a_nh = dnp * rg;
+                    if (!ok) a_r = a_z = a_nx = a_nh = 0.0f;
+                    dc[r] = ok ? dhv * zg : 0.0f;
+                    ai[e] = a_r; af[e] = a_z; ag[r] = a_nx; ao[r] = a_nh;
+                    if (ok) {
+                        d[0] = a_r; d[H] = a_z; d[2 * (G > 1 ? H : 0)] = a_nx; d[3 * (G > 1 ? H : 0)] = a_nh;
+                    }
+                } else if (G == 4) {
                     const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
                     const float tc = tanhf_(vn[e]);
                     const float dhv = dh[r];
@@ -1239,7 +1355,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
                     dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col >> 2)] >> (col & 3)) & 1 ? dx * keep_scale : 0.0f;
                 atomicAdd(p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col), dx);
             }
-            dh[r] = acc[1][r];
+            dh[r] = GRU ? acc[1][r] + dc[r] : acc[1][r];
         }
         PN_STAMP(4 * (p.L - 1 - t) + 3);
     }
@@ -1416,12 +1532,35 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
 
 // sums the split partials and scatters them into the reference layouts g_W_ih [GH,H], g_W_hh [GH,H], g_b_*
 // (accumulate != 0: added to what the previous micro-batches left there)
+// (gru: the four slots r, z, nx, nh map to torch's [3H, H] layouts: W_i{r,z,n} = x halves of slots 0, 1, 2,
+//  W_h{r,z,n} = h halves of slots 0, 1, 3; b_i{r,z,n} = slots 0, 1, 2, b_h{r,z,n} = slots 0, 1, 3)
 __global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const float *__restrict__ part_b, int nsplit,
-                                    int GH, int H, int accumulate, float *__restrict__ g_w_ih,
+                                    int GH, int H, int accumulate, int gru, float *__restrict__ g_w_ih,
                                     float *__restrict__ g_w_hh, float *__restrict__ g_b_ih,
                                     float *__restrict__ g_b_hh) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nw = (int64_t)GH * 2 * H;
+    if (gru) {
+        if (i < nw) {
+            const int m = (int)(i / (2 * H)), n = (int)(i - (int64_t)m * 2 * H), slot = m / H, j = m - slot * H;
+            const bool xhalf = n < H;
+            if ((slot == 2 && !xhalf) || (slot == 3 && xhalf)) return;        // products with the zero halves
+            float s = 0.0f;
+            for (int z = 0; z < nsplit; z++) s += part_w[(int64_t)z * nw + i];
+            float *dst = xhalf ? g_w_ih : g_w_hh;
+            if (!dst) return;
+            dst += (int64_t)gru_weight_row(slot, j, H) * H + (xhalf ? n : n - H);
+            *dst = accumulate ? *dst + s : s;
+        } else if (i < nw + GH) {
+            const int m = (int)(i - nw), slot = m / H, j = m - slot * H;
+            float s = 0.0f;
+            for (int z = 0; z < nsplit; z++) s += part_b[(int64_t)z * GH + m];
+            const int wr = gru_weight_row(slot, j, H);
+            if (g_b_ih && slot != 3) g_b_ih[wr] = accumulate ? g_b_ih[wr] + s : s;
+            if (g_b_hh && slot != 2) g_b_hh[wr] = accumulate ? g_b_hh[wr] + s : s;
+        }
+        return;
+    }
     if (i < nw) {
         float s = 0.0f;
         for (int z = 0; z < nsplit; z++) s += part_w[(int64_t)z * nw + i];
@@ -1479,8 +1618,8 @@ template <int H, int G>
 int launch_seq_bwd(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;
     constexpr int MT = 32 * RG;
-    const size_t lds_bytes = (size_t)3 * MT * (2 * (G == 4 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4 +
-                             (size_t)2 * MT * (H / 4);
+    const size_t lds_bytes = (size_t)3 * MT * (2 * (G >= 3 ? 2 * H : H) + 16) + (size_t)(MT * sp.L + MT) * 4 +
+                             (size_t)2 * MT * (H / 4);      // (G = 3: GRU, on four gate slots)
     auto kern = seq_bwd3_kernel<H, G, RG>;
     if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
     const int blocks = (sp.P + MT - 1) / MT;
@@ -1536,8 +1675,10 @@ int dispatch_seq_fwd(pn_context *ctx, hipStream_t stream, int H, const SeqFwdPar
 // ================================================================================================
 // shape bookkeeping and workspace layout
 // ================================================================================================
+enum { CELL_LSTM = 1, CELL_RNN = 2, CELL_GRU = 3, CELL_MEAN = 4, CELL_SUM = 5 };   // = PN_CELL_*
 struct Dims {
-    int variant, N, F, H, C, S, W, L, G, SV;
+    int variant, N, F, H, C, S, W, L, G, SV;    // G: gate slots of the recurrent kernels (4: LSTM and GRU, 1: RNN, 0: mean / sum)
+    int cell, Gw;                               // cell kind; Gw: gates of the caller's weight tensors (4, 1, 3, 0)
     int S_total, group_begin;
     int Sb;             // pooling groups per micro-batch
     int nb;             // micro-batches of this call
@@ -1584,6 +1725,7 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
                 (64 * 1024 - 48 * s.H) / 64, s.H);
     if (s.variant == PN_VARIANT_PAGG && s.L != 4)
         PN_FAIL(PN_ERR_ARG, "PAGG has exactly four distance layers nei0..nei3 (copy.py:310-313); L=%d", s.L);
+    if (s.cell < 0 || s.cell > CELL_SUM) PN_FAIL(PN_ERR_ARG, "unknown cell %d", s.cell);
     const int S_total = s.S_total > 0 ? s.S_total : s.S;
     if (s.group_begin < 0 || (int64_t)s.group_begin + s.S > S_total || s.batch_groups < 0)
         PN_FAIL(PN_ERR_ARG, "bad slice: groups [%d, +%d) of a batch of %d, batch_groups=%d", s.group_begin, s.S,
@@ -1594,7 +1736,9 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
                 (long long)S_total * s.W, (long long)s.N * s.L);
     d.variant = s.variant;
     d.N = s.N, d.F = s.F, d.H = s.H, d.C = s.C, d.S = s.S, d.W = s.W, d.L = s.L;
-    d.G = s.variant == PN_VARIANT_PAGG ? 1 : 4;
+    d.cell = s.cell ? s.cell : (s.variant == PN_VARIANT_PAGG ? CELL_RNN : CELL_LSTM);
+    d.G = d.cell == CELL_RNN ? 1 : (d.cell == CELL_LSTM || d.cell == CELL_GRU) ? 4 : 0;
+    d.Gw = d.cell == CELL_GRU ? 3 : d.G;
     d.SV = d.G == 4 ? 5 : 1;
     d.S_total = S_total;
     d.group_begin = s.group_begin;
@@ -1629,12 +1773,12 @@ WsLayout ws_layout(const Dims &d) {
     };
     w.Xh = take(N * H * 4);
     w.Z = take(N * L * H * 4);
-    w.Wp = take(G * H * 3 * H * 4);
+    w.Wp = take(G * H * 3 * H * 4);          // (G = 0, the mean / sum encoders: no recurrent weights, no saved gates)
     w.biasc = take(G * H * 4);
     w.WpT = take(G * H * 3 * H * 4);
     {
         // split of the Pb*L rows of the weight-gradient GEMM: one 8-wave workgroup per CU
-        const size_t rows = Pb * L, tiles = ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN);
+        const size_t rows = Pb * L, tiles = std::max<size_t>(1, ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN));
         size_t nz = (256 + tiles - 1) / tiles;
         const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
         if (nz > max_nz) nz = max_nz;
@@ -1745,8 +1889,40 @@ int run_plan(const Call &c, hipStream_t s, int b) {
 
 int run_pack_fwd(const Call &c, hipStream_t s) {
     const Dims &d = c.d;
+    if (d.G == 0) return PN_OK;         // mean / sum: nothing to pack
     hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((d.G * d.H * d.H / 4 + 255) / 256)), dim3(256), 0, s, c.a->w_ih,
-                       c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, c.at<u32x4>(c.w.Wp), c.at<float>(c.w.biasc));
+                       c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.Wp),
+                       c.at<float>(c.w.biasc));
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+// the order-agnostic encoders (cell = mean / sum): forward or backward of micro-batch b
+int run_seq_reduce(const Call &c, int b, bool backward) {
+    const Dims &d = c.d;
+    const pn_pagg_args *a = c.a;
+    SeqReduceParams rp{};
+    rp.Z = c.Z;
+    rp.rowidx = c.at<int32_t>(c.w.rowidx);
+    rp.slotof = c.at<int32_t>(c.w.slotof);
+    rp.hn = c.at<float>(c.w.hn);
+    rp.dhn = c.at<float>(c.w.dhn);
+    rp.dZ = c.at<float>(c.w.dZ);
+    rp.P = c.groups(b) * d.W;
+    rp.L = d.L;
+    rp.H = d.H;
+    rp.Pmask = d.P_total;
+    rp.scale = d.cell == CELL_MEAN ? 1.0f / (float)d.L : 1.0f;
+    rp.p_drop = a->p_seq;
+    rp.seed = a->seed;
+    rp.dyn = a->step_state;
+    rp.mask = a->mask_seq;
+    const int64_t n = (int64_t)rp.P * (d.H / 4);
+    StageTimer tm(c.ctx, backward ? ST_SEQ_BWD : ST_SEQ_FWD, c.stream);
+    if (backward)
+        hipLaunchKernelGGL(seq_reduce_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, rp);
+    else
+        hipLaunchKernelGGL(seq_reduce_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, rp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -1754,6 +1930,7 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
 int run_seq_fwd(const Call &c, int b, bool save) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
+    if (d.G == 0) return run_seq_reduce(c, b, false);
     SeqFwdParams sp{};
     sp.Z = c.Z;
     sp.rowidx = c.at<int32_t>(c.w.rowidx);
@@ -1772,7 +1949,9 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     sp.dyn = a->step_state;
     sp.mask = a->mask_seq;
     StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
-    return d.G == 4 ? dispatch_seq_fwd<4>(c.ctx, c.stream, d.H, sp) : dispatch_seq_fwd<1>(c.ctx, c.stream, d.H, sp);
+    return d.cell == CELL_GRU    ? dispatch_seq_fwd<3>(c.ctx, c.stream, d.H, sp)
+           : d.cell == CELL_LSTM ? dispatch_seq_fwd<4>(c.ctx, c.stream, d.H, sp)
+                                 : dispatch_seq_fwd<1>(c.ctx, c.stream, d.H, sp);
 }
 
 int run_pool_fwd(const Call &c, int b, float *out) {
@@ -1931,9 +2110,9 @@ int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     Call c;
     if (int rc = resolve_call(c, ctx, a, stream, "pn_pagg_forward")) return rc;
     const Dims &d = c.d;
-    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->bank_b || !a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh ||
-        !a->fc2_w || !a->fc2_b || !a->out)
+    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->bank_b || !a->fc2_w || !a->fc2_b || !a->out)
         PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null tensor");
+    if (d.G > 0 && (!a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh)) PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: recurrent weights missing");
     if (!a->Xh_in && !a->reuse_tables && (!a->X || !a->fc0_w || !a->fc0_b))
         PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: X / fc0 missing");
     if (d.variant != PN_VARIANT_PAGG && (!a->att_w || !a->att_b)) PN_FAIL(PN_ERR_ARG, "attention weights missing");
@@ -1986,13 +2165,14 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     Call c;
     if (int rc = resolve_call(c, ctx, a, stream, "pn_pagg_backward")) return rc;
     const Dims &d = c.d;
-    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->w_ih || !a->w_hh || !a->fc2_w || !a->g_out)
+    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->fc2_w || !a->g_out)
         PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null tensor");
+    if (d.G > 0 && (!a->w_ih || !a->w_hh)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: recurrent weights missing");
     if (!a->Xh_in && (!a->X || !a->fc0_w)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: X / fc0 missing");
     if (a->Xh_in && !a->g_Xh) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: g_Xh is required with Xh_in");
-    if (d.nb > 1 && (!a->b_ih || !a->b_hh || !a->fc2_b || (d.variant != PN_VARIANT_PAGG && !a->att_b)))
+    if (d.nb > 1 && ((d.G > 0 && (!a->b_ih || !a->b_hh)) || !a->fc2_b || (d.variant != PN_VARIANT_PAGG && !a->att_b)))
         PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: micro-batches re-run the forward and need every forward tensor");
-    const int H = d.H, L = d.L, G = d.G, GH = G * H;
+    const int H = d.H, L = d.L, G = d.G, GH = G * H, GwH = d.Gw * H;     // GH: gate slots, GwH: rows of the caller's weights
     const int homo = d.variant == PN_VARIANT_HOMO;
     const bool has_att = d.variant != PN_VARIANT_PAGG;
     const float *Xh = c.Xh;
@@ -2036,10 +2216,10 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     }
     if (d.S == 0) {
         if (int rc = flush_zero()) return rc;
-        if (int rc = zero(a->g_w_ih, (size_t)GH * H)) return rc;
-        if (int rc = zero(a->g_w_hh, (size_t)GH * H)) return rc;
-        if (int rc = zero(a->g_b_ih, (size_t)GH)) return rc;
-        if (int rc = zero(a->g_b_hh, (size_t)GH)) return rc;
+        if (int rc = zero(a->g_w_ih, (size_t)GwH * H)) return rc;
+        if (int rc = zero(a->g_w_hh, (size_t)GwH * H)) return rc;
+        if (int rc = zero(a->g_b_ih, (size_t)GwH)) return rc;
+        if (int rc = zero(a->g_b_hh, (size_t)GwH)) return rc;
         if (int rc = zero(a->g_X, (size_t)d.N * d.F)) return rc;
         return flush_zero();
     }
@@ -2047,10 +2227,10 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
 
     JoinGuard joiner{ctx, stream};
     const bool side_ok = !profiling_every_stage(ctx);     // (per-stage timings are taken serially)
-    {
+    if (G > 0) {
         StageTimer tm(ctx, ST_PLAN_PACK, stream);      // (its own bracket: ST_SEQ_BWD times the BPTT kernel alone)
         hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
-                           a->w_hh, H, G, c.at<u32x4>(c.w.WpT));
+                           a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.WpT));
         PN_CHECK_HIP(hipGetLastError());
     }
     for (int b = 0; b < d.nb; b++) {
@@ -2118,8 +2298,10 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             PN_CHECK_HIP(hipGetLastError());
         }
 
-        // BPTT + gather-backward scatter
-        {
+        // BPTT + gather-backward scatter (mean / sum encoders: the scatter alone)
+        if (G == 0) {
+            if (int rc = run_seq_reduce(c, b, true)) return rc;
+        } else {
             StageTimer tm(ctx, ST_SEQ_BWD, stream);
             SeqBwdParams sp{};
             sp.saved = c.at<float>(c.w.saved);
@@ -2136,12 +2318,14 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             sp.p_drop = a->p_seq;
             sp.seed = a->seed;
             sp.mask = a->mask_seq;
-            if (int rc = (G == 4 ? dispatch_seq_bwd<4>(ctx, stream, H, sp) : dispatch_seq_bwd<1>(ctx, stream, H, sp)))
+            if (int rc = (d.cell == CELL_GRU    ? dispatch_seq_bwd<3>(ctx, stream, H, sp)
+                          : d.cell == CELL_LSTM ? dispatch_seq_bwd<4>(ctx, stream, H, sp)
+                                                : dispatch_seq_bwd<1>(ctx, stream, H, sp)))
                 return rc;
         }
 
         // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG)
-        if (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh) {
+        if (G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) {
             hipStream_t wstream = stream;
             if (PN_BWD_OVERLAP && side_ok)
                 if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;
@@ -2171,8 +2355,8 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
                 PN_CHECK_HIP(hipGetLastError());
                 const int64_t nred = (int64_t)GH * 2 * H + GH;
                 hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
-                                   wp.part_w, wp.part_b, nz_used, GH, H, b > 0 ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih,
-                                   a->g_b_hh);
+                                   wp.part_w, wp.part_b, nz_used, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
+                                   a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
                 PN_CHECK_HIP(hipGetLastError());
             }
             if (wstream != stream)

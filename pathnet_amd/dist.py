@@ -276,7 +276,7 @@ class ShardedAggregator:
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=self._seed_gen).item()) if p > 0 else 0
         cfg = dict(variant=m.variant, N=self.n_total, F=X_loc.shape[1], H=m.hidden_size, C=m.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb, seed=seed,
-                   S_total=S_total, group_begin=begin, index_rows_local=local_rows and world > 1,
+                   S_total=S_total, group_begin=begin, index_rows_local=local_rows and world > 1, cell=m._cell_kind,
                    mask_seq=None, mask_cls=None)
         if world == 1:
             cfg["S_total"], cfg["group_begin"] = 0, 0
@@ -284,7 +284,7 @@ class ShardedAggregator:
             cfg["mask_seq"], cfg["mask_cls"] = self.mask_seq, self.mask_cls
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["batch_groups"] = M.pick_batch_groups(m.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
-                                                  cfg["L"], m.workspace_budget) if isinstance(self.ops, HipOps) else 0
+                                                  cfg["L"], m.workspace_budget, cell=m._cell_kind) if isinstance(self.ops, HipOps) else 0
         return _ShardedFn.apply(self, cfg, X_loc.contiguous().float(), ids, codes, sel, *params)
 
     def set_batch_counts(self, counts):

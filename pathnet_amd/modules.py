@@ -23,6 +23,9 @@ from . import _lib
 dropout = 0.7
 
 _VARIANT = {"hetero": _lib.VARIANT_HETERO, "homo": _lib.VARIANT_HOMO, "pagg": _lib.VARIANT_PAGG}
+# path encoders: the classes' own (lstm / rnn) and the ablation rows of the paper's table (gru / mean / sum, README.md:118)
+_CELL = {None: _lib.CELL_DEFAULT, "lstm": _lib.CELL_LSTM, "rnn": _lib.CELL_RNN, "gru": _lib.CELL_GRU,
+         "mean": _lib.CELL_MEAN, "sum": _lib.CELL_SUM}
 _HEAD_PARAMS = ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b")
 
 
@@ -32,35 +35,35 @@ _HEAD_PARAMS = ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_
 WORKSPACE_BUDGET_BYTES = 48 << 30
 
 
-def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0):
-    return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L, S_total, group_begin, batch_groups)
+def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None):
+    return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L, S_total, group_begin, batch_groups, _CELL[cell])
 
 
 def _cfg_shape(cfg):
     return _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
-                  cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0))
+                  cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"))
 
 
-def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0):
+def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None):
     n = ctypes.c_int64(0)
-    sh = _shape(variant, N, F, H, C, S, W, L, S_total, group_begin, batch_groups)
+    sh = _shape(variant, N, F, H, C, S, W, L, S_total, group_begin, batch_groups, cell)
     _lib.check(_lib.load().pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(n)))
     return n.value
 
 
-def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None):
+def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None):
     """0 when the whole batch fits the workspace budget, else the largest micro-batch (in masked nodes) that does."""
     budget = WORKSPACE_BUDGET_BYTES if budget is None else int(budget)
-    if S <= 1 or workspace_bytes(variant, N, F, H, C, S, W, L) <= budget:
+    if S <= 1 or workspace_bytes(variant, N, F, H, C, S, W, L, cell=cell) <= budget:
         return 0
-    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L)
-    per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L) - fixed) // 1024, 1)
+    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L, cell=cell)
+    per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L, cell=cell) - fixed) // 1024, 1)
     return int(max(1, min(S, (budget - fixed) // per_group if budget > fixed else 1)))
 
 
 def _cfg_workspace_bytes(cfg):
     return workspace_bytes(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
-                           cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0))
+                           cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"))
 
 
 def _split_params(params, L):
@@ -194,8 +197,13 @@ def _as_index_tensors(neis, layer_type, indices, num_w, walk_len, device, n_node
 class _Aggregator(nn.Module):
     variant = None
 
-    def _common_init(self, feature_length, hidden_size, out_size, dropout_p):
+    def _common_init(self, feature_length, hidden_size, out_size, dropout_p, cell=None):
         _lib.load()     # fail at construction if the HIP library is missing
+        if cell not in _CELL:
+            raise ValueError("cell must be one of %s" % sorted(k for k in _CELL if k))
+        # None: the class's own path encoder (its state_dict is the reference's); "gru" / "mean" / "sum" / "lstm" / "rnn":
+        # the ablation rows of the paper's table ("Changing the PAGG class can deliver other variants", README.md:118)
+        self.cell = cell
         self.feature_length, self.hidden_size, self.out_size = feature_length, hidden_size, out_size
         self._dropout = dropout_p
         self._ws_eval = None
@@ -216,8 +224,21 @@ class _Aggregator(nn.Module):
     def _bank_layers(self):
         raise NotImplementedError
 
+    def _make_cell(self, default):
+        """the recurrent sub-module, under the attribute name torch users expect (LSTM / RNN / GRU); none for mean / sum"""
+        kind = self.cell or default
+        H = self.hidden_size
+        if kind == "lstm":
+            self.LSTM = nn.LSTM(H, H)
+        elif kind == "rnn":
+            self.RNN = nn.RNN(H, H)
+        elif kind == "gru":
+            self.GRU = nn.GRU(H, H)
+        self._cell_kind = kind
+
     def _cell(self):
-        raise NotImplementedError
+        return {"lstm": getattr(self, "LSTM", None), "rnn": getattr(self, "RNN", None),
+                "gru": getattr(self, "GRU", None)}.get(self._cell_kind)
 
     def _bank(self):
         """The L distance layers as ONE contiguous [L,H,H] / [L,H] pair (what the kernels read), without a
@@ -244,7 +265,8 @@ class _Aggregator(nn.Module):
         fw, fb, ws, bs = self._bank()
         cell = self._cell()
         att = getattr(self, "attw", None)
-        head = (self.fc0.weight, self.fc0.bias, cell.weight_ih_l0, cell.weight_hh_l0, cell.bias_ih_l0, cell.bias_hh_l0,
+        rec = (cell.weight_ih_l0, cell.weight_hh_l0, cell.bias_ih_l0, cell.bias_hh_l0) if cell is not None else (None,) * 4
+        head = (self.fc0.weight, self.fc0.bias) + rec + (
                 att.weight if att is not None else None, att.bias if att is not None else None,
                 self.fc2.weight, self.fc2.bias)
         return fw, fb, head + tuple(ws) + tuple(bs)
@@ -266,7 +288,7 @@ class _Aggregator(nn.Module):
         p = self.dropout_p() if training else 0.0
         cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=self.hidden_size, C=self.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
-                   step_state=self.step_state,
+                   step_state=self.step_state, cell=self._cell_kind,
                    seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.step_state is None) else 0)
         if group_slice is not None:
             begin, count = int(group_slice[0]), int(group_slice[1])
@@ -281,7 +303,7 @@ class _Aggregator(nn.Module):
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["grad"] = torch.is_grad_enabled()
         cfg["batch_groups"] = pick_batch_groups(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
-                                                cfg["L"], self.workspace_budget)
+                                                cfg["L"], self.workspace_budget, cell=self._cell_kind)
         if not cfg["grad"]:
             need = _cfg_workspace_bytes(cfg)
             fits = self._ws_eval is not None and self._ws_eval.numel() >= need and self._ws_eval.device == dev
@@ -302,11 +324,11 @@ class PathNet(_Aggregator):
     """PathNet_run.py:150-211.  state_dict: fc0, LSTM, fc2, nets.<d>, attw."""
     variant = "hetero"
 
-    def __init__(self, feature_length, hidden_size, out_size, wl, dropout=None, **kwargs):
+    def __init__(self, feature_length, hidden_size, out_size, wl, dropout=None, cell=None, **kwargs):
         super().__init__()
-        self._common_init(feature_length, hidden_size, out_size, dropout)
+        self._common_init(feature_length, hidden_size, out_size, dropout, cell)
         self.fc0 = nn.Linear(feature_length, hidden_size)
-        self.LSTM = nn.LSTM(hidden_size, hidden_size)
+        self._make_cell("lstm")
         self.fc2 = nn.Linear(2 * hidden_size, out_size)
         self.nets = nn.ModuleList([nn.Linear(hidden_size, hidden_size) for _ in range(wl)])
         self.attw = nn.Linear(2 * hidden_size, 1)
@@ -315,16 +337,13 @@ class PathNet(_Aggregator):
     def _bank_layers(self):
         return list(self.nets)
 
-    def _cell(self):
-        return self.LSTM
-
 
 class PathNet_homo(PathNet):
     """PathNet_run.py:214-278 (xavier_uniform on fc0/fc2, :236-237)."""
     variant = "homo"
 
-    def __init__(self, feature_length, hidden_size, out_size, wl, dropout=None, **kwargs):
-        super().__init__(feature_length, hidden_size, out_size, wl, dropout=dropout, **kwargs)
+    def __init__(self, feature_length, hidden_size, out_size, wl, dropout=None, cell=None, **kwargs):
+        super().__init__(feature_length, hidden_size, out_size, wl, dropout=dropout, cell=cell, **kwargs)
         nn.init.xavier_uniform_(self.fc0.weight)
         nn.init.xavier_uniform_(self.fc2.weight)
 
@@ -333,12 +352,12 @@ class PAGG(_Aggregator):
     """baseline/GPRGNN/src/copy.py:299-359.  state_dict: fc0, RNN, fc2, nei0..nei3.  dropout is 0.9 there."""
     variant = "pagg"
 
-    def __init__(self, feature_length, hidden_size, out_size, node_num, dropout=0.9, **kwargs):
+    def __init__(self, feature_length, hidden_size, out_size, node_num, dropout=0.9, cell=None, **kwargs):
         super().__init__()
-        self._common_init(feature_length, hidden_size, out_size, dropout)
+        self._common_init(feature_length, hidden_size, out_size, dropout, cell)
         self.node_num = node_num
         self.fc0 = nn.Linear(feature_length, hidden_size)
-        self.RNN = nn.RNN(hidden_size, hidden_size)
+        self._make_cell("rnn")
         self.fc2 = nn.Linear(2 * hidden_size, out_size)
         self.nei0 = nn.Linear(hidden_size, hidden_size)
         self.nei1 = nn.Linear(hidden_size, hidden_size)
@@ -349,6 +368,3 @@ class PAGG(_Aggregator):
 
     def _bank_layers(self):
         return [self.nei0, self.nei1, self.nei2, self.nei3]
-
-    def _cell(self):
-        return self.RNN

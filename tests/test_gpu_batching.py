@@ -436,3 +436,78 @@ def test_step_captured_in_a_hip_graph_replays_with_fresh_epoch_seed_and_adam_ste
     assert max(abs(a - b) for a, b in zip(losses_a, losses_b)) < 1e-4, (losses_a, losses_b)
     for (k, va), (_, vb) in zip(ma.state_dict().items(), mb.state_dict().items()):
         assert (va - vb).abs().max().item() < 5e-4, k
+
+
+@pytest.mark.parametrize("variant,cell", [("hetero", "gru"), ("homo", "gru"), ("pagg", "gru"), ("hetero", "mean"),
+                                          ("homo", "sum"), ("pagg", "mean"), ("pagg", "lstm"), ("hetero", "rnn")])
+@pytest.mark.parametrize("H,train", [(64, False), (128, True)])
+def test_ablation_cells_match_the_oracle(variant, cell, H, train):
+    """the path encoders of the paper's ablation rows (GRU / mean / sum, README.md:118 -- no code in the
+    reference; pinned to torch.nn.GRU and the definitions in tests/test_oracle_pagg.py) and the classes' own cells
+    swapped (LSTM in PAGG, RNN in PathNet): logits and every gradient against the CPU oracle, eval and with injected
+    dropout masks; the GRU rides on the LSTM kernels' four gate slots."""
+    import pathnet_amd
+    torch.manual_seed(71)
+    rng = np.random.default_rng(71)
+    N, F, C, W, L, S = 70, 20, 4, 13, 4, 29
+    cls = {"hetero": pathnet_amd.PathNet, "homo": pathnet_amd.PathNet_homo, "pagg": pathnet_amd.PAGG}[variant]
+    m = cls(F, H, C, L if variant != "pagg" else N, cell=cell).cuda()
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith("bias") or "bias_" in k:
+                v.uniform_(-0.3, 0.3)
+    assert not (cell in ("mean", "sum") and any("weight_ih" in k for k in m.state_dict()))
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F)
+    G = torch.randn(S, C)
+    drop_seq = drop_cls = None
+    if train:
+        drop_seq = (torch.rand(L, S * W, H) >= 0.5).float() / 0.5
+        drop_cls = (torch.rand(S, 2 * H) >= 0.5).float() / 0.5
+        m.train()
+        m._mask_seq, m._mask_cls = drop_seq.cuda(), drop_cls.cuda()
+    else:
+        m.eval()
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    (out * G.cuda()).sum().backward()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Xo = X.clone().requires_grad_(True)
+    want = po.forward(variant, pr, Xo, ids, codes, sel, W, L, drop_seq=drop_seq, drop_cls=drop_cls, cell=cell)
+    (want * G).sum().backward()
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT
+    bad = {}
+    for k, v in m.named_parameters():
+        ref = pr[k].grad.numpy()
+        err = np.abs(v.grad.cpu().numpy() - ref).max()
+        if not err < grad_tol(ref):
+            bad[k] = (err, grad_tol(ref))
+    assert not bad, bad
+    assert (Xd.grad.cpu() - Xo.grad).abs().max().item() < grad_tol(Xo.grad.numpy())
+
+
+@pytest.mark.parametrize("cell", ["gru", "sum"])
+def test_ablation_cells_in_micro_batches_with_builtin_dropout(cell, monkeypatch):
+    from pathnet_amd import modules
+    import pathnet_amd
+    torch.manual_seed(72)
+    rng = np.random.default_rng(72)
+    N, F, H, C, W, L, S = 80, 16, 64, 3, 10, 4, 37
+    m = pathnet_amd.PathNet(F, H, C, L, dropout=0.4, cell=cell).cuda().train()
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F).cuda()
+    G = torch.randn(S, C).cuda()
+
+    def run(bg):
+        monkeypatch.setattr(modules, "pick_batch_groups", lambda *a, **k: bg)
+        m.zero_grad()
+        torch.manual_seed(9)
+        out = run_module(m, X, ids, codes, mask, W, L)
+        (out * G).sum().backward()
+        return out.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()}
+
+    o1, g1 = run(0)
+    o2, g2 = run(11)
+    assert (o1 - o2).abs().max().item() < 2e-6
+    for k in g1:
+        assert (g1[k] - g2[k]).abs().max().item() < 2e-5 * max(1.0, g1[k].abs().max().item()), k

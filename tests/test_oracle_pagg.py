@@ -97,3 +97,36 @@ def test_state_dict_contract_cornell_pth():
         want["nets.%d.weight" % d] = (128, 128)
         want["nets.%d.bias" % d] = (128,)
     assert {k: tuple(v.shape) for k, v in sd.items()} == want
+
+
+def test_oracle_gru_cell_is_torch_nn_gru():
+    """The ablation cells have no code in the reference (README.md:118): the oracle's "gru" is pinned to torch.nn.GRU
+    itself, "mean" / "sum" to the definitions, on the bank outputs the oracle reports."""
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    N, F, H, C, W, L, S = 40, 12, 32, 3, 6, 4, 9
+    lin = torch.nn.Linear
+    gru = torch.nn.GRU(H, H)
+    params = {"fc0.weight": lin(F, H).weight, "fc0.bias": torch.randn(H), "fc2.weight": lin(2 * H, C).weight,
+              "fc2.bias": torch.randn(C), "attw.weight": lin(2 * H, 1).weight, "attw.bias": torch.randn(1)}
+    for d in range(L):
+        params["nets.%d.weight" % d] = lin(H, H).weight
+        params["nets.%d.bias" % d] = torch.randn(H) * 0.1
+    for k, v in gru.named_parameters():
+        params["GRU." + k] = v
+    params = {k: v.detach() for k, v in params.items()}
+    X = torch.rand(N, F)
+    sel = np.sort(rng.permutation(N)[:S])
+    ids = rng.integers(0, N, (S, W, L))
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    for variant in ("hetero", "homo"):
+        out, inter = po.forward(variant, params, X, ids, codes, sel, W, L, cell="gru", return_intermediates=True)
+        with torch.no_grad():
+            _, hn = gru(inter["y"].transpose(0, 1).contiguous())
+        assert (inter["h"] - hn[0]).abs().max().item() < 1e-6
+        _, im = po.forward(variant, params, X, ids, codes, sel, W, L, cell="mean", return_intermediates=True)
+        _, isum = po.forward(variant, params, X, ids, codes, sel, W, L, cell="sum", return_intermediates=True)
+        assert torch.allclose(im["h"], inter["y"].mean(dim=1), atol=1e-7)
+        assert torch.allclose(isum["h"], inter["y"].sum(dim=1), atol=1e-6)
+    with pytest.raises(ValueError):
+        po.forward("homo", params, X, ids, codes, sel, W, L, cell="lstm2")
