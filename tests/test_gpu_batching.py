@@ -511,3 +511,80 @@ def test_ablation_cells_in_micro_batches_with_builtin_dropout(cell, monkeypatch)
     assert (o1 - o2).abs().max().item() < 2e-6
     for k in g1:
         assert (g1[k] - g2[k]).abs().max().item() < 2e-5 * max(1.0, g1[k].abs().max().item()), k
+
+
+def test_empty_batch_gives_empty_logits_and_zero_gradients():
+    """an epoch whose mask selects no node (a rank of the sharded path whose block holds no masked node)"""
+    torch.manual_seed(73)
+    for variant in ("hetero", "homo", "pagg"):
+        N, F, H, C, W, L = 30, 12, 64, 3, 7, 4
+        m = build_module(variant, F, H, C, L, N, None).train()
+        X = torch.rand(N, F).cuda().requires_grad_(True)
+        mask = np.zeros(N, bool)
+        out = m(X, torch.zeros((0, W * L), dtype=torch.int64), W, L, mask, torch.zeros((0, W, L), dtype=torch.int64), None)
+        assert out.shape == (0, C)
+        out.sum().backward()
+        assert all(v.grad is not None and float(v.grad.abs().max()) == 0.0 for v in m.parameters())
+        assert float(X.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("variant", ["hetero", "homo", "pagg"])
+@pytest.mark.parametrize("S,W,L,N", [(1, 1, 1, 5), (1, 40, 4, 3), (7, 33, 4, 20), (5, 100, 4, 16), (3, 1, 6, 9),
+                                     (24, 3, 2, 24), (2, 65, 3, 40)])
+def test_ragged_and_degenerate_shapes_match_the_oracle(variant, S, W, L, N):
+    """one masked node, one path, one step; path counts that are not multiples of the 32-row tile or exceed a
+    wavefront's 64 lanes; every node masked; L = 1 .. 6 -- forward and all gradients against the oracle."""
+    if variant == "pagg" and L != 4:
+        pytest.skip("PAGG has exactly four distance layers nei0..nei3 (copy.py:310-313)")
+    torch.manual_seed(74)
+    rng = np.random.default_rng(74)
+    F, H, C = 9, 64, 3
+    m = build_module(variant, F, H, C, L, N, None).eval()
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if "bias" in k:
+                v.uniform_(-0.3, 0.3)
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F)
+    G = torch.randn(S, C)
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    (out * G.cuda()).sum().backward()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Xo = X.clone().requires_grad_(True)
+    want = po.forward(variant, pr, Xo, ids, codes, sel, W, L)
+    (want * G).sum().backward()
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT
+    bad = {}
+    for k, v in m.named_parameters():
+        ref = pr[k].grad.numpy() if pr[k].grad is not None else np.zeros(tuple(v.shape), np.float32)
+        err = np.abs(v.grad.cpu().numpy() - ref).max()
+        if not err < grad_tol(ref):
+            bad[k] = (err, grad_tol(ref))
+    assert not bad, bad
+    assert (Xd.grad.cpu() - Xo.grad).abs().max().item() < grad_tol(Xo.grad.numpy())
+
+
+def test_indices_outside_the_graph_are_refused_or_clamped():
+    """the reference indexes X / the Linear list with whatever the path file holds and dies with an IndexError; here
+    host-side index lists are validated and device-resident ids / codes are clamped by the kernels (no out-of-bounds
+    access whatever the file contained)"""
+    torch.manual_seed(75)
+    N, F, H, C, W, L, S = 12, 8, 64, 3, 5, 4, 4
+    m = build_module("homo", F, H, C, L, N, None).eval()
+    X = torch.rand(N, F).cuda()
+    ids = torch.randint(0, N, (S, W, L))
+    codes = torch.randint(0, L, (S, W, L))
+    with pytest.raises(IndexError):
+        m(X, ids.reshape(S, -1), W, L, np.array([0, 1, 2, N]), codes, None)
+    bad_ids = ids.clone()
+    bad_ids[0, 0, 1] = 10 ** 6
+    bad_ids[1, 2, 3] = -5
+    bad_codes = codes.clone()
+    bad_codes[2, 1, 2] = 200
+    with torch.no_grad():
+        out = m(X, bad_ids.reshape(S, -1), W, L, np.array([0, 1, 2, 3]), bad_codes, None)
+        fixed_ids = bad_ids.clamp(0, N - 1)
+        fixed_codes = bad_codes.clamp(0, L - 1)
+        want = m(X, fixed_ids.reshape(S, -1), W, L, np.array([0, 1, 2, 3]), fixed_codes, None)
+    assert torch.isfinite(out).all() and torch.equal(out, want)
