@@ -258,9 +258,10 @@ typedef struct pn_pagg_args {
     pn_pagg_shape shape;
     /* inputs */
     const float *X;       /* [N, F] */
-    const int32_t *ids;   /* [S, W, L] path node ids, path-major as in the path file */
-    const uint8_t *codes; /* [S, W, L] distance codes */
-    const int32_t *sel;   /* [S] node index of each masked node (nonzero(indices)) */
+    const int32_t *ids;   /* [S_total, W, L] path node ids of the whole batch, path-major as in the path file */
+    const uint8_t *codes; /* [S_total, W, L] distance codes */
+    const int32_t *sel;   /* [S_total] node index of each masked node (nonzero(indices));
+                           * with index_rows_local: the slice's rows only ([S, ...]) */
     /* parameters */
     const float *fc0_w, *fc0_b;   /* [H, F], [H] */
     const float *bank_w, *bank_b; /* [L, H, H], [L, H]   nets.<d> / nei<d> stacked by d */
@@ -274,10 +275,10 @@ typedef struct pn_pagg_args {
      * reference's mask. */
     float p_seq, p_cls;
     uint64_t seed;
-    const float *mask_seq; /* [L, P, H] or NULL */
-    const float *mask_cls; /* [S, 2H]  or NULL */
+    const float *mask_seq; /* [L, S_total*W, H] (positions in the whole batch) or NULL */
+    const float *mask_cls; /* [S_total, 2H] or NULL */
     /* outputs */
-    float *out; /* [S, C] logits */
+    float *out; /* [S, C] logits of the slice's masked nodes */
     /* saved-for-backward + scratch, sized by pn_pagg_workspace_bytes */
     void *workspace;
     int64_t workspace_bytes;
