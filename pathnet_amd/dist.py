@@ -48,9 +48,10 @@ class Comm:
     """The four collectives of a step over a torch.distributed group; seconds spent are accumulated per kind
     (device-synchronised only when timing is switched on)."""
 
-    def __init__(self, group=None, timing=False):
+    def __init__(self, group=None, timing=False, always=False):
         self.group = group
         self.timing = timing
+        self.always = always        # run the collectives even in a one-rank group (exercises RCCL on a single GPU)
         self.seconds = {"all_gather_Xh": 0.0, "reduce_scatter_dXh": 0.0, "all_reduce_grads": 0.0, "all_gather_index": 0.0}
 
     def world(self):
@@ -58,6 +59,10 @@ class Comm:
 
     def rank(self):
         return dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+
+    def active(self):
+        """collectives are issued: more than one rank, or forced"""
+        return self.world() > 1 or (self.always and dist.is_available() and dist.is_initialized())
 
     def _timed(self, kind, fn, tensor):
         if not self.timing:
@@ -199,8 +204,7 @@ class _ShardedFn(torch.autograd.Function):
         p = M._split_params(params, cfg["L"])
         ops, comm = runner.ops, runner.comm
         Xh_loc = ops.project(cfg["variant"], X_loc, p["fc0_w"], p["fc0_b"])
-        world = comm.world()
-        Xh = comm.all_gather_rows(Xh_loc) if world > 1 else Xh_loc          # the one forward collective
+        Xh = comm.all_gather_rows(Xh_loc) if comm.active() else Xh_loc      # the one forward collective
         out, state = ops.forward(cfg, Xh, ids, codes, sel, p)
         ctx.runner, ctx.state, ctx.cfg = runner, state, cfg
         ctx.save_for_backward(X_loc, Xh_loc, p["fc0_w"])
@@ -213,7 +217,7 @@ class _ShardedFn(torch.autograd.Function):
         ops, comm = runner.ops, runner.comm
         X_loc, Xh_loc, fc0_w = ctx.saved_tensors
         g_Xh, grads = ops.backward(ctx.state, g_out)
-        g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0]) if comm.world() > 1 else g_Xh   # the one backward collective
+        g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0]) if comm.active() else g_Xh   # the one backward collective
         grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w)
         L = cfg["L"]
         head = tuple(grads.get(k) if pres else None for k, pres in zip(M._HEAD_PARAMS, ctx.present[:10]))
@@ -233,7 +237,7 @@ class ShardedAggregator:
         self.comm = comm if comm is not None else Comm(group)
         self.group = self.comm.group
         self.ops = ops if ops is not None else HipOps()
-        self.distributed = self.comm.world() > 1
+        self.distributed = self.comm.active()
         if self.row_count * self.comm.world() != self.n_total:
             raise ValueError("node blocks must be equal: %d rows x %d ranks != %d nodes (pad the graph)"
                              % (self.row_count, self.comm.world(), self.n_total))
@@ -255,8 +259,8 @@ class ShardedAggregator:
         fw, fb, params = m._param_inputs()
         p = m.dropout_p() if m.training else 0.0
         comm = self.comm
-        world = comm.world()
-        if world == 1:
+        multi = comm.active()           # several ranks (or a one-rank group forced through the multi-rank path)
+        if not multi:
             counts = [S]
         elif self._fixed_counts is not None:
             counts = self._fixed_counts
@@ -268,7 +272,7 @@ class ShardedAggregator:
         self.batch_counts = counts
         S_total, begin = sum(counts), sum(counts[:comm.rank()])
         local_rows = True
-        if world > 1 and m.variant == "hetero":
+        if multi and m.variant == "hetero":
             # the [W, S] re-view reads other ranks' paths: every rank gets the whole batch's index arrays
             ids, codes, sel = (comm.all_gather_ragged(t, counts) for t in (ids, codes, sel))
             local_rows = False
@@ -276,9 +280,9 @@ class ShardedAggregator:
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=self._seed_gen).item()) if p > 0 else 0
         cfg = dict(variant=m.variant, N=self.n_total, F=X_loc.shape[1], H=m.hidden_size, C=m.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb, seed=seed,
-                   S_total=S_total, group_begin=begin, index_rows_local=local_rows and world > 1, cell=m._cell_kind,
+                   S_total=S_total, group_begin=begin, index_rows_local=local_rows and multi, cell=m._cell_kind,
                    mask_seq=None, mask_cls=None)
-        if world == 1:
+        if not multi:
             cfg["S_total"], cfg["group_begin"] = 0, 0
         if m.training and (self.mask_seq is not None or self.mask_cls is not None):
             cfg["mask_seq"], cfg["mask_cls"] = self.mask_seq, self.mask_cls

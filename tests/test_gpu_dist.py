@@ -119,3 +119,55 @@ def test_two_ranks_hip_ops_match_the_single_process_module(variant):
         for k, v in m.named_parameters():
             ref = v.grad.cpu().numpy()
             assert np.abs(grads[k] - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), (rank, k)
+
+
+RCCL_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))       # backend "nccl" IS RCCL on ROCm
+from pathnet_amd import dist as pdist
+sys.path.insert(0, os.path.join(%r, "tests"))
+from test_gpu_dist import make_case, build
+for variant in ("homo", "hetero"):
+    case = make_case()
+    m = build(variant, case).eval()
+    S = len(case["sel"])
+    mask = np.zeros(case["N"], bool); mask[case["sel"]] = True
+    X = case["X"].cuda()
+    want = m(X, torch.as_tensor(case["ids"].reshape(S, -1)), case["W"], case["L"], mask, torch.as_tensor(case["codes"]), None)
+    (want * case["G"].cuda()).sum().backward()
+    ref = {k: v.grad.clone() for k, v in m.named_parameters()}
+    m.zero_grad()
+    runner = pdist.ShardedAggregator(m, case["N"], 0, case["N"], comm=pdist.Comm(always=True, timing=True))
+    assert runner.distributed
+    out = runner(X, torch.as_tensor(case["ids"].reshape(S, -1)), case["W"], case["L"],
+                 torch.as_tensor(case["sel"].astype(np.int32)), torch.as_tensor(case["codes"]))
+    (out * case["G"].cuda()).sum().backward()
+    runner.allreduce_grads(average=True)
+    torch.cuda.synchronize()
+    assert (out - want).abs().max().item() < 2e-6, variant
+    for k, v in m.named_parameters():
+        assert (v.grad - ref[k]).abs().max().item() < 3e-5 * max(1.0, ref[k].abs().max().item()), (variant, k)
+    assert all(t >= 0 for t in runner.comm.seconds.values()) and runner.comm.seconds["all_gather_Xh"] > 0
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+'''
+
+
+def test_rccl_collectives_in_a_one_rank_group():
+    """The collectives of the sharded step through RCCL itself (backend "nccl"), in a one-rank group forced through
+    the multi-rank path (Comm(always=True)): all-gather of Xh, of the counts and of the hetero class's index arrays,
+    reduce-scatter of dXh, all-reduce of the flat gradient buffer -- identities at world size 1, but the very calls
+    `bench.py --gpus N` makes on an 8-GPU node, here on the one GPU a test box has."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", RCCL_SCRIPT % (root, root)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
