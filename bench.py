@@ -234,6 +234,22 @@ def pubmed_workload(seed=3):
     return dict(n=n, n_loc=n, F=F, C=C, H=H, W=W, L=L, graph=g, X=X, Y=Y, mask=mask)
 
 
+def bgp_workload(world=1, seed=5):
+    """BASELINE.json configs[3] (BGP, other_data: bgp.in and other_data.zip are absent from the reference mount): a
+    synthetic stand-in of the published size of that dataset -- 63 977 nodes, 287 features, 8 classes -- with the class
+    the reference uses for it, PathNet (hetero, PathNet_run.py:286-291).  With world > 1 the node count is padded to a
+    multiple of the world size (equal row blocks)."""
+    n0, F, C, H, W, L = 63977, 287, 8, 128, 40, 4
+    n = (n0 + world - 1) // world * world
+    g = synthetic_graph(n, seed, avg_und_deg=3.2)
+    rng = np.random.default_rng(seed + 1)
+    X = rng.random((n, F)).astype(np.float32)
+    Y = rng.integers(0, C, n)
+    mask = np.zeros(n, bool)
+    mask[rng.permutation(n0)[: int(0.48 * n0)]] = True
+    return dict(n=n, n_loc=n // world, F=F, C=C, H=H, W=W, L=L, graph=g, X=X, Y=Y, mask=mask, cls="PathNet")
+
+
 class StepRunner:
     """One training step of the reference loop on a workload, everything resident on the GPU."""
 
@@ -244,7 +260,7 @@ class StepRunner:
         gn, u, v, p = wl["graph"]
         self.smp = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev, hops=hops)
         torch.manual_seed(0)
-        self.model = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.7).to(dev)
+        self.model = getattr(pathnet_amd, wl.get("cls", "PathNet_homo"))(F, H, C, L, dropout=0.7).to(dev)
         self.opt = pathnet_amd.Adam(self.model.parameters(), lr=0.005, weight_decay=0.0005)  # torch.optim.Adam's update, one launch
         self.lossf = pathnet_amd.CrossEntropyLoss()                                          # torch.nn.CrossEntropyLoss(), one launch
         Y = torch.from_numpy(wl["Y"]).to(dev)
@@ -411,6 +427,21 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
                                          "reference's n = 100050 cap use"}
     del ids_p, codes_p, otf, psr
 
+    # ---- configs[3] on one GPU: BGP-sized graph, the hetero class (the 8-GPU run shards exactly this step) ------------
+    bw = bgp_workload()
+    bsr = StepRunner(bw, dev, 0, 1, sharded=False)
+    steps_b = max(3, args.steps // 5)
+    mb = measure(bsr, lib, ctx, names, steps_b, 2, torch.cuda.synchronize)
+    Pb = bsr.S * W
+    out["bgp_scale_step"] = {
+        "config": "configs[3] stand-in, synthetic: N=%d F=%d C=%d hid=%d W=%d L=%d, %d masked nodes = %d paths/step, "
+                  "PathNet (hetero), dropout 0.7, Adam; dense hop table %d MB" %
+                  (bw["n"], bw["F"], bw["C"], H, W, L, bsr.S, Pb, bw["n"] ** 2 >> 20),
+        "value": Pb / (mb["elapsed"] / steps_b), "unit": "paths/s", "ms_per_step": mb["elapsed"] / steps_b * 1e3,
+        "steps": steps_b, "roofline": roofline_block(mb["dominant"], mb["dom_ms"], mb["dom_launches"], Pb, L, H, None),
+        "stages_ms": mb["stages_ms"]}
+    del bsr
+
     # ---- the path-feature gather against HBM: a table that cannot sit in the 256 MB Infinity Cache -------------------
     Ng, Sg = 1 << 20, 9464                      # Z table [2^20, L, H] fp32 = 2 GB; Pubmed's path count
     table = torch.randn(Ng, L, H, device=dev)
@@ -461,9 +492,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline configuration only")
-    ap.add_argument("--workload", choices=["cora", "pubmed"], default="cora",
+    ap.add_argument("--workload", choices=["cora", "pubmed", "bgp"], default="cora",
                     help="cora = BASELINE.json configs[1], what `value` is quoted on; pubmed = configs[2] as the timed "
-                         "workload (profiling runs: tools/pmc_passes.sh)")
+                         "workload (profiling runs: tools/pmc_passes.sh); bgp = configs[3] stand-in (hetero class, "
+                         "node-sharded with --gpus N: strong scaling of one 63 977-node graph)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -488,7 +520,8 @@ def main():
 
     if args.workload == "pubmed" and world > 1:
         raise SystemExit("--workload pubmed is a single-GPU profiling aid")
-    wl = workload(rank, world) if args.workload == "cora" else pubmed_workload()
+    wl = (workload(rank, world) if args.workload == "cora" else pubmed_workload() if args.workload == "pubmed"
+          else bgp_workload(world))
     n, F, C, H, W, L = wl["n"], wl["F"], wl["C"], wl["H"], wl["W"], wl["L"]
     sharded = world > 1 or os.environ.get("PN_BENCH_FORCE_SHARDED") == "1"   # the env hook exercises the N>1 code path on one GPU
     sr = StepRunner(wl, dev, rank, world, sharded)
@@ -546,14 +579,15 @@ def main():
     result = {
         "metric": "paths aggregated/sec (PAGG fwd+bwd, one training step incl. on-GPU MERW sampling + Adam)",
         "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong" if args.workload == "bgp" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "dtype_note": "fp32 in, fp32 out, fp32 accumulation; the recurrent GEMM products run as 3-plane bf16 splits "
                       "(6 bf16 MFMAs per fp32 product), everything else in fp32",
-        "config": {"workload": ("Cora-shaped synthetic (configs[1])" if args.workload == "cora" else
-                                "Pubmed-shaped synthetic (configs[2])") + ": N=%d F=%d C=%d hid=%d path_num=%d path_len=%d, "
-                               "%d masked nodes = %d paths/step, PathNet_homo, dropout 0.7, Adam" %
-                               (n, F, C, H, W, L, S_total, S_total * W),
+        "config": {"workload": {"cora": "Cora-shaped synthetic (configs[1])", "pubmed": "Pubmed-shaped synthetic (configs[2])",
+                                "bgp": "BGP-sized synthetic, hetero class (configs[3])"}[args.workload] + ": N=%d F=%d C=%d hid=%d path_num=%d path_len=%d, "
+                               "%d masked nodes = %d paths/step, %s, dropout 0.7, Adam" %
+                               (n, F, C, H, W, L, S_total, S_total * W, wl.get("cls", "PathNet_homo")),
                    "nodes": n, "paths_per_step": S_total * W, "parallelism": "node-shard x%d" % world},
         "roofline": roofline,
         "stages_ms": m["stages_ms"],

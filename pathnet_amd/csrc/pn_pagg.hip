@@ -59,6 +59,13 @@ using namespace pn;
 #ifndef PN_BWD_REVERSE
 #define PN_BWD_REVERSE 1
 #endif
+#ifndef PN_FWD_RB
+#define PN_FWD_RB 1         // row blocks of 32 paths per WAVE of the forward.  2: each weight fragment is used for two MFMAs, the
+                            // L2 -> CU fragment stream per path halves; one workgroup of 512-register waves per CU.  Correct
+                            // (GPU suite), measured SLOWER: 0.411 vs 0.308 ms -- one wave per SIMD hides nothing, and a deeper
+                            // fragment ring to make up for it pushes hipcc to shuffle asm-load destinations through AGPRs
+                            // before their s_waitcnt (memory faults): profiles/README.md
+#endif
 #ifndef PN_WGRAD_STRIDED
 #define PN_WGRAD_STRIDED 1
 #endif
@@ -484,24 +491,27 @@ template <int H, int RG>
 constexpr int fwd_waves() { return H == 32 && RG == 1 ? 1 : (H > 128 || RG > 1) ? 2 : PN_FWD_WAVES; }
 
 // GC: 4 = LSTM, 1 = tanh RNN, 3 = GRU (on the LSTM's four gate slots, see pack_fwd3_kernel)
-template <int H, int GC, int RG>
-__global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fwd3_kernel(SeqFwdParams p) {
+// RB: row blocks of 32 paths per wave.  RB = 2: a wave keeps two accumulator sets and uses every weight fragment twice --
+// the fragment stream per path, which bounds the kernel, halves; the 64-row tile takes 101 KB of LDS, so
+// one workgroup per CU, one wave per SIMD with the whole register file.
+template <int H, int GC, int RG, int RB = 1>
+__global__ __launch_bounds__(H / 32 * 64 * RG, (RB > 1 ? 1 : fwd_waves<H, RG>())) void seq_fwd3_kernel(SeqFwdParams p) {
     constexpr int G = GC == 3 ? 4 : GC;
     constexpr bool GRU = GC == 3;
-    constexpr int MT = 32 * RG;
+    constexpr int MT = 32 * RG * RB;
     constexpr int NW = H / 32, NT = NW * 64 * RG, SV = (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
     constexpr int PB = 4 * H + 16;            // row pitch of a plane of the tile [x | h], bytes: conflict-free ds_read_b128
     constexpr int PLANE = MT * PB;
     // three workgroups per CU (168 registers): no register room for the x_{t+1} rows or a second plane-0 fragment set,
     // the third workgroup covers those latencies instead
-    constexpr bool PREFETCH_X = fwd_waves<H, RG>() < 3, PING_PONG = fwd_waves<H, RG>() < 3;
+    constexpr bool PREFETCH_X = RB > 1 || fwd_waves<H, RG>() < 3, PING_PONG = RB > 1 || fwd_waves<H, RG>() < 3;
     // LDS: three bf16 planes of the tile [MT][x_t | h_{t-1}] | row indices
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 3 * PLANE);  // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
-    const int ws = wave % NW, r0 = 32 * (wave / NW);            // column slice / first tile row of this wave
+    const int ws = wave % NW, r0 = 32 * RB * (wave / NW);       // column slice / first tile row of this wave
     const int q0 = blockIdx.x * MT;
     const int col = 32 * ws + li;
     const int ws_u = __builtin_amdgcn_readfirstlane(ws);        // the wave's column slice as a scalar (weight stream base)
@@ -509,9 +519,11 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = q0 + i / p.L < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
     for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
 
-    f32x16 cst;
+    f32x16 cst[RB];
 #pragma unroll
-    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
+    for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) cst[rb][r] = 0.0f;
     const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     const bool builtin_drop = !p.mask && p.p_drop > 0.0f;
     const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
     //      ones to their use -- with the dropout keep bits drawn right behind them; with three workgroups per CU the
     //      rows are fetched in the cell-update phase instead (the other workgroups cover the latency).  Either
     //      way the mask is applied when the rows are committed to LDS.
-    constexpr int NLD = 4;        // float4 per thread = MT * (H/4) / NT
+    constexpr int NLD = 4 * RB;   // float4 per thread = MT * (H/4) / NT
     f32x4 xr[NLD];
     uint32_t keepbits = 0;        // 4 bits per row of this thread
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -558,7 +570,10 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
         keepbits = bits;
     };
     auto gather_commit = [&](int t) {
-        wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
+        if constexpr (RB == 1)
+            wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
+        else
+            wait_vm<0>(xr[0], xr[1], xr[2], xr[3], xr[4 % NLD], xr[5 % NLD], xr[6 % NLD], xr[7 % NLD]);
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
             const int idx = tid_g + NT * i;
@@ -604,12 +619,14 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
         if (PREFETCH_X && t + 1 < p.L) gather_issue(t + 1);
         PN_STAMP(4 * t + 1);
 
-        f32x16 acc[G];
+        f32x16 acc[RB][G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const float bias = p.biasc[g * H + col];      // (re-read per step: G registers less across the kernel)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[g][r] = bias;
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[rb][g][r] = bias;
         }
 
         // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T.  Weight fragments stream L2 -> VGPR ahead of their MFMAs: the
@@ -634,116 +651,128 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (fwd_waves<H, RG>())) void seq_fw
             // a2.P0, a1.P0, a0.P0 | a1.P1, a0.P1 | a0.P2, so plane 2 of the A tile is dead after the first G MFMAs, plane
             // 1 after the P1 group, plane 0 at the end -- each is re-read for k-step s+1 right there, and the next
             // k-step again starts with a2 (read longest ago) and needs a0 (read last) only after 2G MFMAs.
-            u32x4 a[3];
-            auto aread = [&](int s, int pl) {
-                return *reinterpret_cast<const u32x4 *>(arow + 32 * s + pl * PLANE);
+            u32x4 a[RB][3];
+            auto aread = [&](int rb, int s, int pl) {
+                return *reinterpret_cast<const u32x4 *>(arow + rb * 32 * PB + 32 * s + pl * PLANE);
+            };
+            // all RB row blocks of a product before the next product: every weight fragment feeds RB MFMAs
+            auto prod = [&](int pa, u32x4 (&B)[G]) {
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) acc[rb][g] = mfma_bf16(a[rb][pa], B[g], acc[rb][g]);
+            };
+            auto areads = [&](int s, int pl) {
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++) a[rb][pl] = aread(rb, s, pl);
             };
             auto kstep = [&](int s, u32x4 (&P0)[G], u32x4 (&P0next)[G]) {
                 const int sn = min(s + 1, nsteps - 1);
                 if (PING_PONG) load(P0next, sn, 0);
                 wait_frag<(PING_PONG ? 3 : 2) * G, G>(P0);
-#pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[2], P0[g], acc[g]);
-                a[2] = aread(sn, 2);
-#pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[1], P0[g], acc[g]);
-#pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P0[g], acc[g]);
+                prod(2, P0);
+                areads(sn, 2);
+                prod(1, P0);
+                prod(0, P0);
                 if (!PING_PONG) load(P0, sn, 0);
                 wait_frag<2 * G, G>(P1);
-#pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[1], P1[g], acc[g]);
-                a[1] = aread(sn, 1);
-#pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P1[g], acc[g]);
+                prod(1, P1);
+                areads(sn, 1);
+                prod(0, P1);
                 load(P1, sn, 1);
                 wait_frag<2 * G, G>(P2);
-#pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = mfma_bf16(a[0], P2[g], acc[g]);
-                a[0] = aread(sn, 0);
+                prod(0, P2);
+                areads(sn, 0);
                 load(P2, sn, 2);
             };
 #pragma unroll
-            for (int pl = 0; pl < 3; pl++) a[pl] = aread(0, pl);
-            load(P0a, 0, 0);
-            load(P1, 0, 1);
-            load(P2, 0, 2);
+            for (int pl = 0; pl < 3; pl++) areads(0, pl);
+            {
+                load(P0a, 0, 0);
+                load(P1, 0, 1);
+                load(P2, 0, 2);
 #pragma unroll 1
-            for (int s = 0; s < nsteps; s += 2) {
-                if (PING_PONG) {
-                    kstep(s, P0a, P0b);
-                    kstep(s + 1, P0b, P0a);
-                } else {
-                    kstep(s, P0a, P0a);
-                    kstep(s + 1, P0a, P0a);
+                for (int s = 0; s < nsteps; s += 2) {
+                    if (PING_PONG) {
+                        kstep(s, P0a, P0b);
+                        kstep(s + 1, P0b, P0a);
+                    } else {
+                        kstep(s, P0a, P0a);
+                        kstep(s + 1, P0a, P0a);
+                    }
                 }
+                wait_frag<0, G>(P0a);                         // drain (harmless re-loads of the last k-step)
+                wait_frag<0, G>(P1);
+                wait_frag<0, G>(P2);
             }
-            wait_frag<0, G>(P0a);                         // drain (harmless re-loads of the last k-step)
-            wait_frag<0, G>(P1);
-            wait_frag<0, G>(P2);
         }
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
         PN_STAMP(4 * t + 2);
 
         // ---- cell update in registers; h_t goes back to LDS (split) for the next step ----------------------
-        float hv[16];
         const int lane_o = fresh_lane();    // row offsets are re-derived in every step: hoisted out of the t loop they spill
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = r0 + acc_row(r, lane_o);
-            const int q = q0 + row;
-            float h;
-            if (GRU) {
-                // saved: r, z, n, the pre-activation W_hn h + b_hn, h_{t-1}
-                const float rg = sigmoidf_(acc[0][r]);
-                const float zg = sigmoidf_(acc[G > 1 ? 1 : 0][r]);
-                const float nh = acc[G > 3 ? 3 : 0][r];
-                const float ng = tanhf_(acc[G > 2 ? 2 : 0][r] + rg * nh);
-                const float hp = cst[r];
-                h = (1.0f - zg) * ng + zg * hp;
-                cst[r] = h;
-                if (saved_t && q < p.P) {
-                    float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
-                    sv[0] = rg; sv[H] = zg; sv[2 * H] = ng; sv[3 * H] = nh; sv[4 * H] = hp;
+        for (int rb = 0; rb < RB; rb++) {
+            float hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = r0 + 32 * rb + acc_row(r, lane_o);
+                const int q = q0 + row;
+                float h;
+                if (GRU) {
+                    // saved: r, z, n, the pre-activation W_hn h + b_hn, h_{t-1}
+                    const float rg = sigmoidf_(acc[rb][0][r]);
+                    const float zg = sigmoidf_(acc[rb][G > 1 ? 1 : 0][r]);
+                    const float nh = acc[rb][G > 3 ? 3 : 0][r];
+                    const float ng = tanhf_(acc[rb][G > 2 ? 2 : 0][r] + rg * nh);
+                    const float hp = cst[rb][r];
+                    h = (1.0f - zg) * ng + zg * hp;
+                    cst[rb][r] = h;
+                    if (saved_t && q < p.P) {
+                        float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
+                        sv[0] = rg; sv[H] = zg; sv[2 * H] = ng; sv[3 * H] = nh; sv[4 * H] = hp;
+                    }
+                } else if (G == 4) {
+                    const float ig = sigmoidf_(acc[rb][0][r]);
+                    const float fg = sigmoidf_(acc[rb][G > 1 ? 1 : 0][r]);
+                    const float gg = tanhf_(acc[rb][G > 2 ? 2 : 0][r]);
+                    const float og = sigmoidf_(acc[rb][G > 3 ? 3 : 0][r]);
+                    const float c = fg * cst[rb][r] + ig * gg;
+                    cst[rb][r] = c;
+                    h = og * tanhf_(c);
+                    if (saved_t && q < p.P) {
+                        // (constant displacements on top of base + zext(offset) fold into the instructions' immediates)
+                        float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
+                        sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+                    }
+                } else {
+                    h = tanhf_(acc[rb][0][r]);
+                    if (saved_t && q < p.P) at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)H + col) * 4u) = h;
                 }
-            } else if (G == 4) {
-                const float ig = sigmoidf_(acc[0][r]);
-                const float fg = sigmoidf_(acc[G > 1 ? 1 : 0][r]);
-                const float gg = tanhf_(acc[G > 2 ? 2 : 0][r]);
-                const float og = sigmoidf_(acc[G > 3 ? 3 : 0][r]);
-                const float c = fg * cst[r] + ig * gg;
-                cst[r] = c;
-                h = og * tanhf_(c);
-                if (saved_t && q < p.P) {
-                    // (constant displacements on top of base + zext(offset) fold into the instructions' immediates)
-                    float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
-                    sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+                hv[r] = h;
+                if (q < p.P) {
+                    if (t == p.L - 1)
+                        at_bytes(hn_t, ((uint32_t)row * (uint32_t)H + col) * 4u) = h;
+                    else if (xh_t)
+                        at_bytes(xh_t, (((uint32_t)row * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col) * 4u) = h;
                 }
-            } else {
-                h = tanhf_(acc[0][r]);
-                if (saved_t && q < p.P) at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)H + col) * 4u) = h;
             }
-            hv[r] = h;
-            if (q < p.P) {
-                if (t == p.L - 1)
-                    at_bytes(hn_t, ((uint32_t)row * (uint32_t)H + col) * 4u) = h;
-                else if (xh_t)
-                    at_bytes(xh_t, (((uint32_t)row * (uint32_t)p.L + t + 1) * (uint32_t)(2 * H) + H + col) * 4u) = h;
+            if (t + 1 < p.L) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
+                    uint32_t h0, h1, h2;
+                    split3(hv[r], hv[r + 1], h0, h1, h2);
+                    unsigned char *d = ldsb + (r0 + 32 * rb + acc_row(r, lane_o)) * PB + 2 * (H + col);
+                    *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
+                    *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
+                    *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
+                    *reinterpret_cast<uint16_t *>(d + PLANE + PB) = (uint16_t)(h1 >> 16);
+                    *reinterpret_cast<uint16_t *>(d + 2 * PLANE) = (uint16_t)h2;
+                    *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(h2 >> 16);
+                }
             }
         }
         if (t + 1 < p.L) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
-                uint32_t h0, h1, h2;
-                split3(hv[r], hv[r + 1], h0, h1, h2);
-                unsigned char *d = ldsb + (r0 + acc_row(r, lane_o)) * PB + 2 * (H + col);
-                *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
-                *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
-                *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
-                *reinterpret_cast<uint16_t *>(d + PLANE + PB) = (uint16_t)(h1 >> 16);
-                *reinterpret_cast<uint16_t *>(d + 2 * PLANE) = (uint16_t)h2;
-                *reinterpret_cast<uint16_t *>(d + 2 * PLANE + PB) = (uint16_t)(h2 >> 16);
-            }
             tid_g = wave_u * 64 + fresh_lane();
             if (!PREFETCH_X) gather_issue(t + 1);
             gather_commit(t + 1);     // (every wave is past its reads of x_t)
@@ -1646,9 +1675,10 @@ int dispatch_seq_bwd(pn_context *ctx, hipStream_t stream, int H, const SeqBwdPar
 template <int H, int G>
 int launch_seq_fwd(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
     constexpr int RG = H <= 128 ? PN_SEQ_RG : 1;      // H = 256: one row group already fills the LDS
-    constexpr int MT = 32 * RG;
+    constexpr int RB = ((H == 64 || H == 128) && RG == 1) ? PN_FWD_RB : 1;      // two row blocks per wave: 101 KB of LDS at H = 128
+    constexpr int MT = 32 * RG * RB;
     const size_t lds_bytes = (size_t)3 * MT * (4 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
-    auto kern = seq_fwd3_kernel<H, G, RG>;
+    auto kern = seq_fwd3_kernel<H, G, RG, RB>;
     if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
     const int blocks = (sp.P + MT - 1) / MT;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64 * RG), lds_bytes, stream, sp);
