@@ -442,6 +442,19 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
         "stages_ms": mb["stages_ms"]}
     del bsr
 
+    # ---- hid = 512 on the bench graph: the step-by-step recurrence that serves hidden sizes beyond the fused kernels ---
+    hw = dict(wl, H=512)
+    hsr = StepRunner(hw, dev, 0, 1, sharded=False)
+    steps_h = max(3, args.steps // 5)
+    mh = measure(hsr, lib, ctx, names, steps_h, 2, torch.cuda.synchronize)
+    Ph = hsr.S * W
+    out["hid512_step"] = {
+        "config": "bench graph, hid=512 (generic recurrence: one fp32 GEMM per step + cell kernels), %d paths/step" % Ph,
+        "value": Ph / (mh["elapsed"] / steps_h), "unit": "paths/s", "ms_per_step": mh["elapsed"] / steps_h * 1e3,
+        "steps": steps_h, "roofline": roofline_block(mh["dominant"], mh["dom_ms"], mh["dom_launches"], Ph, L, 512, None),
+        "stages_ms": mh["stages_ms"]}
+    del hsr
+
     # ---- the path-feature gather against HBM: a table that cannot sit in the 256 MB Infinity Cache -------------------
     Ng, Sg = 1 << 20, 9464                      # Z table [2^20, L, H] fp32 = 2 GB; Pubmed's path count
     table = torch.randn(Ng, L, H, device=dev)

@@ -222,7 +222,8 @@ int pn_paths_read_bin(const char *path, int32_t *L_out, int32_t *ids, uint8_t *c
 
 typedef struct pn_pagg_shape {
     int32_t variant;
-    int32_t N, F, H, C; /* nodes, input features, hidden (a multiple of 32, <= 256), classes */
+    int32_t N, F, H, C; /* nodes, input features, hidden (a multiple of 32: fused recurrent kernels up to 256, a
+                         * step-by-step recurrence on the fp32 MFMA GEMM up to 1024), classes */
     int32_t S, W, L;    /* masked nodes this call aggregates (rows of out), paths per node, path length */
     /* A call may aggregate a slice of a larger batch: S_total masked nodes in the batch (0 means S), of which this
      * call computes the pooling groups [group_begin, group_begin + S).  ids / codes / sel / the explicit masks always

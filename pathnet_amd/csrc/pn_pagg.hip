@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <type_traits>
@@ -410,6 +411,168 @@ __global__ __launch_bounds__(256) void seq_reduce_kernel(SeqReduceParams p) {
     }
 }
 
+__device__ __forceinline__ int gru_weight_row(int slot, int j, int H);      // (defined with pack_fwd3_kernel)
+
+// ================================================================================================
+// Generic recurrence for hidden sizes the fused kernels do not cover (256 < H <= 1024, e.g. the reference's -hid=1024
+// runs, results/result_for_Nba.txt): step by step -- gather + dropout kernel, one fp32 MFMA GEMM for the gate
+// pre-activations, an element-wise cell kernel; backward the same way round plus one GEMM for the weight gradients.
+// Same tensors and layouts as the fused path (saved [P,L,SV,H], xh [P,L,2H], dG [P,L,GH]), same dropout counters, so
+// pooling, micro-batches, slices and the caller see no difference.  A functional path, ~10 launches per step.
+// ================================================================================================
+struct GenParams {
+    const float *Z;            // [N*L, H]
+    const int32_t *rowidx;     // [P, L]
+    const int32_t *slotof;     // [P]
+    float *xh;                 // [P, L, 2H]
+    float *pre;                // [P, L, GH]  forward: gate pre-activations of step t; backward: dG
+    float *saved;              // [P, L, SV, H] or null
+    float *state;              // [P, H] running cell / hidden state (forward), d c / the GRU's direct term (backward)
+    float *hn;                 // [P, H]
+    float *dh;                 // [P, H] backward: d loss / d h_t, updated in place
+    const float *gx;           // [P, 2H] backward: [dx_t | dh_{t-1}] of the step's GEMM
+    float *dZ;
+    const float *biasc;
+    int P, L, H, G, cell, t;
+    int64_t Pmask;
+    float p_drop;
+    uint64_t seed;
+    const pn_step_state *dyn;
+    const float *mask;
+};
+
+__device__ __forceinline__ float4 gen_mask(const GenParams &p, uint64_t seed, int t, int64_t slot, int c4) {
+    const int hv = p.H / 4;
+    if (p.mask) return reinterpret_cast<const float4 *>(p.mask)[((int64_t)t * p.Pmask + slot) * hv + c4];
+    if (p.p_drop > 0.0f) return dropout4(seed, ((uint64_t)t * p.Pmask + slot) * hv + c4, 1u, p.p_drop);
+    return make_float4(1.f, 1.f, 1.f, 1.f);
+}
+
+// xh[q, t, 0:H] = mask * Z[row(q, t)];  t = 0 also clears the h half
+__global__ __launch_bounds__(256) void gen_x_kernel(GenParams p) {
+    const int hv = p.H / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.P * hv) return;
+    const int q = (int)(i / hv), c4 = (int)(i - (int64_t)q * hv);
+    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+    const float4 m = gen_mask(p, seed, p.t, p.slotof[q], c4);
+    const size_t row = (size_t)(uint32_t)p.rowidx[(int64_t)q * p.L + p.t];
+    float4 v = reinterpret_cast<const float4 *>(p.Z)[row * hv + c4];
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    float4 *dst = reinterpret_cast<float4 *>(p.xh) + ((size_t)q * p.L + p.t) * (2 * hv) + c4;
+    dst[0] = v;
+    if (p.t == 0) dst[hv] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// one element (path q, hidden unit j) of the cell update of step t
+__global__ __launch_bounds__(256) void gen_cell_fwd_kernel(GenParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.P * p.H) return;
+    const int H = p.H, q = (int)(i / H), j = (int)(i - (int64_t)q * H);
+    const float *pre = p.pre + ((size_t)q * p.L + p.t) * ((size_t)p.G * H) + j;
+    const int SV = p.G == 4 ? 5 : 1;
+    float *sv = p.saved ? p.saved + (((size_t)q * p.L + p.t) * SV) * H + j : nullptr;
+    float h;
+    if (p.cell == 3) {                     // GRU on the four slots r, z, nx, nh
+        const float rg = sigmoidf_(pre[0]), zg = sigmoidf_(pre[H]), nh = pre[3 * (size_t)H];
+        const float ng = tanhf_(pre[2 * (size_t)H] + rg * nh);
+        const float hp = p.t > 0 ? p.state[i] : 0.0f;
+        h = (1.0f - zg) * ng + zg * hp;
+        p.state[i] = h;
+        if (sv) { sv[0] = rg; sv[H] = zg; sv[2 * (size_t)H] = ng; sv[3 * (size_t)H] = nh; sv[4 * (size_t)H] = hp; }
+    } else if (p.G == 4) {                 // LSTM
+        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[H]), gg = tanhf_(pre[2 * (size_t)H]), og = sigmoidf_(pre[3 * (size_t)H]);
+        const float c = fg * (p.t > 0 ? p.state[i] : 0.0f) + ig * gg;
+        p.state[i] = c;
+        h = og * tanhf_(c);
+        if (sv) { sv[0] = ig; sv[H] = fg; sv[2 * (size_t)H] = gg; sv[3 * (size_t)H] = og; sv[4 * (size_t)H] = c; }
+    } else {                                // tanh RNN
+        h = tanhf_(pre[0]);
+        if (sv) sv[0] = h;
+    }
+    if (p.t == p.L - 1)
+        p.hn[i] = h;
+    else
+        p.xh[((size_t)q * p.L + p.t + 1) * (2 * (size_t)H) + H + j] = h;
+}
+
+// cell backward of step t: dh (in place buffer) and the carried state -> the gate-slot gradients dG[q, t, :]
+__global__ __launch_bounds__(256) void gen_cell_bwd_kernel(GenParams p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.P * p.H) return;
+    const int H = p.H, q = (int)(i / H), j = (int)(i - (int64_t)q * H);
+    const int SV = p.G == 4 ? 5 : 1;
+    const float *sv = p.saved + (((size_t)q * p.L + p.t) * SV) * H + j;
+    float *d = p.pre + ((size_t)q * p.L + p.t) * ((size_t)p.G * H) + j;
+    const float dhv = p.dh[i];
+    if (p.cell == 3) {
+        const float rg = sv[0], zg = sv[H], ng = sv[2 * (size_t)H], nh = sv[3 * (size_t)H], hp = sv[4 * (size_t)H];
+        const float dnp = dhv * (1.0f - zg) * (1.0f - ng * ng);
+        d[0] = dnp * nh * rg * (1.0f - rg);
+        d[H] = dhv * (hp - ng) * zg * (1.0f - zg);
+        d[2 * (size_t)H] = dnp;
+        d[3 * (size_t)H] = dnp * rg;
+        p.state[i] = dhv * zg;              // the direct path d h_t / d h_{t-1}
+    } else if (p.G == 4) {
+        const float ig = sv[0], fg = sv[H], gg = sv[2 * (size_t)H], og = sv[3 * (size_t)H], c = sv[4 * (size_t)H];
+        const float cprev = p.t > 0 ? sv[-(ptrdiff_t)H] : 0.0f;       // slot 4 of step t-1
+        const float tc = tanhf_(c);
+        const float dct = (p.t < p.L - 1 ? p.state[i] : 0.0f) + dhv * og * (1.0f - tc * tc);
+        d[0] = dct * gg * ig * (1.0f - ig);
+        d[H] = dct * cprev * fg * (1.0f - fg);
+        d[2 * (size_t)H] = dct * ig * (1.0f - gg * gg);
+        d[3 * (size_t)H] = dhv * tc * og * (1.0f - og);
+        p.state[i] = dct * fg;
+    } else {
+        const float h = sv[0];
+        d[0] = dhv * (1.0f - h * h);
+    }
+}
+
+// after the step's GEMM gx = dG_t . [W_ih | W_hh]: scatter mask * dx into dZ, dh_{t-1} into the dh buffer
+__global__ __launch_bounds__(256) void gen_scatter_kernel(GenParams p) {
+    const int hv = p.H / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.P * hv) return;
+    const int q = (int)(i / hv), c4 = (int)(i - (int64_t)q * hv);
+    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+    const float4 m = gen_mask(p, seed, p.t, p.slotof[q], c4);
+    const float4 *g = reinterpret_cast<const float4 *>(p.gx) + (size_t)q * (2 * hv) + c4;
+    const float4 dx = g[0];
+    const size_t row = (size_t)(uint32_t)p.rowidx[(int64_t)q * p.L + p.t];
+    float *dz = p.dZ + row * p.H + 4 * c4;
+    atomicAdd(dz + 0, dx.x * m.x); atomicAdd(dz + 1, dx.y * m.y); atomicAdd(dz + 2, dx.z * m.z); atomicAdd(dz + 3, dx.w * m.w);
+    if (p.t > 0) {
+        float4 dh = g[hv];
+        if (p.cell == 3) {
+            const float4 direct = reinterpret_cast<const float4 *>(p.state)[i];
+            dh.x += direct.x; dh.y += direct.y; dh.z += direct.z; dh.w += direct.w;
+        }
+        reinterpret_cast<float4 *>(p.dh)[i] = dh;
+    }
+}
+
+// Wcat [GH, 2H] = [W_ih | W_hh] in fp32 (GRU: the four slots with their zero halves), biasc as in pack_fwd3_kernel
+__global__ void gen_pack_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G, int gru,
+                                float *__restrict__ Wcat, float *__restrict__ biasc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)G * H) {
+        if (!gru) {
+            biasc[i] = b_ih[i] + b_hh[i];
+        } else {
+            const int slot = (int)(i / H), j = (int)(i - (int64_t)slot * H), wr = gru_weight_row(slot, j, H);
+            biasc[i] = slot < 2 ? b_ih[wr] + b_hh[wr] : slot == 2 ? b_ih[wr] : b_hh[wr];
+        }
+    }
+    if (i >= (int64_t)G * H * 2 * H) return;
+    const int m = (int)(i / (2 * H)), k = (int)(i - (int64_t)m * 2 * H), slot = m / H, j = m - slot * H;
+    const int row = gru ? gru_weight_row(slot, j, H) : m;
+    float v = k < H ? w_ih[(int64_t)row * H + k] : w_hh[(int64_t)row * H + (k - H)];
+    if (gru && ((slot == 2 && k >= H) || (slot == 3 && k < H))) v = 0.0f;
+    Wcat[i] = v;
+}
+
 struct SeqFwdParams {
     const float *Z;         // [N*L, H] bank output (post activation)
     const int32_t *rowidx;  // [P, L]
@@ -783,6 +946,255 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (RB > 1 ? 1 : fwd_waves<H, RG>())
 }
 
 // ================================================================================================
+// The recurrence as one launch per step, the weights stationary in LDS (LSTM / GRU, hid <= 192).
+//
+// The fused kernels above keep a tile's rows in LDS and stream the weights past them: 786 KB of fragments per 32-row
+// tile and step (hid = 128) through the vector-memory path, which is what bounds them.  Here the roles
+// are swapped.  A workgroup owns a SLICE of 16 hidden units -- their 4 gate columns over all of K = [x | h], as the
+// three bf16 planes: 768 H bytes, 96 KB at hid = 128 -- loads it into LDS once, and its 8 waves then walk 32-row tiles
+// of the batch independently (no barrier after the prologue): the A operand [x_t | h_{t-1}] comes straight from
+// global memory into registers (32 KB per tile, split into planes in registers), the B fragments from LDS.  A tile's
+// rows are read by all H/16 slices -- 256 KB per tile and step at hid = 128, a third of the weight stream it replaces
+// -- and those H/16 workgroups sit on the same XCD and walk the same tiles at the same time, so all but the first read
+// hit that XCD's L2.  h_t of a slice's units goes to xh[q, t+1, H + unit]; the next step's launch reads it from there
+// (the kernel boundary is the only synchronisation between steps), c_t lives in a [P, H] buffer.
+//   v_mfma_f32_16x16x32_bf16: the four N tiles of a wave are the four gates of its 16 units, so a lane holds i, f, g, o
+//   of the same (row, unit) and the cell update needs no exchange.
+//   Wst[((slice*KC + kc)*4 + gate)*3 + plane][lane] (16 B) = plane of Wcat[gate*H + 16 slice + (lane & 15)]
+//                                                              [32 kc + 4 (lane >> 4) + {0..3, 16..19}],   KC = 2H/32
+// ================================================================================================
+__global__ void pack_step_fwd_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                     const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int gru,
+                                     u32x4 *__restrict__ Wst, float *__restrict__ biasc) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 4 * H) {
+        if (!gru) {
+            biasc[idx] = b_ih[idx] + b_hh[idx];
+        } else {
+            const int slot = idx / H, j = idx - slot * H, wr = gru_weight_row(slot, j, H);
+            biasc[idx] = slot < 2 ? b_ih[wr] + b_hh[wr] : slot == 2 ? b_ih[wr] : b_hh[wr];
+        }
+    }
+    const int KC = H / 16, NS = H / 16;
+    if (idx >= NS * KC * 4 * 64) return;
+    const int lane = idx & 63;
+    int rest = idx >> 6;
+    const int g = rest & 3;
+    rest >>= 2;
+    const int kc = rest % KC, slice = rest / KC;
+    // the 8 k values of a lane: 32 kc + 4 (lane >> 4) + {0..3} and the same + 16, so that the A rows are fetched as two
+    // loads of 64 contiguous bytes per row (step_fwd_kernel)
+    const int j = 16 * slice + (lane & 15), k = 32 * kc + 4 * (lane >> 4);
+    const int row = gru ? gru_weight_row(g, j, H) : g * H + j;
+    const float *src = k < H ? w_ih + (int64_t)row * H + k : w_hh + (int64_t)row * H + (k - H);
+    float4 v0 = reinterpret_cast<const float4 *>(src)[0], v1 = reinterpret_cast<const float4 *>(src)[4];
+    if (gru && ((g == 2 && k >= H) || (g == 3 && k < H))) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    u32x4 q0, q1, q2;
+    uint32_t x0, x1, x2;
+    split3(v0.x, v0.y, x0, x1, x2); q0[0] = x0; q1[0] = x1; q2[0] = x2;
+    split3(v0.z, v0.w, x0, x1, x2); q0[1] = x0; q1[1] = x1; q2[1] = x2;
+    split3(v1.x, v1.y, x0, x1, x2); q0[2] = x0; q1[2] = x1; q2[2] = x2;
+    split3(v1.z, v1.w, x0, x1, x2); q0[3] = x0; q1[3] = x1; q2[3] = x2;
+    u32x4 *dst = Wst + ((int64_t)((slice * KC + kc) * 4 + g) * 3) * 64 + lane;
+    dst[0] = q0;
+    dst[64] = q1;
+    dst[128] = q2;
+}
+
+// xh[q, t, 0:H] = mask * Z[row(q, t)] for every step of the micro-batch, the h half of step 0 cleared, and the keep
+// bits of the built-in dropout for the backward (the fused forward does all this while it gathers)
+struct XhFillParams {
+    GenParams g;
+    uint8_t *keep;              // [P, L, H/4] or null
+};
+__global__ __launch_bounds__(256) void xh_fill_kernel(XhFillParams xp) {
+    const GenParams &p = xp.g;
+    const int hv = p.H / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.P * p.L * hv) return;
+    const int64_t qt = i / hv;
+    const int c4 = (int)(i - qt * hv), q = (int)(qt / p.L), t = (int)(qt - (int64_t)q * p.L);
+    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+    const float4 m = gen_mask(p, seed, t, p.slotof[q], c4);
+    const size_t row = (size_t)(uint32_t)p.rowidx[qt];
+    float4 v = reinterpret_cast<const float4 *>(p.Z)[row * hv + c4];
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    float4 *dst = reinterpret_cast<float4 *>(p.xh) + (size_t)qt * (2 * hv) + c4;
+    dst[0] = v;
+    if (t == 0) dst[hv] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xp.keep)
+        xp.keep[(size_t)qt * hv + c4] =
+            (uint8_t)((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) | (m.w != 0.f ? 8u : 0u));
+}
+
+struct StepFwdParams {
+    float *xh;              // [P, L, 2H]: x halves filled by xh_fill_kernel, h halves step by step by this kernel
+    const u32x4 *Wst;       // the slices (pack_step_fwd_kernel)
+    const float *biasc;     // [4H]
+    float *state;           // [P, H] c_t (LSTM) / h_t (GRU)
+    float *saved;           // [P, L, 5, H] or null
+    float *hn;              // [P, H]
+    int P, L, t;
+    int rgx;                // row groups (workgroups of one slice) per XCD: the grid is 8 * (H/16) * rgx
+    int dbg;
+};
+
+template <int H, bool GRU, bool FIRST>
+__global__ __launch_bounds__(512, 1) void step_fwd_kernel(StepFwdParams p) {
+    constexpr int NS = H / 16, KC = H / 16, KCN = FIRST ? KC / 2 : KC;      // step 0 (h_{-1} = 0): the x half of K
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    u32x4 *wl = reinterpret_cast<u32x4 *>(ldsb);
+    const int tid = threadIdx.x;
+    // workgroup -> (XCD, slice, row group): consecutive workgroup ids go to consecutive XCDs, so the NS slices of a row
+    // group share an XCD (and its L2, for the rows they all read)
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, slice = bi % NS, rg = bi / NS;
+    {
+        const u32x4 *src = p.Wst + (size_t)slice * (KC * 12 * 64);
+        for (int j = tid; j < KCN * 12 * 64; j += 512) wl[j] = src[j];
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int ntiles = (p.P + 31) >> 5, nstreams = 64 * p.rgx;
+    const int unit = 16 * slice + lr;
+    float bias[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) bias[n] = p.biasc[n * H + unit];
+
+    for (int tile = (xcd * p.rgx + rg) * 8 + wave; tile < ntiles; tile += nstreams) {
+        const float *arow[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++) {
+            const int row = min(tile * 32 + mb * 16 + lr, p.P - 1);
+            arow[mb] = p.xh + ((size_t)row * p.L + p.t) * (2 * H) + 4 * lk;
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) acc[mb][n] = f32x4{bias[n], bias[n], bias[n], bias[n]};
+        float cold[2][4];
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = min(tile * 32 + mb * 16 + 4 * lk + j, p.P - 1);
+                cold[mb][j] = FIRST ? 0.0f : p.state[(size_t)row * H + unit];
+            }
+        // A rows of k-chunk kc + 1 are fetched (asm loads: the compiler neither sinks nor hoists them) under the MFMAs of
+        // chunk kc and split into planes behind them
+        f32x4 raw[4];
+        u32x4 a[2][3];
+        auto fetch = [&](int kc) {
+            async_load_b128(raw[0], arow[0] + 32 * kc);          // 16 rows x 64 contiguous bytes per load
+            async_load_b128(raw[1], arow[0] + 32 * kc + 16);
+            async_load_b128(raw[2], arow[1] + 32 * kc);
+            async_load_b128(raw[3], arow[1] + 32 * kc + 16);
+        };
+        auto commit = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) : : "memory");
+#pragma unroll
+            for (int mb = 0; mb < 2; mb++) {
+                uint32_t x0, x1, x2;
+                split3(raw[2 * mb][0], raw[2 * mb][1], x0, x1, x2); a[mb][0][0] = x0; a[mb][1][0] = x1; a[mb][2][0] = x2;
+                split3(raw[2 * mb][2], raw[2 * mb][3], x0, x1, x2); a[mb][0][1] = x0; a[mb][1][1] = x1; a[mb][2][1] = x2;
+                split3(raw[2 * mb + 1][0], raw[2 * mb + 1][1], x0, x1, x2); a[mb][0][2] = x0; a[mb][1][2] = x1; a[mb][2][2] = x2;
+                split3(raw[2 * mb + 1][2], raw[2 * mb + 1][3], x0, x1, x2); a[mb][0][3] = x0; a[mb][1][3] = x1; a[mb][2][3] = x2;
+            }
+        };
+        fetch(0);
+        commit();
+        // B fragments: one register set per plane, re-read from LDS for the next k-chunk right behind the set's last
+        // MFMA.  Products run plane-major (a2.b0 a1.b0 a0.b0 | a1.b1 a0.b1 | a0.b2), each over the 8 accumulators of the
+        // wave, so that a dependent MFMA is 8 issues behind its predecessor.
+        const u32x4 *bl = wl + lane;
+        u32x4 b0[4], b1[4], b2[4];
+        auto bread = [&](u32x4 (&b)[4], const u32x4 *base, int pl) {
+#pragma unroll
+            for (int n = 0; n < 4; n++) b[n] = base[(n * 3 + pl) * 64];
+        };
+        auto prod = [&](int pa, u32x4 (&b)[4]) {
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+#pragma unroll
+                for (int mb = 0; mb < 2; mb++) acc[mb][n] = mfma16_bf16(a[mb][pa], b[n], acc[mb][n]);
+        };
+        bread(b0, bl, 0);
+        bread(b1, bl, 1);
+        bread(b2, bl, 2);
+#pragma unroll 1
+        for (int kc = 0; kc < ((p.dbg & 2) ? 0 : KCN); kc++) {
+            fetch(min(kc + 1, KCN - 1));        // (the last k-chunk re-reads itself: no branch between load and wait)
+            __builtin_amdgcn_sched_barrier(0);  // the loads go out before the first MFMA, not wherever the scheduler likes
+            const u32x4 *bn = kc + 1 < KCN ? bl + 12 * 64 : wl + lane;      // (the last one wraps around)
+            prod(2, b0);
+            prod(1, b0);
+            prod(0, b0);
+            bread(b0, bn, 0);
+            prod(1, b1);
+            prod(0, b1);
+            bread(b1, bn, 1);
+            prod(0, b2);
+            bread(b2, bn, 2);
+            bl = bn;
+            commit();
+        }
+        // ---- cell update: lane = (unit, 4 consecutive rows of each row block) ----------------------------------------
+#pragma unroll
+        for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = tile * 32 + mb * 16 + 4 * lk + j;
+                if (row >= p.P) continue;
+                if ((p.dbg & 1) && acc[mb][0][j] != 12345.f) continue;
+                const size_t ru = (size_t)row * H + unit;
+                float *sv = p.saved ? p.saved + (((size_t)row * p.L + p.t) * 5) * H + unit : nullptr;
+                float h;
+                if (GRU) {
+                    const float rg_ = sigmoidf_(acc[mb][0][j]), zg = sigmoidf_(acc[mb][1][j]), nh = acc[mb][3][j];
+                    const float ng = tanhf_(acc[mb][2][j] + rg_ * nh), hp = cold[mb][j];
+                    h = (1.0f - zg) * ng + zg * hp;
+                    p.state[ru] = h;
+                    if (sv) { sv[0] = rg_; sv[H] = zg; sv[2 * H] = ng; sv[3 * H] = nh; sv[4 * H] = hp; }
+                } else {
+                    const float ig = sigmoidf_(acc[mb][0][j]), fg = sigmoidf_(acc[mb][1][j]);
+                    const float gg = tanhf_(acc[mb][2][j]), og = sigmoidf_(acc[mb][3][j]);
+                    const float c = fg * cold[mb][j] + ig * gg;
+                    p.state[ru] = c;
+                    h = og * tanhf_(c);
+                    if (sv) { sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c; }
+                }
+                if (p.t == p.L - 1)
+                    p.hn[ru] = h;
+                else
+                    p.xh[((size_t)row * p.L + p.t + 1) * (2 * H) + H + unit] = h;
+            }
+    }
+}
+
+template <int H>
+int launch_step_fwd(pn_context *ctx, hipStream_t s, bool gru, const StepFwdParams &sp) {
+    void (*kern)(StepFwdParams) = gru ? (sp.t == 0 ? step_fwd_kernel<H, true, true> : step_fwd_kernel<H, true, false>)
+                                      : (sp.t == 0 ? step_fwd_kernel<H, false, true> : step_fwd_kernel<H, false, false>);
+    const int lds_bytes = 768 * H;
+    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds_bytes)) return rc;
+    hipLaunchKernelGGL(kern, dim3(8 * (H / 16) * sp.rgx), dim3(512), lds_bytes, s, sp);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+int dispatch_step_fwd(pn_context *ctx, hipStream_t s, int H, bool gru, const StepFwdParams &sp) {
+    switch (H) {
+    case 32: return launch_step_fwd<32>(ctx, s, gru, sp);
+    case 64: return launch_step_fwd<64>(ctx, s, gru, sp);
+    case 96: return launch_step_fwd<96>(ctx, s, gru, sp);
+    case 128: return launch_step_fwd<128>(ctx, s, gru, sp);
+    case 160: return launch_step_fwd<160>(ctx, s, gru, sp);
+    case 192: return launch_step_fwd<192>(ctx, s, gru, sp);
+    }
+    PN_FAIL(PN_ERR_ARG, "step kernels: hidden size %d", H);
+}
+
+// ================================================================================================
 // pool_fwd_kernel: one wavefront per pooling group (= output node).
 // ================================================================================================
 struct PoolParams {
@@ -932,6 +1344,8 @@ struct PoolBwdParams {
     float *g_att_w, *g_att_b;
 };
 
+// HI: 64-column chunks of H a lane walks (4 covers H <= 256, the fused kernels' range; 16 covers the generic path's H <= 1024)
+template <int HI>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -945,7 +1359,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
     const int g = blockIdx.x * 4 + wave;
     const bool active = g < p.S;
     const float inv_w = 1.0f / (float)W;
-    float gaw_h[4] = {0.f, 0.f, 0.f, 0.f}, gaw_e[4] = {0.f, 0.f, 0.f, 0.f}, gab = 0.0f;
+    float gaw_h[HI], gaw_e[HI], gab = 0.0f;
+#pragma unroll
+    for (int i = 0; i < HI; i++) gaw_h[i] = gaw_e[i] = 0.0f;
 
     if (active) {
         for (int mem = lane; mem < W; mem += 64) {
@@ -1009,11 +1425,13 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
         // The attention-ego gradient of consecutive members usually lands on the same table row (all W paths of a
         // node start at that node): it is accumulated in registers and flushed with one atomic per row change.
         int64_t cur_row = -1;
-        float ego_acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float ego_acc[HI];
+#pragma unroll
+        for (int i = 0; i < HI; i++) ego_acc[i] = 0.0f;
         auto flush = [&]() {
             if (cur_row < 0) return;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < HI; i++) {
                 const int j = lane + 64 * i;
                 if (j < H) atomicAdd(&p.dego[cur_row + j], ego_acc[i]);
                 ego_acc[i] = 0.0f;
@@ -1029,7 +1447,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 cur_row = erow;
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < HI; i++) {
                 const int j = lane + 64 * i;
                 if (j < H) {
                     float dh = cf * dp[j];
@@ -1048,7 +1466,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
     }
     if (p.variant == PN_VARIANT_PAGG) return;   // block-uniform
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < HI; i++) {
         const int j = lane + 64 * i;
         if (j < H) {
             red[wave * 2 * H + j] = gaw_h[i];
@@ -1709,6 +2127,8 @@ enum { CELL_LSTM = 1, CELL_RNN = 2, CELL_GRU = 3, CELL_MEAN = 4, CELL_SUM = 5 };
 struct Dims {
     int variant, N, F, H, C, S, W, L, G, SV;    // G: gate slots of the recurrent kernels (4: LSTM and GRU, 1: RNN, 0: mean / sum)
     int cell, Gw;                               // cell kind; Gw: gates of the caller's weight tensors (4, 1, 3, 0)
+    bool generic;                               // H > 256: the step-by-step recurrence (gen_*_kernel) instead of the fused kernels
+    bool stepk;                                 // LSTM / GRU, H <= 192: one launch per step, weights stationary in LDS
     int S_total, group_begin;
     int Sb;             // pooling groups per micro-batch
     int nb;             // micro-batches of this call
@@ -1743,10 +2163,22 @@ int launch_gemm_split(hipStream_t stream, const float *A, int64_t sAm, int64_t s
     return PN_OK;
 }
 
+// PN_SEQ_STEP=0/1 in the environment picks the fused / the per-step recurrent kernels (A/B runs); default below
+#ifndef PN_SEQ_STEP_DEFAULT
+#define PN_SEQ_STEP_DEFAULT 0
+#endif
+bool seq_step_enabled() {
+    static const int v = [] {
+        const char *e = getenv("PN_SEQ_STEP");
+        return e && *e ? atoi(e) : PN_SEQ_STEP_DEFAULT;
+    }();
+    return v != 0;
+}
+
 int make_dims(const pn_pagg_shape &s, Dims &d) {
     if (s.variant < 0 || s.variant > 2) PN_FAIL(PN_ERR_ARG, "unknown variant %d", s.variant);
-    if (s.H < 32 || s.H > 256 || s.H % 32 != 0)
-        PN_FAIL(PN_ERR_ARG, "hidden size %d not supported (multiples of 32 up to 256)", s.H);
+    if (s.H < 32 || s.H > 1024 || s.H % 32 != 0)
+        PN_FAIL(PN_ERR_ARG, "hidden size %d not supported (multiples of 32 up to 1024; fused kernels up to 256)", s.H);
     if (s.N < 1 || s.F < 1 || s.C < 1 || s.S < 0 || s.W < 1 || s.L < 1 || s.L > 64)
         PN_FAIL(PN_ERR_ARG, "bad aggregator shape N=%d F=%d C=%d S=%d W=%d L=%d", s.N, s.F, s.C, s.S, s.W, s.L);
     // the pooling kernels keep per-walk scores, coefficients and ego rows of four nodes in LDS (64 W + 48 H bytes)
@@ -1770,6 +2202,8 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     d.G = d.cell == CELL_RNN ? 1 : (d.cell == CELL_LSTM || d.cell == CELL_GRU) ? 4 : 0;
     d.Gw = d.cell == CELL_GRU ? 3 : d.G;
     d.SV = d.G == 4 ? 5 : 1;
+    d.generic = s.H > 256 && d.G > 0;
+    d.stepk = d.G == 4 && s.H <= 192 && seq_step_enabled();
     d.S_total = S_total;
     d.group_begin = s.group_begin;
     d.Sb = (s.batch_groups > 0 && s.batch_groups < s.S) ? s.batch_groups : s.S;
@@ -1785,7 +2219,7 @@ struct WsLayout {
     size_t Xh, Z;                                                        // node tables (first: reuse_tables relies on it)
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
-    size_t xh, keep, dG, dhn, dl1;                                       // per micro-batch, saved / backward
+    size_t xh, keep, dG, dhn, dl1, gx;                                   // per micro-batch, saved / backward
     int wgrad_split;
     size_t total;
 };
@@ -1836,6 +2270,7 @@ WsLayout ws_layout(const Dims &d) {
     w.dG = take(Pb * L * G * H * 4);
     w.dhn = take(Pb * H * 4);
     w.dl1 = take(Sb * 2 * H * 4 + 1024);
+    w.gx = take(d.generic ? Pb * 2 * H * 4 : 0);        // [dx_t | dh_{t-1}] of a step of the generic recurrence
     w.total = at;
     return w;
 }
@@ -1917,9 +2352,125 @@ int run_plan(const Call &c, hipStream_t s, int b) {
     return PN_OK;
 }
 
+// ---- the generic recurrence (H > 256): step-by-step kernels + the fp32 GEMM ------------------------------------------
+GenParams gen_params(const Call &c, int b) {
+    const Dims &d = c.d;
+    const pn_pagg_args *a = c.a;
+    GenParams gp{};
+    gp.Z = c.Z;
+    gp.rowidx = c.at<int32_t>(c.w.rowidx);
+    gp.slotof = c.at<int32_t>(c.w.slotof);
+    gp.xh = c.at<float>(c.w.xh);
+    gp.pre = c.at<float>(c.w.dG);
+    gp.hn = c.at<float>(c.w.hn);
+    gp.gx = c.at<float>(c.w.gx);
+    gp.dZ = c.at<float>(c.w.dZ);
+    gp.biasc = c.at<float>(c.w.biasc);
+    gp.P = c.groups(b) * d.W;
+    gp.L = d.L;
+    gp.H = d.H;
+    gp.G = d.G;
+    gp.cell = d.cell;
+    gp.Pmask = d.P_total;
+    gp.p_drop = a->p_seq;
+    gp.seed = a->seed;
+    gp.dyn = a->step_state;
+    gp.mask = a->mask_seq;
+    return gp;
+}
+
+int run_seq_fwd_generic(const Call &c, int b, bool save) {
+    const Dims &d = c.d;
+    GenParams gp = gen_params(c, b);
+    gp.saved = save ? c.at<float>(c.w.saved) : nullptr;
+    gp.state = c.at<float>(c.w.dhn);            // (a backward-only buffer: the running cell / hidden state lives there)
+    const int H = d.H, GH = d.G * H, P = gp.P;
+    const float *Wcat = c.at<const float>(c.w.Wp);
+    const unsigned bx = (unsigned)(((int64_t)P * (H / 4) + 255) / 256), be = (unsigned)(((int64_t)P * H + 255) / 256);
+    StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
+    for (int t = 0; t < d.L; t++) {
+        gp.t = t;
+        hipLaunchKernelGGL(gen_x_kernel, dim3(bx), dim3(256), 0, c.stream, gp);
+        PN_CHECK_HIP(hipGetLastError());
+        // pre[q, :] = [x_t | h_{t-1}] . Wcat^T + b      (step 0: h_{-1} = 0, the x half of K suffices)
+        if (int rc = launch_gemm(c.stream, gp.xh + (size_t)t * 2 * H, (int64_t)d.L * 2 * H, 1, nullptr, Wcat, 2 * H, 1,
+                                 gp.pre + (size_t)t * GH, (int64_t)d.L * GH, gp.biasc, P, GH, t == 0 ? H : 2 * H, 0,
+                                 GEMM_STORE, 1))
+            return rc;
+        hipLaunchKernelGGL(gen_cell_fwd_kernel, dim3(be), dim3(256), 0, c.stream, gp);
+        PN_CHECK_HIP(hipGetLastError());
+    }
+    return PN_OK;
+}
+
+// BPTT of micro-batch b + the weight-gradient GEMM (accumulating into the caller's gradients when accumulate != 0)
+int run_seq_bwd_generic(const Call &c, int b, int accumulate) {
+    const Dims &d = c.d;
+    const pn_pagg_args *a = c.a;
+    GenParams gp = gen_params(c, b);
+    gp.saved = c.at<float>(c.w.saved);
+    gp.dh = c.at<float>(c.w.dhn);               // d loss / d h_n from the pooling backward, then d h_{t-1} step by step
+    gp.state = c.at<float>(c.w.hn);             // (the pooling backward is done with h_n: d c / the GRU's direct term live there)
+    const int H = d.H, GH = d.G * H, P = gp.P;
+    const float *Wcat = c.at<const float>(c.w.Wp);
+    float *gx = c.at<float>(c.w.gx);
+    const unsigned bx = (unsigned)(((int64_t)P * (H / 4) + 255) / 256), be = (unsigned)(((int64_t)P * H + 255) / 256);
+    {
+        StageTimer tm(c.ctx, ST_SEQ_BWD, c.stream);
+        for (int t = d.L - 1; t >= 0; t--) {
+            gp.t = t;
+            hipLaunchKernelGGL(gen_cell_bwd_kernel, dim3(be), dim3(256), 0, c.stream, gp);
+            PN_CHECK_HIP(hipGetLastError());
+            // [dx_t | dh_{t-1}] = dG_t . [W_ih | W_hh]      (step 0: the dx half suffices)
+            if (int rc = launch_gemm(c.stream, gp.pre + (size_t)t * GH, (int64_t)d.L * GH, 1, nullptr, Wcat, 1, 2 * H, gx,
+                                     2 * H, nullptr, P, t == 0 ? H : 2 * H, GH, 0, GEMM_STORE, 1))
+                return rc;
+            hipLaunchKernelGGL(gen_scatter_kernel, dim3(bx), dim3(256), 0, c.stream, gp);
+            PN_CHECK_HIP(hipGetLastError());
+        }
+    }
+    if (!(a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) return PN_OK;
+    // [g_W_ih | g_W_hh] = dG^T . xh, g_b = colsum(dG): one split-K GEMM with atomics into a zeroed [GH, 2H] + [GH] buffer
+    StageTimer tm(c.ctx, ST_WGRAD, c.stream);
+    float *part_w = c.at<float>(c.w.wpart), *part_b = part_w + (size_t)c.w.wgrad_split * GH * 2 * H;
+    ZeroList zl{};
+    zl.ptr[0] = part_w;
+    zl.count[0] = (unsigned long long)GH * 2 * H;
+    zl.ptr[1] = part_b;
+    zl.count[1] = (unsigned long long)GH;
+    zl.n = 2;
+    hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, c.stream, zl);
+    PN_CHECK_HIP(hipGetLastError());
+    const int64_t R = (int64_t)P * d.L;
+    if (R > 2000000000LL) PN_FAIL(PN_ERR_ARG, "generic recurrence: %lld path steps in one micro-batch", (long long)R);
+    if (int rc = launch_gemm(c.stream, gp.pre, 1, GH, nullptr, gp.xh, 1, 2 * H, part_w, 2 * H, nullptr, GH, 2 * H, (int)R, 0,
+                             GEMM_ATOMIC, (int)((R + 511) / 512), part_b))
+        return rc;
+    const int64_t nred = (int64_t)GH * 2 * H + GH;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, c.stream, part_w, part_b, 1,
+                       GH, H, accumulate, d.cell == CELL_GRU ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
 int run_pack_fwd(const Call &c, hipStream_t s) {
     const Dims &d = c.d;
     if (d.G == 0) return PN_OK;         // mean / sum: nothing to pack
+    if (d.generic) {
+        const int64_t n = (int64_t)d.G * d.H * 2 * d.H;
+        hipLaunchKernelGGL(gen_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.a->w_ih, c.a->w_hh,
+                           c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, c.at<float>(c.w.Wp),
+                           c.at<float>(c.w.biasc));
+        PN_CHECK_HIP(hipGetLastError());
+        return PN_OK;
+    }
+    if (d.stepk) {
+        const int n = std::max((d.H / 16) * (d.H / 16) * 4 * 64, 4 * d.H);
+        hipLaunchKernelGGL(pack_step_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, c.a->w_ih, c.a->w_hh, c.a->b_ih,
+                           c.a->b_hh, d.H, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.Wp), c.at<float>(c.w.biasc));
+        PN_CHECK_HIP(hipGetLastError());
+        return PN_OK;
+    }
     hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((d.G * d.H * d.H / 4 + 255) / 256)), dim3(256), 0, s, c.a->w_ih,
                        c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.Wp),
                        c.at<float>(c.w.biasc));
@@ -1961,6 +2512,35 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
     if (d.G == 0) return run_seq_reduce(c, b, false);
+    if (d.generic) return run_seq_fwd_generic(c, b, save);
+    if (d.stepk) {
+        StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
+        XhFillParams xp{};
+        xp.g = gen_params(c, b);
+        xp.keep = (!save || a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : c.at<uint8_t>(c.w.keep);
+        const int64_t nfill = (int64_t)xp.g.P * d.L * (d.H / 4);
+        if (nfill > 0) {
+            hipLaunchKernelGGL(xh_fill_kernel, dim3((unsigned)((nfill + 255) / 256)), dim3(256), 0, c.stream, xp);
+            PN_CHECK_HIP(hipGetLastError());
+        }
+        StepFwdParams sp{};
+        sp.xh = xp.g.xh;
+        sp.Wst = c.at<const u32x4>(c.w.Wp);
+        sp.biasc = xp.g.biasc;
+        sp.state = c.at<float>(c.w.dhn);        // (a backward-only buffer otherwise)
+        sp.saved = save ? c.at<float>(c.w.saved) : nullptr;
+        sp.hn = xp.g.hn;
+        sp.P = xp.g.P;
+        sp.L = d.L;
+        sp.rgx = std::max(1, 32 / (d.H / 16));
+        sp.dbg = getenv("PN_STEP_DBG") ? atoi(getenv("PN_STEP_DBG")) : 0;
+        if (sp.P <= 0) return PN_OK;
+        for (int t = 0; t < d.L; t++) {
+            sp.t = t;
+            if (int rc = dispatch_step_fwd(c.ctx, c.stream, d.H, d.cell == CELL_GRU, sp)) return rc;
+        }
+        return PN_OK;
+    }
     SeqFwdParams sp{};
     sp.Z = c.Z;
     sp.rowidx = c.at<int32_t>(c.w.rowidx);
@@ -2257,7 +2837,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
 
     JoinGuard joiner{ctx, stream};
     const bool side_ok = !profiling_every_stage(ctx);     // (per-stage timings are taken serially)
-    if (G > 0) {
+    if (G > 0 && !d.generic) {
         StageTimer tm(ctx, ST_PLAN_PACK, stream);      // (its own bracket: ST_SEQ_BWD times the BPTT kernel alone)
         hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
                            a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.WpT));
@@ -2324,13 +2904,20 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
             const size_t lds_bytes = (size_t)(4 * (2 * d.W + H) + 8 * H + 8 * d.W) * sizeof(float);
             StageTimer tm(ctx, ST_POOL_BWD, stream);
-            hipLaunchKernelGGL(pool_bwd_kernel, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
+            if (H <= 256) {
+                hipLaunchKernelGGL(pool_bwd_kernel<4>, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
+            } else {
+                if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_bwd_kernel<16>), (int)lds_bytes)) return rc;
+                hipLaunchKernelGGL(pool_bwd_kernel<16>, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
+            }
             PN_CHECK_HIP(hipGetLastError());
         }
 
         // BPTT + gather-backward scatter (mean / sum encoders: the scatter alone)
         if (G == 0) {
             if (int rc = run_seq_reduce(c, b, true)) return rc;
+        } else if (d.generic) {
+            if (int rc = run_seq_bwd_generic(c, b, b > 0 ? 1 : 0)) return rc;
         } else {
             StageTimer tm(ctx, ST_SEQ_BWD, stream);
             SeqBwdParams sp{};
@@ -2355,7 +2942,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
         }
 
         // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG)
-        if (G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) {
+        if (G > 0 && !d.generic && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) {
             hipStream_t wstream = stream;
             if (PN_BWD_OVERLAP && side_ok)
                 if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;

@@ -134,7 +134,7 @@ def test_hidden_sizes_that_are_multiples_of_32(variant, H):
 
 def test_unsupported_hidden_sizes_fail_loudly():
     from pathnet_amd import _lib
-    for H in (48, 288, 512):
+    for H in (48, 272, 1056):
         m = build_module("homo", 8, H, 3, 4, 20, None).eval()
         with pytest.raises(_lib.PnError):
             run_module(m, torch.rand(20, 8).cuda(), np.zeros((2, 3, 4), np.int64), np.zeros((2, 3, 4), np.int64),
@@ -484,6 +484,83 @@ def test_ablation_cells_match_the_oracle(variant, cell, H, train):
             bad[k] = (err, grad_tol(ref))
     assert not bad, bad
     assert (Xd.grad.cpu() - Xo.grad).abs().max().item() < grad_tol(Xo.grad.numpy())
+
+
+@pytest.mark.parametrize("variant,cell,H,train", [("hetero", None, 288, True), ("homo", None, 512, True),
+                                                  ("pagg", None, 320, False), ("hetero", "gru", 384, True),
+                                                  ("homo", "rnn", 1024, False), ("pagg", "lstm", 512, True),
+                                                  ("homo", "mean", 512, True)])
+def test_hidden_sizes_beyond_the_fused_kernels(variant, cell, H, train):
+    """-hid is any integer in the reference (PathNet_run.py:52).  Past 256 the recurrence runs step by step -- one fp32
+    (3 x bf16 MFMA) GEMM per step on [x_t | h_{t-1}], element-wise cell kernels around it, the BPTT the same way in
+    reverse, the weight gradient one split-K GEMM -- for every multiple of 32 up to 1024: logits and every gradient
+    against the CPU oracle."""
+    import pathnet_amd
+    torch.manual_seed(73)
+    rng = np.random.default_rng(73)
+    N, F, C, W, L, S = 50, 20, 4, 7, 4, 19
+    cls = {"hetero": pathnet_amd.PathNet, "homo": pathnet_amd.PathNet_homo, "pagg": pathnet_amd.PAGG}[variant]
+    kw = {"cell": cell} if cell else {}
+    m = cls(F, H, C, L if variant != "pagg" else N, **kw).cuda()
+    with torch.no_grad():
+        for k, v in m.named_parameters():
+            if k.endswith("bias") or "bias_" in k:
+                v.uniform_(-0.3, 0.3)
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F)
+    G = torch.randn(S, C)
+    drop_seq = drop_cls = None
+    if train:
+        drop_seq = (torch.rand(L, S * W, H) >= 0.5).float() / 0.5
+        drop_cls = (torch.rand(S, 2 * H) >= 0.5).float() / 0.5
+        m.train()
+        m._mask_seq, m._mask_cls = drop_seq.cuda(), drop_cls.cuda()
+    else:
+        m.eval()
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    (out * G.cuda()).sum().backward()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Xo = X.clone().requires_grad_(True)
+    want = po.forward(variant, pr, Xo, ids, codes, sel, W, L, drop_seq=drop_seq, drop_cls=drop_cls, cell=cell)
+    (want * G).sum().backward()
+    scale = max(1.0, want.detach().abs().max().item())
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT * scale
+    bad = {}
+    for k, v in m.named_parameters():
+        ref = pr[k].grad.numpy()
+        err = np.abs(v.grad.cpu().numpy() - ref).max()
+        if not err < grad_tol(ref):
+            bad[k] = (err, grad_tol(ref))
+    assert not bad, bad
+    assert (Xd.grad.cpu() - Xo.grad).abs().max().item() < grad_tol(Xo.grad.numpy())
+
+
+def test_generic_recurrence_in_micro_batches_with_builtin_dropout(monkeypatch):
+    """hid = 512 walked in micro-batches with the Philox masks: same logits and gradients as one batch"""
+    from pathnet_amd import modules
+    import pathnet_amd
+    torch.manual_seed(74)
+    rng = np.random.default_rng(74)
+    N, F, H, C, W, L, S = 60, 16, 512, 3, 6, 4, 23
+    m = pathnet_amd.PathNet(F, H, C, L, dropout=0.4).cuda().train()
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    X = torch.rand(N, F).cuda()
+    G = torch.randn(S, C).cuda()
+
+    def run(bg):
+        monkeypatch.setattr(modules, "pick_batch_groups", lambda *a, **k: bg)
+        m.zero_grad()
+        torch.manual_seed(9)
+        out = run_module(m, X, ids, codes, mask, W, L)
+        (out * G).sum().backward()
+        return out.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()}
+
+    o1, g1 = run(0)
+    o2, g2 = run(9)
+    assert (o1 - o2).abs().max().item() < 2e-6 * max(1.0, o1.abs().max().item())
+    for k in g1:
+        assert (g1[k] - g2[k]).abs().max().item() < 3e-5 * max(1.0, g1[k].abs().max().item()), k
 
 
 @pytest.mark.parametrize("cell", ["gru", "sum"])
