@@ -33,12 +33,6 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
                                                    0, 0);
 }
-// v_mfma_f32_16x16x32_bf16: lane l supplies A[i = l & 15][k = 8 (l >> 4) .. +7] and B[k = 8 (l >> 4) .. +7][j = l & 15];
-// accumulator register r of lane l is D[row = 4 (l >> 4) + r][col = l & 15].
-__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0,
-                                                   0, 0);
-}
 // v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even), `lo` in bits 0-15
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

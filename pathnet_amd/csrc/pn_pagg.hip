@@ -946,255 +946,6 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (RB > 1 ? 1 : fwd_waves<H, RG>())
 }
 
 // ================================================================================================
-// The recurrence as one launch per step, the weights stationary in LDS (LSTM / GRU, hid <= 192).
-//
-// The fused kernels above keep a tile's rows in LDS and stream the weights past them: 786 KB of fragments per 32-row
-// tile and step (hid = 128) through the vector-memory path, which is what bounds them.  Here the roles
-// are swapped.  A workgroup owns a SLICE of 16 hidden units -- their 4 gate columns over all of K = [x | h], as the
-// three bf16 planes: 768 H bytes, 96 KB at hid = 128 -- loads it into LDS once, and its 8 waves then walk 32-row tiles
-// of the batch independently (no barrier after the prologue): the A operand [x_t | h_{t-1}] comes straight from
-// global memory into registers (32 KB per tile, split into planes in registers), the B fragments from LDS.  A tile's
-// rows are read by all H/16 slices -- 256 KB per tile and step at hid = 128, a third of the weight stream it replaces
-// -- and those H/16 workgroups sit on the same XCD and walk the same tiles at the same time, so all but the first read
-// hit that XCD's L2.  h_t of a slice's units goes to xh[q, t+1, H + unit]; the next step's launch reads it from there
-// (the kernel boundary is the only synchronisation between steps), c_t lives in a [P, H] buffer.
-//   v_mfma_f32_16x16x32_bf16: the four N tiles of a wave are the four gates of its 16 units, so a lane holds i, f, g, o
-//   of the same (row, unit) and the cell update needs no exchange.
-//   Wst[((slice*KC + kc)*4 + gate)*3 + plane][lane] (16 B) = plane of Wcat[gate*H + 16 slice + (lane & 15)]
-//                                                              [32 kc + 4 (lane >> 4) + {0..3, 16..19}],   KC = 2H/32
-// ================================================================================================
-__global__ void pack_step_fwd_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
-                                     const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int gru,
-                                     u32x4 *__restrict__ Wst, float *__restrict__ biasc) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < 4 * H) {
-        if (!gru) {
-            biasc[idx] = b_ih[idx] + b_hh[idx];
-        } else {
-            const int slot = idx / H, j = idx - slot * H, wr = gru_weight_row(slot, j, H);
-            biasc[idx] = slot < 2 ? b_ih[wr] + b_hh[wr] : slot == 2 ? b_ih[wr] : b_hh[wr];
-        }
-    }
-    const int KC = H / 16, NS = H / 16;
-    if (idx >= NS * KC * 4 * 64) return;
-    const int lane = idx & 63;
-    int rest = idx >> 6;
-    const int g = rest & 3;
-    rest >>= 2;
-    const int kc = rest % KC, slice = rest / KC;
-    // the 8 k values of a lane: 32 kc + 4 (lane >> 4) + {0..3} and the same + 16, so that the A rows are fetched as two
-    // loads of 64 contiguous bytes per row (step_fwd_kernel)
-    const int j = 16 * slice + (lane & 15), k = 32 * kc + 4 * (lane >> 4);
-    const int row = gru ? gru_weight_row(g, j, H) : g * H + j;
-    const float *src = k < H ? w_ih + (int64_t)row * H + k : w_hh + (int64_t)row * H + (k - H);
-    float4 v0 = reinterpret_cast<const float4 *>(src)[0], v1 = reinterpret_cast<const float4 *>(src)[4];
-    if (gru && ((g == 2 && k >= H) || (g == 3 && k < H))) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    u32x4 q0, q1, q2;
-    uint32_t x0, x1, x2;
-    split3(v0.x, v0.y, x0, x1, x2); q0[0] = x0; q1[0] = x1; q2[0] = x2;
-    split3(v0.z, v0.w, x0, x1, x2); q0[1] = x0; q1[1] = x1; q2[1] = x2;
-    split3(v1.x, v1.y, x0, x1, x2); q0[2] = x0; q1[2] = x1; q2[2] = x2;
-    split3(v1.z, v1.w, x0, x1, x2); q0[3] = x0; q1[3] = x1; q2[3] = x2;
-    u32x4 *dst = Wst + ((int64_t)((slice * KC + kc) * 4 + g) * 3) * 64 + lane;
-    dst[0] = q0;
-    dst[64] = q1;
-    dst[128] = q2;
-}
-
-// xh[q, t, 0:H] = mask * Z[row(q, t)] for every step of the micro-batch, the h half of step 0 cleared, and the keep
-// bits of the built-in dropout for the backward (the fused forward does all this while it gathers)
-struct XhFillParams {
-    GenParams g;
-    uint8_t *keep;              // [P, L, H/4] or null
-};
-__global__ __launch_bounds__(256) void xh_fill_kernel(XhFillParams xp) {
-    const GenParams &p = xp.g;
-    const int hv = p.H / 4;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)p.P * p.L * hv) return;
-    const int64_t qt = i / hv;
-    const int c4 = (int)(i - qt * hv), q = (int)(qt / p.L), t = (int)(qt - (int64_t)q * p.L);
-    const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
-    const float4 m = gen_mask(p, seed, t, p.slotof[q], c4);
-    const size_t row = (size_t)(uint32_t)p.rowidx[qt];
-    float4 v = reinterpret_cast<const float4 *>(p.Z)[row * hv + c4];
-    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-    float4 *dst = reinterpret_cast<float4 *>(p.xh) + (size_t)qt * (2 * hv) + c4;
-    dst[0] = v;
-    if (t == 0) dst[hv] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (xp.keep)
-        xp.keep[(size_t)qt * hv + c4] =
-            (uint8_t)((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) | (m.w != 0.f ? 8u : 0u));
-}
-
-struct StepFwdParams {
-    float *xh;              // [P, L, 2H]: x halves filled by xh_fill_kernel, h halves step by step by this kernel
-    const u32x4 *Wst;       // the slices (pack_step_fwd_kernel)
-    const float *biasc;     // [4H]
-    float *state;           // [P, H] c_t (LSTM) / h_t (GRU)
-    float *saved;           // [P, L, 5, H] or null
-    float *hn;              // [P, H]
-    int P, L, t;
-    int rgx;                // row groups (workgroups of one slice) per XCD: the grid is 8 * (H/16) * rgx
-    int dbg;
-};
-
-template <int H, bool GRU, bool FIRST>
-__global__ __launch_bounds__(512, 1) void step_fwd_kernel(StepFwdParams p) {
-    constexpr int NS = H / 16, KC = H / 16, KCN = FIRST ? KC / 2 : KC;      // step 0 (h_{-1} = 0): the x half of K
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    u32x4 *wl = reinterpret_cast<u32x4 *>(ldsb);
-    const int tid = threadIdx.x;
-    // workgroup -> (XCD, slice, row group): consecutive workgroup ids go to consecutive XCDs, so the NS slices of a row
-    // group share an XCD (and its L2, for the rows they all read)
-    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, slice = bi % NS, rg = bi / NS;
-    {
-        const u32x4 *src = p.Wst + (size_t)slice * (KC * 12 * 64);
-        for (int j = tid; j < KCN * 12 * 64; j += 512) wl[j] = src[j];
-    }
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    const int ntiles = (p.P + 31) >> 5, nstreams = 64 * p.rgx;
-    const int unit = 16 * slice + lr;
-    float bias[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) bias[n] = p.biasc[n * H + unit];
-
-    for (int tile = (xcd * p.rgx + rg) * 8 + wave; tile < ntiles; tile += nstreams) {
-        const float *arow[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++) {
-            const int row = min(tile * 32 + mb * 16 + lr, p.P - 1);
-            arow[mb] = p.xh + ((size_t)row * p.L + p.t) * (2 * H) + 4 * lk;
-        }
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-            for (int n = 0; n < 4; n++) acc[mb][n] = f32x4{bias[n], bias[n], bias[n], bias[n]};
-        float cold[2][4];
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = min(tile * 32 + mb * 16 + 4 * lk + j, p.P - 1);
-                cold[mb][j] = FIRST ? 0.0f : p.state[(size_t)row * H + unit];
-            }
-        // A rows of k-chunk kc + 1 are fetched (asm loads: the compiler neither sinks nor hoists them) under the MFMAs of
-        // chunk kc and split into planes behind them
-        f32x4 raw[4];
-        u32x4 a[2][3];
-        auto fetch = [&](int kc) {
-            async_load_b128(raw[0], arow[0] + 32 * kc);          // 16 rows x 64 contiguous bytes per load
-            async_load_b128(raw[1], arow[0] + 32 * kc + 16);
-            async_load_b128(raw[2], arow[1] + 32 * kc);
-            async_load_b128(raw[3], arow[1] + 32 * kc + 16);
-        };
-        auto commit = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]) : : "memory");
-#pragma unroll
-            for (int mb = 0; mb < 2; mb++) {
-                uint32_t x0, x1, x2;
-                split3(raw[2 * mb][0], raw[2 * mb][1], x0, x1, x2); a[mb][0][0] = x0; a[mb][1][0] = x1; a[mb][2][0] = x2;
-                split3(raw[2 * mb][2], raw[2 * mb][3], x0, x1, x2); a[mb][0][1] = x0; a[mb][1][1] = x1; a[mb][2][1] = x2;
-                split3(raw[2 * mb + 1][0], raw[2 * mb + 1][1], x0, x1, x2); a[mb][0][2] = x0; a[mb][1][2] = x1; a[mb][2][2] = x2;
-                split3(raw[2 * mb + 1][2], raw[2 * mb + 1][3], x0, x1, x2); a[mb][0][3] = x0; a[mb][1][3] = x1; a[mb][2][3] = x2;
-            }
-        };
-        fetch(0);
-        commit();
-        // B fragments: one register set per plane, re-read from LDS for the next k-chunk right behind the set's last
-        // MFMA.  Products run plane-major (a2.b0 a1.b0 a0.b0 | a1.b1 a0.b1 | a0.b2), each over the 8 accumulators of the
-        // wave, so that a dependent MFMA is 8 issues behind its predecessor.
-        const u32x4 *bl = wl + lane;
-        u32x4 b0[4], b1[4], b2[4];
-        auto bread = [&](u32x4 (&b)[4], const u32x4 *base, int pl) {
-#pragma unroll
-            for (int n = 0; n < 4; n++) b[n] = base[(n * 3 + pl) * 64];
-        };
-        auto prod = [&](int pa, u32x4 (&b)[4]) {
-#pragma unroll
-            for (int n = 0; n < 4; n++)
-#pragma unroll
-                for (int mb = 0; mb < 2; mb++) acc[mb][n] = mfma16_bf16(a[mb][pa], b[n], acc[mb][n]);
-        };
-        bread(b0, bl, 0);
-        bread(b1, bl, 1);
-        bread(b2, bl, 2);
-#pragma unroll 1
-        for (int kc = 0; kc < ((p.dbg & 2) ? 0 : KCN); kc++) {
-            fetch(min(kc + 1, KCN - 1));        // (the last k-chunk re-reads itself: no branch between load and wait)
-            __builtin_amdgcn_sched_barrier(0);  // the loads go out before the first MFMA, not wherever the scheduler likes
-            const u32x4 *bn = kc + 1 < KCN ? bl + 12 * 64 : wl + lane;      // (the last one wraps around)
-            prod(2, b0);
-            prod(1, b0);
-            prod(0, b0);
-            bread(b0, bn, 0);
-            prod(1, b1);
-            prod(0, b1);
-            bread(b1, bn, 1);
-            prod(0, b2);
-            bread(b2, bn, 2);
-            bl = bn;
-            commit();
-        }
-        // ---- cell update: lane = (unit, 4 consecutive rows of each row block) ----------------------------------------
-#pragma unroll
-        for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = tile * 32 + mb * 16 + 4 * lk + j;
-                if (row >= p.P) continue;
-                if ((p.dbg & 1) && acc[mb][0][j] != 12345.f) continue;
-                const size_t ru = (size_t)row * H + unit;
-                float *sv = p.saved ? p.saved + (((size_t)row * p.L + p.t) * 5) * H + unit : nullptr;
-                float h;
-                if (GRU) {
-                    const float rg_ = sigmoidf_(acc[mb][0][j]), zg = sigmoidf_(acc[mb][1][j]), nh = acc[mb][3][j];
-                    const float ng = tanhf_(acc[mb][2][j] + rg_ * nh), hp = cold[mb][j];
-                    h = (1.0f - zg) * ng + zg * hp;
-                    p.state[ru] = h;
-                    if (sv) { sv[0] = rg_; sv[H] = zg; sv[2 * H] = ng; sv[3 * H] = nh; sv[4 * H] = hp; }
-                } else {
-                    const float ig = sigmoidf_(acc[mb][0][j]), fg = sigmoidf_(acc[mb][1][j]);
-                    const float gg = tanhf_(acc[mb][2][j]), og = sigmoidf_(acc[mb][3][j]);
-                    const float c = fg * cold[mb][j] + ig * gg;
-                    p.state[ru] = c;
-                    h = og * tanhf_(c);
-                    if (sv) { sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c; }
-                }
-                if (p.t == p.L - 1)
-                    p.hn[ru] = h;
-                else
-                    p.xh[((size_t)row * p.L + p.t + 1) * (2 * H) + H + unit] = h;
-            }
-    }
-}
-
-template <int H>
-int launch_step_fwd(pn_context *ctx, hipStream_t s, bool gru, const StepFwdParams &sp) {
-    void (*kern)(StepFwdParams) = gru ? (sp.t == 0 ? step_fwd_kernel<H, true, true> : step_fwd_kernel<H, true, false>)
-                                      : (sp.t == 0 ? step_fwd_kernel<H, false, true> : step_fwd_kernel<H, false, false>);
-    const int lds_bytes = 768 * H;
-    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), lds_bytes)) return rc;
-    hipLaunchKernelGGL(kern, dim3(8 * (H / 16) * sp.rgx), dim3(512), lds_bytes, s, sp);
-    PN_CHECK_HIP(hipGetLastError());
-    return PN_OK;
-}
-
-int dispatch_step_fwd(pn_context *ctx, hipStream_t s, int H, bool gru, const StepFwdParams &sp) {
-    switch (H) {
-    case 32: return launch_step_fwd<32>(ctx, s, gru, sp);
-    case 64: return launch_step_fwd<64>(ctx, s, gru, sp);
-    case 96: return launch_step_fwd<96>(ctx, s, gru, sp);
-    case 128: return launch_step_fwd<128>(ctx, s, gru, sp);
-    case 160: return launch_step_fwd<160>(ctx, s, gru, sp);
-    case 192: return launch_step_fwd<192>(ctx, s, gru, sp);
-    }
-    PN_FAIL(PN_ERR_ARG, "step kernels: hidden size %d", H);
-}
-
-// ================================================================================================
 // pool_fwd_kernel: one wavefront per pooling group (= output node).
 // ================================================================================================
 struct PoolParams {
@@ -2128,7 +1879,6 @@ struct Dims {
     int variant, N, F, H, C, S, W, L, G, SV;    // G: gate slots of the recurrent kernels (4: LSTM and GRU, 1: RNN, 0: mean / sum)
     int cell, Gw;                               // cell kind; Gw: gates of the caller's weight tensors (4, 1, 3, 0)
     bool generic;                               // H > 256: the step-by-step recurrence (gen_*_kernel) instead of the fused kernels
-    bool stepk;                                 // LSTM / GRU, H <= 192: one launch per step, weights stationary in LDS
     int S_total, group_begin;
     int Sb;             // pooling groups per micro-batch
     int nb;             // micro-batches of this call
@@ -2163,18 +1913,6 @@ int launch_gemm_split(hipStream_t stream, const float *A, int64_t sAm, int64_t s
     return PN_OK;
 }
 
-// PN_SEQ_STEP=0/1 in the environment picks the fused / the per-step recurrent kernels (A/B runs); default below
-#ifndef PN_SEQ_STEP_DEFAULT
-#define PN_SEQ_STEP_DEFAULT 0
-#endif
-bool seq_step_enabled() {
-    static const int v = [] {
-        const char *e = getenv("PN_SEQ_STEP");
-        return e && *e ? atoi(e) : PN_SEQ_STEP_DEFAULT;
-    }();
-    return v != 0;
-}
-
 int make_dims(const pn_pagg_shape &s, Dims &d) {
     if (s.variant < 0 || s.variant > 2) PN_FAIL(PN_ERR_ARG, "unknown variant %d", s.variant);
     if (s.H < 32 || s.H > 1024 || s.H % 32 != 0)
@@ -2203,7 +1941,6 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     d.Gw = d.cell == CELL_GRU ? 3 : d.G;
     d.SV = d.G == 4 ? 5 : 1;
     d.generic = s.H > 256 && d.G > 0;
-    d.stepk = d.G == 4 && s.H <= 192 && seq_step_enabled();
     d.S_total = S_total;
     d.group_begin = s.group_begin;
     d.Sb = (s.batch_groups > 0 && s.batch_groups < s.S) ? s.batch_groups : s.S;
@@ -2464,13 +2201,6 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
         PN_CHECK_HIP(hipGetLastError());
         return PN_OK;
     }
-    if (d.stepk) {
-        const int n = std::max((d.H / 16) * (d.H / 16) * 4 * 64, 4 * d.H);
-        hipLaunchKernelGGL(pack_step_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, c.a->w_ih, c.a->w_hh, c.a->b_ih,
-                           c.a->b_hh, d.H, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.Wp), c.at<float>(c.w.biasc));
-        PN_CHECK_HIP(hipGetLastError());
-        return PN_OK;
-    }
     hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((d.G * d.H * d.H / 4 + 255) / 256)), dim3(256), 0, s, c.a->w_ih,
                        c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.Wp),
                        c.at<float>(c.w.biasc));
@@ -2513,34 +2243,6 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     const pn_pagg_args *a = c.a;
     if (d.G == 0) return run_seq_reduce(c, b, false);
     if (d.generic) return run_seq_fwd_generic(c, b, save);
-    if (d.stepk) {
-        StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
-        XhFillParams xp{};
-        xp.g = gen_params(c, b);
-        xp.keep = (!save || a->mask_seq || !(a->p_seq > 0.0f)) ? nullptr : c.at<uint8_t>(c.w.keep);
-        const int64_t nfill = (int64_t)xp.g.P * d.L * (d.H / 4);
-        if (nfill > 0) {
-            hipLaunchKernelGGL(xh_fill_kernel, dim3((unsigned)((nfill + 255) / 256)), dim3(256), 0, c.stream, xp);
-            PN_CHECK_HIP(hipGetLastError());
-        }
-        StepFwdParams sp{};
-        sp.xh = xp.g.xh;
-        sp.Wst = c.at<const u32x4>(c.w.Wp);
-        sp.biasc = xp.g.biasc;
-        sp.state = c.at<float>(c.w.dhn);        // (a backward-only buffer otherwise)
-        sp.saved = save ? c.at<float>(c.w.saved) : nullptr;
-        sp.hn = xp.g.hn;
-        sp.P = xp.g.P;
-        sp.L = d.L;
-        sp.rgx = std::max(1, 32 / (d.H / 16));
-        sp.dbg = getenv("PN_STEP_DBG") ? atoi(getenv("PN_STEP_DBG")) : 0;
-        if (sp.P <= 0) return PN_OK;
-        for (int t = 0; t < d.L; t++) {
-            sp.t = t;
-            if (int rc = dispatch_step_fwd(c.ctx, c.stream, d.H, d.cell == CELL_GRU, sp)) return rc;
-        }
-        return PN_OK;
-    }
     SeqFwdParams sp{};
     sp.Z = c.Z;
     sp.rowidx = c.at<int32_t>(c.w.rowidx);
