@@ -946,7 +946,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (RB > 1 ? 1 : fwd_waves<H, RG>())
 }
 
 // ================================================================================================
-// pool_fwd_kernel: one wavefront per pooling group (= output node).
+// pool_fwd_kernel: one workgroup (4 waves) per pooling group (= output node).
 // ================================================================================================
 struct PoolParams {
     int variant, S, W, H, C;
@@ -968,30 +968,27 @@ struct PoolParams {
 };
 
 __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
-    extern __shared__ float lds[];  // [4][W]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + wave;
-    if (g >= p.S) return;
-    float *sc = lds + wave * p.W;
-    const int H = p.H;
-    const float inv_w = 1.0f / (float)p.W;
-    // the ego rows of the group's members, fetched up front: the score loop then has no index -> row dependent load pair
-    int *s_erow = reinterpret_cast<int *>(lds + 4 * p.W) + wave * p.W;
-    if (p.variant != PN_VARIANT_PAGG) {
-        for (int mem = lane; mem < p.W; mem += 64) s_erow[mem] = p.egoidx[(int64_t)g * p.W + mem];
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-    }
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = blockIdx.x, H = p.H, W = p.W;
+    float *sc = lds;                                            // [W] scores, then coefficients
+    int *s_erow = reinterpret_cast<int *>(sc + W);              // [W] ego rows of the group's members
+    float *part4 = reinterpret_cast<float *>(s_erow + W);       // [4][H] the waves' partial pooled sums
+    float *l1s = part4 + 4 * H;                                 // [2H] classifier input
+    const float inv_w = 1.0f / (float)W;
 
     if (p.variant != PN_VARIANT_PAGG) {
-        // attention scores, 8 members at a time: lane = (member lane>>3, eighth of H lane&7); the eight partial
+        // the ego rows, fetched up front: the score loop then has no index -> row dependent load pair
+        for (int mem = tid; mem < W; mem += 256) s_erow[mem] = p.egoidx[(int64_t)g * W + mem];
+        __syncthreads();
+        // attention scores, 8 members per wave at a time: lane = (member lane>>3, eighth of H lane&7); the eight partial
         // dot products of a member are summed with three xor-shuffles
         const float ab = p.att_b[0];
         const int m8 = lane >> 3, part = lane & 7, jw = H / 8;
-        for (int m0 = 0; m0 < p.W; m0 += 8) {
+        for (int m0 = 8 * wave; m0 < W; m0 += 32) {
             const int mem = m0 + m8;
-            const int memc = min(mem, p.W - 1);
-            const int64_t s = (int64_t)g * p.W + memc;
+            const int memc = min(mem, W - 1);
+            const int64_t s = (int64_t)g * W + memc;
             const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + s * H + part * jw);
             const float4 *e4 = reinterpret_cast<const float4 *>(p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
             const float4 *a4 = reinterpret_cast<const float4 *>(p.att_w + part * jw);
@@ -1005,50 +1002,60 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             acc += __shfl_xor(acc, 4, 64);
-            if (part == 0 && mem < p.W) {
+            if (part == 0 && mem < W) {
                 sc[mem] = acc + ab;
-                p.rawsc[(int64_t)g * p.W + mem] = acc + ab;
+                p.rawsc[(int64_t)g * W + mem] = acc + ab;
             }
         }
+        __syncthreads();
     }
-    __builtin_amdgcn_wave_barrier();
     if (p.variant == PN_VARIANT_HETERO) {
-        // softmax over the W members of LeakyReLU(score) (F.softmax implicit dim 0 of [W,S,1])
+        // softmax over the W members of LeakyReLU(score) (F.softmax implicit dim 0 of [W,S,1]); every wave reduces
+        // all W scores (same order, same result), then each thread rewrites its own entries
         float mx = -3.4e38f;
-        for (int mem = lane; mem < p.W; mem += 64) {
+        for (int mem = lane; mem < W; mem += 64) {
             float v = sc[mem];
             v = v > 0.0f ? v : 0.01f * v;
             mx = fmaxf(mx, v);
         }
         mx = wave_max(mx);
         float sum = 0.0f;
-        for (int mem = lane; mem < p.W; mem += 64) {
+        for (int mem = lane; mem < W; mem += 64) {
             float v = sc[mem];
             v = v > 0.0f ? v : 0.01f * v;
             sum += expf(v - mx);
         }
         sum = wave_sum(sum);
-        for (int mem = lane; mem < p.W; mem += 64) {
+        __syncthreads();
+        for (int mem = tid; mem < W; mem += 256) {
             float v = sc[mem];
             v = v > 0.0f ? v : 0.01f * v;
             sc[mem] = expf(v - mx) / sum;
         }
     } else if (p.variant == PN_VARIANT_HOMO) {
-        for (int mem = lane; mem < p.W; mem += 64) sc[mem] = 1.0f + sc[mem];
+        for (int mem = tid; mem < W; mem += 256) sc[mem] = 1.0f + sc[mem];
     } else {
-        for (int mem = lane; mem < p.W; mem += 64) sc[mem] = 1.0f;
+        for (int mem = tid; mem < W; mem += 256) sc[mem] = 1.0f;
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int mem = lane; mem < p.W; mem += 64) p.coef[(int64_t)g * p.W + mem] = sc[mem];
+    __syncthreads();
+    for (int mem = tid; mem < W; mem += 256) p.coef[(int64_t)g * W + mem] = sc[mem];
 
-    // pooled = mean_w coef_w * h_w ; layer1 = dropout([Xh[sel[g]] ; pooled])
+    // pooled = mean_w coef_w * h_w: each wave sums its quarter of the members, the quarters meet in LDS (fixed order)
+    {
+        const int per = (W + 3) / 4, mem_end = min(W, (wave + 1) * per);
+        for (int j = lane; j < H; j += 64) {
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int mem = wave * per; mem < mem_end; mem++) acc += sc[mem] * p.hn[((int64_t)g * W + mem) * H + j];
+            part4[wave * H + j] = acc;
+        }
+    }
+    __syncthreads();
+    // layer1 = dropout([Xh[sel[g]] ; pooled])
     float *l1 = p.layer1 + (int64_t)g * 2 * H;
     const float *ego = p.Xh + (int64_t)p.sel[g] * H;
-    for (int j = lane; j < H; j += 64) {
-        float acc = 0.0f;
-#pragma unroll 8
-        for (int mem = 0; mem < p.W; mem++) acc += sc[mem] * p.hn[((int64_t)g * p.W + mem) * H + j];
-        float a = ego[j], b = acc * inv_w;
+    for (int j = tid; j < H; j += 256) {
+        float a = ego[j], b = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
         const uint64_t gg = (uint64_t)(p.goff + g);
         if (p.mask) {
             a *= p.mask[gg * 2 * H + j];
@@ -1063,12 +1070,13 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
         }
         l1[j] = a;
         l1[H + j] = b;
+        l1s[j] = a;
+        l1s[H + j] = b;
     }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    for (int c = 0; c < p.C; c++) {
+    __syncthreads();
+    for (int c = wave; c < p.C; c += 4) {
         float part = 0.0f;
-        for (int j = lane; j < 2 * H; j += 64) part += l1[j] * p.fc2_w[(int64_t)c * 2 * H + j];
+        for (int j = lane; j < 2 * H; j += 64) part += l1s[j] * p.fc2_w[(int64_t)c * 2 * H + j];
         part = wave_sum(part);
         if (lane == 0) p.out[(int64_t)g * p.C + c] = part + p.fc2_b[c];
     }
@@ -1732,48 +1740,70 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
 // (accumulate != 0: added to what the previous micro-batches left there)
 // (gru: the four slots r, z, nx, nh map to torch's [3H, H] layouts: W_i{r,z,n} = x halves of slots 0, 1, 2,
 //  W_h{r,z,n} = h halves of slots 0, 1, 3; b_i{r,z,n} = slots 0, 1, 2, b_h{r,z,n} = slots 0, 1, 3)
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part_w, const float *__restrict__ part_b, int nsplit,
-                                    int GH, int H, int accumulate, int gru, float *__restrict__ g_w_ih,
-                                    float *__restrict__ g_w_hh, float *__restrict__ g_b_ih,
-                                    float *__restrict__ g_b_hh) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nw = (int64_t)GH * 2 * H;
-    if (gru) {
-        if (i < nw) {
-            const int m = (int)(i / (2 * H)), n = (int)(i - (int64_t)m * 2 * H), slot = m / H, j = m - slot * H;
-            const bool xhalf = n < H;
-            if ((slot == 2 && !xhalf) || (slot == 3 && xhalf)) return;        // products with the zero halves
-            float s = 0.0f;
-            for (int z = 0; z < nsplit; z++) s += part_w[(int64_t)z * nw + i];
-            float *dst = xhalf ? g_w_ih : g_w_hh;
-            if (!dst) return;
-            dst += (int64_t)gru_weight_row(slot, j, H) * H + (xhalf ? n : n - H);
-            *dst = accumulate ? *dst + s : s;
-        } else if (i < nw + GH) {
-            const int m = (int)(i - nw), slot = m / H, j = m - slot * H;
-            float s = 0.0f;
-            for (int z = 0; z < nsplit; z++) s += part_b[(int64_t)z * GH + m];
-            const int wr = gru_weight_row(slot, j, H);
-            if (g_b_ih && slot != 3) g_b_ih[wr] = accumulate ? g_b_ih[wr] + s : s;
-            if (g_b_hh && slot != 2) g_b_hh[wr] = accumulate ? g_b_hh[wr] + s : s;
+// A block of 256 threads sums 64 float4 columns: thread (zg = tid >> 6, c = tid & 63) adds the splits z = zg, zg + 4, ...
+// with eight loads in flight, the four partial sums meet in LDS (fixed order: deterministic).  (One thread per element
+// walking all splits alone took 46 us for the 67 MB of partials of the bench workload.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part_w,
+                                                           const float *__restrict__ part_b, int nsplit, int GH, int H,
+                                                           int accumulate, int gru, float *__restrict__ g_w_ih,
+                                                           float *__restrict__ g_w_hh, float *__restrict__ g_b_ih,
+                                                           float *__restrict__ g_b_hh) {
+    __shared__ float4 red[3][64];
+    const int zg = threadIdx.x >> 6, c = threadIdx.x & 63;
+    const int64_t nw = (int64_t)GH * 2 * H, ntot = nw + GH;      // weights [GH, 2H], then the bias sums [GH]
+    const int64_t i0 = ((int64_t)blockIdx.x * 64 + c) * 4;       // (nw and GH are multiples of 4: no float4 straddles)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 < ntot) {
+        const bool bias = i0 >= nw;
+        const float *src = bias ? part_b + (i0 - nw) : part_w + i0;
+        const int64_t pitch = bias ? GH : nw;
+        float4 t[8];
+        int z = zg;
+        for (; z + 28 < nsplit; z += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = *reinterpret_cast<const float4 *>(src + (int64_t)(z + 4 * u) * pitch);
+#pragma unroll
+            for (int u = 0; u < 8; u++) s.x += t[u].x, s.y += t[u].y, s.z += t[u].z, s.w += t[u].w;
         }
-        return;
+        for (; z < nsplit; z += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)z * pitch);
+            s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+        }
     }
-    if (i < nw) {
-        float s = 0.0f;
-        for (int z = 0; z < nsplit; z++) s += part_w[(int64_t)z * nw + i];
-        const int m = (int)(i / (2 * H)), n = (int)(i - (int64_t)m * 2 * H);
-        if (n < H) {
-            if (g_w_ih) g_w_ih[(int64_t)m * H + n] = accumulate ? g_w_ih[(int64_t)m * H + n] + s : s;
-        } else if (g_w_hh) {
-            g_w_hh[(int64_t)m * H + (n - H)] = accumulate ? g_w_hh[(int64_t)m * H + (n - H)] + s : s;
+    if (zg > 0) red[zg - 1][c] = s;
+    __syncthreads();
+    if (zg > 0 || i0 >= ntot) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s.x += red[k][c].x, s.y += red[k][c].y, s.z += red[k][c].z, s.w += red[k][c].w;
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int64_t i = i0 + e;
+        const float v = sv[e];
+        if (i < nw) {
+            const int m = (int)(i / (2 * H)), n = (int)(i - (int64_t)m * 2 * H);
+            const bool xhalf = n < H;
+            int row = m;
+            if (gru) {
+                const int slot = m / H, j = m - slot * H;
+                if ((slot == 2 && !xhalf) || (slot == 3 && xhalf)) continue;        // products with the zero halves
+                row = gru_weight_row(slot, j, H);
+            }
+            float *dst = xhalf ? g_w_ih : g_w_hh;
+            if (!dst) continue;
+            dst += (int64_t)row * H + (xhalf ? n : n - H);
+            *dst = accumulate ? *dst + v : v;
+        } else {
+            const int m = (int)(i - nw);
+            if (gru) {
+                const int slot = m / H, j = m - slot * H, wr = gru_weight_row(slot, j, H);
+                if (g_b_ih && slot != 3) g_b_ih[wr] = accumulate ? g_b_ih[wr] + v : v;
+                if (g_b_hh && slot != 2) g_b_hh[wr] = accumulate ? g_b_hh[wr] + v : v;
+            } else {
+                if (g_b_ih) g_b_ih[m] = accumulate ? g_b_ih[m] + v : v;
+                if (g_b_hh) g_b_hh[m] = accumulate ? g_b_hh[m] + v : v;
+            }
         }
-    } else if (i < nw + GH) {
-        const int m = (int)(i - nw);
-        float s = 0.0f;
-        for (int z = 0; z < nsplit; z++) s += part_b[(int64_t)z * GH + m];
-        if (g_b_ih) g_b_ih[m] = accumulate ? g_b_ih[m] + s : s;
-        if (g_b_hh) g_b_hh[m] = accumulate ? g_b_hh[m] + s : s;
     }
 }
 
@@ -1919,7 +1949,7 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
         PN_FAIL(PN_ERR_ARG, "hidden size %d not supported (multiples of 32 up to 1024; fused kernels up to 256)", s.H);
     if (s.N < 1 || s.F < 1 || s.C < 1 || s.S < 0 || s.W < 1 || s.L < 1 || s.L > 64)
         PN_FAIL(PN_ERR_ARG, "bad aggregator shape N=%d F=%d C=%d S=%d W=%d L=%d", s.N, s.F, s.C, s.S, s.W, s.L);
-    // the pooling kernels keep per-walk scores, coefficients and ego rows of four nodes in LDS (64 W + 48 H bytes)
+    // the pooling kernels keep per-walk scores, coefficients, ego rows and a few rows of H floats in LDS
     if (64 * (int64_t)s.W + 48 * s.H > 64 * 1024)
         PN_FAIL(PN_ERR_ARG, "W=%d walks per node exceed the pooling kernels' LDS budget (W <= %d at H=%d)", s.W,
                 (64 * 1024 - 48 * s.H) / 64, s.H);
@@ -2295,7 +2325,7 @@ int run_pool_fwd(const Call &c, int b, float *out) {
     pp.layer1 = c.at<float>(c.w.layer1);
     pp.out = out;
     StageTimer tm(c.ctx, ST_POOL_FWD, c.stream);
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3((pp.S + 3) / 4), dim3(256), (size_t)8 * d.W * sizeof(float), c.stream, pp);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(pp.S), dim3(256), (size_t)(2 * d.W + 6 * d.H) * sizeof(float), c.stream, pp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
