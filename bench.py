@@ -455,6 +455,16 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
         "stages_ms": mh["stages_ms"]}
     del hsr
 
+    # ---- configs[4] on one GPU: 10 M-node Erdos-Renyi graph, path_len 6, exact on-the-fly sampler + a micro-batched step -
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs4
+        torch.cuda.empty_cache()
+        out["configs4_one_gpu_step"] = bench_configs4.run(10_000_000, 100_000, 2)
+    except Exception as e:      # (an untimed extra must not take the headline line down with it)
+        out["configs4_one_gpu_step"] = {"error": repr(e)[:300]}
+    torch.cuda.empty_cache()
+
     # ---- the path-feature gather against HBM: a table that cannot sit in the 256 MB Infinity Cache -------------------
     Ng, Sg = 1 << 20, 9464                      # Z table [2^20, L, H] fp32 = 2 GB; Pubmed's path count
     table = torch.randn(Ng, L, H, device=dev)

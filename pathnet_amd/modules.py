@@ -33,6 +33,7 @@ _HEAD_PARAMS = ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_
 # below this many bytes: a batch with more paths is walked in micro-batches inside the library (pn_pagg_shape
 # .batch_groups), the backward re-running each micro-batch's recurrence.  Cora / Pubmed-size batches fit in one.
 WORKSPACE_BUDGET_BYTES = 48 << 30
+MIN_BATCH_BYTES = 8 << 30           # floor of the per-micro-batch part (pick_batch_groups)
 
 
 def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None):
@@ -53,12 +54,14 @@ def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batc
 
 def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None):
     """0 when the whole batch fits the workspace budget, else the largest micro-batch (in masked nodes) that does."""
+    floor = MIN_BATCH_BYTES if budget is None else 0       # an explicit budget is kept to the byte
     budget = WORKSPACE_BUDGET_BYTES if budget is None else int(budget)
     if S <= 1 or workspace_bytes(variant, N, F, H, C, S, W, L, cell=cell) <= budget:
         return 0
-    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L, cell=cell)
+    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L, cell=cell)         # the node tables: needed whatever the batch
     per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L, cell=cell) - fixed) // 1024, 1)
-    return int(max(1, min(S, (budget - fixed) // per_group if budget > fixed else 1)))
+    avail = max(budget - fixed, floor)       # default budget: graphs whose tables alone exceed it still get real batches
+    return int(max(1, min(S, avail // per_group if avail > 0 else 1)))
 
 
 def _cfg_workspace_bytes(cfg):
