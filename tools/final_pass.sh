@@ -1,0 +1,20 @@
+#!/bin/bash
+# One GPU session that regenerates what profiles/ quotes for the current build (every step under its own timeout):
+#   bash tools/final_pass.sh gpurun_out/final
+set -u
+OUT=${1:-gpurun_out/final}
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --maxfail=10 > $OUT/tests.log 2>&1
+tail -3 $OUT/tests.log
+timeout 420 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -2 $OUT/bench.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/kt.log 2>&1
+DB=$(find $OUT/kt -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats.md > /dev/null
+CSV=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
+[ -n "$CSV" ] && cp $CSV $OUT/kernel_stats.csv
+PMC_TIMEOUT=240 bash tools/pmc_passes.sh $OUT/pmc
+PN_BENCH_FORCE_SHARDED=1 timeout 200 python bench.py --workload bgp --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $OUT/bgp_sharded_path.json 2> $OUT/bgp_sharded_path.err
+tail -1 $OUT/bgp_sharded_path.err
+ls $OUT $OUT/pmc

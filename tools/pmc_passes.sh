@@ -11,7 +11,7 @@ mkdir -p $OUT
 run_set() {   # workload, pass number, counters...
   local WL=$1; local N=$2; shift 2
   mkdir -p $OUT/$WL
-  rocprofv3 --pmc "$@" --kernel-include-regex "$RE" --output-format csv -d $OUT/$WL/pass$N -o p$N -- \
+  timeout ${PMC_TIMEOUT:-240} rocprofv3 --pmc "$@" --kernel-include-regex "$RE" --output-format csv -d $OUT/$WL/pass$N -o p$N -- \
      python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --workload $WL > $OUT/$WL/pass$N.log 2>&1
   echo "$WL pass $N rc=$?" >> $OUT/summary.txt
 }
