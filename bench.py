@@ -526,12 +526,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    local_rank %= max(1, torch.cuda.device_count())     # (ranks share GPUs only in the one-GPU tests of the N > 1 path)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # PN_DIST_BACKEND=gloo: the N > 1 path with the ranks sharing one GPU (tests; RCCL needs a GPU per rank) -- dist.Comm
+    # stages the device tensors through the host, the scalars below travel as host tensors
+    backend = os.environ.get("PN_DIST_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import pathnet_amd      # noqa: F401
     from pathnet_amd import _lib
@@ -563,10 +571,10 @@ def main():
     collectives = None
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s_tot = torch.tensor([S], dtype=torch.int64, device=dev)
+        s_tot = torch.tensor([S], dtype=torch.int64, device=red_dev)
         dist.all_reduce(s_tot)
         S_total = int(s_tot.item())
         # untimed: a few steps with every collective bracketed by device synchronisation, per rank

@@ -76,15 +76,34 @@ class Comm:
         self.seconds[kind] += time.perf_counter() - t0
         return out
 
-    # -- primitives (overridden by the host-staging test double) ---------------------------------------------------
+    # -- primitives: RCCL moves device memory; a backend that moves host memory (gloo: two ranks on ONE GPU in the tests,
+    #    where RCCL refuses to run) gets the device tensors staged through the host ------------------------------------
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
     def _all_gather(self, out, inp):
-        dist.all_gather_into_tensor(out, inp, group=self.group)
+        if self._staged(inp):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def _reduce_scatter(self, out, inp):
-        dist.reduce_scatter_tensor(out, inp, group=self.group)
+        if self._staged(inp):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.reduce_scatter_tensor(o, inp.cpu(), group=self.group)
+            out.copy_(o)
+        else:
+            dist.reduce_scatter_tensor(out, inp, group=self.group)
 
     def _all_reduce(self, t):
-        dist.all_reduce(t, group=self.group)
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
 
     # -- what a step uses ----------------------------------------------------------------------------------------------
     def all_gather_rows(self, t, kind="all_gather_Xh"):
