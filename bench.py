@@ -449,7 +449,7 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
     mh = measure(hsr, lib, ctx, names, steps_h, 2, torch.cuda.synchronize)
     Ph = hsr.S * W
     out["hid512_step"] = {
-        "config": "bench graph, hid=512 (generic recurrence: one fp32 GEMM per step + cell kernels), %d paths/step" % Ph,
+        "config": "bench graph, hid=512 (generic recurrence: one bf16x3 MFMA GEMM per step + cell kernels), %d paths/step" % Ph,
         "value": Ph / (mh["elapsed"] / steps_h), "unit": "paths/s", "ms_per_step": mh["elapsed"] / steps_h * 1e3,
         "steps": steps_h, "roofline": roofline_block(mh["dominant"], mh["dom_ms"], mh["dom_launches"], Ph, L, 512, None),
         "stages_ms": mh["stages_ms"]}

@@ -237,6 +237,129 @@ int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, co
     return PN_OK;
 }
 
+// ================================================================================================
+// gemm3_kernel: C[m][n] = sum_k A[m*lda + k] * B[n*ldb + k] (+ bias[n]) with fp32 results from the bf16 matrix pipe
+// (pn_kernels.h: three planes, six MFMAs per product) -- the step GEMMs of the generic recurrence (hid > 256), where
+// the fp32-input MFMA of gemm_kernel is the bound.  Both operands K-contiguous, K a multiple of 32.
+//   128 x 128 block tile, 4 waves of 64 x 64 (2 x 2 MFMA tiles of 32 x 32 x 16), K tile 32.  A thread fetches four
+//   float4 of each operand per K tile (asm loads, one K tile ahead), splits them into the three planes on the way to
+//   LDS; plane rows are 64 B of bf16 + 16 B of padding: conflict-free ds_read_b128 fragments.  60 KB of LDS: two
+//   workgroups per CU.
+// ================================================================================================
+constexpr int G3_BM = 128, G3_BN = 128, G3_KT = 32, G3_PITCH = 80, G3_PLANE = 128 * G3_PITCH;
+struct Gemm3Params {
+    const float *A;
+    int64_t lda;
+    const float *B;
+    int64_t ldb;
+    float *C;
+    int64_t ldc;
+    const float *bias;
+    int M, N, K;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[6 * G3_PLANE];     // A planes 0..2 | B planes 0..2
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * G3_BM, n0 = blockIdx.x * G3_BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    // staging: thread -> rows lr + 32 i (i < 4) of the tile, floats lk .. lk + 3 of the K tile (rows past M / N: clamped,
+    // their results are never stored)
+    const int lr = tid >> 3, lk = 4 * (tid & 7);
+    const float *ap[4], *bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ap[i] = p.A + (int64_t)min(m0 + lr + 32 * i, p.M - 1) * p.lda + lk;
+        bp[i] = p.B + (int64_t)min(n0 + lr + 32 * i, p.N - 1) * p.ldb + lk;
+    }
+    f32x4 ra[4], rb[4];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            async_load_b128(ra[i], ap[i] + k0);
+            async_load_b128(rb[i], bp[i] + k0);
+        }
+    };
+    auto commit = [&]() {
+        wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned char *da = lds + (lr + 32 * i) * G3_PITCH + 2 * lk, *db = da + 3 * G3_PLANE;
+            uint32_t x0, x1, x2, y0, y1, y2;
+            split3(ra[i][0], ra[i][1], x0, x1, x2);
+            split3(ra[i][2], ra[i][3], y0, y1, y2);
+            *reinterpret_cast<uint2 *>(da) = make_uint2(x0, y0);
+            *reinterpret_cast<uint2 *>(da + G3_PLANE) = make_uint2(x1, y1);
+            *reinterpret_cast<uint2 *>(da + 2 * G3_PLANE) = make_uint2(x2, y2);
+            split3(rb[i][0], rb[i][1], x0, x1, x2);
+            split3(rb[i][2], rb[i][3], y0, y1, y2);
+            *reinterpret_cast<uint2 *>(db) = make_uint2(x0, y0);
+            *reinterpret_cast<uint2 *>(db + G3_PLANE) = make_uint2(x1, y1);
+            *reinterpret_cast<uint2 *>(db + 2 * G3_PLANE) = make_uint2(x2, y2);
+        }
+    };
+    const unsigned char *fa = lds + (wm * 64 + li) * G3_PITCH + 16 * hk;
+    const unsigned char *fb = lds + 3 * G3_PLANE + (wn * 64 + li) * G3_PITCH + 16 * hk;
+    issue(0);
+    for (int k0 = 0; k0 < p.K; k0 += G3_KT) {
+        commit();
+        __syncthreads();
+        issue(min(k0 + G3_KT, p.K - G3_KT));        // last trip: harmless re-load, drained below (no branch before the wait)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            u32x4 a[2][3], b[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    a[t][pl] = *reinterpret_cast<const u32x4 *>(fa + pl * G3_PLANE + t * 32 * G3_PITCH + 32 * ks);
+                    b[t][pl] = *reinterpret_cast<const u32x4 *>(fb + pl * G3_PLANE + t * 32 * G3_PITCH + 32 * ks);
+                }
+            // a2.b0 a1.b0 a0.b0 | a1.b1 a0.b1 | a0.b2, each over the four accumulators
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const int pa = q == 0 ? 2 : (q == 1 || q == 3) ? 1 : 0, pb = q < 3 ? 0 : q < 5 ? 1 : 2;
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = mfma_bf16(a[i][pa], b[j][pb], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int col = n0 + wn * 64 + j * 32 + li;
+        if (col >= p.N) continue;
+        const float bias = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (row < p.M) p.C[(int64_t)row * p.ldc + col] = acc[i][j][r] + bias;
+            }
+    }
+}
+
+int launch_gemm3(hipStream_t stream, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
+                 const float *bias, int M, int N, int K) {
+    if (M <= 0 || N <= 0) return PN_OK;
+    if (K < G3_KT || K % G3_KT != 0) PN_FAIL(PN_ERR_ARG, "gemm3: K=%d is not a multiple of %d", K, G3_KT);
+    Gemm3Params p{A, lda, B, ldb, C, ldc, bias, M, N, K};
+    hipLaunchKernelGGL(gemm3_kernel, dim3((N + G3_BN - 1) / G3_BN, (M + G3_BM - 1) / G3_BM), dim3(256), 0, stream, p);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
 // ---- deterministic split-K for the STORE / ADD GEMMs -------------------------------------------------------------
 // The node-level GEMMs (fc0: 2708 x 128 x 1433, the bank backward) are 86 workgroups of 64 x 64 -- a third of the
 // CUs, each walking all of K alone, one wave per SIMD.  With K cut into nz chunks there are nz times as many
@@ -552,10 +675,11 @@ __global__ __launch_bounds__(256) void gen_scatter_kernel(GenParams p) {
     }
 }
 
-// Wcat [GH, 2H] = [W_ih | W_hh] in fp32 (GRU: the four slots with their zero halves), biasc as in pack_fwd3_kernel
+// Wcat [GH, 2H] = [W_ih | W_hh] in fp32 (GRU: the four slots with their zero halves) and its transpose, biasc as in
+// pack_fwd3_kernel
 __global__ void gen_pack_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G, int gru,
-                                float *__restrict__ Wcat, float *__restrict__ biasc) {
+                                float *__restrict__ Wcat, float *__restrict__ WcatT, float *__restrict__ biasc) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (int64_t)G * H) {
         if (!gru) {
@@ -571,6 +695,7 @@ __global__ void gen_pack_kernel(const float *__restrict__ w_ih, const float *__r
     float v = k < H ? w_ih[(int64_t)row * H + k] : w_hh[(int64_t)row * H + (k - H)];
     if (gru && ((slot == 2 && k >= H) || (slot == 3 && k < H))) v = 0.0f;
     Wcat[i] = v;
+    WcatT[(int64_t)k * G * H + m] = v;      // [2H, GH]: the BPTT's GEMM wants its B operand K-contiguous too
 }
 
 struct SeqFwdParams {
@@ -2160,9 +2285,8 @@ int run_seq_fwd_generic(const Call &c, int b, bool save) {
         hipLaunchKernelGGL(gen_x_kernel, dim3(bx), dim3(256), 0, c.stream, gp);
         PN_CHECK_HIP(hipGetLastError());
         // pre[q, :] = [x_t | h_{t-1}] . Wcat^T + b      (step 0: h_{-1} = 0, the x half of K suffices)
-        if (int rc = launch_gemm(c.stream, gp.xh + (size_t)t * 2 * H, (int64_t)d.L * 2 * H, 1, nullptr, Wcat, 2 * H, 1,
-                                 gp.pre + (size_t)t * GH, (int64_t)d.L * GH, gp.biasc, P, GH, t == 0 ? H : 2 * H, 0,
-                                 GEMM_STORE, 1))
+        if (int rc = launch_gemm3(c.stream, gp.xh + (size_t)t * 2 * H, (int64_t)d.L * 2 * H, Wcat, 2 * H,
+                                  gp.pre + (size_t)t * GH, (int64_t)d.L * GH, gp.biasc, P, GH, t == 0 ? H : 2 * H))
             return rc;
         hipLaunchKernelGGL(gen_cell_fwd_kernel, dim3(be), dim3(256), 0, c.stream, gp);
         PN_CHECK_HIP(hipGetLastError());
@@ -2170,16 +2294,15 @@ int run_seq_fwd_generic(const Call &c, int b, bool save) {
     return PN_OK;
 }
 
-// BPTT of micro-batch b + the weight-gradient GEMM (accumulating into the caller's gradients when accumulate != 0)
-int run_seq_bwd_generic(const Call &c, int b, int accumulate) {
+// BPTT of micro-batch b (the weight gradient dG^T . [x | h] is the fused path's wgrad3_kernel: it has no size limit)
+int run_seq_bwd_generic(const Call &c, int b) {
     const Dims &d = c.d;
-    const pn_pagg_args *a = c.a;
     GenParams gp = gen_params(c, b);
     gp.saved = c.at<float>(c.w.saved);
     gp.dh = c.at<float>(c.w.dhn);               // d loss / d h_n from the pooling backward, then d h_{t-1} step by step
     gp.state = c.at<float>(c.w.hn);             // (the pooling backward is done with h_n: d c / the GRU's direct term live there)
     const int H = d.H, GH = d.G * H, P = gp.P;
-    const float *Wcat = c.at<const float>(c.w.Wp);
+    const float *WcatT = c.at<const float>(c.w.WpT);
     float *gx = c.at<float>(c.w.gx);
     const unsigned bx = (unsigned)(((int64_t)P * (H / 4) + 255) / 256), be = (unsigned)(((int64_t)P * H + 255) / 256);
     {
@@ -2189,34 +2312,13 @@ int run_seq_bwd_generic(const Call &c, int b, int accumulate) {
             hipLaunchKernelGGL(gen_cell_bwd_kernel, dim3(be), dim3(256), 0, c.stream, gp);
             PN_CHECK_HIP(hipGetLastError());
             // [dx_t | dh_{t-1}] = dG_t . [W_ih | W_hh]      (step 0: the dx half suffices)
-            if (int rc = launch_gemm(c.stream, gp.pre + (size_t)t * GH, (int64_t)d.L * GH, 1, nullptr, Wcat, 1, 2 * H, gx,
-                                     2 * H, nullptr, P, t == 0 ? H : 2 * H, GH, 0, GEMM_STORE, 1))
+            if (int rc = launch_gemm3(c.stream, gp.pre + (size_t)t * GH, (int64_t)d.L * GH, WcatT, GH, gx, 2 * H, nullptr, P,
+                                      t == 0 ? H : 2 * H, GH))
                 return rc;
             hipLaunchKernelGGL(gen_scatter_kernel, dim3(bx), dim3(256), 0, c.stream, gp);
             PN_CHECK_HIP(hipGetLastError());
         }
     }
-    if (!(a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) return PN_OK;
-    // [g_W_ih | g_W_hh] = dG^T . xh, g_b = colsum(dG): one split-K GEMM with atomics into a zeroed [GH, 2H] + [GH] buffer
-    StageTimer tm(c.ctx, ST_WGRAD, c.stream);
-    float *part_w = c.at<float>(c.w.wpart), *part_b = part_w + (size_t)c.w.wgrad_split * GH * 2 * H;
-    ZeroList zl{};
-    zl.ptr[0] = part_w;
-    zl.count[0] = (unsigned long long)GH * 2 * H;
-    zl.ptr[1] = part_b;
-    zl.count[1] = (unsigned long long)GH;
-    zl.n = 2;
-    hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, c.stream, zl);
-    PN_CHECK_HIP(hipGetLastError());
-    const int64_t R = (int64_t)P * d.L;
-    if (R > 2000000000LL) PN_FAIL(PN_ERR_ARG, "generic recurrence: %lld path steps in one micro-batch", (long long)R);
-    if (int rc = launch_gemm(c.stream, gp.pre, 1, GH, nullptr, gp.xh, 1, 2 * H, part_w, 2 * H, nullptr, GH, 2 * H, (int)R, 0,
-                             GEMM_ATOMIC, (int)((R + 511) / 512), part_b))
-        return rc;
-    const int64_t nred = (int64_t)GH * 2 * H + GH;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, c.stream, part_w, part_b, 1,
-                       GH, H, accumulate, d.cell == CELL_GRU ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
-    PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
 
@@ -2227,7 +2329,7 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
         const int64_t n = (int64_t)d.G * d.H * 2 * d.H;
         hipLaunchKernelGGL(gen_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.a->w_ih, c.a->w_hh,
                            c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, c.at<float>(c.w.Wp),
-                           c.at<float>(c.w.biasc));
+                           c.at<float>(c.w.WpT), c.at<float>(c.w.biasc));
         PN_CHECK_HIP(hipGetLastError());
         return PN_OK;
     }
@@ -2649,7 +2751,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
         if (G == 0) {
             if (int rc = run_seq_reduce(c, b, true)) return rc;
         } else if (d.generic) {
-            if (int rc = run_seq_bwd_generic(c, b, b > 0 ? 1 : 0)) return rc;
+            if (int rc = run_seq_bwd_generic(c, b)) return rc;
         } else {
             StageTimer tm(ctx, ST_SEQ_BWD, stream);
             SeqBwdParams sp{};
@@ -2674,7 +2776,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
         }
 
         // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG)
-        if (G > 0 && !d.generic && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) {
+        if (G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) {
             hipStream_t wstream = stream;
             if (PN_BWD_OVERLAP && side_ok)
                 if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;
