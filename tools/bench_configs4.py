@@ -48,7 +48,7 @@ def run(n=10_000_000, S=400_000, steps=2):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        return loss
+        return float(loss.detach())     # (a live loss would keep the step's graph -- and its 74 GB workspace -- alive)
 
     step(0)
     torch.cuda.synchronize()
@@ -67,7 +67,7 @@ def run(n=10_000_000, S=400_000, steps=2):
         "config": "configs[4] on one GPU: Erdos-Renyi n=%d deg~16 (%d edge rows), feat=%d hid=%d path_num=%d path_len=%d, "
                   "%d masked nodes = %d paths/step, PathNet_homo, dropout 0.7, Adam; exact on-the-fly hop codes" %
                   (n, len(g[1]), F, H, W, L, S, S * W),
-        "seconds_per_step": dt, "paths_per_s": S * W / dt, "loss": float(loss.detach()),
+        "seconds_per_step": dt, "paths_per_s": S * W / dt, "loss": loss,
         "micro_batch_nodes": bg, "micro_batches": (S + bg - 1) // bg if bg else 1,
         "workspace_GB": round(modules.workspace_bytes("homo", n, F, H, C, S, W, L, batch_groups=bg) / 2 ** 30, 1),
         "torch_max_allocated_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
