@@ -382,6 +382,26 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
                       "ms_per_launch": dt * 1e3, "hop_table": "dense %d^2 B (cache resident)" % wl["n"]}
     del ids_big, codes_big
 
+    # ---- forward only (metric (i): "report forward-only too"): the inference forward of the headline
+    #      workload -- eval mode, nothing saved for a backward -- and the training forward (dropout, saved tensors) ----------
+    ids_f, codes_f = sr.ids_buf[0], sr.codes_buf[0]
+
+    def fwd_eval():
+        with torch.no_grad():
+            sr.model(sr.X, ids_f, W, L, sr.sel32, codes_f, None)
+
+    def fwd_train():
+        sr.model(sr.X, ids_f, W, L, sr.sel32, codes_f, None)
+    sr.model.eval()
+    dt_e = time_launches(fwd_eval, 50)
+    sr.model.train()
+    dt_t = time_launches(fwd_train, 50)
+    out["forward_only"] = {"inference": {"value": sr.S * W / dt_e, "unit": "paths/s", "ms": dt_e * 1e3},
+                           "training_forward": {"value": sr.S * W / dt_t, "unit": "paths/s", "ms": dt_t * 1e3},
+                           "note": "PAGG forward alone on the headline workload (paths already sampled and resident): fc0, "
+                                   "bank, recurrence, pooling, classifier; the training forward also draws the dropout masks "
+                                   "and writes the tensors the backward reads"}
+
     # ---- configs[2]: Pubmed-scale full training step (on-GPU MERW sampler + PAGG fwd/bwd + Adam) ---------------------
     pw = pubmed_workload()
     t0 = time.time()
