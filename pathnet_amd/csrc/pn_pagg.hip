@@ -1675,18 +1675,61 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
         __syncthreads();
         PN_STAMP(4 * (p.L - 1 - t) + 2);
 
+        // ---- gather backward: dZ[row(q, t)] += mask * dx.  Step 0 is the last one of the kernel and its rows are the
+        //      paths' own start nodes: the W paths of a node all add to the same table row, 32 atomics per column on one
+        //      address (0.033 of the kernel's 0.49 ms, by ablation).  There the wave parks its 32 x 32 block in the (now dead)
+        //      plane region, and each half-wave walks 16 rows in order, adding up runs of equal table rows: one atomic per
+        //      run and column -- two to four instead of thirty-two.
+        // (hidden sizes that are not powers of two sit at the register limit already: they keep the plain scatter)
+        constexpr bool MERGE_STEP0 = (H & (H - 1)) == 0;
+        if (MERGE_STEP0 && t == 0) {
+            static_assert(3 * PLANE >= NW * RG * 32 * 33 * 4, "the scatter scratch fits the plane region");
+            const int lane_s = fresh_lane(), li_s = lane_s & 31;       // (re-derived here: nothing of this block is hoisted)
+            float *scr = reinterpret_cast<float *>(ldsb) + wave_u * (32 * 33);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = r0 + acc_row(r, lane_t);
-            if (q0 + row < p.P) {
+            for (int r = 0; r < 16; r++) {
+                const int rl = acc_row(r, lane_s), row = r0 + rl;
                 float dx = acc[0][r];
-                if (p.mask)
-                    dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col];
-                else if (p.keep)
-                    dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col >> 2)] >> (col & 3)) & 1 ? dx * keep_scale : 0.0f;
-                atomicAdd(p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col), dx);
+                if (q0 + row < p.P) {
+                    if (p.mask)
+                        dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col];
+                    else if (p.keep)
+                        dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col >> 2)] >> (col & 3)) & 1 ? dx * keep_scale : 0.0f;
+                }
+                scr[rl * 33 + li_s] = dx;
             }
-            dh[r] = GRU ? acc[1][r] + dc[r] : acc[1][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int hk = lane_s >> 5;
+            int cur = -1;
+            float run = 0.0f;
+#pragma unroll 1
+            for (int i = 0; i < 16; i++) {
+                const int rl = 16 * hk + i, row = r0 + rl;
+                const int rid = q0 + row < p.P ? s_rowidx[row * p.L] : -1;       // (uniform over a half-wave)
+                if (rid != cur) {
+                    if (cur >= 0) atomicAdd(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
+                    cur = rid;
+                    run = 0.0f;
+                }
+                run += scr[rl * 33 + li_s];
+            }
+            if (cur >= 0) atomicAdd(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = r0 + acc_row(r, lane_t);
+                if (q0 + row < p.P) {
+                    float dx = acc[0][r];
+                    if (p.mask)
+                        dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col];
+                    else if (p.keep)
+                        dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col >> 2)] >> (col & 3)) & 1 ? dx * keep_scale : 0.0f;
+                    atomicAdd(p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col), dx);
+                }
+                dh[r] = GRU ? acc[1][r] + dc[r] : acc[1][r];
+            }
         }
         PN_STAMP(4 * (p.L - 1 - t) + 3);
     }
