@@ -1373,6 +1373,7 @@ struct SeqBwdParams {
     float *dG;              // [P, L, G*H] pre-activation gate gradients (input of the weight-gradient GEMM)
     float *dZ;              // [N*L, H]    += d x_t   (atomic scatter: the backward of the row gather)
     int P, L;
+    int merge0;             // step 0 scatters the W paths of a node into one table row (homo / PAGG index plans): add up runs first
     int64_t Pmask;          // slots of the whole batch (explicit mask [L, Pmask, H])
     float p_drop;
     uint64_t seed;
@@ -1682,7 +1683,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
         //      run and column -- two to four instead of thirty-two.
         // (hidden sizes that are not powers of two sit at the register limit already: they keep the plain scatter)
         constexpr bool MERGE_STEP0 = (H & (H - 1)) == 0;
-        if (MERGE_STEP0 && t == 0) {
+        if (MERGE_STEP0 && t == 0 && p.merge0) {
             static_assert(3 * PLANE >= NW * RG * 32 * 33 * 4, "the scatter scratch fits the plane region");
             const int lane_s = fresh_lane(), li_s = lane_s & 31;       // (re-derived here: nothing of this block is hoisted)
             float *scr = reinterpret_cast<float *>(ldsb) + wave_u * (32 * 33);
@@ -2812,6 +2813,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             sp.p_drop = a->p_seq;
             sp.seed = a->seed;
             sp.mask = a->mask_seq;
+            sp.merge0 = d.variant != PN_VARIANT_HETERO;     // (the hetero plan's step-0 rows are other paths' far ends: no runs)
             if (int rc = (d.cell == CELL_GRU    ? dispatch_seq_bwd<3>(ctx, stream, H, sp)
                           : d.cell == CELL_LSTM ? dispatch_seq_bwd<4>(ctx, stream, H, sp)
                                                 : dispatch_seq_bwd<1>(ctx, stream, H, sp)))
