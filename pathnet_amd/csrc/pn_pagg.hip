@@ -38,6 +38,7 @@
 
 #include "pn_internal.h"
 #include "pn_kernels.h"
+#include "pn_seq.h"
 
 using namespace pn;
 
@@ -698,25 +699,7 @@ __global__ void gen_pack_kernel(const float *__restrict__ w_ih, const float *__r
     WcatT[(int64_t)k * G * H + m] = v;      // [2H, GH]: the BPTT's GEMM wants its B operand K-contiguous too
 }
 
-struct SeqFwdParams {
-    const float *Z;         // [N*L, H] bank output (post activation)
-    const int32_t *rowidx;  // [P, L]
-    const int32_t *slotof;  // [P]
-    const float *Wp;        // packed recurrent weights
-    const float *biasc;     // [G*H]
-    float *hn;              // [P, H] final hidden state per slot'
-    float *saved;           // [P, L, SV, H]  SV = 5 (i,f,g,o,c) for LSTM, 1 (h_t) for RNN; may be null
-    float *xh;              // [P, L, 2H]     the recurrent GEMM's input rows [x_t (after dropout) | h_{t-1}]:
-                            //                the weight-gradient GEMM of the backward reads them back; may be null
-    uint8_t *keep;          // [P, L, H/4]    built-in dropout: keep bits of columns 4c .. 4c+3 in bits 0-3 (the backward
-                            //                reads them instead of re-drawing the Philox stream); may be null
-    int P, L;               // slots of this launch (one micro-batch), path length
-    int64_t Pmask;          // slots of the WHOLE batch: the dropout counters / the explicit mask are [L, Pmask, H]
-    float p_drop;
-    uint64_t seed;
-    const pn_step_state *dyn;   // seed in device memory when set (hipGraph replay)
-    const float *mask;      // [L, Pmask, H] explicit mask (reference order: original slot q) or null
-};
+// (SeqFwdParams: pn_seq.h)
 
 // ================================================================================================
 // The same recurrence on the bf16 matrix pipe (pn_kernels.h: fp32 = three bf16 planes, six MFMAs per product).
@@ -1364,21 +1347,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 }
 
 // ---- BPTT through the recurrent cell, fused with the gather-backward scatter ---------------------
-struct SeqBwdParams {
-    const float *saved;     // [P, L, SV, H]
-    const uint8_t *keep;    // [P, L, H/4] keep bits of the forward's built-in dropout, or null
-    const float *dhn;       // [P, H]
-    const int32_t *rowidx, *slotof;
-    const float *WpT;
-    float *dG;              // [P, L, G*H] pre-activation gate gradients (input of the weight-gradient GEMM)
-    float *dZ;              // [N*L, H]    += d x_t   (atomic scatter: the backward of the row gather)
-    int P, L;
-    int merge0;             // step 0 scatters the W paths of a node into one table row (homo / PAGG index plans): add up runs first
-    int64_t Pmask;          // slots of the whole batch (explicit mask [L, Pmask, H])
-    float p_drop;
-    uint64_t seed;
-    const float *mask;
-};
+// (SeqBwdParams: pn_seq.h)
 
 // ---- the same BPTT on the bf16 matrix pipe (pn_kernels.h) --------------------------------------------------------
 //   [dx_t | dh_{t-1}] = dG_t [32, G*H] . [W_ih | W_hh]:  K = G*H gate columns, wave w owns columns 32w..32w+31 of dx and of dh.
@@ -1744,15 +1713,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
 //      wgrad_reduce_kernel (deterministic, no atomics). -----------------------------------------------
 constexpr int WG_BM = 256, WG_BN = 256, WG_KT = 32, WG_THREADS = 512;
 
-struct WgradParams {
-    const float *dG;   // [R, GH]
-    const float *xh;   // [R, 2H]
-    int64_t R;
-    int GH, H2;
-    int64_t rows_per_split;
-    float *part_w;     // [nsplit, GH, 2H]
-    float *part_b;     // [nsplit, GH]
-};
+// (WgradParams: pn_seq.h)
 
 // ---- the same GEMM on the bf16 matrix pipe (pn_kernels.h: six bf16 MFMAs = one fp32-accurate product) -----------
 // Both operands have the reduction dimension (rows) outermost, the bf16 MFMA wants 8 consecutive k per lane.  A
@@ -2377,6 +2338,9 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
         PN_CHECK_HIP(hipGetLastError());
         return PN_OK;
     }
+    if (seq4_select(d.H, d.G, d.L) & SEQ4_FWD)      // the 128-path kernel reads its own fragment order (pn_seq4.hip)
+        return launch_pack_fwd4(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0,
+                                c.at<void>(c.w.Wp), c.at<float>(c.w.biasc));
     hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((d.G * d.H * d.H / 4 + 255) / 256)), dim3(256), 0, s, c.a->w_ih,
                        c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.Wp),
                        c.at<float>(c.w.biasc));
@@ -2437,6 +2401,11 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     sp.dyn = a->step_state;
     sp.mask = a->mask_seq;
     StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
+    if (seq4_select(d.H, d.G, d.L) & SEQ4_FWD) {
+        sp.xh = c.at<float>(c.w.xh);        // h_t travels to the next step through these rows, saved or not
+        sp.store_x = save ? 1 : 0;
+        return launch_seq_fwd4(c.ctx, c.stream, d.cell == CELL_GRU ? 3 : 4, sp);
+    }
     return d.cell == CELL_GRU    ? dispatch_seq_fwd<3>(c.ctx, c.stream, d.H, sp)
            : d.cell == CELL_LSTM ? dispatch_seq_fwd<4>(c.ctx, c.stream, d.H, sp)
                                  : dispatch_seq_fwd<1>(c.ctx, c.stream, d.H, sp);
@@ -2717,9 +2686,13 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     const bool side_ok = !profiling_every_stage(ctx);     // (per-stage timings are taken serially)
     if (G > 0 && !d.generic) {
         StageTimer tm(ctx, ST_PLAN_PACK, stream);      // (its own bracket: ST_SEQ_BWD times the BPTT kernel alone)
-        hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
-                           a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.WpT));
-        PN_CHECK_HIP(hipGetLastError());
+        if (seq4_select(H, G, L) & SEQ4_BWD) {
+            if (int rc = launch_pack_bwd4(stream, a->w_ih, a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<void>(c.w.WpT))) return rc;
+        } else {
+            hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
+                               a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<u32x4>(c.w.WpT));
+            PN_CHECK_HIP(hipGetLastError());
+        }
     }
     for (int b = 0; b < d.nb; b++) {
         const int Sb = c.groups(b);
@@ -2814,9 +2787,11 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             sp.seed = a->seed;
             sp.mask = a->mask_seq;
             sp.merge0 = d.variant != PN_VARIANT_HETERO;     // (the hetero plan's step-0 rows are other paths' far ends: no runs)
-            if (int rc = (d.cell == CELL_GRU    ? dispatch_seq_bwd<3>(ctx, stream, H, sp)
-                          : d.cell == CELL_LSTM ? dispatch_seq_bwd<4>(ctx, stream, H, sp)
-                                                : dispatch_seq_bwd<1>(ctx, stream, H, sp)))
+            if (seq4_select(H, G, L) & SEQ4_BWD) {
+                if (int rc = launch_seq_bwd4(ctx, stream, d.cell == CELL_GRU ? 3 : 4, sp)) return rc;
+            } else if (int rc = (d.cell == CELL_GRU    ? dispatch_seq_bwd<3>(ctx, stream, H, sp)
+                                 : d.cell == CELL_LSTM ? dispatch_seq_bwd<4>(ctx, stream, H, sp)
+                                                       : dispatch_seq_bwd<1>(ctx, stream, H, sp)))
                 return rc;
         }
 

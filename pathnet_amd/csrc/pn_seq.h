@@ -1,0 +1,75 @@
+// pn_seq.h -- launch parameters of the three recurrent kernels (forward recurrence, BPTT, weight gradient), shared by
+// pn_pagg.hip (the fused kernels for every hidden size up to 256) and pn_seq4.hip (the 128-row-tile kernels for the
+// headline shape, hidden size 128 with four gate slots).  Not part of the ABI.
+#pragma once
+#include <cstdint>
+
+#include "pn_internal.h"
+
+namespace pn {
+
+struct SeqFwdParams {
+    const float *Z;         // [N*L, H] bank output (post activation)
+    const int32_t *rowidx;  // [P, L]
+    const int32_t *slotof;  // [P]
+    const float *Wp;        // packed recurrent weights
+    const float *biasc;     // [G*H]
+    float *hn;              // [P, H] final hidden state per slot'
+    float *saved;           // [P, L, SV, H]  SV = 5 (i,f,g,o,c) for LSTM, 1 (h_t) for RNN; may be null
+    float *xh;              // [P, L, 2H]     the recurrent GEMM's input rows [x_t (after dropout) | h_{t-1}]:
+                            //                the weight-gradient GEMM of the backward reads them back; may be null
+                            //                (seq_fwd4_kernel: never null -- h_t travels to the next step through it;
+                            //                 store_x tells whether the x halves are kept as well)
+    uint8_t *keep;          // [P, L, H/4]    built-in dropout: keep bits of columns 4c .. 4c+3 in bits 0-3 (the backward
+                            //                reads them instead of re-drawing the Philox stream); may be null
+    int P, L;               // slots of this launch (one micro-batch), path length
+    int64_t Pmask;          // slots of the WHOLE batch: the dropout counters / the explicit mask are [L, Pmask, H]
+    float p_drop;
+    uint64_t seed;
+    const pn_step_state *dyn;   // seed in device memory when set (hipGraph replay)
+    const float *mask;      // [L, Pmask, H] explicit mask (reference order: original slot q) or null
+    int store_x;            // seq_fwd4_kernel: keep x_t (after dropout) in xh for the weight-gradient GEMM
+};
+
+struct SeqBwdParams {
+    const float *saved;     // [P, L, SV, H]
+    const uint8_t *keep;    // [P, L, H/4] keep bits of the forward's built-in dropout, or null
+    const float *dhn;       // [P, H]
+    const int32_t *rowidx, *slotof;
+    const float *WpT;
+    float *dG;              // [P, L, G*H] pre-activation gate gradients (input of the weight-gradient GEMM)
+    float *dZ;              // [N*L, H]    += d x_t   (atomic scatter: the backward of the row gather)
+    int P, L;
+    int merge0;             // step 0 scatters the W paths of a node into one table row (homo / PAGG index plans): add up runs first
+    int64_t Pmask;          // slots of the whole batch (explicit mask [L, Pmask, H])
+    float p_drop;
+    uint64_t seed;
+    const float *mask;
+};
+
+struct WgradParams {
+    const float *dG;   // [R, GH]
+    const float *xh;   // [R, 2H]
+    int64_t R;
+    int GH, H2;
+    int64_t rows_per_split;
+    float *part_w;     // [nsplit, GH, 2H]
+    float *part_b;     // [nsplit, GH]
+};
+
+// ---- pn_seq4.hip: the recurrent kernels with 128 paths per workgroup -------------------------------------------------
+// which of the three kernels take the 128-row path for this shape (bit 0: forward, bit 1: BPTT, bit 2: weight gradient);
+// 0 when the shape is outside what they are built for.  PN_SEQ4 in the environment (a bit mask) narrows it.
+enum { SEQ4_FWD = 1, SEQ4_BWD = 2, SEQ4_WGRAD = 4 };
+int seq4_select(int H, int G, int L);
+// weight packing for seq_fwd4_kernel / seq_bwd4_kernel (same workspace slots and sizes as pack_fwd3 / pack_bwd3)
+int launch_pack_fwd4(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
+                     int gru, void *Wp, float *biasc);
+int launch_pack_bwd4(void *stream, const float *w_ih, const float *w_hh, int H, int G, int gru, void *WpT);
+// gc: 4 = LSTM, 3 = GRU on the LSTM's four gate slots
+int launch_seq_fwd4(pn_context *ctx, void *stream, int gc, const SeqFwdParams &sp);
+int launch_seq_bwd4(pn_context *ctx, void *stream, int gc, const SeqBwdParams &sp);
+// the weight-gradient GEMM; nsplit row splits as laid out by the caller (part_w / part_b hold nsplit partials)
+int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nsplit);
+
+}  // namespace pn
