@@ -2820,13 +2820,20 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
             {
                 StageTimer tm(ctx, ST_WGRAD, wstream);
-                if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(wgrad3_kernel), W3_LDS_BYTES)) return rc;
-                hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
-                                   dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
-                PN_CHECK_HIP(hipGetLastError());
+                int nz_red = nz_used;
+                if (seq4_select(H, G, L) & SEQ4_WGRAD) {        // two-stage pipeline over K tiles of 16 rows (pn_seq4.hip)
+                    const int64_t nt16 = (wp.R + 15) / 16;
+                    nz_red = (int)(nt16 < nz ? nt16 : nz);
+                    if (int rc = launch_wgrad4(ctx, wstream, wp, nz_red)) return rc;
+                } else {
+                    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(wgrad3_kernel), W3_LDS_BYTES)) return rc;
+                    hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
+                                       dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
+                    PN_CHECK_HIP(hipGetLastError());
+                }
                 const int64_t nred = (int64_t)GH * 2 * H + GH;
                 hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
-                                   wp.part_w, wp.part_b, nz_used, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
+                                   wp.part_w, wp.part_b, nz_red, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
                                    a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
                 PN_CHECK_HIP(hipGetLastError());
             }

@@ -48,8 +48,32 @@ using namespace pn;
 #ifndef PN_TRACE4
 #define PN_TRACE4 0
 #endif
-#ifndef PN_B4_REGSTAGE
-#define PN_B4_REGSTAGE 1    // BPTT: weight stages through registers (plain loads + ds_write_b128) instead of LDS-DMA
+#ifndef PN_B4_NOFRAG
+#define PN_B4_NOFRAG 0      // ablations of the BPTT kernel (tuning builds; results are wrong)
+#endif
+#ifndef PN_B4_NOMFMA
+#define PN_B4_NOMFMA 0
+#endif
+#ifndef PN_B4_NOLOAD
+#define PN_B4_NOLOAD 0
+#endif
+#ifndef PN_B4_NOCELL
+#define PN_B4_NOCELL 0
+#endif
+#ifndef PN_B4_NOSCAT
+#define PN_B4_NOSCAT 0
+#endif
+#ifndef PN_W4_NOSPLIT
+#define PN_W4_NOSPLIT 0     // ablations of the weight-gradient GEMM (tuning builds; results are wrong)
+#endif
+#ifndef PN_W4_NOMFMA
+#define PN_W4_NOMFMA 0
+#endif
+#ifndef PN_W4_NOLOAD
+#define PN_W4_NOLOAD 0
+#endif
+#ifndef PN_W4_NOFRAG
+#define PN_W4_NOFRAG 0
 #endif
 #if PN_TRACE4
 __device__ long long *g_trace4 = nullptr;       // [blocks][2][T4_SLOTS]
@@ -61,10 +85,6 @@ constexpr int T4_SLOTS = 512;
     } while (0)
 #else
 #define T4_STAMP(slot) do { } while (0)
-#endif
-
-#ifndef PN_SEQ4_SKEW
-#define PN_SEQ4_SKEW 1      // 1: the two row groups of a workgroup run products / everything else in opposite order
 #endif
 
 namespace {
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(NT4, 2) void seq_fwd4_kernel(SeqFwdParams p) {
     if (rg == 1) slot_barrier();
 #pragma unroll 1
     for (int j = 0; j < NK; j++) {
-        const int t = step_of(j), s = ks_of(j);
+        const int t = step_of(j);
         const bool step_end = j + 1 == NK || step_of(j + 1) != t;
         const int j2 = min(j + 2, NK - 1), t2 = step_of(j2), s2 = ks_of(j2);
         T4_STAMP(8 + 5 * j + 0);
@@ -422,10 +442,6 @@ __global__ __launch_bounds__(NT4, 2) void seq_fwd4_kernel(SeqFwdParams p) {
 // =====================================================================================================================
 constexpr int B_NS = G4 * H4 / 32;                          // stages per step
 constexpr int B_BSTAGE = 2 * 2 * NW4 * 3 * 1024;            // 49 152
-constexpr int B_ASTAGE = 2 * (MT4 / 32) * 3 * 1024;         // 24 576
-constexpr int B_A_OFF = 2 * B_BSTAGE;
-constexpr int B_IDX_OFF = B_A_OFF + 2 * B_ASTAGE;           // 147 456: row indices [128][L], slots [128], keep bytes [2][128][H/4]
-constexpr int B_NB = 16;                                    // accumulator elements per batch of saved-gate loads
 
 // WpT4[(((u * 2 + half) * 2 + kk) * NW + ub) * 3 + plane][lane] (16 bytes) =
 //     plane of Wcat[k = 32 u + 16 kk + 8 (lane >> 5) .. +7][n = half * H + 32 ub + (lane & 31)]
@@ -465,23 +481,31 @@ __global__ void pack_bwd4_kernel(const float *__restrict__ w_ih, const float *__
     dst[128] = q2;
 }
 
-template <int GC>
-__global__ __launch_bounds__(NT4, 2) void seq_bwd4_kernel(SeqBwdParams p) {
+// NRG: row groups of 64 paths per workgroup (2: 128 paths, 8 waves, one workgroup per CU, the two groups share every weight
+//      fragment in LDS; 1: 64 paths, 4 waves, two workgroups per CU whose phases overlap).  KK: k-steps per stage.
+template <int GC, int NRG, int KK>
+__global__ __launch_bounds__(256 * NRG, 2) void seq_bwd4_kernel(SeqBwdParams p) {
     constexpr bool GRU = GC == 3;
-    constexpr int H = H4, G = G4, GH = G * H, SV = SV4, NB = B_NB;
+    constexpr int H = H4, G = G4, GH = G * H, SV = SV4;
+    constexpr int MT = 64 * NRG, NT = 256 * NRG;
+    constexpr int BST = KK * 2 * NW4 * 3 * 1024;            // weight stage: [half][kk][ub][plane] fragments
+    constexpr int AST = KK * (MT / 32) * 3 * 1024;          // activation stage: [kk][row block][plane]
+    constexpr int A_OFF = 2 * BST, IDX_OFF = A_OFF + 2 * AST;
+    constexpr int NS = GH / (16 * KK);                      // stages per step
+    static_assert((NRG == 2 && KK == 2) || (NRG == 1 && KK == 1), "three 1 KB loads per wave and half of a stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     const int L = p.L;
-    int *s_rowidx = reinterpret_cast<int *>(ldsb + B_IDX_OFF);     // [MT][L]
-    int *s_slotof = s_rowidx + MT4 * L;                             // [MT]
-    uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_slotof + MT4);  // [2][MT][H/4] keep bits of step t (t & 1)
+    int *s_rowidx = reinterpret_cast<int *>(ldsb + IDX_OFF);     // [MT][L]
+    int *s_slotof = s_rowidx + MT * L;                             // [MT]
+    uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_slotof + MT);  // [2][MT][H/4] keep bits of step t (t & 1)
     const int tid = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave_u >> 2, ub = wave_u & 3;
     // tiles in descending order: the forward wrote the saved tensors of the last tiles last (Infinity Cache)
-    const int q0 = (int)(gridDim.x - 1 - blockIdx.x) * MT4;
+    const int q0 = (int)(gridDim.x - 1 - blockIdx.x) * MT;
 
-    for (int i = tid; i < MT4 * L; i += NT4) s_rowidx[i] = q0 + i / L < p.P ? p.rowidx[(int64_t)q0 * L + i] : 0;
-    for (int i = tid; i < MT4; i += NT4) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
+    for (int i = tid; i < MT * L; i += NT) s_rowidx[i] = q0 + i / L < p.P ? p.rowidx[(int64_t)q0 * L + i] : 0;
+    for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
 
     const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     const size_t tile_row = (size_t)q0 * (size_t)L;
@@ -489,70 +513,87 @@ __global__ __launch_bounds__(NT4, 2) void seq_bwd4_kernel(SeqBwdParams p) {
     float *dG_t = p.dG + tile_row * GH;
     const uint8_t *keep_t = p.keep ? p.keep + tile_row * (H / 4) : nullptr;
     const float *dhn_t = p.dhn + (size_t)q0 * H;
-    const int rows_here = min(MT4, p.P - q0);            // >= 1
+    const int rows_here = min(MT, p.P - q0);            // >= 1
     const unsigned char *wp_b = reinterpret_cast<const unsigned char *>(p.WpT);
 
-    f32x16 accx[2], acch[2], dc[2];     // dx_t, dh_{t-1} (it enters the next step's cell backward as dh_t), d c_t
+    f32x16 accx[2], acch[2];            // dx_t, dh_{t-1} of the step in the GEMM (accumulator layout)
+    // The element-wise phases run in a second layout of the wave's 64 paths x 32 hidden units: lane (row8 = l >> 3,
+    // chunk = l & 7) holds units 4 chunk .. +3 of the rows row8 + 8 i (i = 0..3) of each row block -- 16 bytes per lane
+    // and whole 128-byte lines per 8 lanes for every global access (a wave instruction costs the CU's vector memory
+    // pipe ~16 cycles whatever its width: one unit per lane, the accumulator layout, quadruples the instructions).
+    // dh_t crosses from the accumulator layout through a wave-private LDS block.
+    f32x4 dhq[2][4], dcq[2][4];         // d h_t, d c_t (GRU: the direct path d h_t / d h_{t-1})
+    const int q_row8 = (tid & 63) >> 3, q_col = 32 * ub + 4 * (tid & 7);
     {
-        const int lane = tid & 63, col = 32 * ub + (lane & 31);
 #pragma unroll
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = 64 * rg + 32 * rb + acc_row(r, lane);
-                const float dh0 = at_bytes(dhn_t, ((uint32_t)min(row, rows_here - 1) * (uint32_t)H + col) * 4u);
-                acch[rb][r] = row < rows_here ? dh0 : 0.0f;
-                dc[rb][r] = 0.0f;
-                accx[rb][r] = 0.0f;
+            for (int i = 0; i < 4; i++) {
+                const int row = 64 * rg + 32 * rb + q_row8 + 8 * i;
+                const f32x4 dh0 = *reinterpret_cast<const f32x4 *>(
+                    &at_bytes(dhn_t, ((uint32_t)min(row, rows_here - 1) * (uint32_t)H + q_col) * 4u));
+                dhq[rb][i] = row < rows_here ? dh0 : f32x4{0.f, 0.f, 0.f, 0.f};
+                dcq[rb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
     }
+    constexpr int XP = 36;              // row pitch (floats) of the 32 x 32 crossing block
+    // accumulator layout -> the quad layout, through this wave's block at `scr` (the caller has made sure nobody reads
+    // the stage buffers it lies in)
+    auto cross = [&](const f32x16 &v, float *scr, f32x4 (&out)[4]) {
+        const int lane = fresh_lane();
+#pragma unroll
+        for (int r = 0; r < 16; r++) scr[acc_row(r, lane) * XP + (lane & 31)] = v[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = *reinterpret_cast<const f32x4 *>(scr + ((lane >> 3) + 8 * i) * XP + 4 * (lane & 7));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
 
     // ---- the producer of the A stage: thread (path pr, lane quarter pp) owns k = 8 pp .. +7 of a stage's 32 -------------
     const int pr = tid >> 2, pp = tid & 3;
     const bool row_ok = pr < rows_here;
     const uint32_t prc = (uint32_t)min(pr, rows_here - 1);
-    const uint32_t a_wr = (uint32_t)((((pp >> 1) * 4 + (pr >> 5)) * 3) * 1024 +
-                                     ((((pr & 31) + 32 * (pp & 1)) ^ ((pp & 1) << 1) ^ ((pp >> 1) << 2)) << 4));
+    // (KK = 1: 16 columns per stage, two of a path's four lanes produce them)
+    const int kkp = KK == 2 ? pp >> 1 : 0;
+    const bool a_active = KK == 2 || pp < 2;
+    const uint32_t a_wr = (uint32_t)(((kkp * (MT / 32) + (pr >> 5)) * 3) * 1024 +
+                                     ((((pr & 31) + 32 * (pp & 1)) ^ ((pp & 1) << 1) ^ (kkp << 2)) << 4));
     f32x4 xr0, xr1;
-    auto dma_stage = [&](int u, int stage, bool both) {     // this wave's eighth of stage u's weight fragments
-        const int bytes = both ? B_BSTAGE / 8 : B_BSTAGE / 16;
-        const unsigned char *g = wp_b + (size_t)u * B_BSTAGE + wave_u * bytes + (threadIdx.x & 63) * 16;
-        unsigned char *l = ldsb + stage * B_BSTAGE + wave_u * bytes;
-        dma16(g, l);
-        dma16(g + 1024, l + 1024);
-        dma16(g + 2048, l + 2048);
-        if (both) {
-            dma16(g + 3072, l + 3072);
-            dma16(g + 4096, l + 4096);
-            dma16(g + 5120, l + 5120);
-        }
-    };
-    // the same copy through registers (PN_B4_REGSTAGE): plain 16-byte loads move 1 KB per ~16 cycles of the CU's vector
-    // memory pipe, an LDS-DMA instruction of the same size measured ~60 (profiles/README.md, round 3)
+    // this wave's eighth of a stage's weight fragments, global -> registers -> LDS.  (Plain 16-byte loads: an LDS-DMA
+    // instruction of the same 1 KB costs the CU's vector-memory pipe ~60 cycles, ~4x a plain load -- profiles/README.md)
     f32x4 braw[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) braw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto b_issue = [&](int u, auto both_tag) {
+    // stage v: its first k-step is s0 = v * KK; half h of it sits at stage image (s0 >> 1), piece (h * 2 + (s0 & 1)) of 12 KB
+    // (KK = 2: the two k-steps of a half are adjacent, 24 KB); every wave moves 3 KB of each half
+    auto b_issue = [&](int v, auto both_tag) {
         constexpr bool both = decltype(both_tag)::value;
-        constexpr int bytes = both ? B_BSTAGE / 8 : B_BSTAGE / 16;
-        const unsigned char *g = wp_b + (size_t)u * B_BSTAGE + wave_u * bytes + (threadIdx.x & 63) * 16;
+        const int s0 = v * KK;
+        const unsigned char *g = wp_b + (size_t)(s0 >> 1) * B_BSTAGE + (s0 & 1) * (NW4 * 3 * 1024) + wave_u * 3072 + (threadIdx.x & 63) * 16;
 #pragma unroll
-        for (int i = 0; i < bytes / 1024; i++) async_load_b128(braw[i], g + i * 1024);
+        for (int i = 0; i < 3; i++) async_load_b128(braw[i], g + i * 1024);
+        if constexpr (both) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) async_load_b128(braw[3 + i], g + B_BSTAGE / 2 + i * 1024);
+        }
     };
     auto b_commit = [&](int stage, auto both_tag) {
         constexpr bool both = decltype(both_tag)::value;
-        constexpr int bytes = both ? B_BSTAGE / 8 : B_BSTAGE / 16;
-        unsigned char *l = ldsb + stage * B_BSTAGE + wave_u * bytes + (threadIdx.x & 63) * 16;
+        unsigned char *l = ldsb + stage * BST + wave_u * 3072 + (threadIdx.x & 63) * 16;
 #pragma unroll
-        for (int i = 0; i < bytes / 1024; i++) *reinterpret_cast<f32x4 *>(l + i * 1024) = braw[i];
+        for (int i = 0; i < 3; i++) *reinterpret_cast<f32x4 *>(l + i * 1024) = braw[i];
+        if constexpr (both) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) *reinterpret_cast<f32x4 *>(l + BST / 2 + i * 1024) = braw[3 + i];
+        }
     };
     auto a_issue = [&](int t, int u) {
-        const float *src = dG_t + ((size_t)(prc * (uint32_t)L + t) * GH + 32 * u + 8 * pp);
+        const float *src = dG_t + ((size_t)(prc * (uint32_t)L + t) * GH + 16 * KK * u + 8 * (KK == 2 ? pp : (pp & 1)));
         async_load_b128(xr0, src);
         async_load_b128(xr1, src + 4);
     };
     auto a_commit = [&](int stage, bool write) {
-        if (!write) return;
+        if (!write || !a_active) return;
         float v[8] = {xr0[0], xr0[1], xr0[2], xr0[3], xr1[0], xr1[1], xr1[2], xr1[3]};
         u32x4 q0v, q1v, q2v;
 #pragma unroll
@@ -561,90 +602,81 @@ __global__ __launch_bounds__(NT4, 2) void seq_bwd4_kernel(SeqBwdParams p) {
             split3(row_ok ? v[2 * h] : 0.0f, row_ok ? v[2 * h + 1] : 0.0f, x0, x1, x2);
             q0v[h] = x0; q1v[h] = x1; q2v[h] = x2;
         }
-        unsigned char *d = ldsb + B_A_OFF + stage * B_ASTAGE + a_wr;
+        unsigned char *d = ldsb + A_OFF + stage * AST + a_wr;
         *reinterpret_cast<u32x4 *>(d) = q0v;
         *reinterpret_cast<u32x4 *>(d + 1024) = q1v;
         *reinterpret_cast<u32x4 *>(d + 2048) = q2v;
     };
     __syncthreads();        // the index arrays
-    int cur = 0;
-    if (PN_B4_REGSTAGE) {   // weight stage 0 of the first step (the later steps' comes with the last stage of the step before)
-        b_issue(0, std::true_type{});
-        wait_vm<0>(braw[0], braw[1], braw[2], braw[3], braw[4], braw[5], xr0, xr1);
-        b_commit(cur, std::true_type{});
-    }
-
 #pragma unroll 1
     for (int t = L - 1; t >= 0; t--) {
         // the first weight stage of this step does not depend on anything: in flight under the cell backward
         [[maybe_unused]] const int ti = L - 1 - t;
         T4_STAMP(8 * ti + 0);
-        if (!PN_B4_REGSTAGE) dma_stage(0, cur, t > 0);
         const int lane_t = fresh_lane();
-        const int col = 32 * ub + (lane_t & 31);
         if (p.keep) {       // this step's keep bytes (MT rows x H/4) -> LDS, read by the scatter phase below
             const int tid_t = wave_u * 64 + lane_t;
-            for (int i = tid_t; i < MT4 * (H / 16); i += NT4) {
+            for (int i = tid_t; i < MT * (H / 16); i += NT) {
                 const int row = i / (H / 16), w = i - row * (H / 16);
                 const uint32_t rc = (uint32_t)min(row, rows_here - 1);
-                reinterpret_cast<uint32_t *>(s_keep + (t & 1) * MT4 * (H / 4))[i] =
+                reinterpret_cast<uint32_t *>(s_keep + (t & 1) * MT * (H / 4))[i] =
                     at_bytes(reinterpret_cast<const uint32_t *>(keep_t), (rc * (uint32_t)L + t) * (uint32_t)(H / 4) + 4u * w);
             }
         }
-        // ---- cell backward: all loads of a batch of NB accumulator elements are issued together (unconditionally:
-        //      padded rows read a clamped row and are zeroed afterwards) -- one memory round trip per batch
+        // ---- cell backward in the quad layout: the 24 loads of a row block are issued together (unconditionally: padded
+        //      rows read a clamped row and are zeroed afterwards) -- one memory round trip per row block
 #pragma unroll
-        for (int rb = 0; rb < 2; rb++) {
+        for (int rb = 0; rb < (PN_B4_NOCELL ? 0 : 2); rb++) {
+            f32x4 vi[4], vf[4], vg[4], vo[4], vc[4], vn[4];
 #pragma unroll
-            for (int half = 0; half < 16 / NB; half++) {
-                float vi[NB], vf[NB], vg[NB], vo[NB], vc[NB], vn[NB];
-#pragma unroll
-                for (int e = 0; e < NB; e++) {
-                    const int r = half * NB + e;
-                    const int rc = min(64 * rg + 32 * rb + acc_row(r, lane_t), rows_here - 1);
-                    const float *sv = &at_bytes(saved_t, (((uint32_t)rc * (uint32_t)L + t) * (uint32_t)(SV * H) + col) * 4u);
-                    vi[e] = sv[0]; vf[e] = sv[H]; vg[e] = sv[2 * H];
-                    vo[e] = sv[3 * H];
-                    if (GRU) {
-                        vc[e] = sv[4 * H];                          // h_{t-1}
-                        vn[e] = 0.0f;
-                    } else {
-                        vc[e] = t > 0 ? sv[-H] : 0.0f;              // c_{t-1} = slot 4 of step t-1
-                        vn[e] = sv[4 * H];                          // c_t
-                    }
+            for (int i = 0; i < 4; i++) {
+                const int rc = min(64 * rg + 32 * rb + q_row8 + 8 * i, rows_here - 1);
+                const f32x4 *sv = reinterpret_cast<const f32x4 *>(
+                    &at_bytes(saved_t, (((uint32_t)rc * (uint32_t)L + t) * (uint32_t)(SV * H) + q_col) * 4u));
+                vi[i] = sv[0]; vf[i] = sv[H / 4]; vg[i] = sv[2 * H / 4];
+                vo[i] = sv[3 * H / 4];
+                if (GRU) {
+                    vc[i] = sv[4 * H / 4];                                              // h_{t-1}
+                    vn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    vc[i] = t > 0 ? sv[-(H / 4)] : f32x4{0.f, 0.f, 0.f, 0.f};           // c_{t-1} = slot 4 of step t-1
+                    vn[i] = sv[4 * H / 4];                                              // c_t
                 }
+            }
 #pragma unroll
-                for (int e = 0; e < NB; e++) {
-                    const int r = half * NB + e;
-                    const int row = 64 * rg + 32 * rb + acc_row(r, lane_t);
-                    const bool ok = row < rows_here;
-                    float *d = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)L + t) * (uint32_t)GH + col) * 4u);
-                    const float dhv = acch[rb][r];
-                    float a0, a1, a2, a3;
+            for (int i = 0; i < 4; i++) {
+                const int row = 64 * rg + 32 * rb + q_row8 + 8 * i;
+                const bool ok = row < rows_here;
+                f32x4 *d = reinterpret_cast<f32x4 *>(
+                    &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)L + t) * (uint32_t)GH + q_col) * 4u));
+                f32x4 a0, a1, a2, a3;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float dhv = dhq[rb][i][e];
                     if (GRU) {
                         // h = (1 - z) n + z h_prev,  n = tanh(nx + r nh): gradients of the slots r, z, nx, nh; the direct path
-                        // d h_t / d h_{t-1} = z is carried in dc[] across the GEMM and added to its dh output
-                        const float rgt = vi[e], zg = vf[e], ng = vg[e], nh = vo[e], hp = vc[e];
+                        // d h_t / d h_{t-1} = z is carried in dcq across the GEMM and added to its dh output
+                        const float rgt = vi[i][e], zg = vf[i][e], ng = vg[i][e], nh = vo[i][e], hp = vc[i][e];
                         const float dnp = dhv * (1.0f - zg) * (1.0f - ng * ng);
-                        a0 = dnp * nh * rgt * (1.0f - rgt);
-                        a1 = dhv * (hp - ng) * zg * (1.0f - zg);
-                        a2 = dnp;
-                        a3 = dnp * rgt;
-                        dc[rb][r] = ok ? dhv * zg : 0.0f;
+                        a0[e] = dnp * nh * rgt * (1.0f - rgt);
+                        a1[e] = dhv * (hp - ng) * zg * (1.0f - zg);
+                        a2[e] = dnp;
+                        a3[e] = dnp * rgt;
+                        dcq[rb][i][e] = ok ? dhv * zg : 0.0f;
                     } else {
-                        const float ig = vi[e], fg = vf[e], gg = vg[e], og = vo[e], cprev = vc[e];
-                        const float tc = tanhf_(vn[e]);
+                        const float ig = vi[i][e], fg = vf[i][e], gg = vg[i][e], og = vo[i][e], cprev = vc[i][e];
+                        const float tc = tanhf_(vn[i][e]);
                         const float d_o = dhv * tc;
-                        const float dct = dc[rb][r] + dhv * og * (1.0f - tc * tc);
-                        a0 = dct * gg * ig * (1.0f - ig);
-                        a1 = dct * cprev * fg * (1.0f - fg);
-                        a2 = dct * ig * (1.0f - gg * gg);
-                        a3 = d_o * og * (1.0f - og);
-                        dc[rb][r] = dct * fg;
+                        const float dct = dcq[rb][i][e] + dhv * og * (1.0f - tc * tc);
+                        a0[e] = dct * gg * ig * (1.0f - ig);
+                        a1[e] = dct * cprev * fg * (1.0f - fg);
+                        a2[e] = dct * ig * (1.0f - gg * gg);
+                        a3[e] = d_o * og * (1.0f - og);
+                        dcq[rb][i][e] = dct * fg;
                     }
-                    if (ok) {
-                        d[0] = a0; d[H] = a1; d[2 * H] = a2; d[3 * H] = a3;
-                    }
+                }
+                if (ok) {
+                    d[0] = a0; d[H / 4] = a1; d[2 * H / 4] = a2; d[3 * H / 4] = a3;
                 }
             }
         }
@@ -653,74 +685,100 @@ __global__ __launch_bounds__(NT4, 2) void seq_bwd4_kernel(SeqBwdParams p) {
         T4_STAMP(8 * ti + 2);
         __syncthreads();
 
-        // ---- the GEMM over B_NS stages --------------------------------------------------------------------------------
+        // ---- the GEMM over NS stages --------------------------------------------------------------------------------
 #pragma unroll
         for (int rb = 0; rb < 2; rb++)
 #pragma unroll
             for (int r = 0; r < 16; r++) accx[rb][r] = acch[rb][r] = 0.0f;
-        a_issue(t, 0);
-        wait_vm<0>(xr0, xr1);
-        a_commit(cur, true);
-        __syncthreads();
         T4_STAMP(8 * ti + 3);
         auto gemm = [&](auto ntn_tag) {
             constexpr int NTN = decltype(ntn_tag)::value;       // 2: dx and dh, 1: dx only (step 0)
-#pragma unroll 1
-            for (int u = 0; u < B_NS; u++) {
-                const bool has_next = u + 1 < B_NS;
-                // the next weight stage; behind the last stage of a step, stage 0 of the next step (the same fragments)
-                if (PN_B4_REGSTAGE)
-                    b_issue(has_next ? u + 1 : 0, std::integral_constant<bool, NTN == 2>{});
-                else if (has_next)
-                    dma_stage(u + 1, cur ^ 1, NTN == 2);
-                a_issue(t, has_next ? u + 1 : u);
-                T4_STAMP(64 + (ti * B_NS + u) * 4 + 0);
-                {
-                    const int lane_k = fresh_lane();
-                    const unsigned char *ab = ldsb + B_A_OFF + cur * B_ASTAGE + rg * (2 * 3 * 1024);
-                    const uint32_t slot0 = (uint32_t)(lane_k ^ ((lane_k >> 5) << 1));
-                    const unsigned char *bb = ldsb + cur * (NTN == 2 ? B_BSTAGE : B_BSTAGE) + ub * (3 * 1024) + (lane_k << 4);
+            using Both = std::integral_constant<bool, NTN == 2>;
+            // stage u (clamped) into flight / out of flight / into LDS buffer u & 1
+            auto issue = [&](int u) {
+                if (PN_B4_NOLOAD) return;
+                const int uc = min(u, NS - 1);
+                b_issue(uc, Both{});
+                a_issue(t, uc);
+            };
+            auto wait_all = [&]() { wait_vm<0>(braw[0], braw[1], braw[2], braw[3], braw[4], braw[5], xr0, xr1); };
+            auto commit = [&](int u) {
+                if (u < NS && !PN_B4_NOLOAD) {
+                    b_commit(u & 1, Both{});
+                    a_commit(u & 1, true);
+                }
+            };
+            // the 48 (24 at step 0) MFMAs of stage u
+            auto products = [&](int u) {
+                const int lane_k = fresh_lane();
+                const unsigned char *ab = ldsb + A_OFF + (u & 1) * AST + rg * (2 * 3 * 1024);
+                const uint32_t slot0 = (uint32_t)(lane_k ^ ((lane_k >> 5) << 1));
+                const unsigned char *bb = ldsb + (u & 1) * BST + ub * (3 * 1024) + (lane_k << 4);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int kk = 0; kk < 2; kk++) {
-                        const unsigned char *abk = ab + kk * (4 * 3 * 1024) + ((slot0 ^ (uint32_t)(kk << 2)) << 4);
-                        auto afrag = [&](int rb, int pl) { return *reinterpret_cast<const u32x4 *>(abk + (rb * 3 + pl) * 1024); };
-                        auto bfrag = [&](int half, int pl) {
-                            return *reinterpret_cast<const u32x4 *>(bb + ((half * 2 + kk) * NW4 * 3 + pl) * 1024);
-                        };
-                        u32x4 a[2][3], bx[3], bh[3];
-                        auto prod = [&](int pa, int pb) {
+                for (int kk = 0; kk < KK; kk++) {
+                    const unsigned char *abk = ab + kk * ((MT / 32) * 3 * 1024) + ((slot0 ^ (uint32_t)(kk << 2)) << 4);
+                    auto afrag = [&](int rb, int pl) { return *reinterpret_cast<const u32x4 *>(abk + (rb * 3 + pl) * 1024); };
+                    auto bfrag = [&](int half, int pl) {
+                        return *reinterpret_cast<const u32x4 *>(bb + ((half * KK + kk) * NW4 * 3 + pl) * 1024);
+                    };
+                    u32x4 a[2][3], bx[3], bh[3];
+                    auto prod = [&](int pa, int pb) {
+                        if (PN_B4_NOMFMA) return;
 #pragma unroll
-                            for (int rb = 0; rb < 2; rb++) {
-                                accx[rb] = mfma_bf16(a[rb][pa], bx[pb], accx[rb]);
-                                if constexpr (NTN == 2) acch[rb] = mfma_bf16(a[rb][pa], bh[pb], acch[rb]);
-                            }
-                        };
+                        for (int rb = 0; rb < 2; rb++) {
+                            accx[rb] = mfma_bf16(a[rb][pa], bx[pb], accx[rb]);
+                            if constexpr (NTN == 2) acch[rb] = mfma_bf16(a[rb][pa], bh[pb], acch[rb]);
+                        }
+                    };
+                    if (PN_B4_NOFRAG) {     // operands from registers: no LDS traffic
 #pragma unroll
                         for (int pl = 0; pl < 3; pl++) {
-                            bx[pl] = bfrag(0, pl);
-                            if constexpr (NTN == 2) bh[pl] = bfrag(1, pl);
+                            bx[pl] = u32x4{(uint32_t)lane_k, 1u, 2u, 3u};
+                            bh[pl] = u32x4{(uint32_t)lane_k, 5u, 2u, 3u};
+#pragma unroll
+                            for (int rb = 0; rb < 2; rb++) a[rb][pl] = u32x4{(uint32_t)lane_k, 7u, (uint32_t)rb, 3u};
                         }
+                    } else {
 #pragma unroll
-                        for (int pl = 0; pl < 3; pl++)
-#pragma unroll
-                            for (int rb = 0; rb < 2; rb++) a[rb][pl] = afrag(rb, pl);
-                        prod(2, 0);
-                        prod(1, 0);
-                        prod(0, 0);
-                        prod(1, 1);
-                        prod(0, 1);
-                        prod(0, 2);
+                    for (int pl = 0; pl < 3; pl++) {
+                        bx[pl] = bfrag(0, pl);
+                        if constexpr (NTN == 2) bh[pl] = bfrag(1, pl);
                     }
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++)
+#pragma unroll
+                        for (int rb = 0; rb < 2; rb++) a[rb][pl] = afrag(rb, pl);
+                    }
+                    prod(2, 0);
+                    prod(1, 0);
+                    prod(0, 0);
+                    prod(1, 1);
+                    prod(0, 1);
+                    prod(0, 2);
                 }
-                T4_STAMP(64 + (ti * B_NS + u) * 4 + 1);
-                wait_vm<0>(braw[0], braw[1], braw[2], braw[3], braw[4], braw[5], xr0, xr1);
-                if (PN_B4_REGSTAGE) b_commit(cur ^ 1, std::integral_constant<bool, NTN == 2>{});
-                a_commit(cur ^ 1, has_next);
-                T4_STAMP(64 + (ti * B_NS + u) * 4 + 2);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            // lockstep, products first: the loads of stage u+2 are issued behind the products of stage u and stay in
+            // flight across the barrier: [products u][wait, commit u+1][issue u+2][barrier]
+            issue(0);
+            wait_all();
+            commit(0);
+            issue(1);
+            __syncthreads();
+#pragma unroll 1
+            for (int u = 0; u < NS; u++) {
+                T4_STAMP(64 + (ti * NS + u) * 4 + 0);
+                products(u);
+                T4_STAMP(64 + (ti * NS + u) * 4 + 1);
+                wait_all();
+                commit(u + 1);
+                issue(u + 2);
+                T4_STAMP(64 + (ti * NS + u) * 4 + 2);
                 __syncthreads();
-                T4_STAMP(64 + (ti * B_NS + u) * 4 + 3);
-                cur ^= 1;
+                T4_STAMP(64 + (ti * NS + u) * 4 + 3);
             }
+            wait_all();
         };
         if (t > 0)
             gemm(std::integral_constant<int, 2>{});
@@ -732,10 +790,28 @@ __global__ __launch_bounds__(NT4, 2) void seq_bwd4_kernel(SeqBwdParams p) {
         //      dead) stage region and each half-wave walks 16 rows in order, adding up runs of equal table rows: one
         //      atomic per run and column instead of one per path.
         T4_STAMP(8 * ti + 4);
+        // d h_{t-1} into the quad layout (the k loop ended with a barrier: the stage buffers are free; the scatter's
+        // scratch below uses the same block afterwards -- both are wave-private)
+        if (t > 0) {
+            float *xs = reinterpret_cast<float *>(ldsb) + wave_u * (32 * XP);
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                cross(acch[rb], xs, dhq[rb]);
+                if (GRU) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) dhq[rb][i] += dcq[rb][i];
+                }
+            }
+        }
         const int lane_s = fresh_lane(), li_s = lane_s & 31;
         const int col_s = 32 * ub + li_s;
-        if (t == 0 && p.merge0) {
-            float *scr = reinterpret_cast<float *>(ldsb) + wave_u * (32 * 33);
+        if (PN_B4_NOSCAT) {
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) asm volatile("" ::"v"(accx[rb][r]));
+        } else if (t == 0 && p.merge0) {
+            float *scr = reinterpret_cast<float *>(ldsb) + wave_u * (32 * XP);
 #pragma unroll 1
             for (int rb = 0; rb < 2; rb++) {
 #pragma unroll
@@ -746,7 +822,7 @@ __global__ __launch_bounds__(NT4, 2) void seq_bwd4_kernel(SeqBwdParams p) {
                         if (p.mask)
                             dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col_s];
                         else if (p.keep)
-                            dx = (s_keep[((t & 1) * MT4 + row) * (H / 4) + (col_s >> 2)] >> (col_s & 3)) & 1 ? dx * keep_scale : 0.0f;
+                            dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col_s >> 2)] >> (col_s & 3)) & 1 ? dx * keep_scale : 0.0f;
                     }
                     scr[rl * 33 + li_s] = dx;
                 }
@@ -783,14 +859,177 @@ __global__ __launch_bounds__(NT4, 2) void seq_bwd4_kernel(SeqBwdParams p) {
                         if (p.mask)
                             dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col_s];
                         else if (p.keep)
-                            dx = (s_keep[((t & 1) * MT4 + row) * (H / 4) + (col_s >> 2)] >> (col_s & 3)) & 1 ? dx * keep_scale : 0.0f;
+                            dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col_s >> 2)] >> (col_s & 3)) & 1 ? dx * keep_scale : 0.0f;
                         atomicAdd(p.dZ + ((size_t)(uint32_t)s_rowidx[row * L + t] * (uint32_t)H + col_s), dx);
                     }
-                    if (GRU) acch[rb][r] += dc[rb][r];
                 }
         }
         T4_STAMP(8 * ti + 5);
     }
+}
+
+
+// =====================================================================================================================
+// weight gradient:  [g_W_ih | g_W_hh] [G*H, 2H] = dG^T [G*H, R] . XH [R, 2H]   (R = P*L rows; colsum(dG) = bias gradient)
+//   Same decomposition as wgrad3_kernel (pn_pagg.hip): 256 x 256 output tile per workgroup (8 waves, 64 x 128 each),
+//   the R rows split over blockIdx.z in strided K tiles, partial tiles to part_w / part_b for wgrad_reduce_kernel.
+//   What changes is the pipeline: K tiles of 16 rows, TWO LDS stages, and the loads of tile i+2 issued behind the
+//   products of tile i, in flight across the barrier -- wgrad3 alternates "stage 32 rows" and "96 MFMAs per wave" in
+//   lockstep with one buffer and had the matrix pipe busy 48 % of the time.
+//   Staging task of a thread per tile: operand op, rows 4 rq .. +3 of the 16, columns 4 cq .. +3: four coalesced 16-byte
+//   loads; per column the four rows are split into their bf16 planes (two packed pairs = 8 bytes per plane) and written
+//   to the half (rq & 1) of the column's 16-byte k-octet slot -- the transposition to "8 consecutive k per lane" is free.
+//   LDS image per (plane, operand, k-octet): 256 columns, column c at slot (c & 3) * 68 + (c >> 2)  (as wgrad3).
+// =====================================================================================================================
+constexpr int W4_BM = 256, W4_BN = 256, W4_KT = 16, W4_THREADS = 512;
+constexpr int W4_BLK = 4 * 68;                              // 16-byte slots per (plane, operand, k-octet) block
+constexpr int W4_PLANE = 2 * 2 * W4_BLK;                    // slots per plane: 2 operands x 2 k-octets
+constexpr int W4_STAGE = 3 * W4_PLANE;                      // slots per stage (52 224 bytes)
+constexpr int W4_LDS_BYTES = 2 * W4_STAGE * 16;             // 104 448
+
+__global__ __launch_bounds__(W4_THREADS, 2) void wgrad4_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds4[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * W4_BM, n0 = blockIdx.x * W4_BN;
+    // split z takes the K tiles z, z + nz, z + 2 nz, ...: every workgroup starts on the low rows, which the (reversed)
+    // BPTT wrote last and which are still in the Infinity Cache
+    const int64_t ntiles = (p.R + W4_KT - 1) / W4_KT;
+    const int64_t nz = gridDim.z;
+    const int64_t my_tiles = blockIdx.z < ntiles ? (ntiles - blockIdx.z + nz - 1) / nz : 0;
+    if (my_tiles == 0) return;      // block-uniform
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int op = tid >> 8, rq = (tid >> 6) & 3, cq = tid & 63;
+    const float *src = op == 0 ? p.dG : p.xh;
+    const int ld = op == 0 ? p.GH : p.H2;
+    const int c0 = (op == 0 ? m0 : n0) + 4 * cq;
+    const bool c_ok = c0 < ld;
+    const float *srcc = src + (c_ok ? c0 : 0);
+    f32x4 rg[4];
+    auto row0_of = [&](int64_t i) { return (blockIdx.z + min(i, my_tiles - 1) * nz) * W4_KT; };     // (clamped: harmless re-load)
+    auto issue = [&](int64_t i) {
+        const int64_t k0 = row0_of(i);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (!PN_W4_NOLOAD) async_load_b128(rg[e], srcc + min(k0 + 4 * rq + e, p.R - 1) * ld);
+    };
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};     // column sums of dG over this thread's rows (bias gradient)
+    // operand op, k-octet rq >> 1, column 4 cq + j at slot j * 68 + cq; this thread's rows are half (rq & 1) of the octet
+    unsigned char *stage_wr = reinterpret_cast<unsigned char *>(lds4 + (op * 2 + (rq >> 1)) * W4_BLK + cq) + (rq & 1) * 8;
+    auto commit = [&](int64_t i, int buf) {
+        const int64_t k0 = row0_of(i);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (!(c_ok && k0 + 4 * rq + e < p.R)) rg[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned char *w = stage_wr + (size_t)buf * (W4_STAGE * 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t x0, x1, x2, y0, y1, y2;
+            if (PN_W4_NOSPLIT) {
+                x0 = __float_as_uint(rg[0][j]); x1 = __float_as_uint(rg[1][j]); x2 = x0 ^ x1;
+                y0 = __float_as_uint(rg[2][j]); y1 = __float_as_uint(rg[3][j]); y2 = y0 ^ y1;
+            } else {
+                split3(rg[0][j], rg[1][j], x0, x1, x2);
+                split3(rg[2][j], rg[3][j], y0, y1, y2);
+            }
+            bs[j] += (rg[0][j] + rg[1][j]) + (rg[2][j] + rg[3][j]);
+            *reinterpret_cast<uint2 *>(w + j * 68 * 16) = make_uint2(x0, y0);
+            *reinterpret_cast<uint2 *>(w + (W4_PLANE + j * 68) * 16) = make_uint2(x1, y1);
+            *reinterpret_cast<uint2 *>(w + (2 * W4_PLANE + j * 68) * 16) = make_uint2(x2, y2);
+        }
+    };
+    const int sa = hk * W4_BLK + (li & 3) * 68 + (li >> 2) + wm * 16;                     // operand 0 (dG^T), k-octet hk
+    const int sb = (2 + hk) * W4_BLK + (li & 3) * 68 + (li >> 2) + wn * 32;               // operand 1 ([x|h])
+    auto products = [&](int buf) {
+        if (PN_W4_NOMFMA) return;
+        const u32x4 *fa = lds4 + (PN_W4_NOFRAG ? 0 : buf * W4_STAGE) + sa, *fb = lds4 + (PN_W4_NOFRAG ? 0 : buf * W4_STAGE) + sb;
+        u32x4 a0[2], a1[2], b0[4], b1[4];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a0[i] = fa[i * 8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) b0[j] = fb[j * 8];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) b1[j] = fb[W4_PLANE + j * 8];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a1[i] = fa[W4_PLANE + i * 8];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b1[j], acc[i][j]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) b1[j] = fb[2 * W4_PLANE + j * 8];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 2; i++) a1[i] = fa[2 * W4_PLANE + i * 8];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // the loads of tile i + 2 are issued behind the products of tile i and stay in flight across the barrier
+    issue(0);
+    wait_vm<0>(rg[0], rg[1], rg[2], rg[3]);
+    commit(0, 0);
+    issue(1);
+    __syncthreads();
+#pragma unroll 1
+    for (int64_t i = 0; i < my_tiles; i++) {
+        products((int)(i & 1));
+        wait_vm<0>(rg[0], rg[1], rg[2], rg[3]);
+        if (i + 1 < my_tiles) commit(i + 1, (int)((i + 1) & 1));
+        issue(i + 2);
+        __syncthreads();
+    }
+    wait_vm<0>(rg[0], rg[1], rg[2], rg[3]);     // drain the trailing (clamped) loads
+    float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wn * 128 + j * 32 + li;
+            if (n >= p.H2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (m < p.GH) pw[(int64_t)m * p.H2 + n] = acc[i][j][r];
+            }
+        }
+    // bias gradient: the four row-quad owners of a column add up through LDS
+    if (blockIdx.x != 0) return;   // block-uniform
+    float *fl = reinterpret_cast<float *>(lds4);
+    if (op == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) fl[rq * W4_BM + 4 * cq + j] = bs[j];
+    }
+    __syncthreads();
+    if (tid < W4_BM && m0 + tid < p.GH)
+        p.part_b[(int64_t)blockIdx.z * p.GH + m0 + tid] =
+            (fl[tid] + fl[W4_BM + tid]) + (fl[2 * W4_BM + tid] + fl[3 * W4_BM + tid]);
 }
 
 }  // namespace
@@ -847,18 +1086,32 @@ int launch_pack_bwd4(void *stream, const float *w_ih, const float *w_hh, int H, 
     return PN_OK;
 }
 
+template <int GC, int NRG, int KK>
+static int launch_seq_bwd4_t(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
+    constexpr int MT = 64 * NRG;
+    const size_t lds_bytes = (size_t)2 * KK * (2 * NW4 * 3 * 1024 + (MT / 32) * 3 * 1024) + (size_t)MT * (sp.L + 1) * 4 +
+                             (size_t)2 * MT * (H4 / 4);
+    auto kern = seq_bwd4_kernel<GC, NRG, KK>;
+    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
+    hipLaunchKernelGGL(kern, dim3((sp.P + MT - 1) / MT), dim3(256 * NRG), lds_bytes, stream, sp);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
 int launch_seq_bwd4(pn_context *ctx, void *stream, int gc, const SeqBwdParams &sp) {
-    const size_t lds_bytes = (size_t)B_IDX_OFF + (size_t)MT4 * (sp.L + 1) * 4 + (size_t)2 * MT4 * (H4 / 4);
-    const int blocks = (sp.P + MT4 - 1) / MT4;
-    if (gc == 3) {
-        auto kern = seq_bwd4_kernel<3>;
-        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT4), lds_bytes, (hipStream_t)stream, sp);
-    } else {
-        auto kern = seq_bwd4_kernel<4>;
-        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(NT4), lds_bytes, (hipStream_t)stream, sp);
-    }
+    // PN_B4_WIDE=1: 128 paths per workgroup (one workgroup per CU); default: 64 paths, two workgroups per CU
+    const char *e = getenv("PN_B4_WIDE");
+    const bool wide = e && atoi(e) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (wide) return gc == 3 ? launch_seq_bwd4_t<3, 2, 2>(ctx, st, sp) : launch_seq_bwd4_t<4, 2, 2>(ctx, st, sp);
+    return gc == 3 ? launch_seq_bwd4_t<3, 1, 1>(ctx, st, sp) : launch_seq_bwd4_t<4, 1, 1>(ctx, st, sp);
+}
+
+
+int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nsplit) {
+    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(wgrad4_kernel), W4_LDS_BYTES)) return rc;
+    hipLaunchKernelGGL(wgrad4_kernel, dim3((wp.H2 + W4_BN - 1) / W4_BN, (wp.GH + W4_BM - 1) / W4_BM, nsplit), dim3(W4_THREADS),
+                       W4_LDS_BYTES, (hipStream_t)stream, wp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }

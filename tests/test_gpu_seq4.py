@@ -1,0 +1,106 @@
+"""The opt-in 128-path / 64-path recurrent kernels (pn_seq4.hip, PN_SEQ4 bit mask) against the fused kernels (pn_pagg.hip)
+on the same module, inputs and dropout seed, and against the CPU oracle.
+
+They replace the same reference code as the fused ones -- nn.LSTM forward / autograd backward,
+/root/reference/PathNet_run.py:164,195,265,351 -- so the contract is the same: logits within 1e-5, gradients within
+3e-5 * max(1, |g|_inf).  PN_SEQ4 is read at every launch, which lets one process run both kernel sets."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pagg_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_env():
+    old = {k: os.environ.get(k) for k in ("PN_SEQ4", "PN_B4_WIDE")}
+    yield
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _case(variant, S, W, L, cell=None, drop=0.5, N=400, F=48, C=5, seed=0):
+    import pathnet_amd
+    g = torch.Generator().manual_seed(seed)
+    cls = {"homo": pathnet_amd.PathNet_homo, "hetero": pathnet_amd.PathNet}[variant]
+    torch.manual_seed(seed)
+    m = cls(F, 128, C, L, dropout=drop, cell=cell).cuda().train()
+    X = torch.rand(N, F, generator=g).cuda()
+    sel = torch.randperm(N, generator=g)[:S].sort().values.to(torch.int32)
+    ids = torch.randint(0, N, (S, W, L), generator=g).to(torch.int32)
+    ids[:, :, 0] = sel[:, None]
+    codes = torch.randint(0, L, (S, W, L), generator=g).to(torch.uint8)
+    G = torch.randn(S, C, generator=g).cuda()
+    return m, X, ids.cuda(), codes.cuda(), sel.cuda(), G
+
+
+def _run(case, mask, wide=0, seed=7):
+    m, X, ids, codes, sel, G = case
+    os.environ["PN_SEQ4"] = str(mask)
+    os.environ["PN_B4_WIDE"] = str(wide)
+    torch.manual_seed(seed)          # the module draws its dropout seed from torch's generator
+    m.zero_grad(set_to_none=True)
+    out = m(X, ids, ids.shape[1], ids.shape[2], sel, codes, None)
+    out.backward(G)
+    torch.cuda.synchronize()
+    return out.detach().clone(), {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+
+
+@pytest.mark.parametrize("variant,S,W,L,cell,drop", [
+    ("homo", 97, 7, 4, None, 0.5),          # 679 paths: full tiles and a ragged one, for both tile widths
+    ("homo", 1, 1, 4, None, 0.5),           # a single path
+    ("homo", 64, 8, 4, None, 0.0),          # whole tiles, no dropout
+    ("homo", 40, 9, 6, None, 0.5),          # path length 6 (configs[4])
+    ("homo", 40, 9, 1, None, 0.5),          # one step: no recurrent products at all
+    ("homo", 97, 7, 4, "gru", 0.5),         # GRU on the four gate slots
+    ("hetero", 97, 7, 4, None, 0.5),        # the hetero index plan
+])
+@pytest.mark.parametrize("mask,wide", [(1, 0), (2, 0), (2, 1), (4, 0), (7, 0), (7, 1)])
+def test_seq4_kernels_match_the_fused_kernels(variant, S, W, L, cell, drop, mask, wide):
+    case = _case(variant, S, W, L, cell, drop)
+    ref_out, ref_g = _run(case, 0)
+    out, g = _run(case, mask, wide)
+    assert not torch.isnan(out).any()
+    assert (out - ref_out).abs().max().item() <= 1e-5
+    for k in ref_g:
+        tol = 3e-5 * max(1.0, ref_g[k].abs().max().item())
+        assert (g[k] - ref_g[k]).abs().max().item() <= tol, k
+
+
+def test_seq4_kernels_match_the_oracle():
+    """all three on: forward and every gradient against the CPU oracle with the same explicit dropout masks"""
+    import pathnet_amd
+    torch.manual_seed(1)
+    N, F, H, C, S, W, L = 300, 40, 128, 4, 70, 11, 4
+    g = torch.Generator().manual_seed(5)
+    m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.5).cuda().train()
+    X = torch.rand(N, F, generator=g)
+    sel = np.sort(np.random.default_rng(2).choice(N, S, replace=False))
+    ids = np.random.default_rng(3).integers(0, N, (S, W, L)).astype(np.int32)
+    ids[:, :, 0] = sel[:, None]
+    codes = np.random.default_rng(4).integers(0, L, (S, W, L)).astype(np.uint8)
+    keep = 0.5
+    mask_seq = (torch.rand(L, S * W, H, generator=g) < keep).float() / keep
+    mask_cls = (torch.rand(S, 2 * H, generator=g) < keep).float() / keep
+    m._mask_seq, m._mask_cls = mask_seq.cuda(), mask_cls.cuda()
+    os.environ["PN_SEQ4"] = "7"
+    mask = np.zeros(N, bool)
+    mask[sel] = True
+    out = m(X.cuda(), torch.as_tensor(ids.reshape(S, W * L).astype(np.int64)), W, L, mask,
+            torch.as_tensor(codes.astype(np.int64)), None)
+    Gout = torch.randn(S, C, generator=g)
+    out.backward(Gout.cuda())
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = po.forward("homo", params, X, ids, codes, sel, W, L, drop_seq=mask_seq, drop_cls=mask_cls)
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < 1e-5
+    want.backward(Gout)
+    for k, v in m.named_parameters():
+        ref = params[k].grad
+        assert (v.grad.cpu() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item()), k
