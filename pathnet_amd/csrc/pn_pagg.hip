@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (RB > 1 ? 1 : fwd_waves<H, RG>())
 // pool_fwd_kernel: one workgroup (4 waves) per pooling group (= output node).
 // ================================================================================================
 struct PoolParams {
-    int variant, S, W, H, C;
+    int variant, S, W, H, C, N;      // N: rows of Xh (sel is clamped to it, like ids in plan_kernel)
     int64_t goff;           // position of local group 0 in the whole batch (dropout counters / explicit mask rows)
     const float *hn;        // [P, H] in slot' order
     const float *ego_tab;   // Z (HOMO) or Xh (HETERO)
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
     __syncthreads();
     // layer1 = dropout([Xh[sel[g]] ; pooled])
     float *l1 = p.layer1 + (int64_t)g * 2 * H;
-    const float *ego = p.Xh + (int64_t)p.sel[g] * H;
+    const float *ego = p.Xh + (int64_t)min(max(p.sel[g], 0), p.N - 1) * H;
     for (int j = tid; j < H; j += 256) {
         float a = ego[j], b = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
         const uint64_t gg = (uint64_t)(p.goff + g);
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
 // ================================================================================================
 // ---- pooling / attention / classifier backward: one wavefront per group -------------------------
 struct PoolBwdParams {
-    int variant, S, W, H, C;
+    int variant, S, W, H, C, N;
     int64_t goff;
     const float *hn, *ego_tab;
     const int32_t *egoidx, *sel;
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 a *= dropout1(seed, gg * 2 * H + j, 2u, p.p_drop);
                 b *= dropout1(seed, gg * 2 * H + H + j, 2u, p.p_drop);
             }
-            atomicAdd(&p.dXh[(int64_t)p.sel[g] * H + j], a);
+            atomicAdd(&p.dXh[(int64_t)min(max(p.sel[g], 0), p.N - 1) * H + j], a);
             dp[j] = b * inv_w;
         }
         __builtin_amdgcn_wave_barrier();
@@ -2421,6 +2421,7 @@ int run_pool_fwd(const Call &c, int b, float *out) {
     pp.W = d.W;
     pp.H = d.H;
     pp.C = d.C;
+    pp.N = d.N;
     pp.goff = c.group0(b);
     pp.hn = c.at<float>(c.w.hn);
     pp.ego_tab = homo ? c.Z : c.Xh;
@@ -2622,7 +2623,9 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     Call c;
     if (int rc = resolve_call(c, ctx, a, stream, "pn_pagg_backward")) return rc;
     const Dims &d = c.d;
-    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->fc2_w || !a->g_out)
+    // (S == 0 -- a rank of a sharded batch without masked nodes: its index arrays and g_out are empty tensors, i.e. NULL;
+    //  the call still zero-fills every gradient it was given)
+    if (!a->bank_w || !a->fc2_w || (d.S > 0 && (!a->ids || !a->codes || !a->sel || !a->g_out)))
         PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null tensor");
     if (d.G > 0 && (!a->w_ih || !a->w_hh)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: recurrent weights missing");
     if (!a->Xh_in && (!a->X || !a->fc0_w)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: X / fc0 missing");
@@ -2733,6 +2736,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             pp.W = d.W;
             pp.H = H;
             pp.C = d.C;
+            pp.N = d.N;
             pp.goff = c.group0(b);
             pp.hn = c.at<float>(c.w.hn);
             pp.ego_tab = homo ? Z : Xh;

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     const int64_t e_l = g / per_epoch;
     const int64_t rem = g - e_l * per_epoch;
     const int32_t st_i = (int32_t)(rem / p.W);
-    const int32_t st = p.node_list ? p.node_list[st_i] : p.node_begin + st_i;
+    // (a listed source node outside the graph is clamped: the host checks ranges, not lists in device memory)
+    const int32_t st = p.node_list ? min(max(p.node_list[st_i], 0), p.n - 1) : p.node_begin + st_i;
     const int32_t wi = (int32_t)(rem % p.W);
     const int64_t epoch_begin = p.dyn ? p.dyn->epoch : p.epoch_begin;
     const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int st_l = blockIdx.x * kOtfWaves + wave;
     if (st_l >= p.node_count) return;                       // wave-uniform; no block barriers below
-    const int32_t st = p.node_list ? p.node_list[st_l] : p.node_begin + st_l;
+    const int32_t st = p.node_list ? min(max(p.node_list[st_l], 0), p.n - 1) : p.node_begin + st_l;
     uint32_t *tab = s_tab[wave];
 
     // ---- out-ball of st, radius rf (largest of 2, 1, 0 that keeps the table at most half full) ----------

@@ -36,6 +36,17 @@ WORKSPACE_BUDGET_BYTES = 48 << 30
 MIN_BATCH_BYTES = 8 << 30           # floor of the per-micro-batch part (pick_batch_groups)
 
 
+def default_budget(device=None):
+    """Workspace budget when the module has none of its own: WORKSPACE_BUDGET_BYTES, but never more than 60 % of the
+    HBM that is free on `device` right now (a smaller GPU, or one shared with other tensors, then gets micro-batches
+    instead of an out-of-memory error)."""
+    try:
+        free, _ = torch.cuda.mem_get_info(device)
+        return int(min(WORKSPACE_BUDGET_BYTES, max(0.6 * free, MIN_BATCH_BYTES)))
+    except Exception:       # noqa: BLE001  (no CUDA context yet / CPU-only import)
+        return WORKSPACE_BUDGET_BYTES
+
+
 def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None):
     return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L, S_total, group_begin, batch_groups, _CELL[cell])
 
@@ -52,11 +63,18 @@ def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batc
     return n.value
 
 
-def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None):
-    """0 when the whole batch fits the workspace budget, else the largest micro-batch (in masked nodes) that does."""
+def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, device=None):
+    """0 when the whole batch fits the workspace budget, else the largest micro-batch (in masked nodes) that does.
+    budget=None: default_budget(device) -- queried only when the batch needs more than MIN_BATCH_BYTES, so that ordinary
+    steps make no runtime call."""
+    need = workspace_bytes(variant, N, F, H, C, S, W, L, cell=cell) if S > 1 else 0
     floor = MIN_BATCH_BYTES if budget is None else 0       # an explicit budget is kept to the byte
-    budget = WORKSPACE_BUDGET_BYTES if budget is None else int(budget)
-    if S <= 1 or workspace_bytes(variant, N, F, H, C, S, W, L, cell=cell) <= budget:
+    if budget is None:
+        if need <= MIN_BATCH_BYTES:
+            return 0
+        budget = default_budget(device)
+    budget = int(budget)
+    if S <= 1 or need <= budget:
         return 0
     fixed = workspace_bytes(variant, N, F, H, C, 1, W, L, cell=cell)         # the node tables: needed whatever the batch
     per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L, cell=cell) - fixed) // 1024, 1)
@@ -184,7 +202,8 @@ def _as_index_tensors(neis, layer_type, indices, num_w, walk_len, device, n_node
     if ids.numel() != S * num_w * walk_len or codes.numel() != S * num_w * walk_len:
         raise ValueError("neis / layer_type hold %d / %d entries, %d masked nodes x %d paths x %d steps = %d expected"
                          % (ids.numel(), codes.numel(), S, num_w, walk_len, S * num_w * walk_len))
-    if n_nodes is not None and S and sel.device.type == "cpu":      # (device-resident ids: the kernels clamp)
+    if n_nodes is not None and S and sel.device.type == "cpu":      # (device-resident indices are not read back: the
+                                                                    #  kernels clamp ids, codes and sel to the tables)
         lo, hi = int(sel.min()), int(sel.max())
         if lo < 0 or hi >= n_nodes:
             raise IndexError("indices name node %d, the feature matrix has %d rows" % (lo if lo < 0 else hi, n_nodes))
@@ -227,6 +246,13 @@ class _Aggregator(nn.Module):
     def _bank_layers(self):
         raise NotImplementedError
 
+    def _tables_key(self, X, L):
+        """what the projected feature matrix and the distance bank in the eval workspace were computed from: X (address,
+        shape, in-place version) and the versions of the fc0 / bank parameters (an optimizer step bumps them)"""
+        lins = [self.fc0] + list(self._bank_layers())
+        return (X.data_ptr(), tuple(X.shape), int(X._version), int(L),
+                tuple(int(t._version) for l in lins for t in (l.weight, l.bias)))
+
     def _make_cell(self, default):
         """the recurrent sub-module, under the attribute name torch users expect (LSTM / RNN / GRU); none for mean / sum"""
         kind = self.cell or default
@@ -264,6 +290,39 @@ class _Aggregator(nn.Module):
             self._bank_flat = (fw, fb)
         return fw, fb, [l.weight for l in lins], [l.bias for l in lins]
 
+    def _padded_param_inputs(self, Hk):
+        """The same inputs for a hidden size that is not a multiple of 32 (`-hid` is any integer, PathNet_run.py:52), zero-padded
+        to Hk units as differentiable functions of the parameters.  Exact: a padded unit's projected feature, bank row,
+        gates' inputs and attention / classifier weights are 0, so its cell and hidden state stay 0 (sigmoid(0) * tanh(0))
+        and it feeds nothing into the real units; autograd drops the padded gradient entries on the way back."""
+        H, G = self.hidden_size, {"lstm": 4, "rnn": 1, "gru": 3}.get(self._cell_kind, 0)
+        pad = Hk - H
+        P = torch.nn.functional.pad
+
+        def rows(w):            # [H, *] -> [Hk, *]
+            return P(w, (0, 0) * (w.dim() - 1) + (0, pad))
+
+        def gates(w):           # [G*H, H] -> [G*Hk, Hk]  /  [G*H] -> [G*Hk]
+            if w.dim() == 2:
+                return P(w.view(G, H, H), (0, pad, 0, pad)).reshape(G * Hk, Hk)
+            return P(w.view(G, H), (0, pad)).reshape(G * Hk)
+
+        def halves(w):          # [C, 2H] -> [C, 2Hk]  ([ego | pooled paths])
+            return P(w.view(w.shape[0], 2, H), (0, pad)).reshape(w.shape[0], 2 * Hk)
+        lins = self._bank_layers()
+        ws = [P(l.weight, (0, pad, 0, pad)) for l in lins]
+        bs = [P(l.bias, (0, pad)) for l in lins]
+        cell = self._cell()
+        att = getattr(self, "attw", None)
+        rec = tuple(gates(t) for t in (cell.weight_ih_l0, cell.weight_hh_l0, cell.bias_ih_l0, cell.bias_hh_l0)) \
+            if cell is not None else (None,) * 4
+        head = (rows(self.fc0.weight), P(self.fc0.bias, (0, pad))) + rec + (
+            halves(att.weight) if att is not None else None, att.bias if att is not None else None,
+            halves(self.fc2.weight), self.fc2.bias)
+        with torch.no_grad():
+            fw, fb = torch.stack([w.detach() for w in ws]).contiguous(), torch.stack([b.detach() for b in bs]).contiguous()
+        return fw, fb, head + tuple(ws) + tuple(bs)
+
     def _param_inputs(self):
         fw, fb, ws, bs = self._bank()
         cell = self._cell()
@@ -286,10 +345,12 @@ class _Aggregator(nn.Module):
             raise RuntimeError("pathnet_amd aggregators run on the GPU only (X is on %s); no CPU fallback" % dev)
         X = X.contiguous().float()
         ids, codes, sel, S = _as_index_tensors(neis, layer_type, indices, num_w, walk_len, dev, n_nodes=X.shape[0])
-        fw, fb, params = self._param_inputs()
+        H = self.hidden_size
+        Hk = -(-H // 32) * 32           # the kernels' hidden size: H, or H zero-padded to the next multiple of 32
+        fw, fb, params = self._param_inputs() if Hk == H else self._padded_param_inputs(Hk)
         training = self.training
         p = self.dropout_p() if training else 0.0
-        cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=self.hidden_size, C=self.out_size, S=S,
+        cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=Hk, C=self.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
                    step_state=self.step_state, cell=self._cell_kind,
                    seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.step_state is None) else 0)
@@ -302,24 +363,33 @@ class _Aggregator(nn.Module):
         if len(params) != 10 + 2 * cfg["L"]:
             raise ValueError("walk_len=%d but the module has %d distance layers" % (cfg["L"], (len(params) - 10) // 2))
         if training and (self._mask_seq is not None or self._mask_cls is not None):
-            cfg["mask_seq"], cfg["mask_cls"] = self._mask_seq, self._mask_cls
+            ms, mc = self._mask_seq, self._mask_cls
+            if Hk != H:         # explicit masks are given for the module's own hidden size
+                P = torch.nn.functional.pad
+                ms = P(ms, (0, Hk - H)).contiguous() if ms is not None else None
+                mc = P(mc.view(mc.shape[0], 2, H), (0, Hk - H)).reshape(mc.shape[0], 2 * Hk).contiguous() if mc is not None else None
+            cfg["mask_seq"], cfg["mask_cls"] = ms, mc
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["grad"] = torch.is_grad_enabled()
         cfg["batch_groups"] = pick_batch_groups(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
-                                                cfg["L"], self.workspace_budget, cell=self._cell_kind)
+                                                cfg["L"], self.workspace_budget, cell=self._cell_kind, device=dev)
         if not cfg["grad"]:
             need = _cfg_workspace_bytes(cfg)
             fits = self._ws_eval is not None and self._ws_eval.numel() >= need and self._ws_eval.device == dev
-            if reuse_tables and not (fits and self._ws_tables == (X.data_ptr(), X.shape, cfg["L"])):
+            key = self._tables_key(X, cfg["L"])
+            if reuse_tables and not (fits and self._ws_tables == key):
                 reuse_tables = False        # nothing (valid) to reuse: compute the tables as usual
             if not fits:
                 with torch.cuda.device(dev):
                     self._ws_eval = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
             cfg["workspace"] = self._ws_eval
             cfg["reuse_tables"] = bool(reuse_tables)
-            self._ws_tables = (X.data_ptr(), X.shape, cfg["L"])
+            # the tables are in the workspace after this call only if it computes (or keeps) them: S = 0 returns early
+            self._ws_tables = key if S > 0 else None
         elif reuse_tables:
             raise RuntimeError("reuse_tables is for no-grad (inference) forwards")
+        else:
+            self._ws_tables = None          # a training forward: the weights are about to change
         return _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
 
 

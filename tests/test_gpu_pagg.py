@@ -532,3 +532,51 @@ def test_cora_config_forward_backward_full_parity():
         ref = pr[k].grad
         err = (v.grad.cpu() - ref).abs().max().item()
         assert err < 3e-5 * max(1.0, ref.abs().max().item()) + 1e-7, (k, err, ref.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------
+# hidden sizes that are not multiples of 32 (`-hid` is any integer, /root/reference/PathNet_run.py:52; default 64)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,H,cell", [("homo", 50, None), ("hetero", 100, None), ("pagg", 50, None),
+                                            ("homo", 20, "gru"), ("hetero", 72, "mean")])
+def test_hidden_size_that_is_not_a_multiple_of_32(variant, H, cell):
+    """the module pads the hidden size with zero units up to the kernels' multiple of 32: forward (training mode, injected
+    dropout masks) and every gradient against the CPU oracle at the module's OWN hidden size"""
+    import pathnet_amd
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    N, F, C, W, L, S = 90, 24, 4, 12, 4, 33
+    cls = {"hetero": pathnet_amd.PathNet, "homo": pathnet_amd.PathNet_homo, "pagg": pathnet_amd.PAGG}[variant]
+    m = cls(F, H, C, L if variant != "pagg" else N, cell=cell).cuda().train()
+    pdrop = 0.5
+    mask_seq = (torch.rand(L, S * W, H) >= pdrop).float() / (1 - pdrop)
+    mask_cls = (torch.rand(S, 2 * H) >= pdrop).float() / (1 - pdrop)
+    m._mask_seq, m._mask_cls = mask_seq.cuda(), mask_cls.cuda()
+    X = torch.rand(N, F)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    ids = rng.integers(0, N, (S, W, L))
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    G = torch.randn(S, C)
+    out.backward(G.cuda())
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Xr = X.clone().requires_grad_(True)
+    want = po.forward(variant, params, Xr, ids, codes, sel, W, L, drop_seq=mask_seq, drop_cls=mask_cls, cell=cell)
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < TOL_OUT
+    want.backward(G)
+    for k, v in m.named_parameters():
+        assert v.grad.shape == params[k].shape
+        ref = params[k].grad.numpy()
+        assert np.abs(v.grad.cpu().numpy() - ref).max() <= grad_tol(ref), k
+    assert np.abs(Xd.grad.cpu().numpy() - Xr.grad.numpy()).max() <= grad_tol(Xr.grad.numpy())
+    # inference, built-in dropout off: same values with the padded tables reused by a second forward
+    m.eval()
+    with torch.no_grad():
+        e1 = run_module(m, X.cuda(), ids, codes, mask, W, L)
+        neis = torch.as_tensor(ids.reshape(S, W * L).astype(np.int64))
+        e2 = m(X.cuda(), neis, W, L, mask, torch.as_tensor(codes.astype(np.int64)), None, reuse_tables=True)
+    we = po.forward(variant, {k: v.detach() for k, v in params.items()}, X, ids, codes, sel, W, L, cell=cell)
+    assert (e1.cpu() - we).abs().max().item() < TOL_OUT and torch.equal(e1, e2)
