@@ -489,6 +489,49 @@ def test_pubmed_scale_batch_invariance_and_oracle_subset(variant):
         assert (v.grad - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item()), k
 
 
+def test_bgp_scale_hetero_full_batch_matches_the_oracle():
+    """configs[3]: a BGP-sized batch of the hetero class PathNet (PathNet_run.py:150-211; :286-291 selects it for bgp) --
+    N = 63 977 nodes, F = 287, C = 8, 30 708 masked nodes x 40 paths x 4 steps = 1 228 320 paths.  Its rows read paths
+    of OTHER masked nodes (the [W, S] re-view of an S-major index, :196-197), so no sub-batch can stand in for the
+    batch: the fp32 CPU oracle runs once on the whole batch (forward + autograd backward, about a minute on the GPU
+    box's host cores) and every logit and every parameter gradient is compared.  Then: a slice of the batch
+    (group_slice) is bit for bit those rows of the whole-batch result."""
+    torch.manual_seed(61)
+    rng = np.random.default_rng(61)
+    N, F, H, C, W, L, S = 63977, 287, 128, 8, 40, 4, 30708
+    m = build_module("hetero", F, H, C, L, N, None).eval()
+    X = torch.rand(N, F)
+    sel = np.sort(rng.permutation(N)[:S])
+    mask = np.zeros(N, bool)
+    mask[sel] = True
+    ids = rng.integers(0, N, (S, W, L)).astype(np.int32)
+    ids[:, :, 0] = sel[:, None]
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :]).astype(np.uint8)
+    G = torch.randn(S, C) / S
+    Xd = X.cuda()
+    d_ids, d_codes, d_sel = torch.as_tensor(ids).cuda(), torch.as_tensor(codes).cuda(), torch.as_tensor(sel.astype(np.int32)).cuda()
+    out = m(Xd, d_ids, W, L, d_sel, d_codes, None)
+    (out * G.cuda()).sum().backward()
+    got = out.detach().cpu()
+    grads = {k: v.grad.detach().cpu().clone() for k, v in m.named_parameters()}
+    # slices of the batch: the rows of the whole-batch result, bit for bit
+    with torch.no_grad():
+        for begin, count in ((0, 257), (12345, 1000), (S - 300, 300)):
+            part = m(Xd, d_ids, W, L, d_sel, d_codes, None, group_slice=(begin, count))
+            assert torch.equal(part.cpu(), got[begin:begin + count]), (begin, count)
+    del out, part
+    torch.cuda.empty_cache()
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = po.forward("hetero", pr, X, ids, codes, sel, W, L)
+    (want * G).sum().backward()
+    err = (got - want.detach()).abs()
+    assert err.max().item() < TOL_OUT, (err.max().item(), int(err.argmax()) // C)
+    for k in grads:
+        ref = pr[k].grad
+        e = (grads[k] - ref).abs().max().item()
+        assert e <= 3e-5 * max(1.0, ref.abs().max().item()) + 1e-7, (k, e, ref.abs().max().item())
+
+
 def test_large_batches_are_sized_not_rejected():
     """Round 1 refused S*W*L*5*H >= 2^32 elements; the kernels now address every per-path tensor as a 64-bit tile
     base + a 32-bit in-tile offset, and a batch beyond the workspace budget is walked in micro-batches."""

@@ -152,6 +152,28 @@ def test_pubmed_scale_philox_bit_exact_vs_oracle():
     assert (ids_w.cpu().numpy() == oi[:, lo:lo + cnt]).all() and (codes_w.cpu().numpy() == oc[:, lo:lo + cnt]).all()
 
 
+def test_bgp_scale_dense_table_window_bit_exact_vs_oracle():
+    """configs[3]: a BGP-sized graph (63 977 nodes): the dense hop table dis[n][n] of gen_merw.cpp:101-123 is 4.1 GB in
+    HBM; a window of source nodes (what one of 8 ranks samples) against the C restatement, which walks the same
+    window over its own dense table; node lists (what a training step samples) give the same rows."""
+    from pathnet_amd import DRAW_PHILOX, MerwSampler
+    n, u, v, p = synthetic_graph(63977, 5, 7)
+    W, L = 40, 4
+    smp = MerwSampler(n, u, v, p, L)                 # dense table (n^2 = 4.1 GB <= the 8 GB switch to on-the-fly codes)
+    assert smp.hops == "dense"
+    lo, cnt = 5 * (n // 8), n // 8
+    ids_w, codes_w = smp.sample(W, 99, epoch_begin=3, epoch_count=1, node_begin=lo, node_count=cnt, draw_source=DRAW_PHILOX)
+    off, A, B, S = merw.alias_build(n, u, v, p)
+    dis = merw.bfs_dense(n, u, v, L)
+    oi, oc = merw.walk(n, off, A, B, S, dis, W, L, merw.DRAW_PHILOX, 99, epoch_begin=3, epoch_count=1, node_begin=lo,
+                       node_count=cnt)
+    assert (ids_w.cpu().numpy() == oi).all() and (codes_w.cpu().numpy() == oc).all()
+    nodes = np.sort(np.random.default_rng(1).permutation(cnt)[:2000]) + lo
+    ids_l, codes_l = smp.sample(W, 99, epoch_begin=3, epoch_count=1, nodes=torch.as_tensor(nodes.astype(np.int32)).cuda(),
+                                draw_source=DRAW_PHILOX)
+    assert (ids_l.cpu().numpy() == oi[:, nodes - lo]).all() and (codes_l.cpu().numpy() == oc[:, nodes - lo]).all()
+
+
 # ------------------------------------------------------------------------------------------------
 # on-the-fly hop codes (no dense n*n table): must give the same codes as the reference's bfs()
 # ------------------------------------------------------------------------------------------------
