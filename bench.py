@@ -200,6 +200,106 @@ def cpu_baseline(wl, seconds_budget=20.0):
                       "steps" % (S, len(sel_all), S * W, n, len(times) - 1), "ms_per_step": med * 1e3}
 
 
+class _ReferenceOpsHomo(torch.nn.Module):
+    """The reference's op sequence for the homophilous class (/root/reference/PathNet_run.py:220-278) written with stock
+    torch modules -- what BASELINE.md section 2 asks to be timed on the host ("the reference classes, CPU PyTorch"):
+    fc0 over all N nodes + ReLU, row gather, ALL L distance layers on every gathered row stacked and one selected per
+    row by its code, ReLU, dropout, nn.LSTM over the L steps, attention against the ego row, mean over the paths,
+    concat with the node's own row, dropout, fc2.  (The reference classes themselves cannot travel to the GPU box;
+    this module is measurement infrastructure, used by nothing else.)"""
+
+    def __init__(self, F, H, C, L, p_drop):
+        super().__init__()
+        nn = torch.nn
+        self.fc0, self.fc2, self.attw = nn.Linear(F, H), nn.Linear(2 * H, C), nn.Linear(2 * H, 1)
+        self.nets = nn.ModuleList([nn.Linear(H, H) for _ in range(L)])
+        self.LSTM = nn.LSTM(H, H)
+        self.H, self.p = H, p_drop
+
+    def forward(self, X, neis, W, L, sel, codes):
+        Fn = torch.nn.functional
+        S, H = sel.numel(), self.H
+        Xh = torch.relu(self.fc0(X))
+        nei = Xh[neis.reshape(-1)]                                             # [S*W*L, H]
+        nei = torch.stack([layer(nei) for layer in self.nets], dim=1)           # [S*W*L, L, H]
+        nei = torch.relu(nei[torch.arange(S * W * L), codes.reshape(-1)].view(S * W, L, H))
+        ego_full = nei.reshape(S, W, L, H)[:, :, 0, :]
+        seq = Fn.dropout(nei.transpose(0, 1), p=self.p, training=self.training)
+        _, (h_n, _) = self.LSTM(seq)
+        h_n = h_n.transpose(0, 1).reshape(S, W, H)
+        h_n = ((1 + self.attw(torch.cat((h_n, ego_full), dim=-1))) * h_n).mean(dim=1)
+        layer1 = Fn.dropout(torch.cat((Xh[sel], h_n), dim=1), p=self.p, training=self.training)
+        return self.fc2(layer1)
+
+
+def cpu_baseline_reference_ops(X, Y, ids, codes, sel, F, H, C, W, L, threads=(16, 32, 64, 128), seconds_budget=25.0,
+                               what=""):
+    """fwd + CE + bwd + torch.optim.Adam of _ReferenceOpsHomo on the host, best of a thread sweep (median of the steps
+    after a warm-up for every thread count); the sweep stops when the budget is used up."""
+    torch.manual_seed(0)
+    model = _ReferenceOpsHomo(F, H, C, L, 0.7).train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.005, weight_decay=0.0005)
+    lossf = torch.nn.CrossEntropyLoss()
+    Xt, Yt = torch.as_tensor(X), torch.as_tensor(Y).long()
+    neis, cd, st = torch.as_tensor(ids).long(), torch.as_tensor(codes).long(), torch.as_tensor(sel).long()
+    S = st.numel()
+    old = torch.get_num_threads()
+    t_begin, sweep = time.time(), {}
+    try:
+        for k in [t for t in threads if t <= (os.cpu_count() or 1)] or [old]:
+            torch.set_num_threads(k)
+            times = []
+            for it in range(4):
+                t0 = time.time()
+                loss = lossf(model(Xt, neis, W, L, st, cd), Yt)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                times.append(time.time() - t0)
+            sweep[k] = float(np.median(times[1:]))
+            if time.time() - t_begin > seconds_budget:
+                break
+    finally:
+        torch.set_num_threads(old)
+    best = min(sweep, key=sweep.get)
+    return {"value": S * W / sweep[best], "unit": "paths/s", "cores": best, "kind": "reference-ops",
+            "ms_per_step": sweep[best] * 1e3, "thread_sweep_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
+            "sample": "the reference's op sequence (PathNet_run.py:239-278, :345-352) with stock torch modules -- nn.Linear "
+                      "fc0 over all nodes, L stacked nn.Linear + select by code, nn.LSTM, attention, fc2, CrossEntropyLoss, "
+                      "torch.optim.Adam -- %s: fwd + loss + bwd + Adam step over %d masked nodes (%d paths), median of 3 "
+                      "steps after a warm-up per thread count, best thread count quoted" % (what, S, S * W)}
+
+
+def cpu_baseline_cornell():
+    """configs[0] (Cornell, path_num 40, path_len 4, hid 128: the reference's own CPU-runnable case): the unmodified
+    sampler on the shipped cornell edge list (carried by tests/golden/sampler_cornell_40_4.npz) and the reference-ops
+    aggregator step at Cornell's shape (N = 183, F = 1703, C = 5, 87 train nodes; features synthetic: splits.zip is
+    absent from the reference mount)."""
+    from oracle import merw
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "sampler_cornell_40_4.npz")))
+    n, u, v, p = int(g["n"]), g["u"], g["v"], g["p"]
+    res = {}
+    if merw.have_ref():
+        path = "/tmp/pn_bench_cornell_%d.in" % os.getpid()
+        merw.write_edge_file(path, n, u, v, p)
+        t0 = time.time()
+        merw.run_ref(path, 40, 4, 1, to_devnull=True, timeout=600)
+        dt = time.time() - t0
+        os.remove(path)
+        res["sampler"] = {"value": 1000 * n * 40 / dt, "unit": "sampled paths/s", "cores": 1, "kind": "reference",
+                          "sample": "oracle/_ref/gen_merw (unmodified gen_merw.cpp) on the shipped cornell edge list, "
+                                    "W=40 L=4, its fixed 1000 epochs = %d paths, output to /dev/null, wall %.1f s"
+                                    % (1000 * n * 40, dt)}
+    rng = np.random.default_rng(0)
+    F, C, H, W, L, S = 1703, 5, 128, 40, 4, 87
+    X = (rng.random((n, F)) < 0.05).astype(np.float32)
+    sel = np.sort(rng.permutation(n)[:S])
+    ids, codes = merw.sample_full(n, u, v, p, W, L, merw.DRAW_PHILOX, 1, epoch_count=1)
+    res["pagg"] = cpu_baseline_reference_ops(X, rng.integers(0, C, S), ids[0][sel], codes[0][sel], sel, F, H, C, W, L,
+                                             threads=(1, 4, 16, 64), seconds_budget=8.0, what="Cornell shape")
+    return res
+
+
 def cpu_baseline_sampler(seconds_budget=20.0):
     """The unmodified reference sampler (oracle/_ref/gen_merw, compiled from gen_merw.cpp) on a graph sized
     so that its fixed 1000 epochs take ~10 s; single-threaded like the reference; output -> /dev/null."""
@@ -253,15 +353,20 @@ def bgp_workload(world=1, seed=5):
 class StepRunner:
     """One training step of the reference loop on a workload, everything resident on the GPU."""
 
-    def __init__(self, wl, dev, rank, world, sharded, timing_comm=False, hops="auto"):
+    def __init__(self, wl, dev, rank, world, sharded, timing_comm=False, hops="auto", device_state=False):
+        """device_state: epoch, dropout seed and Adam's step count live in device memory (pathnet_amd.StepState), so that
+        a step captured into a hipGraph replays as the next step (measure_graph)."""
         import pathnet_amd
         self.wl, self.dev, self.world = wl, dev, world
+        self.state = pathnet_amd.StepState(dev, seed=1234, first_epoch=0) if device_state else None
         n, F, C, H, W, L = wl["n"], wl["F"], wl["C"], wl["H"], wl["W"], wl["L"]
         gn, u, v, p = wl["graph"]
         self.smp = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev, hops=hops)
         torch.manual_seed(0)
         self.model = getattr(pathnet_amd, wl.get("cls", "PathNet_homo"))(F, H, C, L, dropout=0.7).to(dev)
-        self.opt = pathnet_amd.Adam(self.model.parameters(), lr=0.005, weight_decay=0.0005)  # torch.optim.Adam's update, one launch
+        self.model.step_state = self.state
+        self.opt = pathnet_amd.Adam(self.model.parameters(), lr=0.005, weight_decay=0.0005,   # torch.optim.Adam's update, one launch
+                                    **({"step_state": self.state} if self.state is not None else {}))
         self.lossf = pathnet_amd.CrossEntropyLoss()                                          # torch.nn.CrossEntropyLoss(), one launch
         Y = torch.from_numpy(wl["Y"]).to(dev)
         self.runner = None
@@ -296,8 +401,13 @@ class StepRunner:
         import pathnet_amd
         wl = self.wl
         W, L = wl["W"], wl["L"]
-        self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, nodes=self.sel32,
-                        draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(self.ids_buf, self.codes_buf))
+        if self.state is not None:
+            self.state.advance()        # (one tiny launch: epoch + 1, Adam step + 1, the step's dropout seed)
+            self.smp.sample(W, 0, nodes=self.sel32, draw_source=pathnet_amd.DRAW_PHILOX, check=False,
+                            out=(self.ids_buf, self.codes_buf), step_state=self.state)
+        else:
+            self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, nodes=self.sel32,
+                            draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(self.ids_buf, self.codes_buf))
         ids, codes = self.ids_buf[0], self.codes_buf[0]
         self.model.train()
         if self.runner is None:
@@ -345,6 +455,36 @@ def measure(sr, lib, ctx, names, steps, warmup, barrier):
     _lib.check(lib.pn_profile_configure(ctx, 0, -1))
     return {"elapsed": elapsed, "dominant": dominant, "dom_ms": dom[0] / dom[1], "dom_launches": dom[1],
             "stages_ms": {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
+
+
+def measure_graph(wl, dev, steps, warmup, barrier):
+    """The same training step captured once into a hipGraph (torch.cuda.CUDAGraph; the library's second stream joins the
+    capture through its fork / join events) and replayed: exactly `steps` replays between two barriers.  Every replay
+    is a NEW step -- epoch, dropout seed and Adam's step count are read from device memory (pn_step_state)."""
+    sr = StepRunner(wl, dev, 0, 1, sharded=False, device_state=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for e in range(max(2, warmup)):
+            sr.step(e)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sr.step(0)
+    for _ in range(3):
+        g.replay()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = sr.state.values()
+    return {"ms_per_step": elapsed / steps * 1e3, "value": sr.S * wl["W"] * steps / elapsed, "unit": "paths/s", "steps": steps,
+            "epochs_sampled": int(st["epoch"]) + 1, "adam_steps": int(st["adam_step"]),
+            "note": "one captured step replayed: same kernels as the eager step (no per-kernel events, no Python between "
+                    "the launches); the sampler's epoch, the dropout seed and Adam's step count advance in device memory"}
 
 
 def time_launches(fn, reps, warm=3):
@@ -535,6 +675,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline configuration only")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the step (N = 1 only)")
     ap.add_argument("--workload", choices=["cora", "pubmed", "bgp"], default="cora",
                     help="cora = BASELINE.json configs[1], what `value` is quoted on; pubmed = configs[2] as the timed "
                          "workload (profiling runs: tools/pmc_passes.sh); bgp = configs[3] stand-in (hetero class, "
@@ -651,9 +792,26 @@ def main():
     }
     if collectives:
         result["collectives"] = collectives
+    if world == 1 and not sharded and not args.no_graph and args.workload == "cora":
+        # the same K steps as one captured hipGraph replayed K times (`value` / `ms_per_step` above stay the eager run)
+        try:
+            result["graph_replay"] = measure_graph(wl, dev, args.steps, args.warmup, barrier)
+            result["graph_replay"]["eager_ms_per_step"] = ms_per_step
+        except Exception as e:      # noqa: BLE001  (an extra must not take the headline line down with it)
+            result["graph_replay"] = {"error": repr(e)[:300]}
     result.update(extras)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(wl)
+        # the stated baseline: the reference's op sequence on stock torch modules, best thread
+        # count; the oracle's port (explicit index plan, cell loop) stays beside it as a second line
+        from oracle import merw as _merw
+        gn, gu, gv, gp = wl["graph"]
+        sel_b = np.flatnonzero(wl["mask"])
+        ids_b, codes_b = _merw.sample_full(gn, gu, gv, gp, wl["W"], wl["L"], _merw.DRAW_PHILOX, 1, epoch_count=1)
+        result["cpu_baseline"] = cpu_baseline_reference_ops(wl["X"], wl["Y"][sel_b], ids_b[0][sel_b], codes_b[0][sel_b], sel_b,
+                                                            wl["F"], wl["H"], wl["C"], wl["W"], wl["L"],
+                                                            what="the bench workload (configs[1] shape)")
+        result["cpu_baseline_port"] = cpu_baseline(wl, seconds_budget=8.0)
+        result["cpu_baseline_configs0"] = cpu_baseline_cornell()
         sb = cpu_baseline_sampler()
         if sb:
             result["cpu_baseline_sampler"] = sb
