@@ -145,22 +145,40 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
     const int64_t g0 = (int64_t)blockIdx.x * kWalkThreads;
     const int64_t g = g0 + threadIdx.x;
 
-    // ---- stage the first-hop tables of the source nodes this block covers (block-uniform) --------
+    // ---- stage the first-hop tables of the source nodes this block covers (block-uniform): a block of 256 walks starts at
+    //      1 + 255 / W source nodes, consecutive in the window -- a node range, or a list of nodes (what a training step
+    //      samples: its masked nodes), whose tables are scattered over the triple array and are staged one by one ------
+    constexpr int kStageNodes = 16;
+    __shared__ int64_t s_o0[kStageNodes];
+    __shared__ int32_t s_len[kStageNodes];
     const int64_t g_last = (g0 + kWalkThreads - 1 < total ? g0 + kWalkThreads - 1 : total - 1);
     const int64_t e_first = g0 / per_epoch, e_last = g_last / per_epoch;
-    int64_t stage_base = 0, stage_cnt = 0;
-    int32_t st_lo = 0, st_hi = -1;
-    if (e_first == e_last && !p.node_list) {
-        st_lo = p.node_begin + (int32_t)((g0 % per_epoch) / p.W);
-        st_hi = p.node_begin + (int32_t)((g_last % per_epoch) / p.W);
-        stage_base = p.off[st_lo];
-        stage_cnt = p.off[st_hi + 1] - stage_base;
-        if (stage_cnt > kStageTriples) {
-            stage_cnt = 0;
-            st_hi = st_lo - 1;
+    const int32_t slot_lo = (int32_t)((g0 % per_epoch) / p.W);
+    int32_t nstage = e_first == e_last ? (int32_t)((g_last % per_epoch) / p.W) - slot_lo + 1 : 0;
+    if (nstage > kStageNodes) nstage = 0;
+    if ((int)threadIdx.x < nstage) {
+        const int32_t sl = slot_lo + (int32_t)threadIdx.x;
+        const int32_t nd = p.node_list ? min(max(p.node_list[sl], 0), p.n - 1) : p.node_begin + sl;
+        int64_t o0;
+        int32_t len;
+        node_table(p, nd, o0, len);
+        s_o0[threadIdx.x] = o0;
+        s_len[threadIdx.x] = len > 0 ? len : 0;
+    }
+    __syncthreads();
+    int32_t my_stage = -1;          // where this walk's first-hop table starts in s_tab (-1: not staged)
+    {
+        int32_t pre = 0, tot = 0;
+        for (int j = 0; j < nstage; j++) tot += s_len[j];
+        if (tot > kStageTriples) nstage = 0;
+        for (int j = 0; j < nstage; j++) {
+            const int64_t o0 = s_o0[j];
+            const int32_t len = s_len[j];
+            for (int32_t i = threadIdx.x; i < len; i += kWalkThreads) s_tab[pre + i] = p.triples[o0 + i];
+            if (g < total && (int32_t)(((g - e_first * per_epoch)) / p.W) - slot_lo == j) my_stage = pre;
+            pre += len;
         }
     }
-    for (int64_t i = threadIdx.x; i < stage_cnt; i += kWalkThreads) s_tab[i] = p.triples[stage_base + i];
     __syncthreads();
     if (g >= total) return;
 
@@ -214,8 +232,8 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
         }                                                                                          \
         const int64_t slot = o0 + (int64_t)(r0 % (uint32_t)len);                                   \
         int4 tr;                                                                                   \
-        if ((t) == 0 && st >= st_lo && st <= st_hi)                                                \
-            tr = s_tab[slot - stage_base];                                                         \
+        if ((t) == 0 && my_stage >= 0)                                                             \
+            tr = s_tab[my_stage + (int32_t)(slot - o0)];                                           \
         else                                                                                       \
             tr = p.triples[slot];                                                                  \
         x = (r1 >= (uint32_t)tr.z) ? tr.x : tr.y;                                                  \

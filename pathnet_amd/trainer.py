@@ -72,30 +72,38 @@ def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices
     ckpt = os.path.join(save_dir, data_name + ".pth")
     best_val, result = 0.0, (0.0, 0.0, 0.0, 0.0, 0.0)
     tr32, va32, te32 = tr.to(torch.int32), va.to(torch.int32), te.to(torch.int32)
+    if from_sampler:
+        # an epoch needs the paths of its train and validation nodes, and the test nodes' only when the validation
+        # accuracy improves: three node-list windows of the sampler instead of all N nodes (a walk's draws depend on
+        # (epoch, source node, walk) alone: the rows are those of a whole-epoch sample -- tests/test_gpu_sampler.py)
+        def paths_of(nodes32, epoch, check=False):
+            i, c = paths.sample(num_w, sampler_seed, epoch_begin=epoch, epoch_count=1, draw_source=DRAW_PHILOX,
+                                check=check, nodes=nodes32)
+            return i[0], c[0]
+    else:
+        def paths_of(nodes32, epoch, check=False):
+            idx = nodes32.long()
+            return ids_all[epoch].index_select(0, idx), codes_all[epoch].index_select(0, idx)
     for epoch in range(epochs):
-        if from_sampler:
-            ids, codes = paths.sample(num_w, sampler_seed, epoch_begin=epoch, epoch_count=1, draw_source=DRAW_PHILOX,
-                                      check=(epoch == 0))
-            ids, codes = ids[0], codes[0]
-        else:
-            ids, codes = ids_all[epoch], codes_all[epoch]
         model.train()
-        out = model(X, ids.index_select(0, tr), num_w, walk_len, tr32, codes.index_select(0, tr), None)
+        ids_tr, codes_tr = paths_of(tr32, epoch, check=(epoch == 0))
+        out = model(X, ids_tr, num_w, walk_len, tr32, codes_tr, None)
         loss = lossf(out, Y[tr])
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
         with torch.no_grad():
             model.eval()
-            pred = model(X, ids.index_select(0, va), num_w, walk_len, va32, codes.index_select(0, va), None).argmax(1)
+            ids_va, codes_va = paths_of(va32, epoch)
+            pred = model(X, ids_va, num_w, walk_len, va32, codes_va, None).argmax(1)
             val_acc = float((pred == Y[va]).double().mean())      # the one host round trip of an epoch
             if best_val < val_acc:
                 best_val = val_acc
                 torch.save(model.state_dict(), ckpt)
                 # same X, same weights as the validation forward just above: its projected features and distance
                 # bank are still in the module's workspace (PathNet_run.py:362 and :378 recompute them)
-                pred = model(X, ids.index_select(0, te), num_w, walk_len, te32, codes.index_select(0, te),
-                             None, reuse_tables=True).argmax(1)
+                ids_te, codes_te = paths_of(te32, epoch)
+                pred = model(X, ids_te, num_w, walk_len, te32, codes_te, None, reuse_tables=True).argmax(1)
                 result = classification_metrics(Y[te], pred, num_classes)
         if verbose and (epoch % 50 == 0 or epoch == epochs - 1):
             print("epoch %d loss %.4f val_acc %.4f test_acc %.4f" % (epoch, float(loss), val_acc, result[4]))

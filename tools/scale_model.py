@@ -1,0 +1,135 @@
+"""Scaling model of the node-sharded step (pathnet_amd/dist.py) for 2 / 4 / 8 MI355X of one box, from SINGLE-GPU
+measurements -- there is no multi-GPU box to measure on, so the arithmetic is written down where it can be checked.
+
+    python tools/scale_model.py [bench.json] [--link-GBs 50] [--latency-us 25] [--md]
+
+Inputs: a bench.py JSON line (stages_ms of the headline configs[1] step and of the configs[3] / configs[4] extras).
+Model, per rank and step, R ranks:
+
+  sharded work   every stage that runs over the rank's masked nodes (sampler, plan, recurrence forward / BPTT, weight
+                 gradient, pooling, classifier gradient): proportional to the rank's paths.
+  own rows       fc0 forward / backward: the rank's N / R rows of X.
+  replicated     the distance bank Z = bank(Xh) and its backward over ALL N rows of the graph, on every rank
+                 (sharding Z instead would all-gather L x the bytes).  With touched-row compaction
+                 (pn_pagg_shape.compact_rows, this round) only the (node, code) rows the rank's paths touch are computed.
+  collectives    all-gather of Xh and reduce-scatter of dXh: every rank sends / receives its N/R x H x 4-byte block
+                 to / from each of the R - 1 peers over its own xGMI link to that peer (the links run concurrently, one
+                 block per link): t = latency + block_bytes / link_rate.  All-reduce of the flat gradient buffer
+                 (G bytes): 2 (R - 1) / R x G / (links x link_rate) + latency.  The hetero class adds the all-gather of
+                 the batch's index arrays (5 bytes per path step).
+  overlap        none assumed (dist.py issues the collectives on the compute stream).
+
+weak scaling (configs[1]: every rank owns a 2708-node block of an R x 2708-node graph, bench.py --gpus R):
+  efficiency = t(1) / t(R).  strong scaling (configs[3], configs[4]: one graph): speed-up = t(1) / t(R).
+"""
+import argparse
+import json
+import os
+import sys
+
+SHARDED = ("sampler_walk", "sampler_fill", "plan_pack", "seq_fwd", "pool_fwd", "fc2_grad", "pool_bwd", "seq_bwd", "wgrad", "gather")
+OWN_ROWS = ("fc0", "fc0_bwd")
+REPLICATED = ("bank", "bank_bwd")
+
+
+def split(stages):
+    s = sum(v for k, v in stages.items() if k in SHARDED)
+    o = sum(v for k, v in stages.items() if k in OWN_ROWS)
+    r = sum(v for k, v in stages.items() if k in REPLICATED)
+    rest = sum(v for k, v in stages.items() if k not in SHARDED + OWN_ROWS + REPLICATED)
+    return s, o, r, rest
+
+
+def collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes=0):
+    if R == 1:
+        return 0.0, {}
+    block = n_total / R * H * 4
+    ag = lat_us * 1e-3 + block / (link_GBs * 1e9) * 1e3
+    rs = ag
+    ar = lat_us * 1e-3 + 2 * (R - 1) / R * grad_bytes / (min(R - 1, 7) * link_GBs * 1e9) * 1e3
+    ix = (lat_us * 1e-3 + idx_bytes / R / (link_GBs * 1e9) * 1e3) if idx_bytes else 0.0
+    return ag + rs + ar + ix, {"all_gather_Xh": ag, "reduce_scatter_dXh": rs, "all_reduce_grads": ar, "all_gather_indices": ix}
+
+
+def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, idx_bytes=0, touched_frac=None):
+    """-> rows (R, t_ms, speedup_or_efficiency, parts).  stages: single-GPU per-stage ms; total_ms: single-GPU wall per
+    step (the part not covered by the stage timers -- loss, Adam, torch glue -- is carried as `other`, per rank)."""
+    s, o, r, rest = split(stages)
+    other = max(total_ms - (s + o + r + rest), 0.0) + rest
+    rows = []
+    for R in (1, 2, 4, 8):
+        if weak:        # per-rank paths and rows stay, the graph grows: the replicated bank grows with it
+            n_total = n_total_1 * R
+            sh, own, rep = s, o, r * R
+        else:           # one graph: paths and rows shrink, the replicated bank does not
+            n_total = n_total_1
+            sh, own, rep = s / R, o / R, r
+        if touched_frac is not None:    # compaction: the bank runs over the rows this rank's paths touch
+            rep = min(rep, (r * (R if weak else 1)) * min(1.0, touched_frac(R)))
+        coll, parts = collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes)
+        t = sh + own + rep + other + coll
+        rows.append((R, t, dict(sharded=sh, own_rows=own, replicated_bank=rep, other=other, collectives=coll, **parts)))
+    t1 = rows[0][1]
+    return [(R, t, (t1 / t) if weak else (t1 / t), p) for R, t, p in rows]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("bench", nargs="?", default=None)
+    ap.add_argument("--link-GBs", type=float, default=50.0, help="sustained rate of one xGMI link, one direction")
+    ap.add_argument("--latency-us", type=float, default=25.0, help="per collective")
+    ap.add_argument("--md", action="store_true")
+    a = ap.parse_args()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = a.bench or next(p for p in (os.path.join(root, "profiles", "r03_bench_final.json"), os.path.join(root, "BENCH_r02.json"))
+                           if os.path.exists(p))
+    b = json.load(open(path))
+    b = b.get("bench", b) if "stages_ms" not in b else b
+    if "stages_ms" not in b:            # the driver's record wraps the line
+        b = json.loads([l for l in b.get("run", {}).get("stdout_tail", "").splitlines() if l.startswith("{")][-1])
+    H = 128
+    out = []
+    # configs[1]: weak scaling of the Cora-shaped block (bench.py --gpus R)
+    F, C, L = 1433, 7, 4
+    grad1 = (F * H + H + L * (H * H + H) + 2 * (4 * H * H + 4 * H) + 2 * H + 1 + 2 * H * C + C) * 4
+    out.append(("configs[1] Cora-shaped block per rank (weak)", "efficiency",
+                model(b["stages_ms"], b["ms_per_step"], 2708, H, grad1, True, a.link_GBs, a.latency_us)))
+    out.append(("configs[1], bank over touched rows only", "efficiency",
+                model(b["stages_ms"], b["ms_per_step"], 2708, H, grad1, True, a.link_GBs, a.latency_us,
+                      touched_frac=lambda R: 1.0 / R + 0.05)))
+    if "bgp_scale_step" in b:
+        g = b["bgp_scale_step"]
+        F3, C3 = 287, 8
+        grad3 = (F3 * H + H + L * (H * H + H) + 2 * (4 * H * H + 4 * H) + 2 * H + 1 + 2 * H * C3 + C3) * 4
+        idx = 30708 * 40 * 4 * 5 + 30708 * 4
+        out.append(("configs[3] BGP-sized, hetero class (strong)", "speed-up",
+                    model(g["stages_ms"], g["ms_per_step"], 63977, H, grad3, False, a.link_GBs, a.latency_us, idx_bytes=idx)))
+    if "configs4_one_gpu_step" in b and b["configs4_one_gpu_step"].get("stage_ms_per_step"):
+        g = b["configs4_one_gpu_step"]
+        st = g["stage_ms_per_step"]
+        F4, C4, L4 = 128, 8, 6
+        grad4 = (F4 * H + H + L4 * (H * H + H) + 2 * (4 * H * H + 4 * H) + 2 * H + 1 + 2 * H * C4 + C4) * 4
+        tot = g["seconds_per_step"] * 1e3
+        out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over all 60 M rows", "speed-up",
+                    model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us)))
+        # touched rows: a rank's 4 M / R paths x 6 steps can touch at most that many of the 60 M (node, code) rows
+        out.append(("configs[4], bank over touched rows only", "speed-up",
+                    model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
+                          touched_frac=lambda R: (100_000 * 40 * 6 / R) / 60e6)))
+    for title, what, rows in out:
+        print(("### " if a.md else "") + title + "   (xGMI link %.0f GB/s, %.0f us per collective; source %s)" % (
+            a.link_GBs, a.latency_us, os.path.basename(path)))
+        if a.md:
+            print("| ranks | ms/step | %s | sharded | own rows (fc0) | bank (replicated) | other | collectives |" % what)
+            print("|---|---|---|---|---|---|---|---|")
+        for R, t, sp, p in rows:
+            fmt = "| %d | %.3f | %.2f | %.3f | %.3f | %.3f | %.3f | %.3f |" if a.md else \
+                "  R=%d  %9.3f ms  %s %.2f   sharded %.3f  fc0 %.3f  bank %.3f  other %.3f  collectives %.3f"
+            args = (R, t, sp, p["sharded"], p["own_rows"], p["replicated_bank"], p["other"], p["collectives"]) if a.md else \
+                (R, t, what, sp, p["sharded"], p["own_rows"], p["replicated_bank"], p["other"], p["collectives"])
+            print(fmt % args)
+        print()
+
+
+if __name__ == "__main__":
+    sys.exit(main())
