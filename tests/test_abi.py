@@ -2,6 +2,8 @@
 and its host-only entry points (no GPU needed) agree with the oracle."""
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -273,3 +275,90 @@ def test_node_ref_pack():
     assert lib.pn_node_ref_pack(4, _lib.np_ptr(off, ctypes.c_int64), _lib.np_ptr(ref, ctypes.c_uint32)) == _lib.PN_ERR_ARG
     bad = np.array([0, 5, 3], np.int64)
     assert lib.pn_node_ref_pack(2, _lib.np_ptr(bad, ctypes.c_int64), _lib.np_ptr(ref, ctypes.c_uint32)) == _lib.PN_ERR_ARG
+
+
+SAN_SCRIPT = r'''
+import ctypes, os, sys, tempfile, types
+import numpy as np
+root, san = sys.argv[1], sys.argv[2]
+# the host helpers of the package without importing the package (torch and the HIP runtime stay out of the sanitized process)
+pkg = types.ModuleType("pathnet_amd"); pkg.__path__ = [os.path.join(root, "pathnet_amd")]; sys.modules["pathnet_amd"] = pkg
+sys.modules["torch"] = types.ModuleType("torch")
+from pathnet_amd import _lib
+_lib.LIB_PATH = san
+probe = ctypes.CDLL(san)
+_lib.SIGNATURES = {k: v for k, v in _lib.SIGNATURES.items() if hasattr(probe, k)}
+assert {"pn_edges_read_text", "pn_alias_build", "pn_hops_dense", "pn_csr_build", "pn_paths_write_text", "pn_paths_read_text",
+        "pn_paths_write_bin", "pn_paths_read_bin", "pn_pairs_read_text", "pn_uniform_build", "pn_glibc_draws",
+        "pn_alias_pack", "pn_node_ref_pack"} <= set(_lib.SIGNATURES)
+from pathnet_amd import sampler, pathfile
+sys.path.insert(0, root)
+from oracle import merw
+g = dict(np.load(os.path.join(root, "tests", "golden", "sampler_citeseer_10_4.npz")))     # negative / > 1 "probabilities"
+n, u, v, p = int(g["n"]), g["u"], g["v"], g["p"]
+d = tempfile.mkdtemp()
+for threads in ("1", "5"):
+    os.environ["PN_HOST_THREADS"] = threads
+    path = os.path.join(d, "e.in")
+    merw.write_edge_file(path, n, u, v, p)
+    n2, u2, v2, p2 = sampler.read_edge_file(path)
+    assert n2 == n and (u2 == u).all() and (v2 == v).all() and (p2 == p).all()
+    off, A, B, S, thr = sampler.build_alias(n, u, v, p)
+    oo, oA, oB, oS = merw.alias_build(n, u, v, p)
+    assert (off == oo).all() and (A == oA).all() and (B == oB).all() and (S == oS).all()
+    packed = np.empty(max(len(A), 1) * 4, np.int32)
+    _lib.check(_lib.load().pn_alias_pack(len(A), _lib.np_ptr(A, ctypes.c_int32), _lib.np_ptr(B, ctypes.c_int32),
+                                         _lib.np_ptr(thr, ctypes.c_uint32), _lib.np_ptr(packed, ctypes.c_int32)))
+    ref = np.empty(2 * n, np.uint32)
+    _lib.check(_lib.load().pn_node_ref_pack(n, _lib.np_ptr(np.ascontiguousarray(off), ctypes.c_int64), _lib.np_ptr(ref, ctypes.c_uint32)))
+    dis, d2 = sampler.hops_dense(n, u, v, 4), merw.bfs_dense(n, u, v, 4)
+    within = (d2 >= 1) & (d2 <= 4)          # what a walk of 4 nodes can reach (the reference's bfs labels one ring more)
+    assert (dis[within] == d2[within]).all() and (dis[~within] == 0).all()
+    for rev in (False, True):
+        o, a = sampler.csr_build(n, u, v, reverse=rev)
+        assert o[-1] == len(a) and (np.diff(o) >= 0).all()
+    pairs = os.path.join(d, "p.in")
+    merw.write_pair_file(pairs, n, u[:500], v[:500])
+    n3, u3, v3 = sampler.read_pair_file(pairs)
+    sampler.build_uniform(n3, u3, v3)
+    assert (sampler.glibc_draws(7, 1000, 257) == merw.glibc_stream(7, 257, skip=1000)).all()
+    ids, codes = g["ids"].reshape(-1, 4), g["codes"].reshape(-1, 4)
+    t = os.path.join(d, "paths.txt")
+    pathfile.write_paths(t, ids, codes)
+    ri, rc = pathfile.read_paths(t, 4)
+    assert (ri == ids).all() and (rc == codes).all()
+    pathfile.write_paths_binary(t + ".bin", ids, codes)
+    bi, bc = pathfile.read_paths_binary(t + ".bin")
+    assert (bi == ids).all() and (bc == codes).all()
+    # error paths: malformed lines, truncated binary, missing file
+    open(t, "a").write("[1, 2, x, 4, 0, 1, 2, 3]\n")
+    for bad in (lambda: pathfile.read_paths(t, 4), lambda: pathfile.read_paths(os.path.join(d, "nope"), 4)):
+        try:
+            bad()
+            raise SystemExit("expected an error")
+        except _lib.PnError:
+            pass
+    open(t + ".bin", "r+b").truncate(40)
+    try:
+        pathfile.read_paths_binary(t + ".bin")
+        raise SystemExit("expected an error")
+    except _lib.PnError:
+        pass
+print("SAN_OK")
+'''
+
+
+def test_host_code_under_asan_and_ubsan(tmp_path):
+    """SURVEY.md section 5 ("race detection": an ASan / UBSan build of the host C++ is cheap): pn_host.cpp -- edge / pair file
+    parsers (threaded and not), alias build, dense hop table, CSR lists, glibc stream, path-file writers and readers with
+    their error paths -- compiled with -fsanitize=address,undefined (make sanitize) and run in a child process."""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "pathnet_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "sanitize"], check=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-c", SAN_SCRIPT, ROOT, os.path.join(csrc, "_obj", "libpn_host_san.so")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SAN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
