@@ -117,7 +117,16 @@ struct GemmParams {
     int relu, mode;
     int kchunk;  // K range per blockIdx.z
     float *rowsum;  // optional [M]: += sum_k A(m,k) (after gating) -- the bias gradient that goes with a dW GEMM
+    // Compact rows (the distance bank over the (node, code) rows a batch touches, GEMM_IND_*): `list` holds the node of every
+    // compact row, the launch covers rows [seg[0], seg[1]) of it -- counts that exist in device memory only; M (or K) given
+    // on the host is their upper bound (it sizes the grid), workgroups past the real count leave at once.
+    const int32_t *seg, *list;
+    int ind;
 };
+enum { GEMM_IND_NONE = 0,
+       GEMM_IND_A_ROWS = 1,     // A row m = list[b + m] (rows of Xh by node), C row m = b + m (compact rows)
+       GEMM_IND_C_ROWS = 2,     // A row m = b + m (compact rows), C row m = list[b + m]
+       GEMM_IND_K = 3 };        // reduction index k: A column k = b + k (compact rows), B column k = list[b + k]
 
 template <bool A_KCONTIG, bool B_KCONTIG, bool GATE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
@@ -126,8 +135,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
+    int pM = p.M, pK = p.K, ib = 0;
+    if (p.ind != GEMM_IND_NONE) {       // (block-uniform)
+        ib = p.seg[0];
+        const int cnt = p.seg[1] - ib;
+        if (p.ind == GEMM_IND_K) pK = min(pK, cnt); else pM = min(pM, cnt);
+        if (m0 >= pM || (int)blockIdx.z * p.kchunk >= pK) return;
+    }
     const int kbeg = blockIdx.z * p.kchunk;
-    const int kend = min(p.K, kbeg + p.kchunk);
+    const int kend = min(pK, kbeg + p.kchunk);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
@@ -144,11 +160,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int i = 0; i < 8; i++) {
             const int idx = tid + 256 * i;
             const int am = A_KCONTIG ? (idx >> 5) : (idx & 63), ak = A_KCONTIG ? (idx & 31) : (idx >> 6);
-            const int64_t at = (int64_t)min(m0 + am, p.M - 1) * p.sAm + (int64_t)min(k0 + ak, kend - 1) * p.sAk;
+            int arow = min(m0 + am, pM - 1), acol = min(k0 + ak, kend - 1);
+            if (p.ind == GEMM_IND_A_ROWS) arow = p.list[ib + arow];
+            else if (p.ind == GEMM_IND_C_ROWS) arow += ib;
+            else if (p.ind == GEMM_IND_K) acol += ib;
+            const int64_t at = (int64_t)arow * p.sAm + (int64_t)acol * p.sAk;
             async_load_b32(ra[i], p.A + at);
             if (GATE) async_load_b32(rg[i], p.gateA + at);
             const int bn = B_KCONTIG ? (idx >> 5) : (idx & 63), bk = B_KCONTIG ? (idx & 31) : (idx >> 6);
-            async_load_b32(rb[i], p.B + (int64_t)min(n0 + bn, p.N - 1) * p.sBn + (int64_t)min(k0 + bk, kend - 1) * p.sBk);
+            int bcol = min(k0 + bk, kend - 1);
+            if (p.ind == GEMM_IND_K) bcol = p.list[ib + bcol];
+            async_load_b32(rb[i], p.B + (int64_t)min(n0 + bn, p.N - 1) * p.sBn + (int64_t)bcol * p.sBk);
         }
     };
     if (kbeg < kend) issue(kbeg);
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             const int idx = tid + 256 * i;
             const int am = A_KCONTIG ? (idx >> 5) : (idx & 63), ak = A_KCONTIG ? (idx & 31) : (idx >> 6);
             const int bn = B_KCONTIG ? (idx >> 5) : (idx & 63), bk = B_KCONTIG ? (idx & 31) : (idx >> 6);
-            const bool a_ok = (m0 + am < p.M) && (k0 + ak < kend) && (!GATE || rg[i] > 0.0f);
+            const bool a_ok = (m0 + am < pM) && (k0 + ak < kend) && (!GATE || rg[i] > 0.0f);
             const bool b_ok = (n0 + bn < p.N) && (k0 + bk < kend);
             As[ak * GEMM_PITCH + am] = a_ok ? ra[i] : 0.0f;
             Bs[bk * GEMM_PITCH + bn] = b_ok ? rb[i] : 0.0f;
@@ -179,21 +201,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         __syncthreads();
     }
     if (kbeg < kend) wait_vm_all(ra, rb, rg);
-    if (p.rowsum && blockIdx.x == 0 && tid < GEMM_BM && m0 + tid < p.M) atomicAdd(&p.rowsum[m0 + tid], rsum);
+    if (p.rowsum && blockIdx.x == 0 && tid < GEMM_BM && m0 + tid < pM) atomicAdd(&p.rowsum[m0 + tid], rsum);
     const int col = n0 + wn * 32 + li;
     if (col >= p.N) return;
     const float bias = (p.bias && blockIdx.z == 0 && p.mode != GEMM_PARTIAL) ? p.bias[col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = m0 + wm * 32 + acc_row(r, lane);
-        if (row >= p.M) continue;
+        if (row >= pM) continue;
         float v = acc[r] + bias;
         if (p.mode == GEMM_PARTIAL) {
             p.C[((int64_t)blockIdx.z * p.M + row) * p.ldc + col] = v;
             continue;
         }
         if (p.relu) v = fmaxf(v, 0.0f);
-        float *dst = p.C + (int64_t)row * p.ldc + col;
+        const int crow = p.ind == GEMM_IND_A_ROWS ? ib + row : p.ind == GEMM_IND_C_ROWS ? p.list[ib + row] : row;
+        float *dst = p.C + (int64_t)crow * p.ldc + col;
         if (p.mode == GEMM_STORE)
             *dst = v;
         else if (p.mode == GEMM_ADD)
@@ -217,9 +240,10 @@ void launch_gemm_variant(hipStream_t stream, dim3 grid, bool ak, bool bk, const 
 
 int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
                 int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
-                int mode, int ksplit, float *rowsum = nullptr) {
+                int mode, int ksplit, float *rowsum = nullptr, int ind = GEMM_IND_NONE, const int32_t *seg = nullptr,
+                const int32_t *list = nullptr) {
     if (M <= 0 || N <= 0) return PN_OK;
-    GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0, rowsum};
+    GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0, rowsum, seg, list, ind};
     if (ksplit < 1) ksplit = 1;
     if (mode != GEMM_ATOMIC && mode != GEMM_PARTIAL) ksplit = 1;
     int kchunk = (K + ksplit - 1) / ksplit;
@@ -434,8 +458,9 @@ __device__ __forceinline__ void plan_entry(int variant, const int32_t *ids, cons
 }
 
 // slots [slot_begin, slot_begin + count) of the batch -> rowidx / egoidx / slotof of the local slots 0 .. count-1
+// rank: null (row of the full table: node * L + code) or the compact row of (code, node) -- compact_rows below
 __global__ void plan_kernel(int variant, const int32_t *__restrict__ ids, const uint8_t *__restrict__ codes, PlanDims d,
-                            int64_t slot_begin, int64_t count, int32_t *__restrict__ rowidx,
+                            int64_t slot_begin, int64_t count, const int32_t *__restrict__ rank, int32_t *__restrict__ rowidx,
                             int32_t *__restrict__ egoidx, int32_t *__restrict__ slotof) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count * d.L) return;
@@ -446,12 +471,108 @@ __global__ void plan_kernel(int variant, const int32_t *__restrict__ ids, const 
     plan_entry(variant, ids, codes, d, slot_begin + ls, t, q, node, code);
     node = min(max(node, 0), d.N - 1);
     code = min(code, d.L - 1);
-    rowidx[i] = node * d.L + code;
+    const int32_t row = rank ? rank[(int64_t)code * d.N + node] : node * d.L + code;
+    rowidx[i] = row;
     if (t == 0) {
         slotof[ls] = (int32_t)q;      // position in the whole batch: what the dropout counters / explicit masks index
         // attention ego: HOMO uses the transformed row of (q, step 0) (ego_full, :259-260);
         // HETERO uses the untransformed Xh row of path q's first node (neis[0], :199)
-        egoidx[ls] = variant == PN_VARIANT_HETERO ? min(max(ids[(q - d.row_base) * d.L], 0), d.N - 1) : node * d.L + code;
+        egoidx[ls] = variant == PN_VARIANT_HETERO ? min(max(ids[(q - d.row_base) * d.L], 0), d.N - 1) : row;
+    }
+}
+
+// ---- touched-row compaction ---------------------------------------------------------------------------------------------
+// The distance bank is applied to (node, code) rows, N * L of them, whatever the batch reads (bank-before-gather, DESIGN.md
+// section 4).  When the batch's path steps cannot touch half of them (a 10 M-node graph with 100 000 masked nodes: 24 M path
+// steps, 60 M rows) the bank, its backward and the tables Z / dZ themselves shrink to the rows that ARE touched:
+//   flags[code * N + node] = 1 for every path step (mark_rows_kernel), exclusive scan -> rank, the compact row of every
+//   touched (code, node); list[compact row] = node; seg[c] = first compact row of code c (the rows are code-major, so each
+//   code's rows are one contiguous GEMM against that code's weights); the index plan writes compact rows.
+__global__ void mark_rows_kernel(int variant, const int32_t *__restrict__ ids, const uint8_t *__restrict__ codes, PlanDims d,
+                                 int64_t slot_begin, int64_t count, uint8_t *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * d.L) return;
+    const int64_t ls = i / d.L;
+    int64_t q;
+    int node, code;
+    plan_entry(variant, ids, codes, d, slot_begin + ls, (int)(i - ls * d.L), q, node, code);
+    flags[(int64_t)min(code, d.L - 1) * d.N + min(max(node, 0), d.N - 1)] = 1;
+}
+constexpr int SCAN_BLOCK = 256 * 16;        // flags per workgroup
+__global__ __launch_bounds__(256) void scan_count_kernel(const uint8_t *__restrict__ flags, int64_t n, int32_t *__restrict__ bsum) {
+    __shared__ int red[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 16;
+    int c = 0;
+    if (base + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(flags + base);
+        c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);        // (flags are 0 / 1 bytes)
+    } else {
+        for (int k = 0; k < 16; k++) c += base + k < n ? flags[base + k] : 0;
+    }
+    c = (int)wave_sum((float)c);        // <= 1024 per wave: exact in fp32
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// exclusive scan of the block counts in place (one workgroup walks them: <= 15 k blocks for 60 M rows); total -> seg[L]
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(int32_t *__restrict__ bsum, int nb, int32_t *__restrict__ total) {
+    __shared__ int part[1024];
+    const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = min(nb, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += bsum[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; i++) {
+        const int v = bsum[i];
+        bsum[i] = run;
+        run += v;
+    }
+}
+__global__ __launch_bounds__(256) void scan_rank_kernel(const uint8_t *__restrict__ flags, int64_t n, int N, int L,
+                                                        const int32_t *__restrict__ bsum, int32_t *__restrict__ rank,
+                                                        int32_t *__restrict__ list, int32_t *__restrict__ seg) {
+    __shared__ int wsum[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + threadIdx.x * 16;
+    uint8_t f[16];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        f[k] = base + k < n ? flags[base + k] : 0;
+        c += f[k];
+    }
+    // exclusive scan of the 256 per-thread counts: inside the wave by shuffles, across the four waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int run = bsum[blockIdx.x] + inc - c;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int64_t i = base + k;
+        if (i < n) {
+            rank[i] = run;
+            const int code = (int)(i / N), node = (int)(i - (int64_t)code * N);
+            if (node == 0) seg[code] = run;         // first row of a code (rows are code-major)
+            if (f[k]) list[run] = node;
+            run += f[k];
+        }
     }
 }
 
@@ -2043,6 +2164,8 @@ struct Dims {
     int Sb;             // pooling groups per micro-batch
     int nb;             // micro-batches of this call
     int64_t P_total;    // paths of the whole batch
+    bool compact;       // the bank runs over the (node, code) rows this call's paths touch (compact_rows)
+    int64_t ZR;         // rows of Z / dZ: N * L, or the bound of the touched rows
 };
 
 // K chunks a split node-level GEMM is cut into (1 = not split): aim at ~2 workgroups per CU, at least two K tiles each
@@ -2106,6 +2229,14 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     d.Sb = (s.batch_groups > 0 && s.batch_groups < s.S) ? s.batch_groups : s.S;
     d.nb = d.Sb > 0 ? (s.S + d.Sb - 1) / d.Sb : 1;
     d.P_total = (int64_t)S_total * s.W;
+    {
+        // compaction pays when the path steps of this call cannot touch half of the N * L rows (PN_COMPACT=1 / 0 forces it
+        // on / off: tests, A/B); the hetero class reads paths of the whole batch, a slice marks the whole batch's steps
+        const int64_t steps = (int64_t)(d.variant == PN_VARIANT_HETERO ? S_total : s.S) * s.W * s.L, rows = (int64_t)s.N * s.L;
+        const char *e = getenv("PN_COMPACT");
+        d.compact = d.G >= 0 && s.S > 0 && (e ? atoi(e) != 0 : 2 * steps < rows);
+        d.ZR = d.compact ? std::min(rows, steps) : rows;
+    }
     // rows of one micro-batch's [Pb * L, .] tensors are counted in int32 inside the kernels
     if ((int64_t)d.Sb * s.W * s.L > 2000000000LL)
         PN_FAIL(PN_ERR_ARG, "%lld path steps in one micro-batch exceed int32: set batch_groups", (long long)d.Sb * s.W * s.L);
@@ -2117,6 +2248,7 @@ struct WsLayout {
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
     size_t xh, keep, dG, dhn, dl1, gx;                                   // per micro-batch, saved / backward
+    size_t flags, rank, list, seg, bsum;                                 // touched-row compaction (Dims.compact)
     int wgrad_split;
     size_t total;
 };
@@ -2133,7 +2265,7 @@ WsLayout ws_layout(const Dims &d) {
         return o;
     };
     w.Xh = take(N * H * 4);
-    w.Z = take(N * L * H * 4);
+    w.Z = take((size_t)d.ZR * H * 4);
     w.Wp = take(G * H * 3 * H * 4);          // (G = 0, the mean / sum encoders: no recurrent weights, no saved gates)
     w.biasc = take(G * H * 4);
     w.WpT = take(G * H * 3 * H * 4);
@@ -2151,7 +2283,7 @@ WsLayout ws_layout(const Dims &d) {
         const int nz = std::max(gemm_split_count(d.N, d.H, d.F), gemm_split_count(d.N, d.H, d.L * d.H));
         w.gpart = take(nz > 1 ? (size_t)nz * N * H * 4 : 0);
     }
-    w.dZ = take(N * L * H * 4);
+    w.dZ = take((size_t)d.ZR * H * 4);
     w.dXh = take(N * H * 4);
     w.rowidx = take(Pb * L * 4);
     w.egoidx = take(Pb * 4);
@@ -2168,6 +2300,11 @@ WsLayout ws_layout(const Dims &d) {
     w.dhn = take(Pb * H * 4);
     w.dl1 = take(Sb * 2 * H * 4 + 1024);
     w.gx = take(d.generic ? Pb * 2 * H * 4 : 0);        // [dx_t | dh_{t-1}] of a step of the generic recurrence
+    w.flags = take(d.compact ? N * L + 16 : 0);
+    w.rank = take(d.compact ? N * L * 4 : 0);
+    w.list = take(d.compact ? (size_t)d.ZR * 4 : 0);
+    w.seg = take(d.compact ? (L + 2) * 4 : 0);
+    w.bsum = take(d.compact ? ((N * L + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4 : 0);
     w.total = at;
     return w;
 }
@@ -2243,8 +2380,29 @@ int run_plan(const Call &c, hipStream_t s, int b) {
     const int64_t count = (int64_t)c.groups(b) * d.W, n = count * d.L;
     const PlanDims pd{d.S_total, d.W, d.L, d.N, d.P_total, c.a->index_rows_local ? (int64_t)d.group_begin * d.W : 0};
     hipLaunchKernelGGL(plan_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d.variant, c.a->ids, c.a->codes,
-                       pd, c.group0(b) * d.W, count, c.at<int32_t>(c.w.rowidx), c.at<int32_t>(c.w.egoidx),
-                       c.at<int32_t>(c.w.slotof));
+                       pd, c.group0(b) * d.W, count, d.compact ? c.at<const int32_t>(c.w.rank) : nullptr,
+                       c.at<int32_t>(c.w.rowidx), c.at<int32_t>(c.w.egoidx), c.at<int32_t>(c.w.slotof));
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
+// flags -> rank / list / seg for the (node, code) rows this call's paths touch (the hetero class: the whole batch's)
+int run_compact_rows(const Call &c, hipStream_t s) {
+    const Dims &d = c.d;
+    const bool het = d.variant == PN_VARIANT_HETERO;
+    const int64_t slot0 = het ? 0 : (int64_t)d.group_begin * d.W, count = (int64_t)(het ? d.S_total : d.S) * d.W, n = count * d.L;
+    const int64_t rows = (int64_t)d.N * d.L;
+    const PlanDims pd{d.S_total, d.W, d.L, d.N, d.P_total, c.a->index_rows_local ? (int64_t)d.group_begin * d.W : 0};
+    uint8_t *flags = c.at<uint8_t>(c.w.flags);
+    PN_CHECK_HIP(hipMemsetAsync(flags, 0, (size_t)rows, s));
+    hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d.variant, c.a->ids, c.a->codes, pd,
+                       slot0, count, flags);
+    const int nb = (int)((rows + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    int32_t *seg = c.at<int32_t>(c.w.seg), *bsum = c.at<int32_t>(c.w.bsum);
+    hipLaunchKernelGGL(scan_count_kernel, dim3(nb), dim3(256), 0, s, flags, rows, bsum);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bsum, nb, seg + d.L);
+    hipLaunchKernelGGL(scan_rank_kernel, dim3(nb), dim3(256), 0, s, flags, rows, d.N, d.L, bsum, c.at<int32_t>(c.w.rank),
+                       c.at<int32_t>(c.w.list), seg);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -2581,6 +2739,10 @@ int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     // the index plan (of the first micro-batch) and the weight packing do not depend on fc0 / bank: second stream,
     // joined before the recurrence
     JoinGuard joiner{ctx, stream};
+    if (d.compact) {        // the compact rows first: the index plan and the bank both read them
+        StageTimer tm(ctx, ST_PLAN_PACK, stream);
+        if (int rc = run_compact_rows(c, stream)) return rc;
+    }
     hipStream_t pstream = stream;
     if (PN_SIDE_SMALL && !profiling_every_stage(ctx))
         if (void *side = context_fork(ctx, stream)) pstream = (hipStream_t)side;
@@ -2599,6 +2761,18 @@ int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
                                            a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart)))
                 return rc;
         }
+    }
+    if (d.compact) {
+        // distance bank over the touched rows: code by code, Z[compact row] = act(Xh[node] . bank_w[code]^T + bank_b[code])
+        // (the touched set belongs to this batch: reuse_tables keeps the projected features only)
+        StageTimer tm(ctx, ST_BANK, stream);
+        const int mmax = (int)std::min<int64_t>(d.N, d.ZR);
+        for (int code = 0; code < L; code++)
+            if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w + (size_t)code * H * H, H, 1, c.Z, H,
+                                     a->bank_b + (size_t)code * H, mmax, H, H, homo, GEMM_STORE, 1, nullptr, GEMM_IND_A_ROWS,
+                                     c.at<const int32_t>(c.w.seg) + code, c.at<const int32_t>(c.w.list)))
+                return rc;
+    } else if (!a->reuse_tables) {
         // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
         StageTimer tm(ctx, ST_BANK, stream);
         if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
@@ -2660,7 +2834,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
         return PN_OK;
     };
     float *scratch = c.at<float>(c.w.dl1);
-    if (int rc = zero(dZ, (size_t)d.N * L * H)) return rc;
+    if (int rc = zero(dZ, (size_t)d.ZR * H)) return rc;
     if (int rc = zero(dXh, (size_t)d.N * H)) return rc;
     if (int rc = zero(a->g_att_w, has_att ? (size_t)2 * H : 0)) return rc;
     if (int rc = zero(a->g_att_b, has_att ? 1 : 0)) return rc;
@@ -2851,6 +3025,23 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     // distance bank backward (ReLU gate for HOMO): dXh += dZ' . bank_w ; g_bank_w = dZ'^T . Xh
     const float *zgate = homo ? Z : nullptr;
     auto tm_bank = std::make_unique<StageTimer>(ctx, ST_BANK_BWD, stream);
+    if (d.compact) {
+        // over the touched rows, code by code (the compact rows of a code are distinct nodes: += without atomics):
+        //   dXh[node] += dZ'[row] . bank_w[code],   g_bank_w[code] += dZ'[rows]^T . Xh[nodes],   g_bank_b[code] += colsum
+        if (a->g_bank_b && !a->g_bank_w) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: compact rows need g_bank_w with g_bank_b");
+        const int mmax = (int)std::min<int64_t>(d.N, d.ZR);
+        const int32_t *seg = c.at<const int32_t>(c.w.seg), *list = c.at<const int32_t>(c.w.list);
+        for (int code = 0; code < L; code++) {
+            if (int rc = launch_gemm(stream, dZ, H, 1, zgate, a->bank_w + (size_t)code * H * H, 1, H, dXh, H, nullptr, mmax, H,
+                                     H, 0, GEMM_ADD, 1, nullptr, GEMM_IND_C_ROWS, seg + code, list))
+                return rc;
+            if (a->g_bank_w)
+                if (int rc = launch_gemm(stream, dZ, 1, H, zgate, Xh, 1, H, a->g_bank_w + (size_t)code * H * H, H, nullptr, H,
+                                         H, mmax, 0, GEMM_ATOMIC, (mmax + 255) / 256,
+                                         a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, GEMM_IND_K, seg + code, list))
+                    return rc;
+        }
+    } else {
     if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, d.N, H, L * H,
                                    0, GEMM_ADD, c.at<float>(c.w.gpart)))
         return rc;
@@ -2860,6 +3051,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             return rc;
     } else if (a->g_bank_b) {
         if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, d.N, L * H, a->g_bank_b)) return rc;
+    }
     }
 
     tm_bank.reset();

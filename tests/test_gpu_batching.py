@@ -665,3 +665,87 @@ def test_indices_outside_the_graph_are_refused_or_clamped():
         fixed_codes = bad_codes.clamp(0, L - 1)
         want = m(X, fixed_ids.reshape(S, -1), W, L, np.array([0, 1, 2, 3]), fixed_codes, None)
     assert torch.isfinite(out).all() and torch.equal(out, want)
+
+
+# ------------------------------------------------------------------------------------------------
+# touched-row compaction of the distance bank (pn_pagg.hip: run_compact_rows)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant,cell", [("homo", None), ("hetero", None), ("pagg", None), ("homo", "gru"), ("hetero", "mean")])
+def test_compact_rows_forced_on_small_shapes_match_the_dense_bank(variant, cell, monkeypatch):
+    """PN_COMPACT=1 forces the compact path where it would not pay: same logits (the bank's dot products run in the same
+    order), gradients within the usual tolerance of the dense path and of the oracle; micro-batches and slices included."""
+    import pathnet_amd
+    from pathnet_amd import modules
+    torch.manual_seed(81)
+    rng = np.random.default_rng(81)
+    N, F, H, C, W, L, S = 150, 20, 64, 4, 9, 4, 41
+    cls = {"hetero": pathnet_amd.PathNet, "homo": pathnet_amd.PathNet_homo, "pagg": pathnet_amd.PAGG}[variant]
+    m = cls(F, H, C, L if variant != "pagg" else N, cell=cell).cuda().train()
+    mask, sel, ids, codes = random_case(rng, N, S, W, L)
+    pdrop = 0.5
+    ms = (torch.rand(L, S * W, H) >= pdrop).float() / (1 - pdrop)
+    mc = (torch.rand(S, 2 * H) >= pdrop).float() / (1 - pdrop)
+    m._mask_seq, m._mask_cls = ms.cuda(), mc.cuda()
+    X = torch.rand(N, F)
+    G = torch.randn(S, C).cuda()
+    neis, lt = torch.as_tensor(ids.reshape(S, -1).astype(np.int64)), torch.as_tensor(codes.astype(np.int64))
+
+    def run(compact, bg=None):
+        monkeypatch.setenv("PN_COMPACT", "1" if compact else "0")
+        if bg is not None:
+            monkeypatch.setattr(modules, "pick_batch_groups", lambda *a, **k: bg)
+        m.zero_grad(set_to_none=True)
+        out = m(X.cuda(), neis, W, L, mask, lt, None)
+        out.backward(G)
+        return out.detach().clone(), {k: v.grad.detach().clone() for k, v in m.named_parameters()}
+    dense_out, dense_g = run(False, 0)
+    for bg in (0, 7):
+        out, g = run(True, bg)
+        assert (out - dense_out).abs().max().item() <= 1e-6, bg
+        for k in dense_g:
+            assert (g[k] - dense_g[k]).abs().max().item() <= 3e-5 * max(1.0, dense_g[k].abs().max().item()), (bg, k)
+    with torch.no_grad():       # a slice of the batch, compact
+        part = m(X.cuda(), neis, W, L, mask, lt, None, group_slice=(5, 20))
+    assert (part - dense_out[5:25]).abs().max().item() <= 1e-6
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = po.forward(variant, pr, X, ids, codes, sel, W, L, drop_seq=ms, drop_cls=mc, cell=cell)
+    assert (out.cpu() - want.detach()).abs().max().item() < 1e-5
+    (want * G.cpu()).sum().backward()
+    for k in g:
+        ref = pr[k].grad
+        assert (g[k].cpu() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_compact_rows_on_a_million_node_graph_match_the_oracle():
+    """N = 1 200 000 nodes, path_len 6: 7.2 M (node, code) rows, of which the 300 masked nodes x 12 paths x 6 steps can
+    touch 21 600 (0.3 %): the library switches to compact rows by itself, the workspace shrinks with the tables, and
+    logits and every gradient match the CPU oracle."""
+    import pathnet_amd
+    from pathnet_amd import modules
+    torch.manual_seed(82)
+    rng = np.random.default_rng(82)
+    N, F, H, C, W, L, S = 1_200_000, 16, 128, 5, 12, 6, 300
+    m = pathnet_amd.PathNet_homo(F, H, C, L).cuda().eval()
+    X = torch.rand(N, F)
+    sel = np.sort(rng.permutation(N)[:S])
+    mask = np.zeros(N, bool)
+    mask[sel] = True
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    ids[:, :, 2] = ids[:, :, 1]                                  # repeated (node, code) pairs inside and across paths
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    dense_bytes = N * L * H * 4
+    assert modules.workspace_bytes("homo", N, F, H, C, S, W, L) < 0.6 * 2 * dense_bytes       # Z and dZ are compact
+    Xd = X.cuda().requires_grad_(True)
+    out = run_module(m, Xd, ids, codes, mask, W, L)
+    G = torch.randn(S, C)
+    out.backward(G.cuda())
+    pr = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Xr = X.clone().requires_grad_(True)
+    want = po.forward("homo", pr, Xr, ids, codes, sel, W, L)
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < 1e-5
+    want.backward(G)
+    for k, v in m.named_parameters():
+        ref = pr[k].grad
+        assert (v.grad.cpu() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item()), k
+    assert (Xd.grad.cpu() - Xr.grad).abs().max().item() <= 3e-5 * max(1.0, Xr.grad.abs().max().item())
