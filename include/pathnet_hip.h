@@ -36,10 +36,11 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 4 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
+#define PN_ABI_VERSION 5 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
                           * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
                           *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
-                          *    offsets throughout; pn_clock_probe */
+                          *    offsets throughout; pn_clock_probe
+                          * 5: pn_pagg_shape gained deterministic; pn_linear_backward gained workspace / workspace_bytes */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -244,6 +245,14 @@ typedef struct pn_pagg_shape {
      * other variants", README.md:118; no code in the reference): GRU = torch.nn.GRU's cell (weights [3H, H], gate order
      * r, z, n), MEAN / SUM = the mean / the sum of a path's (dropped-out) step rows, no recurrent weights (w_* / b_* NULL). */
     int32_t cell;
+    /* Non-zero: the backward adds in a fixed order -- bitwise identical gradients from run to run for the same inputs,
+     * seed and shape (torch.use_deterministic_algorithms for this path).  The default backward scatters the gather's
+     * gradient and splits the weight-gradient reductions with fp32 atomics, whose order the hardware picks; here the
+     * scatter contributions are stored, sorted by destination row (stable radix sort) and summed in the order of the
+     * path steps, and every split reduction stores its chunk sums and adds them in chunk order.  Costs workspace
+     * (pn_pagg_workspace_bytes accounts for it: ~600 B per path step at H = 128) and time; the
+     * forward computes the same values either way. */
+    int32_t deterministic;
 } pn_pagg_shape;
 #define PN_CELL_DEFAULT 0
 #define PN_CELL_LSTM 1
@@ -341,9 +350,14 @@ int pn_linear_forward(pn_context *ctx, const float *X, const float *W, const flo
 
 /* Backward of Y = act(X . W^T + b) for `rows` rows (nn.Linear, fc0 of the path: PathNet_run.py:175 / :242):
  * dY [rows, out_f] is gated by [gate > 0] when gate != NULL (ReLU backward, gate = Y), then
- * g_W [out_f, in_f] = dY^T . X,  g_b [out_f] = colsum(dY),  g_X [rows, in_f] = dY . W.  Any output may be NULL. */
+ * g_W [out_f, in_f] = dY^T . X,  g_b [out_f] = colsum(dY),  g_X [rows, in_f] = dY . W.  Any output may be NULL.
+ * The weight gradient splits the `rows` reduction over workgroups.  With a device workspace of at least
+ * PN_LINEAR_BWD_SPLIT_MAX * (out_f * in_f + out_f) * 4 bytes the chunk sums are stored and added in a fixed order --
+ * bitwise reproducible, what the deterministic mode of the aggregator (pn_pagg_shape.deterministic) pairs with on the
+ * node-sharded path; with workspace NULL the chunks are added with fp32 atomics (last bits vary from run to run). */
+#define PN_LINEAR_BWD_SPLIT_MAX 32
 int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, const float *X, const float *W, int32_t rows, int32_t in_f,
-                       int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream);
+                       int32_t out_f, float *g_W, float *g_b, float *g_X, void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- the MERW transition probabilities: what writes edge_input/<name>.in ----------------------
  * preprocess/compute_merw.py:107-121 compute_merw(A), as init_rw.py:76 calls it: (lambda, psi) = dominant eigenpair of

@@ -13,10 +13,11 @@ PN_OK = 0
 PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
-ABI_VERSION = 4               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
+ABI_VERSION = 5               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
 CELL_DEFAULT, CELL_LSTM, CELL_RNN, CELL_GRU, CELL_MEAN, CELL_SUM = 0, 1, 2, 3, 4, 5
 LINEAR_SPLIT_MAX = 8          # PN_LINEAR_SPLIT_MAX: workspace floats per output element of pn_linear_forward
+LINEAR_BWD_SPLIT_MAX = 32     # PN_LINEAR_BWD_SPLIT_MAX: chunk sums of pn_linear_backward's deterministic weight gradient
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -49,7 +50,7 @@ class PaggShape(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int32), ("N", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("C", ctypes.c_int32), ("S", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32),
                 ("S_total", ctypes.c_int32), ("group_begin", ctypes.c_int32), ("batch_groups", ctypes.c_int32),
-                ("cell", ctypes.c_int32)]
+                ("cell", ctypes.c_int32), ("deterministic", ctypes.c_int32)]
 
 
 class PaggArgs(ctypes.Structure):
@@ -116,7 +117,7 @@ SIGNATURES = {
     "pn_linear_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp,
                                          vp, ctypes.c_int64, vp]),
     "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp,
-                                          vp, vp]),
+                                          vp, vp, ctypes.c_int64, vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
     "pn_merw_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, c_i64p]),
     "pn_merw_probabilities": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, vp, vp, vp, vp, vp, c_f64p, ctypes.c_int32,

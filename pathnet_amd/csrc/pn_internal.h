@@ -65,4 +65,9 @@ struct StageTimer {
     void *stream;
 };
 
+// ---- stable radix sort of (int32 key, int32 value) pairs (pn_sort.hip; the deterministic backward) ----------------
+size_t sort_temp_reserve(int64_t n);        // bytes of temporary storage to reserve for n pairs (no device needed)
+int sort_pairs_i32(void *tmp, size_t tmp_bytes, const int32_t *keys_in, int32_t *keys_out, const int32_t *vals_in,
+                   int32_t *vals_out, int64_t n, int key_bits, void *stream);
+
 }  // namespace pn

@@ -117,6 +117,7 @@ struct GemmParams {
     int relu, mode;
     int kchunk;  // K range per blockIdx.z
     float *rowsum;  // optional [M]: += sum_k A(m,k) (after gating) -- the bias gradient that goes with a dW GEMM
+                    // (PARTIAL: [nz][M], chunk z stores its own sums)
     // Compact rows (the distance bank over the (node, code) rows a batch touches, GEMM_IND_*): `list` holds the node of every
     // compact row, the launch covers rows [seg[0], seg[1]) of it -- counts that exist in device memory only; M (or K) given
     // on the host is their upper bound (it sizes the grid), workgroups past the real count leave at once.
@@ -140,10 +141,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         ib = p.seg[0];
         const int cnt = p.seg[1] - ib;
         if (p.ind == GEMM_IND_K) pK = min(pK, cnt); else pM = min(pM, cnt);
-        if (m0 >= pM || (int)blockIdx.z * p.kchunk >= pK) return;
+        // (a chunk past the real K leaves at once -- except in PARTIAL mode, where the finish kernel adds up every chunk:
+        //  it stores zeros)
+        if (m0 >= pM || ((int)blockIdx.z * p.kchunk >= pK && p.mode != GEMM_PARTIAL)) return;
     }
     const int kbeg = blockIdx.z * p.kchunk;
-    const int kend = min(pK, kbeg + p.kchunk);
+    const int kend = max(kbeg, min(pK, kbeg + p.kchunk));
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
@@ -201,7 +204,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         __syncthreads();
     }
     if (kbeg < kend) wait_vm_all(ra, rb, rg);
-    if (p.rowsum && blockIdx.x == 0 && tid < GEMM_BM && m0 + tid < pM) atomicAdd(&p.rowsum[m0 + tid], rsum);
+    if (p.rowsum && blockIdx.x == 0 && tid < GEMM_BM && m0 + tid < pM) {
+        if (p.mode == GEMM_PARTIAL)
+            p.rowsum[(int64_t)blockIdx.z * p.M + m0 + tid] = rsum;       // [nz][M] chunk sums (gemm_finish_kernel)
+        else
+            atomicAdd(&p.rowsum[m0 + tid], rsum);
+    }
     const int col = n0 + wn * 32 + li;
     if (col >= p.N) return;
     const float bias = (p.bias && blockIdx.z == 0 && p.mode != GEMM_PARTIAL) ? p.bias[col] : 0.0f;
@@ -392,8 +400,15 @@ int launch_gemm3(hipStream_t stream, const float *A, int64_t lda, const float *B
 // bias / ReLU / accumulate.
 __global__ __launch_bounds__(256) void gemm_finish_kernel(const float *__restrict__ part, int nz, int M, int N,
                                                           const float *__restrict__ bias, int relu, int mode,
-                                                          float *__restrict__ C, int64_t ldc) {
+                                                          float *__restrict__ C, int64_t ldc,
+                                                          const float *__restrict__ rs_part = nullptr,
+                                                          float *__restrict__ rowsum = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rowsum && i < M) {          // rowsum[m] += the chunk sums, in chunk order
+        float v = 0.0f;
+        for (int z = 0; z < nz; z++) v += rs_part[(int64_t)z * M + i];
+        rowsum[i] += v;
+    }
     if (i >= (int64_t)M * N) return;
     const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
     float v = bias ? bias[col] : 0.0f;
@@ -1330,6 +1345,11 @@ struct PoolBwdParams {
     float *dXh;        // [N, H]  (+= ego of the classifier input; HETERO: += attention ego)
     float *dego;       // table the attention-ego gradient goes to: dZ (HOMO) or dXh (HETERO)
     float *g_att_w, *g_att_b;
+    // deterministic mode (all three set, else null): instead of atomics the kernel stores the ego half of d layer1 per
+    // group, d score per path and the attention-weight terms per workgroup; det_scatter_kernel / det_att_reduce_kernel add
+    float *det_sel;    // [S, H]
+    float *det_ds;     // [P]
+    float *det_att;    // [workgroups][2H + 4]
 };
 
 // HI: 64-column chunks of H a lane walks (4 covers H <= 256, the fused kernels' range; 16 covers the generic path's H <= 1024)
@@ -1375,7 +1395,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 a *= dropout1(seed, gg * 2 * H + j, 2u, p.p_drop);
                 b *= dropout1(seed, gg * 2 * H + H + j, 2u, p.p_drop);
             }
-            atomicAdd(&p.dXh[(int64_t)min(max(p.sel[g], 0), p.N - 1) * H + j], a);
+            if (p.det_sel)
+                p.det_sel[(int64_t)g * H + j] = a;
+            else
+                atomicAdd(&p.dXh[(int64_t)min(max(p.sel[g], 0), p.N - 1) * H + j], a);
             dp[j] = b * inv_w;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1417,7 +1440,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 #pragma unroll
         for (int i = 0; i < HI; i++) ego_acc[i] = 0.0f;
         auto flush = [&]() {
-            if (cur_row < 0) return;
+            if (cur_row < 0 || p.det_ds) return;
 #pragma unroll
             for (int i = 0; i < HI; i++) {
                 const int j = lane + 64 * i;
@@ -1449,6 +1472,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 }
             }
             gab += ds;
+            if (p.det_ds && lane == 0) p.det_ds[s] = ds;
         }
         if (p.variant != PN_VARIANT_PAGG) flush();
     }
@@ -1462,6 +1486,12 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
         }
     }
     __syncthreads();
+    if (p.det_att) {
+        float *out = p.det_att + (int64_t)blockIdx.x * (2 * H + 4);
+        for (int j = threadIdx.x; j < 2 * H; j += 256) out[j] = red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j];
+        if (lane == 0) out[2 * H + wave] = active ? gab : 0.0f;
+        return;
+    }
     for (int j = threadIdx.x; j < 2 * H; j += 256)
         atomicAdd(&p.g_att_w[j], red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j]);
     if (lane == 0 && active) atomicAdd(p.g_att_b, gab);
@@ -2058,6 +2088,134 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
+// ================================================================================================
+// Deterministic scatter-add (pn_pagg_shape.deterministic): dst[key[i]] += contribution i, added in the order of i.
+// The default backward scatters with fp32 atomics, whose order -- and with it the last bits of every gradient -- changes
+// from run to run (the reference inherits the same from torch's index_add / embedding backward).
+// Here the (key, i) pairs are sorted by key (stable radix sort, pn_sort.hip), the sorted array is cut into chunks of
+// DET_CHUNK positions, and one group of H/4 lanes walks a chunk in order:
+//   pass 1  a run of equal keys that lies inside the chunk is added to dst by its one owner; a run that crosses a chunk
+//           boundary leaves its piece in cpart[chunk][lead | trail];
+//   pass 2  the chunk holding the head of a crossing run adds the pieces up in chunk order and adds the sum to dst.
+// Every dst row has exactly one writer per pass and a fixed order of additions: bitwise reproducible.
+// A contribution is a row of `rows` ([K, H]) or scal[i] * vec[0..H) (the attention-ego term of the pooling backward).
+// The BPTT kernels need no second version for this: in deterministic mode they are handed the identity as their row
+// index and the zero-filled contribution buffer as their table -- every atomic then lands on an address of its own,
+// i.e. is a store -- and the scatter proper happens here.
+// ================================================================================================
+constexpr int DET_CHUNK = 32;
+struct DetScatterParams {
+    const int32_t *skey, *ssrc;     // sorted keys; the unsorted position of every sorted one
+    int64_t K;
+    const float *rows;              // [K, H] or null
+    const float *scal, *vec;        // [K], [H]
+    float *dst;                     // [., H]
+    float *cpart;                   // [chunks][2][H]
+    int H;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
+    const int hv = p.H / 4, gpb = 256 / hv;
+    const int grp = threadIdx.x / hv, ln = threadIdx.x - grp * hv;
+    if (grp >= gpb) return;
+    const int64_t c = (int64_t)blockIdx.x * gpb + grp, b = c * DET_CHUNK;
+    if (b >= p.K) return;
+    const int64_t e = min(p.K, b + (int64_t)DET_CHUNK);
+    float4 *dst = reinterpret_cast<float4 *>(p.dst);
+    float4 *cpart = reinterpret_cast<float4 *>(p.cpart);
+    auto add_to = [&](float4 *d, const float4 &a) {
+        float4 v = *d;
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        *d = v;
+    };
+    if (PASS == 1) {
+        const float4 vec = p.rows ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4 *>(p.vec)[ln];
+        int key = p.skey[b];
+        bool lead = b > 0 && p.skey[b - 1] == key;      // the chunk opens inside a run
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = b; i < e; i++) {
+            const int k = p.skey[i];
+            if (k != key) {                              // the run of `key` ends inside the chunk
+                if (lead)
+                    cpart[(c * 2 + 0) * hv + ln] = acc;
+                else
+                    add_to(dst + (int64_t)key * hv + ln, acc);
+                lead = false;
+                key = k;
+                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const int64_t src = p.ssrc[i];
+            if (p.rows) {
+                const float4 v = reinterpret_cast<const float4 *>(p.rows)[src * hv + ln];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            } else {
+                const float sc = p.scal[src];
+                acc.x += sc * vec.x; acc.y += sc * vec.y; acc.z += sc * vec.z; acc.w += sc * vec.w;
+            }
+        }
+        const bool cont = e < p.K && p.skey[e] == key;   // the last run goes on in the next chunk
+        if (lead)
+            cpart[(c * 2 + 0) * hv + ln] = acc;
+        else if (cont)
+            cpart[(c * 2 + 1) * hv + ln] = acc;
+        else
+            add_to(dst + (int64_t)key * hv + ln, acc);
+    } else {
+        const int key = p.skey[e - 1];
+        if (!(e < p.K && p.skey[e] == key)) return;                      // nothing crosses this chunk's end
+        if (p.skey[b] == key && b > 0 && p.skey[b - 1] == key) return;   // a middle chunk of the run: its head's chunk adds
+        float4 acc = cpart[(c * 2 + 1) * hv + ln];
+        for (int64_t c2 = c + 1;; c2++) {
+            const int64_t e2 = min(p.K, (c2 + 1) * (int64_t)DET_CHUNK);
+            const float4 v = cpart[(c2 * 2 + 0) * hv + ln];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            if (p.skey[e2 - 1] != key || !(e2 < p.K && p.skey[e2] == key)) break;
+        }
+        add_to(dst + (int64_t)key * hv + ln, acc);
+    }
+}
+
+// keys of a scatter, clamped to [0, hi], beside the identity permutation the sort carries along
+__global__ __launch_bounds__(256) void det_keys_kernel(const int32_t *__restrict__ in, int64_t n, int hi,
+                                                       int32_t *__restrict__ keys, int32_t *__restrict__ iota) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = min(max(in[i], 0), hi);
+    iota[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void det_iota_kernel(int32_t *__restrict__ iota, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) iota[i] = (int32_t)i;
+}
+
+// the pooling backward's per-workgroup attention terms ([nblk][2H + 4]: g_att_w partials, then one g_att_b term per
+// wave) added up in workgroup order: workgroup j of this kernel owns output j (j = 2H: the bias)
+__global__ __launch_bounds__(256) void det_att_reduce_kernel(const float *__restrict__ part, int nblk, int H,
+                                                             float *__restrict__ g_att_w, float *__restrict__ g_att_b) {
+    __shared__ float red[256];
+    const int j = blockIdx.x, stride = 2 * H + 4;
+    float v = 0.0f;
+    if (j < 2 * H) {
+        for (int b = threadIdx.x; b < nblk; b += 256) v += part[(int64_t)b * stride + j];
+    } else {
+        for (int b = threadIdx.x; b < 4 * nblk; b += 256) v += part[(int64_t)(b >> 2) * stride + 2 * H + (b & 3)];
+    }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (j < 2 * H)
+            g_att_w[j] += red[0];
+        else
+            *g_att_b += red[0];
+    }
+}
+
 // zero-fill of up to 12 buffers in one launch (the accumulated gradients of a backward)
 struct ZeroList {
     float *ptr[12];
@@ -2082,10 +2240,12 @@ __global__ __launch_bounds__(256) void zero_kernel(ZeroList z) {
     }
 }
 
-int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t ld, int M, int N, float *out) {
+int launch_colsum(hipStream_t stream, const float *A, const float *gate, int64_t ld, int M, int N, float *out,
+                  bool det = false) {
     if (M <= 0 || N <= 0) return PN_OK;
     int ysplit = (M + 511) / 512;
     if (ysplit > 1024) ysplit = 1024;
+    if (det) ysplit = 1;        // one workgroup per 64 columns walks every row: a single add per output
     const int rows_per_block = (M + ysplit - 1) / ysplit;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, ysplit), dim3(256), 0, stream, A, gate, ld, M, N,
                        rows_per_block, out);
@@ -2164,6 +2324,7 @@ struct Dims {
     int Sb;             // pooling groups per micro-batch
     int nb;             // micro-batches of this call
     int64_t P_total;    // paths of the whole batch
+    bool det;           // pn_pagg_shape.deterministic: the backward adds in a fixed order (no floating-point atomics)
     bool compact;       // the bank runs over the (node, code) rows this call's paths touch (compact_rows)
     int64_t ZR;         // rows of Z / dZ: N * L, or the bound of the touched rows
 };
@@ -2195,6 +2356,30 @@ int launch_gemm_split(hipStream_t stream, const float *A, int64_t sAm, int64_t s
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
+
+// ---- deterministic weight-gradient GEMM (pn_pagg_shape.deterministic): C += A . B^T and rowsum += row sums of A with the
+// reduction cut into at most DET_MAX_SPLIT chunks whose sums are stored ([nz][M][N], [nz][M]) and added up in chunk order
+// -- where the default path lets the chunks race with atomics.  C and rowsum accumulate (micro-batches).
+constexpr int DET_MAX_SPLIT = 32;
+int launch_gemm_det(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
+                    int64_t sBn, int64_t sBk, float *C, int64_t ldc, int M, int N, int K, int ksplit, float *rowsum,
+                    float *partial, int ind = GEMM_IND_NONE, const int32_t *seg = nullptr, const int32_t *list = nullptr) {
+    if (M <= 0 || N <= 0 || K <= 0) return PN_OK;
+    int nz = std::max(1, std::min(ksplit, DET_MAX_SPLIT));
+    int kchunk = (K + nz - 1) / nz;
+    kchunk = std::max(GEMM_KT, (kchunk + GEMM_KT - 1) / GEMM_KT * GEMM_KT);
+    nz = (K + kchunk - 1) / kchunk;             // (= the grid's z extent launch_gemm derives from the same numbers)
+    float *rs_part = rowsum ? partial + (size_t)nz * M * N : nullptr;
+    if (int rc = launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, partial, N, nullptr, M, N, K, 0, GEMM_PARTIAL, nz,
+                             rs_part, ind, seg, list))
+        return rc;
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, nz, M, N,
+                       (const float *)nullptr, 0, (int)GEMM_ADD, C, ldc, (const float *)rs_part, rowsum);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+inline size_t det_gemm_floats(size_t M, size_t N) { return (size_t)DET_MAX_SPLIT * (M * N + M); }
 
 int make_dims(const pn_pagg_shape &s, Dims &d) {
     if (s.variant < 0 || s.variant > 2) PN_FAIL(PN_ERR_ARG, "unknown variant %d", s.variant);
@@ -2229,6 +2414,7 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     d.Sb = (s.batch_groups > 0 && s.batch_groups < s.S) ? s.batch_groups : s.S;
     d.nb = d.Sb > 0 ? (s.S + d.Sb - 1) / d.Sb : 1;
     d.P_total = (int64_t)S_total * s.W;
+    d.det = s.deterministic != 0;
     {
         // compaction pays when the path steps of this call cannot touch half of the N * L rows (PN_COMPACT=1 / 0 forces it
         // on / off: tests, A/B); the hetero class reads paths of the whole batch, a slice marks the whole batch's steps
@@ -2249,6 +2435,8 @@ struct WsLayout {
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
     size_t xh, keep, dG, dhn, dl1, gx;                                   // per micro-batch, saved / backward
     size_t flags, rank, list, seg, bsum;                                 // touched-row compaction (Dims.compact)
+    size_t dx, keys, iota, skey, ssrc, stmp, cpart, dsel, dds, datt, dgemm;  // deterministic backward (Dims.det)
+    size_t stmp_bytes;
     int wgrad_split;
     size_t total;
 };
@@ -2305,6 +2493,24 @@ WsLayout ws_layout(const Dims &d) {
     w.list = take(d.compact ? (size_t)d.ZR * 4 : 0);
     w.seg = take(d.compact ? (L + 2) * 4 : 0);
     w.bsum = take(d.compact ? ((N * L + SCAN_BLOCK - 1) / SCAN_BLOCK + 1) * 4 : 0);
+    if (d.det) {
+        // contributions of the gather backward ([Pb * L, H] rows), their (destination row, position) pairs before and
+        // after the sort, the sort's temporary storage, the sums of the segments that cross a chunk boundary; the
+        // pooling backward's per-group / per-path / per-workgroup terms; the chunk sums of the weight-gradient GEMMs
+        const size_t K = std::max(Pb * L, Sb), C = d.C, F = d.F;
+        w.dx = take(Pb * L * H * 4);
+        w.keys = take(K * 4);
+        w.iota = take(K * 4);
+        w.skey = take(K * 4);
+        w.ssrc = take(K * 4);
+        w.stmp_bytes = sort_temp_reserve((int64_t)K);
+        w.stmp = take(w.stmp_bytes);
+        w.cpart = take(((K + DET_CHUNK - 1) / DET_CHUNK) * 2 * H * 4);
+        w.dsel = take(Sb * H * 4);
+        w.dds = take(Pb * 4);
+        w.datt = take(((Sb + 3) / 4) * (2 * H + 4) * 4);
+        w.dgemm = take(std::max({det_gemm_floats(C, 2 * H), det_gemm_floats(d.compact ? H : L * H, H), det_gemm_floats(H, F)}) * 4);
+    }
     w.total = at;
     return w;
 }
@@ -2462,6 +2668,7 @@ int run_seq_bwd_generic(const Call &c, int b) {
     const Dims &d = c.d;
     GenParams gp = gen_params(c, b);
     gp.saved = c.at<float>(c.w.saved);
+    if (d.det) gp.rowidx = c.at<int32_t>(c.w.iota), gp.dZ = c.at<float>(c.w.dx);     // (see det_scatter_kernel)
     gp.dh = c.at<float>(c.w.dhn);               // d loss / d h_n from the pooling backward, then d h_{t-1} step by step
     gp.state = c.at<float>(c.w.hn);             // (the pooling backward is done with h_n: d c / the GRU's direct term live there)
     const int H = d.H, GH = d.G * H, P = gp.P;
@@ -2526,6 +2733,7 @@ int run_seq_reduce(const Call &c, int b, bool backward) {
     rp.seed = a->seed;
     rp.dyn = a->step_state;
     rp.mask = a->mask_seq;
+    if (backward && d.det) rp.rowidx = c.at<int32_t>(c.w.iota), rp.dZ = c.at<float>(c.w.dx);     // (see det_scatter_kernel)
     const int64_t n = (int64_t)rp.P * (d.H / 4);
     StageTimer tm(c.ctx, backward ? ST_SEQ_BWD : ST_SEQ_FWD, c.stream);
     if (backward)
@@ -2604,6 +2812,28 @@ int run_pool_fwd(const Call &c, int b, float *out) {
     return PN_OK;
 }
 
+// dst[clamp(keys[i])] += contribution i (rows[i] or scal[i] * vec) for i < K, in the order of i (deterministic mode)
+int run_det_scatter(const Call &c, const int32_t *keys, int64_t K, int64_t max_key, const float *rows, const float *scal,
+                    const float *vec, float *dst) {
+    if (K <= 0) return PN_OK;
+    hipStream_t s = c.stream;
+    int32_t *ck = c.at<int32_t>(c.w.keys), *io = c.at<int32_t>(c.w.iota);
+    int32_t *skey = c.at<int32_t>(c.w.skey), *ssrc = c.at<int32_t>(c.w.ssrc);
+    hipLaunchKernelGGL(det_keys_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, keys, K, (int)max_key, ck, io);
+    PN_CHECK_HIP(hipGetLastError());
+    int bits = 1;
+    while (bits < 31 && (max_key >> bits) != 0) bits++;
+    if (int rc = sort_pairs_i32(c.at<void>(c.w.stmp), c.w.stmp_bytes, ck, skey, io, ssrc, K, bits, s)) return rc;
+    DetScatterParams p{skey, ssrc, K, rows, scal, vec, dst, c.at<float>(c.w.cpart), c.d.H};
+    const int gpb = 256 / (c.d.H / 4);
+    const int64_t chunks = (K + DET_CHUNK - 1) / DET_CHUNK;
+    const unsigned blocks = (unsigned)((chunks + gpb - 1) / gpb);
+    hipLaunchKernelGGL(det_scatter_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(det_scatter_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2638,7 +2868,9 @@ int pn_linear_forward(pn_context *ctx, const float *X, const float *W, const flo
 }
 
 int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, const float *X, const float *W, int32_t rows,
-                       int32_t in_f, int32_t out_f, float *g_W, float *g_b, float *g_X, void *stream_) {
+                       int32_t in_f, int32_t out_f, float *g_W, float *g_b, float *g_X, void *workspace,
+                       int64_t workspace_bytes, void *stream_) {
+    static_assert(PN_LINEAR_BWD_SPLIT_MAX == DET_MAX_SPLIT, "header and kernel agree on the split bound");
     hipStream_t stream = (hipStream_t)stream_;
     if (!dY || rows < 0 || in_f < 1 || out_f < 1) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: bad argument");
     if (int rc = context_check_device(ctx)) return rc;
@@ -2658,12 +2890,18 @@ int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, cons
         PN_CHECK_HIP(hipGetLastError());
     }
     if (rows == 0) return PN_OK;
-    if (g_W) {              // g_b rides along as the row sums of the (gated) A operand dY^T
+    // with a workspace: chunk sums added in a fixed order (bitwise reproducible); without: chunks race with atomics
+    const bool det = workspace && workspace_bytes >= (int64_t)(det_gemm_floats(out_f, in_f) * sizeof(float));
+    if (g_W && det) {
+        if (int rc = launch_gemm_det(stream, dY, 1, out_f, gate, X, 1, in_f, g_W, in_f, out_f, in_f, rows, (rows + 255) / 256,
+                                     g_b, reinterpret_cast<float *>(workspace)))
+            return rc;
+    } else if (g_W) {       // g_b rides along as the row sums of the (gated) A operand dY^T
         if (int rc = launch_gemm(stream, dY, 1, out_f, gate, X, 1, in_f, g_W, in_f, nullptr, out_f, in_f, rows, 0,
                                  GEMM_ATOMIC, (rows + 255) / 256, g_b))
             return rc;
     } else if (g_b) {
-        if (int rc = launch_colsum(stream, dY, gate, out_f, rows, out_f, g_b)) return rc;
+        if (int rc = launch_colsum(stream, dY, gate, out_f, rows, out_f, g_b, workspace != nullptr)) return rc;
     }
     if (g_X) {
         if (!W) PN_FAIL(PN_ERR_ARG, "pn_linear_backward: g_X needs W");
@@ -2860,10 +3098,18 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     if (int rc = flush_zero()) return rc;
 
     JoinGuard joiner{ctx, stream};
-    const bool side_ok = !profiling_every_stage(ctx);     // (per-stage timings are taken serially)
+    // (per-stage timings are taken serially; so is the deterministic mode, whose stages share scratch buffers)
+    const bool side_ok = !profiling_every_stage(ctx) && !d.det;
+    const int seq4 = seq4_select(H, G, L);
+    float *dgemm = d.det ? c.at<float>(c.w.dgemm) : nullptr;
+    if (d.det) {        // the identity the BPTT kernels index the contribution buffer with
+        const int64_t n = std::max<int64_t>((int64_t)d.Sb * d.W * L, d.Sb);
+        hipLaunchKernelGGL(det_iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, c.at<int32_t>(c.w.iota), n);
+        PN_CHECK_HIP(hipGetLastError());
+    }
     if (G > 0 && !d.generic) {
         StageTimer tm(ctx, ST_PLAN_PACK, stream);      // (its own bracket: ST_SEQ_BWD times the BPTT kernel alone)
-        if (seq4_select(H, G, L) & SEQ4_BWD) {
+        if (seq4 & SEQ4_BWD) {
             if (int rc = launch_pack_bwd4(stream, a->w_ih, a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<void>(c.w.WpT))) return rc;
         } else {
             hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
@@ -2891,12 +3137,16 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             if (void *side = context_fork(ctx, stream)) cstream = (hipStream_t)side;
         {
             StageTimer tm(ctx, ST_FC2_GRAD, cstream);
-            if (a->g_fc2_w) {        // g_fc2_b = row sums of the A operand (g_out^T)
+            if (a->g_fc2_w && d.det) {
+                if (int rc = launch_gemm_det(cstream, g_out, 1, d.C, nullptr, c.at<float>(c.w.layer1), 1, 2 * H, a->g_fc2_w,
+                                             2 * H, d.C, 2 * H, Sb, (Sb + 127) / 128, a->g_fc2_b, dgemm))
+                    return rc;
+            } else if (a->g_fc2_w) {        // g_fc2_b = row sums of the A operand (g_out^T)
                 if (int rc = launch_gemm(cstream, g_out, 1, d.C, nullptr, c.at<float>(c.w.layer1), 1, 2 * H, a->g_fc2_w,
                                          2 * H, nullptr, d.C, 2 * H, Sb, 0, GEMM_ATOMIC, (Sb + 127) / 128, a->g_fc2_b))
                     return rc;
             } else if (a->g_fc2_b) {
-                if (int rc = launch_colsum(cstream, g_out, nullptr, d.C, Sb, d.C, a->g_fc2_b)) return rc;
+                if (int rc = launch_colsum(cstream, g_out, nullptr, d.C, Sb, d.C, a->g_fc2_b, d.det)) return rc;
             }
         }
         if (cstream != stream)
@@ -2931,6 +3181,11 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             // attention gradients are optional outputs: fall back to scratch so the kernel needs no branches
             pp.g_att_w = a->g_att_w ? a->g_att_w : scratch;
             pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
+            if (d.det) {
+                pp.det_sel = c.at<float>(c.w.dsel);
+                pp.det_ds = c.at<float>(c.w.dds);
+                pp.det_att = c.at<float>(c.w.datt);
+            }
             const size_t lds_bytes = (size_t)(4 * (2 * d.W + H) + 8 * H + 8 * d.W) * sizeof(float);
             StageTimer tm(ctx, ST_POOL_BWD, stream);
             if (H <= 256) {
@@ -2940,9 +3195,23 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
                 hipLaunchKernelGGL(pool_bwd_kernel<16>, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
             }
             PN_CHECK_HIP(hipGetLastError());
+            if (d.det) {
+                // the ego half of d layer1 onto the masked nodes' rows of dXh; the attention-ego term onto the ego rows;
+                // the attention weights' terms in workgroup order
+                if (int rc = run_det_scatter(c, pp.sel, Sb, d.N - 1, pp.det_sel, nullptr, nullptr, dXh)) return rc;
+                if (has_att) {
+                    if (int rc = run_det_scatter(c, pp.egoidx, Pb, homo ? d.ZR - 1 : (int64_t)d.N - 1, nullptr, pp.det_ds,
+                                                 a->att_w + H, pp.dego))
+                        return rc;
+                    hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, (Sb + 3) / 4, H,
+                                       pp.g_att_w, pp.g_att_b);
+                    PN_CHECK_HIP(hipGetLastError());
+                }
+            }
         }
 
         // BPTT + gather-backward scatter (mean / sum encoders: the scatter alone)
+        if (d.det) PN_CHECK_HIP(hipMemsetAsync(c.at<float>(c.w.dx), 0, (size_t)Pb * L * H * sizeof(float), stream));
         if (G == 0) {
             if (int rc = run_seq_reduce(c, b, true)) return rc;
         } else if (d.generic) {
@@ -2964,12 +3233,18 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             sp.p_drop = a->p_seq;
             sp.seed = a->seed;
             sp.mask = a->mask_seq;
-            sp.merge0 = d.variant != PN_VARIANT_HETERO;     // (the hetero plan's step-0 rows are other paths' far ends: no runs)
-            if (seq4_select(H, G, L) & SEQ4_BWD) {
+            sp.merge0 = d.variant != PN_VARIANT_HETERO && !d.det;   // (the hetero plan's step-0 rows are other paths' far ends: no runs)
+            if (d.det) sp.rowidx = c.at<int32_t>(c.w.iota), sp.dZ = c.at<float>(c.w.dx);     // (see det_scatter_kernel)
+            if (seq4 & SEQ4_BWD) {
                 if (int rc = launch_seq_bwd4(ctx, stream, d.cell == CELL_GRU ? 3 : 4, sp)) return rc;
             } else if (int rc = (d.cell == CELL_GRU    ? dispatch_seq_bwd<3>(ctx, stream, H, sp)
                                  : d.cell == CELL_LSTM ? dispatch_seq_bwd<4>(ctx, stream, H, sp)
                                                        : dispatch_seq_bwd<1>(ctx, stream, H, sp)))
+                return rc;
+        }
+        if (d.det) {        // the stored mask * dx rows onto their table rows, in the order of the path steps
+            StageTimer tm(ctx, ST_SEQ_BWD, stream);
+            if (int rc = run_det_scatter(c, c.at<int32_t>(c.w.rowidx), Pb * L, d.ZR - 1, c.at<float>(c.w.dx), nullptr, nullptr, dZ))
                 return rc;
         }
 
@@ -2999,7 +3274,7 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             {
                 StageTimer tm(ctx, ST_WGRAD, wstream);
                 int nz_red = nz_used;
-                if (seq4_select(H, G, L) & SEQ4_WGRAD) {        // two-stage pipeline over K tiles of 16 rows (pn_seq4.hip)
+                if (seq4 & SEQ4_WGRAD) {        // two-stage pipeline over K tiles of 16 rows (pn_seq4.hip)
                     const int64_t nt16 = (wp.R + 15) / 16;
                     nz_red = (int)(nt16 < nz ? nt16 : nz);
                     if (int rc = launch_wgrad4(ctx, wstream, wp, nz_red)) return rc;
@@ -3035,7 +3310,12 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
             if (int rc = launch_gemm(stream, dZ, H, 1, zgate, a->bank_w + (size_t)code * H * H, 1, H, dXh, H, nullptr, mmax, H,
                                      H, 0, GEMM_ADD, 1, nullptr, GEMM_IND_C_ROWS, seg + code, list))
                 return rc;
-            if (a->g_bank_w)
+            if (a->g_bank_w && d.det) {
+                if (int rc = launch_gemm_det(stream, dZ, 1, H, zgate, Xh, 1, H, a->g_bank_w + (size_t)code * H * H, H, H, H, mmax,
+                                             (mmax + 255) / 256, a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, dgemm,
+                                             GEMM_IND_K, seg + code, list))
+                    return rc;
+            } else if (a->g_bank_w)
                 if (int rc = launch_gemm(stream, dZ, 1, H, zgate, Xh, 1, H, a->g_bank_w + (size_t)code * H * H, H, nullptr, H,
                                          H, mmax, 0, GEMM_ATOMIC, (mmax + 255) / 256,
                                          a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, GEMM_IND_K, seg + code, list))
@@ -3045,12 +3325,16 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, d.N, H, L * H,
                                    0, GEMM_ADD, c.at<float>(c.w.gpart)))
         return rc;
-    if (a->g_bank_w) {       // g_bank_b rides along as the row sums of the same (gated) A operand
+    if (a->g_bank_w && d.det) {
+        if (int rc = launch_gemm_det(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, L * H, H, d.N,
+                                     (d.N + 255) / 256, a->g_bank_b, dgemm))
+            return rc;
+    } else if (a->g_bank_w) {       // g_bank_b rides along as the row sums of the same (gated) A operand
         if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, d.N,
                                  0, GEMM_ATOMIC, (d.N + 255) / 256, a->g_bank_b))
             return rc;
     } else if (a->g_bank_b) {
-        if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, d.N, L * H, a->g_bank_b)) return rc;
+        if (int rc = launch_colsum(stream, dZ, zgate, (int64_t)L * H, d.N, L * H, a->g_bank_b, d.det)) return rc;
     }
     }
 
@@ -3059,12 +3343,16 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     // fc0 backward (ReLU gate for HOMO)
     const float *xgate = homo ? Xh : nullptr;
     StageTimer tm_fc0(ctx, ST_FC0_BWD, stream);
-    if (a->g_fc0_w) {
+    if (a->g_fc0_w && d.det) {
+        if (int rc = launch_gemm_det(stream, dXh, 1, H, xgate, a->X, 1, d.F, a->g_fc0_w, d.F, H, d.F, d.N, (d.N + 255) / 256,
+                                     a->g_fc0_b, dgemm))
+            return rc;
+    } else if (a->g_fc0_w) {
         if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, d.F, a->g_fc0_w, d.F, nullptr, H, d.F, d.N, 0,
                                  GEMM_ATOMIC, (d.N + 255) / 256, a->g_fc0_b))
             return rc;
     } else if (a->g_fc0_b) {
-        if (int rc = launch_colsum(stream, dXh, xgate, H, d.N, H, a->g_fc0_b)) return rc;
+        if (int rc = launch_colsum(stream, dXh, xgate, H, d.N, H, a->g_fc0_b, d.det)) return rc;
     }
     if (a->g_X)
         if (int rc = launch_gemm(stream, dXh, H, 1, xgate, a->fc0_w, 1, d.F, a->g_X, d.F, nullptr, d.N, d.F, H, 0,

@@ -204,16 +204,20 @@ class HipOps:
             _lib.check(lib.pn_pagg_backward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
         return g_Xh, grads
 
-    def linear_backward(self, variant, dXh_loc, Xh_loc, X_loc, w):
+    def linear_backward(self, variant, dXh_loc, Xh_loc, X_loc, w, deterministic=False):
         lib = _lib.load()
         dev = w.device
         with torch.cuda.device(dev):
             dXh_loc = dXh_loc.contiguous()
             g_w, g_b = torch.empty_like(w), torch.empty(w.shape[0], dtype=torch.float32, device=dev)
             gate = Xh_loc.data_ptr() if variant == "homo" else None
+            ws = None       # deterministic: chunk sums of the weight gradient, added in a fixed order
+            if deterministic:
+                ws = torch.empty(_lib.LINEAR_BWD_SPLIT_MAX * (w.numel() + w.shape[0]), dtype=torch.float32, device=dev)
             _lib.check(lib.pn_linear_backward(_lib.context(dev), dXh_loc.data_ptr(), gate, X_loc.data_ptr(), w.data_ptr(),
                                               X_loc.shape[0], w.shape[1], w.shape[0], g_w.data_ptr(), g_b.data_ptr(),
-                                              None, _lib.stream_ptr(dev)))
+                                              None, ws.data_ptr() if ws is not None else None,
+                                              ws.numel() * 4 if ws is not None else 0, _lib.stream_ptr(dev)))
         return g_w, g_b
 
 
@@ -237,7 +241,8 @@ class _ShardedFn(torch.autograd.Function):
         X_loc, Xh_loc, fc0_w = ctx.saved_tensors
         g_Xh, grads = ops.backward(ctx.state, g_out)
         g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0]) if comm.active() else g_Xh   # the one backward collective
-        grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w)
+        grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w,
+                                                             deterministic=cfg.get("deterministic", False))
         L = cfg["L"]
         head = tuple(grads.get(k) if pres else None for k, pres in zip(M._HEAD_PARAMS, ctx.present[:10]))
         return (None, None, None, None, None, None) + head + tuple(grads["bank_w"][d] for d in range(L)) + tuple(
@@ -300,14 +305,16 @@ class ShardedAggregator:
         cfg = dict(variant=m.variant, N=self.n_total, F=X_loc.shape[1], H=m.hidden_size, C=m.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb, seed=seed,
                    S_total=S_total, group_begin=begin, index_rows_local=local_rows and multi, cell=m._cell_kind,
-                   mask_seq=None, mask_cls=None)
+                   mask_seq=None, mask_cls=None,
+                   deterministic=M.deterministic_default() if m.deterministic is None else bool(m.deterministic))
         if not multi:
             cfg["S_total"], cfg["group_begin"] = 0, 0
         if m.training and (self.mask_seq is not None or self.mask_cls is not None):
             cfg["mask_seq"], cfg["mask_cls"] = self.mask_seq, self.mask_cls
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["batch_groups"] = M.pick_batch_groups(m.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
-                                                  cfg["L"], m.workspace_budget, cell=m._cell_kind) if isinstance(self.ops, HipOps) else 0
+                                                  cfg["L"], m.workspace_budget, cell=m._cell_kind,
+                                                  deterministic=cfg["deterministic"]) if isinstance(self.ops, HipOps) else 0
         return _ShardedFn.apply(self, cfg, X_loc.contiguous().float(), ids, codes, sel, *params)
 
     def set_batch_counts(self, counts):

@@ -11,6 +11,7 @@ All arithmetic runs in hand-written HIP kernels through libpathnet_hip.so; there
 fallback -- if the library is missing, construction fails.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -47,27 +48,36 @@ def default_budget(device=None):
         return WORKSPACE_BUDGET_BYTES
 
 
-def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None):
-    return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L, S_total, group_begin, batch_groups, _CELL[cell])
+def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None, deterministic=False):
+    return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L, S_total, group_begin, batch_groups, _CELL[cell],
+                          1 if deterministic else 0)
+
+
+def deterministic_default():
+    """The backward's mode when a module does not say: torch.use_deterministic_algorithms(True) or PN_DETERMINISTIC=1
+    select the fixed-order backward (pn_pagg_shape.deterministic: bitwise reproducible gradients, no fp32 atomics)."""
+    return torch.are_deterministic_algorithms_enabled() or os.environ.get("PN_DETERMINISTIC", "0") not in ("", "0")
 
 
 def _cfg_shape(cfg):
     return _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
-                  cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"))
+                  cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"),
+                  cfg.get("deterministic", False))
 
 
-def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None):
+def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None, deterministic=False):
     n = ctypes.c_int64(0)
-    sh = _shape(variant, N, F, H, C, S, W, L, S_total, group_begin, batch_groups, cell)
+    sh = _shape(variant, N, F, H, C, S, W, L, S_total, group_begin, batch_groups, cell, deterministic)
     _lib.check(_lib.load().pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(n)))
     return n.value
 
 
-def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, device=None):
+def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, device=None, deterministic=False):
     """0 when the whole batch fits the workspace budget, else the largest micro-batch (in masked nodes) that does.
     budget=None: default_budget(device) -- queried only when the batch needs more than MIN_BATCH_BYTES, so that ordinary
     steps make no runtime call."""
-    need = workspace_bytes(variant, N, F, H, C, S, W, L, cell=cell) if S > 1 else 0
+    kw = dict(cell=cell, deterministic=deterministic)
+    need = workspace_bytes(variant, N, F, H, C, S, W, L, **kw) if S > 1 else 0
     floor = MIN_BATCH_BYTES if budget is None else 0       # an explicit budget is kept to the byte
     if budget is None:
         if need <= MIN_BATCH_BYTES:
@@ -76,15 +86,16 @@ def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, devi
     budget = int(budget)
     if S <= 1 or need <= budget:
         return 0
-    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L, cell=cell)         # the node tables: needed whatever the batch
-    per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L, cell=cell) - fixed) // 1024, 1)
+    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L, **kw)          # the node tables: needed whatever the batch
+    per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L, **kw) - fixed) // 1024, 1)
     avail = max(budget - fixed, floor)       # default budget: graphs whose tables alone exceed it still get real batches
     return int(max(1, min(S, avail // per_group if avail > 0 else 1)))
 
 
 def _cfg_workspace_bytes(cfg):
     return workspace_bytes(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
-                           cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"))
+                           cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"),
+                           cfg.get("deterministic", False))
 
 
 def _split_params(params, L):
@@ -232,6 +243,7 @@ class _Aggregator(nn.Module):
         self._ws_tables = None            # (X address, shape, L) whose tables sit in _ws_eval
         self.step_state = None            # pathnet_amd.StepState: dropout seed read from device memory (hipGraph replay)
         self.workspace_budget = None      # bytes; None = modules.WORKSPACE_BUDGET_BYTES (see pick_batch_groups)
+        self.deterministic = None         # True / False: fixed-order backward or not; None: deterministic_default()
         self._mask_seq = None     # test hook: explicit dropout masks (reference order)
         self._mask_cls = None
         self._bank_flat = (None, None)
@@ -353,6 +365,7 @@ class _Aggregator(nn.Module):
         cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=Hk, C=self.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
                    step_state=self.step_state, cell=self._cell_kind,
+                   deterministic=deterministic_default() if self.deterministic is None else bool(self.deterministic),
                    seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.step_state is None) else 0)
         if group_slice is not None:
             begin, count = int(group_slice[0]), int(group_slice[1])
@@ -372,7 +385,8 @@ class _Aggregator(nn.Module):
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["grad"] = torch.is_grad_enabled()
         cfg["batch_groups"] = pick_batch_groups(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
-                                                cfg["L"], self.workspace_budget, cell=self._cell_kind, device=dev)
+                                                cfg["L"], self.workspace_budget, cell=self._cell_kind, device=dev,
+                                                deterministic=cfg["deterministic"])
         if not cfg["grad"]:
             need = _cfg_workspace_bytes(cfg)
             fits = self._ws_eval is not None and self._ws_eval.numel() >= need and self._ws_eval.device == dev

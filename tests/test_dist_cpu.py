@@ -81,7 +81,7 @@ class OracleOps:
         gs = torch.autograd.grad(out, [Xh] + [leaf[k] for k in keys], g_out, allow_unused=True)
         return gs[0], {k: (g if g is not None else torch.zeros_like(leaf[k])) for k, g in zip(keys, gs[1:])}
 
-    def linear_backward(self, variant, dXh_loc, Xh_loc, X_loc, w):
+    def linear_backward(self, variant, dXh_loc, Xh_loc, X_loc, w, deterministic=False):
         g = dXh_loc * (Xh_loc > 0).float() if variant == "homo" else dXh_loc     # ReLU backward, PathNet_run.py:243
         return g.t() @ X_loc, g.sum(0)
 

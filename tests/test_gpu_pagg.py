@@ -72,7 +72,7 @@ def test_linear_forward_and_backward_match_torch():
         dY = torch.randn(rows, out_f, device="cuda")
         gW, gb, gX = torch.full_like(W, 7.0), torch.full_like(b, 7.0), torch.empty_like(X)
         _lib.check(lib.pn_linear_backward(_lib.context("cuda"), dY.data_ptr(), Y1.data_ptr() if relu else None, X.data_ptr(), W.data_ptr(),
-                                          rows, in_f, out_f, gW.data_ptr(), gb.data_ptr(), gX.data_ptr(), None))
+                                          rows, in_f, out_f, gW.data_ptr(), gb.data_ptr(), gX.data_ptr(), None, 0, None))
         d = (dY * (ref > 0)).double() if relu else dY.double()
         scale = max(1.0, rows ** 0.5 / 8)
         assert (gW - (d.t() @ X.double()).float()).abs().max().item() < 1e-4 * scale
@@ -80,7 +80,7 @@ def test_linear_forward_and_backward_match_torch():
         assert (gX - (d @ W.double()).float()).abs().max().item() < 1e-4
         gb2 = torch.full_like(b, 7.0)       # bias gradient alone
         _lib.check(lib.pn_linear_backward(_lib.context("cuda"), dY.data_ptr(), Y1.data_ptr() if relu else None, None, None, rows, in_f, out_f,
-                                          None, gb2.data_ptr(), None, None))
+                                          None, gb2.data_ptr(), None, None, 0, None))
         assert (gb2 - d.sum(0).float()).abs().max().item() < 1e-4 * scale
 
 
