@@ -747,7 +747,16 @@ def main():
         mine = {kk: round(v / k * 1e3, 4) for kk, v in sr.comm.seconds.items()}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
-        collectives = {"ms_per_step_by_rank": gathered,
+        # every rank contributes a one through the backend the step used (backend "nccl" IS RCCL on ROCm) and names the
+        # device it ran on: ranks_seen == n_gpus and as many distinct devices says the N ranks really were N GPUs
+        one = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(one)
+        prop = torch.cuda.get_device_properties(dev)
+        devs = [None] * world
+        dist.all_gather_object(devs, "%s#%d/%s" % (os.uname().nodename, dev.index, getattr(prop, "uuid", "")))
+        collectives = {"rccl_ranks_seen": int(one.item()), "backend": "rccl" if backend == "nccl" else backend,
+                       "distinct_devices": len(set(devs)),
+                       "ms_per_step_by_rank": gathered,
                        "note": "each collective bracketed by torch.cuda.synchronize (serialised: an upper bound on what "
                                "the overlapped step pays)",
                        "bytes_per_step": {"all_gather_Xh": n * H * 4, "reduce_scatter_dXh": n * H * 4,

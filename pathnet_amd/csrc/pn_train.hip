@@ -15,11 +15,11 @@ namespace {
 
 // ---- softmax cross entropy, mean over rows, and d loss / d logits -----------------------------------------------
 // one wavefront per 64 rows is plenty for C <= a few hundred classes: a thread walks its row three times
-__global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restrict__ logits,
+__global__ __launch_bounds__(1024) void cross_entropy_kernel(const float *__restrict__ logits,
                                                              const int64_t *__restrict__ target, int rows, int classes,
                                                              float inv_rows, float *__restrict__ loss,
                                                              float *__restrict__ g_logits) {
-    __shared__ float part[4];
+    __shared__ float part[16];
     float mine = 0.0f;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
         const float *x = logits + (int64_t)r * classes;
@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float *__restr
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, ((part[0] + part[1]) + (part[2] + part[3])) * inv_rows);
+    if (threadIdx.x == 0) {
+        float s = 0.0f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += part[w];
+        atomicAdd(loss, s * inv_rows);      // (one workgroup -- up to CE_ONE_BLOCK_ROWS rows -- or two: an exact, order-free sum)
+    }
 }
 
 // ---- Adam over a list of tensors in one launch -------------------------------------------------------------------
@@ -99,8 +103,13 @@ int pn_cross_entropy(const float *logits, const int64_t *target, int32_t rows, i
     if (rows < 1 || classes < 1) PN_FAIL(PN_ERR_ARG, "pn_cross_entropy: rows=%d classes=%d", rows, classes);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
-    const int blocks = (rows + 255) / 256 < 256 ? (rows + 255) / 256 : 256;
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(blocks), dim3(256), 0, stream, logits, target, rows, classes,
+    // Up to CE_ONE_BLOCK_ROWS rows one workgroup of 1024 threads walks them all (a few microseconds) and the loss is a
+    // fixed-order sum: the same bits on every run.  Beyond that the workgroups add their parts with an atomic -- the
+    // reported loss may then differ in its last bit from run to run; g_logits never does (row-wise).
+    constexpr int CE_ONE_BLOCK_ROWS = 32768;
+    const int threads = rows <= CE_ONE_BLOCK_ROWS ? 1024 : 256;
+    const int blocks = rows <= CE_ONE_BLOCK_ROWS ? 1 : ((rows + 255) / 256 < 256 ? (rows + 255) / 256 : 256);
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(blocks), dim3(threads), 0, stream, logits, target, rows, classes,
                        1.0f / (float)rows, loss, g_logits);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;

@@ -133,12 +133,20 @@ def test_hidden_sizes_that_are_multiples_of_32(variant, H):
 
 
 def test_unsupported_hidden_sizes_fail_loudly():
-    from pathnet_amd import _lib
+    """The C ABI takes hidden sizes that are multiples of 32 up to 1024 and refuses the rest; the modules zero-pad any
+    other size up to the next multiple (tests/test_gpu_pagg.py::test_hidden_size_that_is_not_a_multiple_of_32) and refuse
+    what lies beyond 1024 -- with the library's error, not a fallback."""
+    import ctypes
+    from pathnet_amd import _lib, modules
+    lib = _lib.load()
     for H in (48, 272, 1056):
-        m = build_module("homo", 8, H, 3, 4, 20, None).eval()
-        with pytest.raises(_lib.PnError):
-            run_module(m, torch.rand(20, 8).cuda(), np.zeros((2, 3, 4), np.int64), np.zeros((2, 3, 4), np.int64),
-                       np.arange(20) < 2, 3, 4)
+        n = ctypes.c_int64(0)
+        sh = modules._shape("homo", 20, 8, H, 3, 2, 3, 4)
+        assert lib.pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(n)) == _lib.PN_ERR_ARG
+    m = build_module("homo", 8, 1056, 3, 4, 20, None).eval()
+    with pytest.raises(_lib.PnError):
+        run_module(m, torch.rand(20, 8).cuda(), np.zeros((2, 3, 4), np.int64), np.zeros((2, 3, 4), np.int64),
+                   np.arange(20) < 2, 3, 4)
 
 
 @pytest.mark.parametrize("variant", ["homo", "hetero"])

@@ -186,6 +186,9 @@ def test_bench_with_two_ranks_on_one_gpu(workload):
     assert d["config"]["parallelism"] == "node-shard x2"
     assert d["scaling"] == ("weak" if workload == "cora" else "strong")
     per_rank = d["collectives"]["ms_per_step_by_rank"]
+    # two ranks answered through the backend; here they share one device (on the driver's 8-GPU run: N distinct ones)
+    assert d["collectives"]["rccl_ranks_seen"] == 2 and d["collectives"]["backend"] == "gloo"
+    assert d["collectives"]["distinct_devices"] == 1
     assert len(per_rank) == 2 and all(c["all_gather_Xh"] > 0 and c["all_reduce_grads"] > 0 for c in per_rank)
     if workload == "cora":
         assert d["config"]["nodes"] == 2 * 2708 and abs(d["config"]["paths_per_step"] - 2 * 1299 * 40) <= 2 * 40
