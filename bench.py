@@ -368,6 +368,9 @@ class StepRunner:
         self.opt = pathnet_amd.Adam(self.model.parameters(), lr=0.005, weight_decay=0.0005,   # torch.optim.Adam's update, one launch
                                     **({"step_state": self.state} if self.state is not None else {}))
         self.lossf = pathnet_amd.CrossEntropyLoss()                                          # torch.nn.CrossEntropyLoss(), one launch
+        # forward / loss / backward as three library calls: what a batch that fits the workspace is quicker with (A/B in
+        # profiles/README.md); PN_BENCH_FUSED=1 runs the step through pn_pagg_train_step instead
+        self.fused = os.environ.get("PN_BENCH_FUSED", "0") not in ("", "0")
         Y = torch.from_numpy(wl["Y"]).to(dev)
         self.runner = None
         if not sharded:
@@ -410,13 +413,17 @@ class StepRunner:
                             draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(self.ids_buf, self.codes_buf))
         ids, codes = self.ids_buf[0], self.codes_buf[0]
         self.model.train()
-        if self.runner is None:
-            out = self.model(self.X, ids, W, L, self.sel32, codes, None)
+        if self.runner is None and self.fused:
+            # forward, CrossEntropyLoss and backward in one library call (pn_pagg_train_step): same kernels, same values
+            loss, _ = self.model.forward_loss(self.X, ids, W, L, self.sel32, codes, self.Ysel, fused=True)
         else:
-            out = self.runner(self.X, ids, W, L, self.sel32, codes)
-        loss = self.lossf(out, self.Ysel)
-        if self.loss_scale != 1.0:
-            loss = loss * self.loss_scale
+            if self.runner is None:
+                out = self.model(self.X, ids, W, L, self.sel32, codes, None)
+            else:
+                out = self.runner(self.X, ids, W, L, self.sel32, codes)
+            loss = self.lossf(out, self.Ysel)
+            if self.loss_scale != 1.0:
+                loss = loss * self.loss_scale
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         if self.runner is not None:

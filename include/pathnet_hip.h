@@ -40,7 +40,8 @@ extern "C" {
                           * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
                           *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
                           *    offsets throughout; pn_clock_probe
-                          * 5: pn_pagg_shape gained deterministic; pn_linear_backward gained workspace / workspace_bytes */
+                          * 5: pn_pagg_shape gained deterministic; pn_linear_backward gained workspace / workspace_bytes;
+                          *    pn_pagg_train_step */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -326,6 +327,16 @@ int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 /* Gradients of sum(out * g_out) w.r.t. every parameter (overwritten, not accumulated) and X.
  * Must follow a pn_pagg_forward on the same args/workspace. */
 int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *args, void *stream);
+/* One call for the aggregator's part of a training step (PathNet_run.py:343-351: forward, CrossEntropyLoss, backward):
+ *   out [S, C] = forward(...);  loss[0] = grad_scale * sum over the S rows of softmax-cross-entropy(out[r], target[r]);
+ *   every g_* of args = d loss / d parameter (g_out is not read).
+ * grad_scale = 1 / S gives torch.nn.CrossEntropyLoss()'s mean (a rank of the node-sharded step passes 1 / S_total).
+ * target: dev int64 [S] class indices of the slice's rows; loss: dev float.  Same values as pn_pagg_forward +
+ * pn_cross_entropy + pn_pagg_backward; what it saves is the second forward of every micro-batch: with batch_groups > 0
+ * pn_pagg_forward keeps no per-path tensors and pn_pagg_backward has to re-run each micro-batch's recurrence, here a
+ * micro-batch's forward, loss gradient and backward follow each other on the tensors still in the workspace. */
+int pn_pagg_train_step(pn_context *ctx, const pn_pagg_args *args, const int64_t *target, float grad_scale, float *loss,
+                       void *stream);
 
 /* Stand-alone stages of the same path, exposed for measurement and tests. */
 /* rows[q, t, :] = table[(node(q,t) * L + code(q,t)), :] for the variant's index plan: the

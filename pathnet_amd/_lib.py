@@ -118,6 +118,7 @@ SIGNATURES = {
                                          vp, ctypes.c_int64, vp]),
     "pn_linear_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp,
                                           vp, vp, ctypes.c_int64, vp]),
+    "pn_pagg_train_step": (ctypes.c_int, [vp, ctypes.POINTER(PaggArgs), vp, ctypes.c_float, vp, vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
     "pn_merw_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, c_i64p]),
     "pn_merw_probabilities": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, vp, vp, vp, vp, vp, c_f64p, ctypes.c_int32,

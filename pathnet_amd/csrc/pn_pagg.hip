@@ -129,7 +129,9 @@ enum { GEMM_IND_NONE = 0,
        GEMM_IND_C_ROWS = 2,     // A row m = b + m (compact rows), C row m = list[b + m]
        GEMM_IND_K = 3 };        // reduction index k: A column k = b + k (compact rows), B column k = list[b + k]
 
-template <bool A_KCONTIG, bool B_KCONTIG, bool GATE>
+// (IND is a template parameter: as run-time branches in front of the 24 loads of a K tile the row indirection halved the
+//  speed of every GEMM, indirect or not)
+template <bool A_KCONTIG, bool B_KCONTIG, bool GATE, int IND>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __shared__ float As[GEMM_KT * GEMM_PITCH];
     __shared__ float Bs[GEMM_KT * GEMM_PITCH];
@@ -137,10 +139,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
     int pM = p.M, pK = p.K, ib = 0;
-    if (p.ind != GEMM_IND_NONE) {       // (block-uniform)
+    if (IND != GEMM_IND_NONE) {       // (block-uniform)
         ib = p.seg[0];
         const int cnt = p.seg[1] - ib;
-        if (p.ind == GEMM_IND_K) pK = min(pK, cnt); else pM = min(pM, cnt);
+        if (IND == GEMM_IND_K) pK = min(pK, cnt); else pM = min(pM, cnt);
         // (a chunk past the real K leaves at once -- except in PARTIAL mode, where the finish kernel adds up every chunk:
         //  it stores zeros)
         if (m0 >= pM || ((int)blockIdx.z * p.kchunk >= pK && p.mode != GEMM_PARTIAL)) return;
@@ -164,15 +166,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             const int idx = tid + 256 * i;
             const int am = A_KCONTIG ? (idx >> 5) : (idx & 63), ak = A_KCONTIG ? (idx & 31) : (idx >> 6);
             int arow = min(m0 + am, pM - 1), acol = min(k0 + ak, kend - 1);
-            if (p.ind == GEMM_IND_A_ROWS) arow = p.list[ib + arow];
-            else if (p.ind == GEMM_IND_C_ROWS) arow += ib;
-            else if (p.ind == GEMM_IND_K) acol += ib;
+            if (IND == GEMM_IND_A_ROWS) arow = p.list[ib + arow];
+            else if (IND == GEMM_IND_C_ROWS) arow += ib;
+            else if (IND == GEMM_IND_K) acol += ib;
             const int64_t at = (int64_t)arow * p.sAm + (int64_t)acol * p.sAk;
             async_load_b32(ra[i], p.A + at);
             if (GATE) async_load_b32(rg[i], p.gateA + at);
             const int bn = B_KCONTIG ? (idx >> 5) : (idx & 63), bk = B_KCONTIG ? (idx & 31) : (idx >> 6);
             int bcol = min(k0 + bk, kend - 1);
-            if (p.ind == GEMM_IND_K) bcol = p.list[ib + bcol];
+            if (IND == GEMM_IND_K) bcol = p.list[ib + bcol];
             async_load_b32(rb[i], p.B + (int64_t)min(n0 + bn, p.N - 1) * p.sBn + (int64_t)bcol * p.sBk);
         }
     };
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             continue;
         }
         if (p.relu) v = fmaxf(v, 0.0f);
-        const int crow = p.ind == GEMM_IND_A_ROWS ? ib + row : p.ind == GEMM_IND_C_ROWS ? p.list[ib + row] : row;
+        const int crow = IND == GEMM_IND_A_ROWS ? ib + row : IND == GEMM_IND_C_ROWS ? p.list[ib + row] : row;
         float *dst = p.C + (int64_t)crow * p.ldc + col;
         if (p.mode == GEMM_STORE)
             *dst = v;
@@ -234,16 +236,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
+template <bool GATE, int IND>
+void launch_gemm_layout(hipStream_t stream, dim3 grid, bool ak, bool bk, const GemmParams &p) {
+    if (ak && bk)
+        hipLaunchKernelGGL((gemm_kernel<true, true, GATE, IND>), grid, dim3(256), 0, stream, p);
+    else if (ak && !bk)
+        hipLaunchKernelGGL((gemm_kernel<true, false, GATE, IND>), grid, dim3(256), 0, stream, p);
+    else if (!ak && bk)
+        hipLaunchKernelGGL((gemm_kernel<false, true, GATE, IND>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_kernel<false, false, GATE, IND>), grid, dim3(256), 0, stream, p);
+}
 template <bool GATE>
 void launch_gemm_variant(hipStream_t stream, dim3 grid, bool ak, bool bk, const GemmParams &p) {
-    if (ak && bk)
-        hipLaunchKernelGGL((gemm_kernel<true, true, GATE>), grid, dim3(256), 0, stream, p);
-    else if (ak && !bk)
-        hipLaunchKernelGGL((gemm_kernel<true, false, GATE>), grid, dim3(256), 0, stream, p);
-    else if (!ak && bk)
-        hipLaunchKernelGGL((gemm_kernel<false, true, GATE>), grid, dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_kernel<false, false, GATE>), grid, dim3(256), 0, stream, p);
+    switch (p.ind) {
+        case GEMM_IND_A_ROWS: return launch_gemm_layout<GATE, GEMM_IND_A_ROWS>(stream, grid, ak, bk, p);
+        case GEMM_IND_C_ROWS: return launch_gemm_layout<GATE, GEMM_IND_C_ROWS>(stream, grid, ak, bk, p);
+        case GEMM_IND_K: return launch_gemm_layout<GATE, GEMM_IND_K>(stream, grid, ak, bk, p);
+        default: return launch_gemm_layout<GATE, GEMM_IND_NONE>(stream, grid, ak, bk, p);
+    }
 }
 
 int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
@@ -2433,7 +2444,7 @@ struct WsLayout {
     size_t Xh, Z;                                                        // node tables (first: reuse_tables relies on it)
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
-    size_t xh, keep, dG, dhn, dl1, gx;                                   // per micro-batch, saved / backward
+    size_t xh, keep, dG, dhn, dl1, gx, gout;                             // per micro-batch, saved / backward
     size_t flags, rank, list, seg, bsum;                                 // touched-row compaction (Dims.compact)
     size_t dx, keys, iota, skey, ssrc, stmp, cpart, dsel, dds, datt, dgemm;  // deterministic backward (Dims.det)
     size_t stmp_bytes;
@@ -2488,6 +2499,7 @@ WsLayout ws_layout(const Dims &d) {
     w.dhn = take(Pb * H * 4);
     w.dl1 = take(Sb * 2 * H * 4 + 1024);
     w.gx = take(d.generic ? Pb * 2 * H * 4 : 0);        // [dx_t | dh_{t-1}] of a step of the generic recurrence
+    w.gout = take(Sb * (size_t)d.C * 4);                // d loss / d logits of a micro-batch (pn_pagg_train_step)
     w.flags = take(d.compact ? N * L + 16 : 0);
     w.rank = take(d.compact ? N * L * 4 : 0);
     w.list = take(d.compact ? (size_t)d.ZR * 4 : 0);
@@ -2812,6 +2824,71 @@ int run_pool_fwd(const Call &c, int b, float *out) {
     return PN_OK;
 }
 
+int check_forward_args(const Call &c, const char *who) {
+    const pn_pagg_args *a = c.a;
+    const Dims &d = c.d;
+    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->bank_b || !a->fc2_w || !a->fc2_b || !a->out)
+        PN_FAIL(PN_ERR_ARG, "%s: null tensor", who);
+    if (d.G > 0 && (!a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh)) PN_FAIL(PN_ERR_ARG, "%s: recurrent weights missing", who);
+    if (!a->Xh_in && !a->reuse_tables && (!a->X || !a->fc0_w || !a->fc0_b)) PN_FAIL(PN_ERR_ARG, "%s: X / fc0 missing", who);
+    if (d.variant != PN_VARIANT_PAGG && (!a->att_w || !a->att_b)) PN_FAIL(PN_ERR_ARG, "%s: attention weights missing", who);
+    return PN_OK;
+}
+
+// What a forward does before its first micro-batch: the touched rows, the index plan of micro-batch 0 and the packed
+// weights (second stream), Xh = fc0(X), Z = bank(Xh); joined, so that the recurrence can follow.
+int run_tables(const Call &c, JoinGuard &joiner) {
+    pn_context *ctx = c.ctx;
+    hipStream_t stream = c.stream;
+    const pn_pagg_args *a = c.a;
+    const Dims &d = c.d;
+    const int H = d.H, L = d.L;
+    const int homo = d.variant == PN_VARIANT_HOMO;
+    // the index plan (of the first micro-batch) and the weight packing do not depend on fc0 / bank: second stream,
+    // joined before the recurrence
+    if (d.compact) {        // the compact rows first: the index plan and the bank both read them
+        StageTimer tm(ctx, ST_PLAN_PACK, stream);
+        if (int rc = run_compact_rows(c, stream)) return rc;
+    }
+    hipStream_t pstream = stream;
+    if (PN_SIDE_SMALL && !profiling_every_stage(ctx))
+        if (void *side = context_fork(ctx, stream)) pstream = (hipStream_t)side;
+    {
+        StageTimer tm(ctx, ST_PLAN_PACK, pstream);
+        if (int rc = run_plan(c, pstream, 0)) return rc;
+        if (int rc = run_pack_fwd(c, pstream)) return rc;
+    }
+    if (pstream != stream)
+        if (int rc = joiner.mark()) return rc;
+    if (!a->reuse_tables) {
+        // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
+        if (!a->Xh_in) {
+            StageTimer tm(ctx, ST_FC0, stream);
+            if (int rc = launch_gemm_split(stream, a->X, d.F, 1, nullptr, a->fc0_w, d.F, 1, c.at<float>(c.w.Xh), H,
+                                           a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart)))
+                return rc;
+        }
+    }
+    if (d.compact) {
+        // distance bank over the touched rows: code by code, Z[compact row] = act(Xh[node] . bank_w[code]^T + bank_b[code])
+        // (the touched set belongs to this batch: reuse_tables keeps the projected features only)
+        StageTimer tm(ctx, ST_BANK, stream);
+        const int mmax = (int)std::min<int64_t>(d.N, d.ZR);
+        for (int code = 0; code < L; code++)
+            if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w + (size_t)code * H * H, H, 1, c.Z, H,
+                                     a->bank_b + (size_t)code * H, mmax, H, H, homo, GEMM_STORE, 1, nullptr, GEMM_IND_A_ROWS,
+                                     c.at<const int32_t>(c.w.seg) + code, c.at<const int32_t>(c.w.list)))
+                return rc;
+    } else if (!a->reuse_tables) {
+        // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
+        StageTimer tm(ctx, ST_BANK, stream);
+        if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
+                                 L * H, H, homo, GEMM_STORE, 1))
+            return rc;
+    }
+    return joiner.join();       // the recurrence needs the plan and the packed weights
+}
+
 // dst[clamp(keys[i])] += contribution i (rows[i] or scal[i] * vec) for i < K, in the order of i (deterministic mode)
 int run_det_scatter(const Call &c, const int32_t *keys, int64_t K, int64_t max_key, const float *rows, const float *scal,
                     const float *vec, float *dst) {
@@ -2964,60 +3041,10 @@ int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     Call c;
     if (int rc = resolve_call(c, ctx, a, stream, "pn_pagg_forward")) return rc;
     const Dims &d = c.d;
-    if (!a->ids || !a->codes || !a->sel || !a->bank_w || !a->bank_b || !a->fc2_w || !a->fc2_b || !a->out)
-        PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: null tensor");
-    if (d.G > 0 && (!a->w_ih || !a->w_hh || !a->b_ih || !a->b_hh)) PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: recurrent weights missing");
-    if (!a->Xh_in && !a->reuse_tables && (!a->X || !a->fc0_w || !a->fc0_b))
-        PN_FAIL(PN_ERR_ARG, "pn_pagg_forward: X / fc0 missing");
-    if (d.variant != PN_VARIANT_PAGG && (!a->att_w || !a->att_b)) PN_FAIL(PN_ERR_ARG, "attention weights missing");
+    if (int rc = check_forward_args(c, "pn_pagg_forward")) return rc;
     if (d.S == 0) return PN_OK;
-    const int H = d.H, L = d.L;
-    const int homo = d.variant == PN_VARIANT_HOMO;
-
-    // the index plan (of the first micro-batch) and the weight packing do not depend on fc0 / bank: second stream,
-    // joined before the recurrence
     JoinGuard joiner{ctx, stream};
-    if (d.compact) {        // the compact rows first: the index plan and the bank both read them
-        StageTimer tm(ctx, ST_PLAN_PACK, stream);
-        if (int rc = run_compact_rows(c, stream)) return rc;
-    }
-    hipStream_t pstream = stream;
-    if (PN_SIDE_SMALL && !profiling_every_stage(ctx))
-        if (void *side = context_fork(ctx, stream)) pstream = (hipStream_t)side;
-    {
-        StageTimer tm(ctx, ST_PLAN_PACK, pstream);
-        if (int rc = run_plan(c, pstream, 0)) return rc;
-        if (int rc = run_pack_fwd(c, pstream)) return rc;
-    }
-    if (pstream != stream)
-        if (int rc = joiner.mark()) return rc;
-    if (!a->reuse_tables) {
-        // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
-        if (!a->Xh_in) {
-            StageTimer tm(ctx, ST_FC0, stream);
-            if (int rc = launch_gemm_split(stream, a->X, d.F, 1, nullptr, a->fc0_w, d.F, 1, c.at<float>(c.w.Xh), H,
-                                           a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart)))
-                return rc;
-        }
-    }
-    if (d.compact) {
-        // distance bank over the touched rows: code by code, Z[compact row] = act(Xh[node] . bank_w[code]^T + bank_b[code])
-        // (the touched set belongs to this batch: reuse_tables keeps the projected features only)
-        StageTimer tm(ctx, ST_BANK, stream);
-        const int mmax = (int)std::min<int64_t>(d.N, d.ZR);
-        for (int code = 0; code < L; code++)
-            if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w + (size_t)code * H * H, H, 1, c.Z, H,
-                                     a->bank_b + (size_t)code * H, mmax, H, H, homo, GEMM_STORE, 1, nullptr, GEMM_IND_A_ROWS,
-                                     c.at<const int32_t>(c.w.seg) + code, c.at<const int32_t>(c.w.list)))
-                return rc;
-    } else if (!a->reuse_tables) {
-        // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
-        StageTimer tm(ctx, ST_BANK, stream);
-        if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
-                                 L * H, H, homo, GEMM_STORE, 1))
-            return rc;
-    }
-    if (int rc = joiner.join()) return rc;       // the recurrence needs the plan and the packed weights
+    if (int rc = run_tables(c, joiner)) return rc;
     const bool save = d.nb == 1 && !a->no_save;  // several micro-batches: the backward re-runs each one's recurrence
     for (int b = 0; b < d.nb; b++) {
         if (b > 0) {
@@ -3030,19 +3057,28 @@ int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     return PN_OK;
 }
 
-int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
+// pn_pagg_backward, and -- with `target` -- pn_pagg_train_step: the forward of every micro-batch runs right before its
+// backward (saved tensors in place), the loss gradient of its rows is formed in between
+static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stream_, const int64_t *target, float grad_scale,
+                              float *loss) {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool fused = target != nullptr;
     Call c;
-    if (int rc = resolve_call(c, ctx, a, stream, "pn_pagg_backward")) return rc;
+    if (int rc = resolve_call(c, ctx, a, stream, fused ? "pn_pagg_train_step" : "pn_pagg_backward")) return rc;
     const Dims &d = c.d;
+    if (fused) {
+        if (d.S > 0)
+            if (int rc = check_forward_args(c, "pn_pagg_train_step")) return rc;
+        PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
+    }
     // (S == 0 -- a rank of a sharded batch without masked nodes: its index arrays and g_out are empty tensors, i.e. NULL;
     //  the call still zero-fills every gradient it was given)
-    if (!a->bank_w || !a->fc2_w || (d.S > 0 && (!a->ids || !a->codes || !a->sel || !a->g_out)))
+    if (!a->bank_w || !a->fc2_w || (d.S > 0 && (!a->ids || !a->codes || !a->sel || (!fused && !a->g_out))))
         PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: null tensor");
     if (d.G > 0 && (!a->w_ih || !a->w_hh)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: recurrent weights missing");
     if (!a->Xh_in && (!a->X || !a->fc0_w)) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: X / fc0 missing");
     if (a->Xh_in && !a->g_Xh) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: g_Xh is required with Xh_in");
-    if (d.nb > 1 && ((d.G > 0 && (!a->b_ih || !a->b_hh)) || !a->fc2_b || (d.variant != PN_VARIANT_PAGG && !a->att_b)))
+    if (d.nb > 1 && !fused && ((d.G > 0 && (!a->b_ih || !a->b_hh)) || !a->fc2_b || (d.variant != PN_VARIANT_PAGG && !a->att_b)))
         PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: micro-batches re-run the forward and need every forward tensor");
     const int H = d.H, L = d.L, G = d.G, GH = G * H, GwH = d.Gw * H;     // GH: gate slots, GwH: rows of the caller's weights
     const int homo = d.variant == PN_VARIANT_HOMO;
@@ -3095,9 +3131,14 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
         if (int rc = zero(a->g_X, (size_t)d.N * d.F)) return rc;
         return flush_zero();
     }
-    if (int rc = flush_zero()) return rc;
+    // (the fused step clears them after the forward of its first micro-batch instead: the forward's gigabyte of saved
+    //  tensors would push the freshly zeroed dZ out of the caches the scatter atomics want it in)
+    if (!fused)
+        if (int rc = flush_zero()) return rc;
 
     JoinGuard joiner{ctx, stream};
+    if (fused)
+        if (int rc = run_tables(c, joiner)) return rc;
     // (per-stage timings are taken serially; so is the deterministic mode, whose stages share scratch buffers)
     const bool side_ok = !profiling_every_stage(ctx) && !d.det;
     const int seq4 = seq4_select(H, G, L);
@@ -3120,16 +3161,24 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     for (int b = 0; b < d.nb; b++) {
         const int Sb = c.groups(b);
         const int64_t Pb = (int64_t)Sb * d.W;
-        const float *g_out = a->g_out + (size_t)b * d.Sb * d.C;
-        if (d.nb > 1) {
-            // this micro-batch's recurrence again (same seed and positions in the batch -> same dropout masks), now
-            // keeping what the BPTT needs
-            {
+        const float *g_out = fused ? c.at<const float>(c.w.gout) : a->g_out + (size_t)b * d.Sb * d.C;
+        if (fused || d.nb > 1) {
+            // pn_pagg_backward with micro-batches: this micro-batch's recurrence again (same seed and positions in the
+            // batch -> same dropout masks), now keeping what the BPTT needs.  pn_pagg_train_step: its one and only
+            // forward, the logits go to the caller, their loss gradient to the workspace.
+            if (!(fused && b == 0)) {       // (run_tables made the plan of micro-batch 0)
                 StageTimer tm(ctx, ST_PLAN_PACK, stream);
                 if (int rc = run_plan(c, stream, b)) return rc;
             }
             if (int rc = run_seq_fwd(c, b, true)) return rc;
-            if (int rc = run_pool_fwd(c, b, c.at<float>(c.w.outb))) return rc;
+            float *out_b = fused ? a->out + (size_t)b * d.Sb * d.C : c.at<float>(c.w.outb);
+            if (int rc = run_pool_fwd(c, b, out_b)) return rc;
+            if (fused)
+                if (int rc = launch_cross_entropy(out_b, target + (size_t)b * d.Sb, Sb, d.C, grad_scale, loss,
+                                                  c.at<float>(c.w.gout), stream))
+                    return rc;
+            if (fused && b == 0)
+                if (int rc = flush_zero()) return rc;
         }
         // classifier: g_fc2_w += g_out^T . layer1, g_fc2_b += colsum(g_out) -- nothing below reads them: second stream
         hipStream_t cstream = stream;
@@ -3359,6 +3408,21 @@ int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
                                  GEMM_STORE, 1))
             return rc;
     return PN_OK;
+}
+
+int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *a, void *stream) {
+    return pagg_backward_impl(ctx, a, stream, nullptr, 0.0f, nullptr);
+}
+
+int pn_pagg_train_step(pn_context *ctx, const pn_pagg_args *a, const int64_t *target, float grad_scale, float *loss,
+                       void *stream) {
+    if (!a) PN_FAIL(PN_ERR_ARG, "pn_pagg_train_step: null args");
+    if (!loss || (a->shape.S > 0 && !target)) PN_FAIL(PN_ERR_ARG, "pn_pagg_train_step: null target / loss");
+    if (a->shape.S == 0) {          // nothing to aggregate: zero loss, zero gradients
+        PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream));
+        return pagg_backward_impl(ctx, a, stream, nullptr, 0.0f, nullptr);
+    }
+    return pagg_backward_impl(ctx, a, stream, target, grad_scale, loss);
 }
 
 }  // extern "C"

@@ -95,6 +95,25 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamList a) {
 
 }  // namespace
 
+namespace pn {
+// loss[0] += scale * sum over rows of (logsumexp - logit[target]);  g_logits = (softmax - onehot) * scale
+int launch_cross_entropy(const float *logits, const int64_t *target, int rows, int classes, float scale, float *loss,
+                         float *g_logits, void *stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (rows < 1) return PN_OK;
+    // Up to CE_ONE_BLOCK_ROWS rows one workgroup of 1024 threads walks them all (a few microseconds) and the loss is a
+    // fixed-order sum: the same bits on every run.  Beyond that the workgroups add their parts with an atomic -- the
+    // reported loss may then differ in its last bit from run to run; g_logits never does (row-wise).
+    constexpr int CE_ONE_BLOCK_ROWS = 32768;
+    const int threads = rows <= CE_ONE_BLOCK_ROWS ? 1024 : 256;
+    const int blocks = rows <= CE_ONE_BLOCK_ROWS ? 1 : ((rows + 255) / 256 < 256 ? (rows + 255) / 256 : 256);
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(blocks), dim3(threads), 0, stream, logits, target, rows, classes, scale,
+                       loss, g_logits);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+}  // namespace pn
+
 extern "C" {
 
 int pn_cross_entropy(const float *logits, const int64_t *target, int32_t rows, int32_t classes, float *loss,
@@ -103,16 +122,7 @@ int pn_cross_entropy(const float *logits, const int64_t *target, int32_t rows, i
     if (rows < 1 || classes < 1) PN_FAIL(PN_ERR_ARG, "pn_cross_entropy: rows=%d classes=%d", rows, classes);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
-    // Up to CE_ONE_BLOCK_ROWS rows one workgroup of 1024 threads walks them all (a few microseconds) and the loss is a
-    // fixed-order sum: the same bits on every run.  Beyond that the workgroups add their parts with an atomic -- the
-    // reported loss may then differ in its last bit from run to run; g_logits never does (row-wise).
-    constexpr int CE_ONE_BLOCK_ROWS = 32768;
-    const int threads = rows <= CE_ONE_BLOCK_ROWS ? 1024 : 256;
-    const int blocks = rows <= CE_ONE_BLOCK_ROWS ? 1 : ((rows + 255) / 256 < 256 ? (rows + 255) / 256 : 256);
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(blocks), dim3(threads), 0, stream, logits, target, rows, classes,
-                       1.0f / (float)rows, loss, g_logits);
-    PN_CHECK_HIP(hipGetLastError());
-    return PN_OK;
+    return pn::launch_cross_entropy(logits, target, rows, classes, 1.0f / (float)rows, loss, g_logits, stream);
 }
 
 int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,

@@ -188,6 +188,70 @@ class _PaggFunction(torch.autograd.Function):
             g_bank_b[d] for d in range(L))
 
 
+class _PaggLossFunction(torch.autograd.Function):
+    """loss, logits = one pn_pagg_train_step: forward, softmax cross entropy and backward in one library call (what it
+    saves: the second forward of every micro-batch, include/pathnet_hip.h).  The gradients are computed here and handed
+    out by backward(), scaled by the upstream gradient of the loss."""
+
+    @staticmethod
+    def forward(ctx, cfg, X, ids, codes, sel, target, *params):
+        lib = _lib.load()
+        L = cfg["L"]
+        p = _split_params(params, L)
+        dev = X.device
+        nbytes = _cfg_workspace_bytes(cfg)
+        ws = cfg.get("workspace")
+        with torch.cuda.device(dev):
+            out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
+            loss = torch.zeros((), dtype=torch.float32, device=dev)
+            if ws is None or ws.numel() < nbytes or ws.device != dev:
+                ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+            a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
+            a.out = out.data_ptr()
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+            # every parameter gradient is a view of one flat buffer: backward() scales them by the upstream gradient of
+            # the loss with one launch instead of one per tensor
+            keys = [k for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b")
+                    if p[k] is not None]
+            shapes = [p[k].shape for k in keys] + [cfg["bank_w"].shape, cfg["bank_b"].shape]
+            sizes = [-(-int(np.prod(sh)) // 4) * 4 for sh in shapes]         # 16-byte aligned pieces
+            flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            pieces = [v[:int(np.prod(sh))].view(sh) for v, sh in zip(flat.split(sizes), shapes)]
+            grads = dict(zip(keys, pieces))
+            for k in keys:
+                setattr(a, "g_" + k, grads[k].data_ptr())
+            g_bank_w, g_bank_b = pieces[-2], pieces[-1]
+            a.g_bank_w, a.g_bank_b = g_bank_w.data_ptr(), g_bank_b.data_ptr()
+            gX = torch.empty_like(X) if ctx.needs_input_grad[1] else None
+            a.g_X = gX.data_ptr() if gX is not None else None
+            target = target.to(device=dev, dtype=torch.int64).contiguous()
+            if cfg["S"] > 0:
+                _lib.check(lib.pn_pagg_train_step(_lib.context(dev), ctypes.byref(a), target.data_ptr(),
+                                                  float(cfg["grad_scale"]), loss.data_ptr(), _lib.stream_ptr(dev)))
+            else:
+                flat.zero_()
+                if gX is not None:
+                    gX.zero_()
+        head = tuple(grads.get(k) for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b"))
+        ctx.grads = (gX,) + head + tuple(g_bank_w[d] for d in range(L)) + tuple(g_bank_b[d] for d in range(L))
+        ctx.flat = flat
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        # (the context lets go of the tensors: with a second owner alive autograd's AccumulateGrad would copy every
+        #  gradient into a fresh tensor instead of adopting it -- 18 copy launches per step)
+        grads, flat = ctx.grads, ctx.flat
+        ctx.grads = ctx.flat = None
+        if grads is None:
+            raise RuntimeError("forward_loss: the gradients were handed out already (backward twice)")
+        flat.mul_(g_loss)                       # (d loss' / d loss: 1 for loss.backward())
+        if grads[0] is not None:
+            grads[0].mul_(g_loss)
+        return (None, grads[0], None, None, None, None) + tuple(grads[1:])
+
+
 def _as_index_tensors(neis, layer_type, indices, num_w, walk_len, device, n_nodes=None):
     """Reference argument conventions -> device int32 ids [S,W,L], uint8 codes, int32 sel [S].
     `indices`: a bool mask over the nodes (numpy or torch: the reference's two conventions) or the node ids
@@ -345,7 +409,22 @@ class _Aggregator(nn.Module):
                 self.fc2.weight, self.fc2.bias)
         return fw, fb, head + tuple(ws) + tuple(bs)
 
+    def forward_loss(self, X, neis, num_w, walk_len, indices, layer_type, target, indxx=None, grad_scale=None, fused=None):
+        """(loss, logits) of a training step's forward + torch.nn.CrossEntropyLoss() (PathNet_run.py:343-346); loss.backward()
+        yields the parameter gradients.  target: class index of every masked node, in the order of the logits' rows.
+        grad_scale: weight of a row's loss (default 1 / rows = the mean).
+        fused=True: forward, loss and backward in ONE library call (pn_pagg_train_step; backward() hands out the gradients that
+        call already computed) -- for a batch that runs in micro-batches this saves every micro-batch's second forward (the
+        10 M-node configuration: 0.250 -> 0.222 s per step).  fused=False: the three calls, which is what a batch that fits
+        the workspace is quicker with (measured 1.26 vs 1.29 ms per step at the headline shape).  None: fused exactly when
+        the batch needs micro-batches.  Same values either way."""
+        return self._run(X, neis, num_w, walk_len, indices, layer_type, target=target, grad_scale=grad_scale, fused=fused)
+
     def forward(self, X, neis, num_w, walk_len, indices, layer_type, indxx=None, reuse_tables=False, group_slice=None):
+        return self._run(X, neis, num_w, walk_len, indices, layer_type, reuse_tables=reuse_tables, group_slice=group_slice)
+
+    def _run(self, X, neis, num_w, walk_len, indices, layer_type, reuse_tables=False, group_slice=None, target=None,
+             grad_scale=None, fused=None):
         """reuse_tables (extension, inference only): X and the weights are those of the previous no-grad forward of this
         module -- the validation and the test forward of an epoch (PathNet_run.py:362, :378) -- so the projected
         feature matrix and the distance bank still sitting in the module's workspace are used again.
@@ -404,6 +483,24 @@ class _Aggregator(nn.Module):
             raise RuntimeError("reuse_tables is for no-grad (inference) forwards")
         else:
             self._ws_tables = None          # a training forward: the weights are about to change
+        if target is not None:
+            if not cfg["grad"]:
+                raise RuntimeError("forward_loss computes gradients: call it with grad enabled")
+            target = torch.as_tensor(target)
+            if target.numel() != S:
+                raise ValueError("target holds %d classes, the batch has %d masked nodes" % (target.numel(), S))
+            cfg["grad_scale"] = (1.0 / max(S, 1)) if grad_scale is None else float(grad_scale)
+            target = target.reshape(-1)
+            if fused is None:
+                fused = cfg["batch_groups"] > 0
+            if fused:
+                return _PaggLossFunction.apply(cfg, X, ids, codes, sel, target, *params)
+            from . import optim
+            out = _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
+            loss = optim.CrossEntropyLoss()(out, target.to(device=dev, dtype=torch.int64))        # the mean over the S rows
+            if grad_scale is not None:
+                loss = loss * (float(grad_scale) * max(S, 1))
+            return loss, out
         return _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
 
 

@@ -53,8 +53,12 @@ def _index_tensor(mask_or_index, device):
 
 def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices, test_indices, num_w, hid_size,
                         walk_len, paths, round_i=0, *, epochs=1000, lr=0.005, weight_decay=0.0005, dropout=0.7,
-                        device="cuda:0", save_dir="./saved_models", sampler_seed=0, model=None, verbose=False):
+                        device="cuda:0", save_dir="./saved_models", sampler_seed=0, model=None, verbose=False,
+                        fused_step=None):
     """paths: (ids, codes) tensors [epochs, N, W, L] (int32 / uint8, any device) or a MerwSampler.
+    fused_step: True = forward, loss and backward of the training step in one library call (module.forward_loss ->
+    pn_pagg_train_step), False = three calls, None = fused exactly when the batch needs micro-batches (then it saves every
+    micro-batch's second forward).  Same values.
     Returns (test macro-F1, micro-F1, macro recall, macro precision, accuracy) at the best-validation epoch."""
     dev = torch.device(device)
     X = torch.as_tensor(X).to(dev).float()
@@ -64,7 +68,6 @@ def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices
         cls = modules.PathNet_homo if data_name in HOMO_DATASETS else modules.PathNet
         model = cls(X.shape[-1], hid_size, num_classes, walk_len, dropout=dropout).to(dev)
     opt = optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)     # = torch.optim.Adam, one launch
-    lossf = optim.CrossEntropyLoss()                                          # = torch.nn.CrossEntropyLoss()
     from_sampler = hasattr(paths, "sample")
     if not from_sampler:
         ids_all, codes_all = (torch.as_tensor(t).to(dev) for t in paths)
@@ -87,8 +90,7 @@ def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices
     for epoch in range(epochs):
         model.train()
         ids_tr, codes_tr = paths_of(tr32, epoch, check=(epoch == 0))
-        out = model(X, ids_tr, num_w, walk_len, tr32, codes_tr, None)
-        loss = lossf(out, Y[tr])
+        loss, out = model.forward_loss(X, ids_tr, num_w, walk_len, tr32, codes_tr, Y[tr], fused=fused_step)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()

@@ -1,0 +1,136 @@
+"""pn_pagg_train_step (module.forward_loss): forward + torch.nn.CrossEntropyLoss() + backward of a training step
+(PathNet_run.py:343-351) in one library call.  Same kernels in the same order as forward / pn_cross_entropy / backward,
+so in deterministic mode loss, logits and every gradient are BITWISE those of the three separate calls -- in one batch and
+in micro-batches, where the fused call saves each micro-batch's second forward; and it matches the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pagg_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(variant, S, W, L, H=128, cell=None, N=900, F=40, C=5, seed=0):
+    import pathnet_amd
+    g = torch.Generator().manual_seed(seed)
+    cls = {"homo": pathnet_amd.PathNet_homo, "hetero": pathnet_amd.PathNet, "pagg": pathnet_amd.PAGG}[variant]
+    torch.manual_seed(seed)
+    kw = {} if variant == "pagg" else {"cell": cell}
+    m = cls(F, H, C, L, dropout=0.5, **kw).cuda().train()
+    m.deterministic = True
+    X = torch.rand(N, F, generator=g).cuda()
+    sel = torch.randperm(N, generator=g)[:S].sort().values.to(torch.int32)
+    ids = torch.randint(0, N, (S, W, L), generator=g).to(torch.int32)
+    ids[:, :, 0] = sel[:, None]
+    codes = torch.randint(0, L, (S, W, L), generator=g).to(torch.uint8)
+    y = torch.randint(0, C, (S,), generator=g).cuda()
+    return m, X, ids.cuda(), codes.cuda(), sel.cuda(), y
+
+
+def _separate(case, seed=3):
+    from pathnet_amd import optim
+    m, X, ids, codes, sel, y = case
+    torch.manual_seed(seed)
+    m.zero_grad(set_to_none=True)
+    out = m(X, ids, ids.shape[1], ids.shape[2], sel, codes, None)
+    loss = optim.CrossEntropyLoss()(out, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), out.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()}
+
+
+def _fused(case, seed=3):
+    m, X, ids, codes, sel, y = case
+    torch.manual_seed(seed)
+    m.zero_grad(set_to_none=True)
+    loss, out = m.forward_loss(X, ids, ids.shape[1], ids.shape[2], sel, codes, y, fused=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), out.detach().clone(), {k: v.grad.clone() for k, v in m.named_parameters()}
+
+
+@pytest.mark.parametrize("variant,S,W,L,H,cell,micro", [
+    ("homo", 300, 12, 4, 128, None, 0),
+    ("homo", 300, 12, 4, 128, None, 70),        # five micro-batches, the last one ragged
+    ("hetero", 200, 9, 4, 128, None, 0),
+    ("hetero", 200, 9, 4, 128, None, 64),
+    ("pagg", 150, 8, 4, 64, None, 40),
+    ("homo", 100, 6, 3, 288, "gru", 30),        # generic recurrence
+    ("homo", 100, 6, 5, 100, "mean", 0),        # zero-padded hidden size, order-agnostic encoder
+])
+def test_fused_step_is_the_three_calls(variant, S, W, L, H, cell, micro):
+    from pathnet_amd import modules as M
+    case = _case(variant, S, W, L, H=H, cell=cell)
+    m = case[0]
+    if micro:
+        Hk = -(-H // 32) * 32
+        kw = dict(cell=m._cell_kind, deterministic=True)
+        fixed = M.workspace_bytes(variant, 900, 40, Hk, 5, 1, W, L, **kw)
+        per = (M.workspace_bytes(variant, 900, 40, Hk, 5, 1025, W, L, **kw) - fixed) // 1024
+        m.workspace_budget = fixed + micro * per
+        assert M.pick_batch_groups(variant, 900, 40, Hk, 5, S, W, L, m.workspace_budget, **kw) == micro
+    l0, o0, g0 = _separate(case)
+    l1, o1, g1 = _fused(case)
+    assert torch.equal(o0, o1)
+    assert abs(l0.item() - l1.item()) <= 1e-6 * max(1.0, abs(l0.item()))     # (micro-batches add their parts one after the other)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
+def test_fused_step_matches_the_oracle_and_scales_with_the_upstream_gradient():
+    import pathnet_amd
+    torch.manual_seed(1)
+    N, F, H, C, S, W, L = 300, 40, 128, 4, 70, 11, 4
+    g = torch.Generator().manual_seed(5)
+    m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.5).cuda().train()
+    X = torch.rand(N, F, generator=g)
+    sel = np.sort(np.random.default_rng(2).choice(N, S, replace=False))
+    ids = np.random.default_rng(3).integers(0, N, (S, W, L)).astype(np.int32)
+    ids[:, :, 0] = sel[:, None]
+    codes = np.random.default_rng(4).integers(0, L, (S, W, L)).astype(np.uint8)
+    y = torch.as_tensor(np.random.default_rng(6).integers(0, C, S))
+    keep = 0.5
+    mask_seq = (torch.rand(L, S * W, H, generator=g) < keep).float() / keep
+    mask_cls = (torch.rand(S, 2 * H, generator=g) < keep).float() / keep
+    m._mask_seq, m._mask_cls = mask_seq.cuda(), mask_cls.cuda()
+    mask = np.zeros(N, bool)
+    mask[sel] = True
+    loss, out = m.forward_loss(X.cuda(), torch.as_tensor(ids.reshape(S, W * L).astype(np.int64)), W, L, mask,
+                               torch.as_tensor(codes.astype(np.int64)), y, fused=True)
+    (2.5 * loss).backward()
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = po.forward("homo", params, X, ids, codes, sel, W, L, drop_seq=mask_seq, drop_cls=mask_cls)
+    wl = torch.nn.functional.cross_entropy(want, y)
+    assert (out.detach().cpu() - want.detach()).abs().max().item() < 1e-5
+    assert abs(loss.item() - wl.item()) < 1e-5
+    (2.5 * wl).backward()
+    for k, v in m.named_parameters():
+        ref = params[k].grad
+        assert (v.grad.cpu() - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item()), k
+
+
+def test_forward_loss_picks_the_fused_call_exactly_when_the_batch_needs_micro_batches():
+    from pathnet_amd import modules as M
+    case = _case("homo", 120, 6, 4)
+    m, X, ids, codes, sel, y = case
+    torch.manual_seed(3)
+    loss, out = m.forward_loss(X, ids, 6, 4, sel, codes, y)
+    assert loss.grad_fn is not None and type(loss.grad_fn).__name__ != "_PaggLossFunctionBackward"
+    kw = dict(cell=m._cell_kind, deterministic=True)
+    fixed = M.workspace_bytes("homo", 900, 40, 128, 5, 1, 6, 4, **kw)
+    per = (M.workspace_bytes("homo", 900, 40, 128, 5, 1025, 6, 4, **kw) - fixed) // 1024
+    m.workspace_budget = fixed + 50 * per
+    torch.manual_seed(3)
+    loss2, out2 = m.forward_loss(X, ids, 6, 4, sel, codes, y)
+    assert type(loss2.grad_fn).__name__ == "_PaggLossFunctionBackward"
+    assert torch.equal(out.detach(), out2) and abs(loss.item() - loss2.item()) < 1e-6
+
+
+def test_fused_step_needs_grad_mode_and_matching_targets():
+    case = _case("homo", 20, 4, 4)
+    m, X, ids, codes, sel, y = case
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        m.forward_loss(X, ids, 4, 4, sel, codes, y, fused=True)
+    with pytest.raises(ValueError):
+        m.forward_loss(X, ids, 4, 4, sel, codes, y[:-1])

@@ -41,10 +41,15 @@ def run(n=10_000_000, S=400_000, steps=2):
     import bench
     names = bench.stage_names(lib)
 
+    fused = os.environ.get("PN_BENCH_UNFUSED", "0") in ("", "0")
+
     def step(e):
         smp.sample(W, 77, epoch_begin=e, epoch_count=1, nodes=sel, check=False, out=(ids, codes))
-        out = model(X, ids[0], W, L, sel, codes[0], None)
-        loss = lossf(out, Y)
+        if fused:       # pn_pagg_train_step: a micro-batch's forward, loss gradient and backward follow each other
+            loss, _ = model.forward_loss(X, ids[0], W, L, sel, codes[0], Y, fused=True)
+        else:           # forward (keeps nothing), loss, backward (re-runs every micro-batch's recurrence)
+            out = model(X, ids[0], W, L, sel, codes[0], None)
+            loss = lossf(out, Y)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -68,6 +73,8 @@ def run(n=10_000_000, S=400_000, steps=2):
                   "%d masked nodes = %d paths/step, PathNet_homo, dropout 0.7, Adam; exact on-the-fly hop codes" %
                   (n, len(g[1]), F, H, W, L, S, S * W),
         "seconds_per_step": dt, "paths_per_s": S * W / dt, "loss": loss,
+        "step_calls": "pn_pagg_train_step (forward + loss + backward per micro-batch)" if fused else
+                      "pn_pagg_forward, pn_cross_entropy, pn_pagg_backward (the backward re-runs each micro-batch's forward)",
         "micro_batch_nodes": bg, "micro_batches": (S + bg - 1) // bg if bg else 1,
         "workspace_GB": round(modules.workspace_bytes("homo", n, F, H, C, S, W, L, batch_groups=bg) / 2 ** 30, 1),
         "torch_max_allocated_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
