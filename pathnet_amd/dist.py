@@ -369,3 +369,68 @@ class ShardedAggregator:
         self.comm.all_reduce(self._flat)
         if average:
             self._flat /= self.comm.world()
+
+
+class ReplicatedAggregator(ShardedAggregator):
+    """Plain data parallelism over the masked nodes: every rank holds ALL rows of X and runs the single-GPU aggregator on its
+    own masked nodes; the only collective of a step is the all-reduce of the flat gradient buffer (plus, for the hetero
+    class, the all-gather of the batch's index arrays -- its rows read paths of other masked nodes).
+
+    When it beats node sharding: ShardedAggregator exchanges Xh and d Xh (2 x N x H x 4 bytes per step, 1/R of it per link),
+    this class instead runs fc0 over all N rows on every rank (2 N F H flops, forward and backward).  At F = 128 (the
+    10 M-node configuration) the replicated projection costs ~11 ms per step against ~26 ms of exchange on 8 ranks
+    (tools/scale_model.py); at F = 1433 (Cora) the exchange is the cheaper one.  `cheaper_than_sharding` does the
+    arithmetic.  Results are those of one process on the whole batch (dropout positions are batch-wide; one seed per
+    step from identically seeded generators)."""
+
+    def __init__(self, module, n_total, group=None, comm=None, dropout_seed=0):
+        self.module, self.n_total, self.row_begin, self.row_count = module, int(n_total), 0, int(n_total)
+        self.comm = comm if comm is not None else Comm(group)
+        self.group = self.comm.group
+        self.ops = None
+        self.distributed = self.comm.active()
+        self._flat = None
+        self._flat_ids = None
+        self.batch_counts = None
+        self._fixed_counts = None
+        self._seed_gen = torch.Generator()
+        self._seed_gen.manual_seed(int(dropout_seed))
+        self.mask_seq = self.mask_cls = None
+
+    @staticmethod
+    def cheaper_than_sharding(n_total, in_features, hidden, world, link_GBs=50.0, gemm_TFLOPs=50.0):
+        """fc0 forward + backward over all rows on every rank  vs  all-gather of Xh + reduce-scatter of d Xh."""
+        replicated = 2 * 2.0 * n_total * in_features * hidden * (1.0 - 1.0 / world) / (gemm_TFLOPs * 1e12)
+        exchange = 2 * (n_total / world) * hidden * 4 / (link_GBs * 1e9)
+        return replicated < exchange
+
+    def __call__(self, X, neis, num_w, walk_len, sel_global, layer_type):
+        """X [n_total, F] (the same on every rank); sel_global: this rank's masked nodes; neis / layer_type: their paths.
+        -> logits [S, C] of this rank's masked nodes."""
+        m = self.module
+        dev = X.device
+        comm = self.comm
+        ids, codes, sel, S = M._as_index_tensors(neis, layer_type, sel_global, num_w, walk_len, dev, n_nodes=self.n_total)
+        if not comm.active():
+            self.batch_counts = [S]
+            return m._run(X, ids, num_w, walk_len, sel, codes)
+        if self._fixed_counts is not None:
+            counts = self._fixed_counts
+            if counts[comm.rank()] != S:
+                raise ValueError("set_batch_counts said %d masked nodes for this rank, the call has %d" % (counts[comm.rank()], S))
+        else:
+            counts = comm.counts(S, dev)
+        self.batch_counts = counts
+        S_total, begin = sum(counts), sum(counts[:comm.rank()])
+        p = m.dropout_p() if m.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=self._seed_gen).item()) if p > 0 else None
+        old = m._mask_seq, m._mask_cls
+        if self.mask_seq is not None or self.mask_cls is not None:
+            m._mask_seq, m._mask_cls = self.mask_seq, self.mask_cls
+        try:
+            if m.variant == "hetero":
+                ids, codes, sel = (comm.all_gather_ragged(t, counts) for t in (ids, codes, sel))
+                return m._run(X, ids, num_w, walk_len, sel, codes, group_slice=(begin, S), seed=seed)
+            return m._run(X, ids, num_w, walk_len, sel, codes, batch_position=(S_total, begin), seed=seed)
+        finally:
+            m._mask_seq, m._mask_cls = old

@@ -125,6 +125,7 @@ class _PaggFunction(torch.autograd.Function):
         a.mask_cls = mc.data_ptr() if mc is not None else None
         st = cfg.get("step_state")
         a.step_state = st.ptr() if st is not None else None
+        a.index_rows_local = 1 if cfg.get("index_rows_local") else 0
         return a
 
     @staticmethod
@@ -424,7 +425,7 @@ class _Aggregator(nn.Module):
         return self._run(X, neis, num_w, walk_len, indices, layer_type, reuse_tables=reuse_tables, group_slice=group_slice)
 
     def _run(self, X, neis, num_w, walk_len, indices, layer_type, reuse_tables=False, group_slice=None, target=None,
-             grad_scale=None, fused=None):
+             grad_scale=None, fused=None, batch_position=None, seed=None):
         """reuse_tables (extension, inference only): X and the weights are those of the previous no-grad forward of this
         module -- the validation and the test forward of an epoch (PathNet_run.py:362, :378) -- so the projected
         feature matrix and the distance bank still sitting in the module's workspace are used again.
@@ -445,7 +446,19 @@ class _Aggregator(nn.Module):
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
                    step_state=self.step_state, cell=self._cell_kind,
                    deterministic=deterministic_default() if self.deterministic is None else bool(self.deterministic),
-                   seed=int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and self.step_state is None) else 0)
+                   seed=(int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
+                   if (p > 0 and self.step_state is None) else 0)
+        if batch_position is not None:
+            # (data-parallel ranks, dist.ReplicatedAggregator) the S masked nodes of this call are the rows [begin, begin + S)
+            # of a batch of S_total whose other rows are computed elsewhere; neis / indices / layer_type hold this call's
+            # rows only.  Dropout counters and explicit masks are positions in the whole batch.  Not for the hetero class,
+            # whose rows read paths of other masked nodes: give it the whole batch and a group_slice.
+            if self.variant == "hetero" or group_slice is not None:
+                raise ValueError("batch_position: homo / PAGG classes, without group_slice")
+            S_total, begin = int(batch_position[0]), int(batch_position[1])
+            if begin < 0 or begin + S > S_total:
+                raise ValueError("batch_position (%d, %d): %d rows do not fit" % (S_total, begin, S))
+            cfg["S_total"], cfg["group_begin"], cfg["index_rows_local"] = S_total, begin, True
         if group_slice is not None:
             begin, count = int(group_slice[0]), int(group_slice[1])
             if begin < 0 or count < 0 or begin + count > S:

@@ -44,7 +44,7 @@ def masks(case, p=0.5):
             (torch.rand(S, 2 * H, generator=g) >= p).float() / (1 - p))
 
 
-def worker(rank, world, port, variant, ret, empty_rank1=False):
+def worker(rank, world, port, variant, ret, empty_rank1=False, mode="sharded"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -55,11 +55,17 @@ def worker(rank, world, port, variant, ret, empty_rank1=False):
         n_loc = case["N"] // world
         lo = rank * n_loc
         mine = (case["sel"] >= lo) & (case["sel"] < lo + n_loc)
-        runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, comm=pdist.Comm())      # ops = HipOps (default); gloo: staged
-        assert isinstance(runner.ops, pdist.HipOps) and runner.distributed
+        if mode == "replicated":        # every rank holds all of X: plain data parallelism over the masked nodes
+            runner = pdist.ReplicatedAggregator(m, case["N"], comm=pdist.Comm())
+            X_in = case["X"].cuda()
+        else:
+            runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, comm=pdist.Comm())      # ops = HipOps (default); gloo: staged
+            assert isinstance(runner.ops, pdist.HipOps)
+            X_in = case["X"][lo:lo + n_loc].cuda()
+        assert runner.distributed
         ms, mc = masks(case)
         runner.mask_seq, runner.mask_cls = ms.cuda(), mc.cuda()         # the whole batch's masks
-        out = runner(case["X"][lo:lo + n_loc].cuda(),
+        out = runner(X_in,
                      torch.as_tensor(case["ids"][mine].reshape(int(mine.sum()), case["W"] * case["L"])),
                      case["W"], case["L"], torch.as_tensor(case["sel"][mine].astype(np.int32)),
                      torch.as_tensor(case["codes"][mine]))
@@ -89,6 +95,35 @@ def test_two_ranks_hip_ops_match_the_single_process_module(variant, empty_rank1)
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1), nprocs=world, join=True)
+    case = make_case(empty_rank1=empty_rank1)
+    m = build(variant, case).train()
+    ms, mc = masks(case)
+    m._mask_seq, m._mask_cls = ms.cuda(), mc.cuda()
+    S = len(case["sel"])
+    mask = np.zeros(case["N"], bool)
+    mask[case["sel"]] = True
+    out = m(case["X"].cuda(), torch.as_tensor(case["ids"].reshape(S, -1)), case["W"], case["L"], mask,
+            torch.as_tensor(case["codes"]), None)
+    (out * case["G"].cuda()).sum().backward()
+    want = out.detach().cpu().numpy()
+    for rank in range(world):
+        got, grads, rows = ret[rank]
+        assert got.shape[0] == len(rows)
+        if len(rows):
+            assert np.abs(got - want[rows]).max() < 2e-6, rank
+        for k, v in m.named_parameters():
+            ref = v.grad.cpu().numpy()
+            assert np.abs(grads[k] - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), (rank, k)
+
+
+@pytest.mark.parametrize("variant,empty_rank1", [("homo", False), ("hetero", False), ("pagg", False), ("homo", True)])
+def test_two_ranks_replicated_features_match_the_single_process_module(variant, empty_rank1):
+    """dist.ReplicatedAggregator: all of X on every rank, each rank aggregates its own masked nodes, the flat gradient
+    all-reduce is the only collective of the homo / PAGG classes (the hetero class also gathers the batch's index arrays)"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1, "replicated"), nprocs=world, join=True)
     case = make_case(empty_rank1=empty_rank1)
     m = build(variant, case).train()
     ms, mc = masks(case)

@@ -73,6 +73,7 @@ def run(n=10_000_000, S=400_000, steps=2):
                   "%d masked nodes = %d paths/step, PathNet_homo, dropout 0.7, Adam; exact on-the-fly hop codes" %
                   (n, len(g[1]), F, H, W, L, S, S * W),
         "seconds_per_step": dt, "paths_per_s": S * W / dt, "loss": loss,
+        "compact_rows": (os.environ["PN_COMPACT"] != "0") if "PN_COMPACT" in os.environ else 2 * S * W * L < n * L,
         "step_calls": "pn_pagg_train_step (forward + loss + backward per micro-batch)" if fused else
                       "pn_pagg_forward, pn_cross_entropy, pn_pagg_backward (the backward re-runs each micro-batch's forward)",
         "micro_batch_nodes": bg, "micro_batches": (S + bg - 1) // bg if bg else 1,

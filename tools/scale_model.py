@@ -18,6 +18,8 @@ Model, per rank and step, R ranks:
                  (G bytes): 2 (R - 1) / R x G / (links x link_rate) + latency.  The hetero class adds the all-gather of
                  the batch's index arrays (5 bytes per path step).
   overlap        none assumed (dist.py issues the collectives on the compute stream).
+  replicated     dist.ReplicatedAggregator: every rank holds all of X and runs fc0 over all rows (own rows x R); the only
+                 collective is the gradient all-reduce (plus the hetero class's index arrays).
 
 weak scaling (configs[1]: every rank owns a 2708-node block of an R x 2708-node graph, bench.py --gpus R):
   efficiency = t(1) / t(R).  strong scaling (configs[3], configs[4]: one graph): speed-up = t(1) / t(R).
@@ -51,7 +53,7 @@ def collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes=0):
     return ag + rs + ar + ix, {"all_gather_Xh": ag, "reduce_scatter_dXh": rs, "all_reduce_grads": ar, "all_gather_indices": ix}
 
 
-def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, idx_bytes=0, touched_frac=None):
+def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, idx_bytes=0, touched_frac=None, replicated=False):
     """-> rows (R, t_ms, speedup_or_efficiency, parts).  stages: single-GPU per-stage ms; total_ms: single-GPU wall per
     step (the part not covered by the stage timers -- loss, Adam, torch glue -- is carried as `other`, per rank)."""
     s, o, r, rest = split(stages)
@@ -67,6 +69,11 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
         if touched_frac is not None:    # compaction: the bank runs over the rows this rank's paths touch
             rep = min(rep, (r * (R if weak else 1)) * min(1.0, touched_frac(R)))
         coll, parts = collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes)
+        if replicated:      # dist.ReplicatedAggregator: all of X on every rank, fc0 over all rows, no exchange of Xh / d Xh
+            own = o * (R if weak else 1)
+            if R > 1:
+                coll = parts["all_reduce_grads"] + parts["all_gather_indices"]
+                parts = dict(parts, all_gather_Xh=0.0, reduce_scatter_dXh=0.0)
         t = sh + own + rep + other + coll
         rows.append((R, t, dict(sharded=sh, own_rows=own, replicated_bank=rep, other=other, collectives=coll, **parts)))
     t1 = rows[0][1]
@@ -110,12 +117,24 @@ def main():
         F4, C4, L4 = 128, 8, 6
         grad4 = (F4 * H + H + L4 * (H * H + H) + 2 * (4 * H * H + 4 * H) + 2 * H + 1 + 2 * H * C4 + C4) * 4
         tot = g["seconds_per_step"] * 1e3
-        out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over all 60 M rows", "speed-up",
-                    model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us)))
-        # touched rows: a rank's 4 M / R paths x 6 steps can touch at most that many of the 60 M (node, code) rows
-        out.append(("configs[4], bank over touched rows only", "speed-up",
-                    model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
-                          touched_frac=lambda R: (100_000 * 40 * 6 / R) / 60e6)))
+        import math
+        rows, steps = 60e6, 100_000 * 40 * 6
+        uniq = lambda R: rows * (1.0 - math.exp(-steps / (R * rows)))      # expected distinct (node, code) rows of a rank's steps
+        if g.get("compact_rows", True):
+            # the measured step already runs the bank over the rows its 24 M path steps touch (19.8 M of 60 M expected);
+            # a rank's share of the paths touches uniq(R) of them
+            out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over the touched rows (as measured)",
+                        "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
+                                          touched_frac=lambda R: uniq(R) / uniq(1))))
+            out.append(("configs[4], all of X on every rank (dist.ReplicatedAggregator): fc0 over all rows, gradient all-reduce only",
+                        "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
+                                          touched_frac=lambda R: uniq(R) / uniq(1), replicated=True)))
+        else:
+            out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over all 60 M rows", "speed-up",
+                        model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us)))
+            out.append(("configs[4], bank over touched rows only", "speed-up",
+                        model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
+                              touched_frac=lambda R: uniq(R) / rows)))
     for title, what, rows in out:
         print(("### " if a.md else "") + title + "   (xGMI link %.0f GB/s, %.0f us per collective; source %s)" % (
             a.link_GBs, a.latency_us, os.path.basename(path)))
