@@ -72,6 +72,9 @@ using namespace pn;
 #ifndef PN_W4_NOLOAD
 #define PN_W4_NOLOAD 0
 #endif
+#ifndef PN_W4_SKEW
+#define PN_W4_SKEW 0        // 1 / 2: waves (w, w + 4) / (2k, 2k + 1) run the products / commit schedule half a period apart (measured slower)
+#endif
 #ifndef PN_W4_NOFRAG
 #define PN_W4_NOFRAG 0
 #endif
@@ -912,9 +915,12 @@ __global__ __launch_bounds__(W4_THREADS, 2) void wgrad4_kernel(WgradParams p) {
     const int c0 = (op == 0 ? m0 : n0) + 4 * cq;
     const bool c_ok = c0 < ld;
     const float *srcc = src + (c_ok ? c0 : 0);
-    f32x4 rg[4];
+    // two register sets: the rows of tile i + 1 are split and written to LDS BETWEEN the MFMA groups of tile i (the
+    // matrix pipe works on a group for 256 cycles, the wave's VALU / LDS instructions issue in its shadow), while the
+    // loads of tile i + 2 are in flight into the other set
+    f32x4 rgA[4], rgB[4];
     auto row0_of = [&](int64_t i) { return (blockIdx.z + min(i, my_tiles - 1) * nz) * W4_KT; };     // (clamped: harmless re-load)
-    auto issue = [&](int64_t i) {
+    auto issue = [&](f32x4 (&rg)[4], int64_t i) {
         const int64_t k0 = row0_of(i);
 #pragma unroll
         for (int e = 0; e < 4; e++)
@@ -923,89 +929,97 @@ __global__ __launch_bounds__(W4_THREADS, 2) void wgrad4_kernel(WgradParams p) {
     float bs[4] = {0.f, 0.f, 0.f, 0.f};     // column sums of dG over this thread's rows (bias gradient)
     // operand op, k-octet rq >> 1, column 4 cq + j at slot j * 68 + cq; this thread's rows are half (rq & 1) of the octet
     unsigned char *stage_wr = reinterpret_cast<unsigned char *>(lds4 + (op * 2 + (rq >> 1)) * W4_BLK + cq) + (rq & 1) * 8;
-    auto commit = [&](int64_t i, int buf) {
+    // column j of the thread's 4 x 4 block of tile i -> the three planes of stage buf (tiles past the end: zeros)
+    auto piece = [&](f32x4 (&rg)[4], int64_t i, int buf, int j) {
         const int64_t k0 = row0_of(i);
+        float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++)
-            if (!(c_ok && k0 + 4 * rq + e < p.R)) rg[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; e++) v[e] = (c_ok && i < my_tiles && k0 + 4 * rq + e < p.R) ? rg[e][j] : 0.0f;
         unsigned char *w = stage_wr + (size_t)buf * (W4_STAGE * 16);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t x0, x1, x2, y0, y1, y2;
-            if (PN_W4_NOSPLIT) {
-                x0 = __float_as_uint(rg[0][j]); x1 = __float_as_uint(rg[1][j]); x2 = x0 ^ x1;
-                y0 = __float_as_uint(rg[2][j]); y1 = __float_as_uint(rg[3][j]); y2 = y0 ^ y1;
-            } else {
-                split3(rg[0][j], rg[1][j], x0, x1, x2);
-                split3(rg[2][j], rg[3][j], y0, y1, y2);
-            }
-            bs[j] += (rg[0][j] + rg[1][j]) + (rg[2][j] + rg[3][j]);
-            *reinterpret_cast<uint2 *>(w + j * 68 * 16) = make_uint2(x0, y0);
-            *reinterpret_cast<uint2 *>(w + (W4_PLANE + j * 68) * 16) = make_uint2(x1, y1);
-            *reinterpret_cast<uint2 *>(w + (2 * W4_PLANE + j * 68) * 16) = make_uint2(x2, y2);
+        uint32_t x0, x1, x2, y0, y1, y2;
+        if (PN_W4_NOSPLIT) {
+            x0 = __float_as_uint(v[0]); x1 = __float_as_uint(v[1]); x2 = x0 ^ x1;
+            y0 = __float_as_uint(v[2]); y1 = __float_as_uint(v[3]); y2 = y0 ^ y1;
+        } else {
+            split3(v[0], v[1], x0, x1, x2);
+            split3(v[2], v[3], y0, y1, y2);
         }
+        bs[j] += (v[0] + v[1]) + (v[2] + v[3]);
+        *reinterpret_cast<uint2 *>(w + j * 68 * 16) = make_uint2(x0, y0);
+        *reinterpret_cast<uint2 *>(w + (W4_PLANE + j * 68) * 16) = make_uint2(x1, y1);
+        *reinterpret_cast<uint2 *>(w + (2 * W4_PLANE + j * 68) * 16) = make_uint2(x2, y2);
     };
     const int sa = hk * W4_BLK + (li & 3) * 68 + (li >> 2) + wm * 16;                     // operand 0 (dG^T), k-octet hk
     const int sb = (2 + hk) * W4_BLK + (li & 3) * 68 + (li >> 2) + wn * 32;               // operand 1 ([x|h])
-    auto products = [&](int buf) {
-        if (PN_W4_NOMFMA) return;
+    // The two waves that share a SIMD (w and w + 4) run the same schedule half a period apart: one starts a tile with an
+    // MFMA group, the other with a commit piece, so that one wave's VALU / LDS work falls into the other's matrix time
+    // instead of both meeting at the pipe and then both at the VALU.
+    const bool late = PN_W4_SKEW == 1 ? wave >= 4 : PN_W4_SKEW == 2 ? (wave & 1) != 0 : false;        // (wave-uniform, in an SGPR)
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // products of the tile in stage buf, with the commit of tile inext (registers rg) to the other stage in between.
+    // Program order is pinned by the fences: every LDS fragment read sits one MFMA group ahead of its first use.
+    auto step = [&](int buf, f32x4 (&rg)[4], int64_t inext) {
         const u32x4 *fa = lds4 + (PN_W4_NOFRAG ? 0 : buf * W4_STAGE) + sa, *fb = lds4 + (PN_W4_NOFRAG ? 0 : buf * W4_STAGE) + sb;
         u32x4 a0[2], a1[2], b0[4], b1[4];
-        __builtin_amdgcn_s_setprio(1);
+        auto group = [&](const u32x4 (&a)[2], const u32x4 (&b)[4]) {
+            W4_FENCE();
+            if (!PN_W4_NOMFMA) {
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+            }
+            W4_FENCE();
+        };
 #pragma unroll
         for (int i = 0; i < 2; i++) a0[i] = fa[i * 8];
 #pragma unroll
         for (int j = 0; j < 4; j++) b0[j] = fb[j * 8];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b0[j], acc[i][j]);
-#pragma unroll
         for (int j = 0; j < 4; j++) b1[j] = fb[W4_PLANE + j * 8];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
+        if (late) piece(rg, inext, buf ^ 1, 0);
+        group(a0, b0);                                  // a0.b0
+        if (!late) piece(rg, inext, buf ^ 1, 0);
 #pragma unroll
         for (int i = 0; i < 2; i++) a1[i] = fa[W4_PLANE + i * 8];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b1[j], acc[i][j]);
+        if (late) piece(rg, inext, buf ^ 1, 1);
+        group(a0, b1);                                  // a0.b1
+        if (!late) piece(rg, inext, buf ^ 1, 1);
+        if (late) piece(rg, inext, buf ^ 1, 2);
+        group(a1, b1);                                  // a1.b1
 #pragma unroll
         for (int j = 0; j < 4; j++) b1[j] = fb[2 * W4_PLANE + j * 8];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
+        if (!late) piece(rg, inext, buf ^ 1, 2);
+        if (late) piece(rg, inext, buf ^ 1, 3);
+        group(a1, b0);                                  // a1.b0
 #pragma unroll
         for (int i = 0; i < 2; i++) a1[i] = fa[2 * W4_PLANE + i * 8];
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a0[i], b1[j], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a1[i], b0[j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
+        if (!late) piece(rg, inext, buf ^ 1, 3);
+        group(a0, b1);                                  // a0.b2
+        group(a1, b0);                                  // a2.b0
     };
 
-    // the loads of tile i + 2 are issued behind the products of tile i and stay in flight across the barrier
-    issue(0);
-    wait_vm<0>(rg[0], rg[1], rg[2], rg[3]);
-    commit(0, 0);
-    issue(1);
+    issue(rgA, 0);
+    wait_vm<0>(rgA[0], rgA[1], rgA[2], rgA[3]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) piece(rgA, 0, 0, j);
+    issue(rgB, 1);
     __syncthreads();
+    // two tiles per trip (the register sets and the stages alternate); an odd count runs one tile of zeros
 #pragma unroll 1
-    for (int64_t i = 0; i < my_tiles; i++) {
-        products((int)(i & 1));
-        wait_vm<0>(rg[0], rg[1], rg[2], rg[3]);
-        if (i + 1 < my_tiles) commit(i + 1, (int)((i + 1) & 1));
-        issue(i + 2);
+    for (int64_t i = 0; i < my_tiles; i += 2) {
+        issue(rgA, i + 2);
+        wait_vm<4>(rgB[0], rgB[1], rgB[2], rgB[3]);         // tile i + 1 has arrived (the four loads just issued may be out)
+        step(0, rgB, i + 1);
+        __syncthreads();
+        issue(rgB, i + 3);
+        wait_vm<4>(rgA[0], rgA[1], rgA[2], rgA[3]);
+        step(1, rgA, i + 2);
         __syncthreads();
     }
-    wait_vm<0>(rg[0], rg[1], rg[2], rg[3]);     // drain the trailing (clamped) loads
+    wait_vm<0>(rgA[0], rgA[1], rgA[2], rgA[3]);     // drain the trailing (clamped) loads
+    wait_vm<0>(rgB[0], rgB[1], rgB[2], rgB[3]);
+#undef W4_FENCE
     float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -1044,7 +1058,10 @@ namespace pn {
 
 int seq4_select(int H, int G, int L) {
     if (H != H4 || G != G4 || L < 1 || L > 8) return 0;      // (LDS: the index arrays of a 128-path tile)
-    int mask = 0;       // (default: off until measured)
+    // default: the weight-gradient GEMM of this file (commit of the next K tile between the MFMA groups of the current
+    // one: 0.278 vs 0.297 ms, A/B in one session); its forward and BPTT measured slower than the fused kernels and stay
+    // opt-in (PN_SEQ4 = bit mask, 0 = every fused kernel)
+    int mask = SEQ4_WGRAD;
     if (const char *e = getenv("PN_SEQ4")) mask = atoi(e);
     return mask & (SEQ4_FWD | SEQ4_BWD | SEQ4_WGRAD);
 }
