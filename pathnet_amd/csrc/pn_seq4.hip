@@ -72,8 +72,8 @@ using namespace pn;
 #ifndef PN_W4_NOLOAD
 #define PN_W4_NOLOAD 0
 #endif
-#ifndef PN_W4_SKEW
-#define PN_W4_SKEW 0        // 1 / 2: waves (w, w + 4) / (2k, 2k + 1) run the products / commit schedule half a period apart (measured slower)
+#ifndef PN_W4_PRIO
+#define PN_W4_PRIO 0        // 1: s_setprio 1 for waves 4..7 before the main loop
 #endif
 #ifndef PN_W4_NOFRAG
 #define PN_W4_NOFRAG 0
@@ -86,8 +86,16 @@ constexpr int T4_SLOTS = 512;
         if (g_trace4 && (threadIdx.x & 255) == 0 && (slot) < T4_SLOTS)                                              \
             g_trace4[((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * T4_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
+// (the weight-gradient GEMM: workgroup = blockIdx.z * gridDim.y + blockIdx.y, waves 0 and 4 stamp)
+#define W4_STAMP(slot)                                                                                              \
+    do {                                                                                                            \
+        if (g_trace4 && (threadIdx.x & 255) == 0 && (slot) >= 0 && (slot) < T4_SLOTS)                               \
+            g_trace4[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * 2 + (threadIdx.x >> 8)) * T4_SLOTS + (slot)] =  \
+                (long long)__builtin_readcyclecounter();                                                            \
+    } while (0)
 #else
 #define T4_STAMP(slot) do { } while (0)
+#define W4_STAMP(slot) do { } while (0)
 #endif
 
 namespace {
@@ -917,7 +925,8 @@ __global__ __launch_bounds__(W4_THREADS, 2) void wgrad4_kernel(WgradParams p) {
     const float *srcc = src + (c_ok ? c0 : 0);
     // two register sets: the rows of tile i + 1 are split and written to LDS BETWEEN the MFMA groups of tile i (the
     // matrix pipe works on a group for 256 cycles, the wave's VALU / LDS instructions issue in its shadow), while the
-    // loads of tile i + 2 are in flight into the other set
+    // loads of tile i + 2 are in flight into the other set.  (A finer cut -- one register set, one (row pair, column)
+    // between half groups of four MFMAs -- measured the same: 0.281-0.283 vs 0.280-0.286 ms.)
     f32x4 rgA[4], rgB[4];
     auto row0_of = [&](int64_t i) { return (blockIdx.z + min(i, my_tiles - 1) * nz) * W4_KT; };     // (clamped: harmless re-load)
     auto issue = [&](f32x4 (&rg)[4], int64_t i) {
@@ -951,52 +960,56 @@ __global__ __launch_bounds__(W4_THREADS, 2) void wgrad4_kernel(WgradParams p) {
     };
     const int sa = hk * W4_BLK + (li & 3) * 68 + (li >> 2) + wm * 16;                     // operand 0 (dG^T), k-octet hk
     const int sb = (2 + hk) * W4_BLK + (li & 3) * 68 + (li >> 2) + wn * 32;               // operand 1 ([x|h])
-    // The two waves that share a SIMD (w and w + 4) run the same schedule half a period apart: one starts a tile with an
-    // MFMA group, the other with a commit piece, so that one wave's VALU / LDS work falls into the other's matrix time
-    // instead of both meeting at the pipe and then both at the VALU.
-    const bool late = PN_W4_SKEW == 1 ? wave >= 4 : PN_W4_SKEW == 2 ? (wave & 1) != 0 : false;        // (wave-uniform, in an SGPR)
 #define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
-    // products of the tile in stage buf, with the commit of tile inext (registers rg) to the other stage in between.
-    // Program order is pinned by the fences: every LDS fragment read sits one MFMA group ahead of its first use.
-    auto step = [&](int buf, f32x4 (&rg)[4], int64_t inext) {
+    // One step = the products of the tile in stage buf, the commit of tile inext (registers rg) to the other stage in the
+    // gaps after the first four MFMA groups, ONE barrier, then the last two groups -- under which the first fragments of the
+    // next tile are already fetched from the stage just completed, so that the next step starts on full registers instead
+    // of an empty matrix pipe behind the barrier.  Program order is pinned by the fences; every LDS fragment read sits a
+    // group ahead of its first use.  On entry A0 / B0 hold (or are receiving) the plane-0 fragments of this tile and B1 its
+    // plane-1 b fragments; on exit the same holds for the next tile with the roles of B0 and B1 exchanged.
+    u32x4 fA0[2], fA1[2], fB0[4], fB1[4];
+    auto group = [&](const u32x4 (&a)[2], const u32x4 (&b)[4]) {
+        W4_FENCE();
+        if (!PN_W4_NOMFMA) {
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
+        }
+        W4_FENCE();
+    };
+    auto step = [&](int buf, u32x4 (&A0)[2], u32x4 (&A1)[2], u32x4 (&B0)[4], u32x4 (&B1)[4], f32x4 (&rg)[4], int64_t inext) {
+        [[maybe_unused]] const int ts = ((int)inext - 1 - 8) * 5;       // (tuning builds stamp tiles 8 .. 8 + 101)
+        W4_STAMP(ts + 1);
         const u32x4 *fa = lds4 + (PN_W4_NOFRAG ? 0 : buf * W4_STAGE) + sa, *fb = lds4 + (PN_W4_NOFRAG ? 0 : buf * W4_STAGE) + sb;
-        u32x4 a0[2], a1[2], b0[4], b1[4];
-        auto group = [&](const u32x4 (&a)[2], const u32x4 (&b)[4]) {
-            W4_FENCE();
-            if (!PN_W4_NOMFMA) {
+        const u32x4 *na = lds4 + (PN_W4_NOFRAG ? 0 : (buf ^ 1) * W4_STAGE) + sa, *nb = lds4 + (PN_W4_NOFRAG ? 0 : (buf ^ 1) * W4_STAGE) + sb;
+        group(A0, B0);                                  // a0.b0
+        piece(rg, inext, buf ^ 1, 0);
 #pragma unroll
-                for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++) A1[i] = fa[W4_PLANE + i * 8];
+        group(A0, B1);                                  // a0.b1
+        piece(rg, inext, buf ^ 1, 1);
+        group(A1, B1);                                  // a1.b1
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[i][j] = mfma_bf16(a[i], b[j], acc[i][j]);
-            }
-            W4_FENCE();
-        };
+        for (int j = 0; j < 4; j++) B1[j] = fb[2 * W4_PLANE + j * 8];
+        piece(rg, inext, buf ^ 1, 2);
+        group(A1, B0);                                  // a1.b0
 #pragma unroll
-        for (int i = 0; i < 2; i++) a0[i] = fa[i * 8];
+        for (int i = 0; i < 2; i++) A1[i] = fa[2 * W4_PLANE + i * 8];
+        piece(rg, inext, buf ^ 1, 3);
+        W4_FENCE();
+        W4_STAMP(ts + 2);
+        __syncthreads();        // stage buf ^ 1 is complete; every read of stage buf has been issued and has landed
+        W4_STAMP(ts + 3);
+        group(A0, B1);                                  // a0.b2
 #pragma unroll
-        for (int j = 0; j < 4; j++) b0[j] = fb[j * 8];
+        for (int i = 0; i < 2; i++) A0[i] = na[i * 8];                          // next tile: a plane 0
 #pragma unroll
-        for (int j = 0; j < 4; j++) b1[j] = fb[W4_PLANE + j * 8];
-        if (late) piece(rg, inext, buf ^ 1, 0);
-        group(a0, b0);                                  // a0.b0
-        if (!late) piece(rg, inext, buf ^ 1, 0);
+        for (int j = 0; j < 4; j++) B1[j] = nb[j * 8];                          //            b plane 0 (the next step's B0)
+        group(A1, B0);                                  // a2.b0
 #pragma unroll
-        for (int i = 0; i < 2; i++) a1[i] = fa[W4_PLANE + i * 8];
-        if (late) piece(rg, inext, buf ^ 1, 1);
-        group(a0, b1);                                  // a0.b1
-        if (!late) piece(rg, inext, buf ^ 1, 1);
-        if (late) piece(rg, inext, buf ^ 1, 2);
-        group(a1, b1);                                  // a1.b1
-#pragma unroll
-        for (int j = 0; j < 4; j++) b1[j] = fb[2 * W4_PLANE + j * 8];
-        if (!late) piece(rg, inext, buf ^ 1, 2);
-        if (late) piece(rg, inext, buf ^ 1, 3);
-        group(a1, b0);                                  // a1.b0
-#pragma unroll
-        for (int i = 0; i < 2; i++) a1[i] = fa[2 * W4_PLANE + i * 8];
-        if (!late) piece(rg, inext, buf ^ 1, 3);
-        group(a0, b1);                                  // a0.b2
-        group(a1, b0);                                  // a2.b0
+        for (int j = 0; j < 4; j++) B0[j] = nb[W4_PLANE + j * 8];               //            b plane 1 (the next step's B1)
+        W4_STAMP(ts + 4);
     };
 
     issue(rgA, 0);
@@ -1005,20 +1018,33 @@ __global__ __launch_bounds__(W4_THREADS, 2) void wgrad4_kernel(WgradParams p) {
     for (int j = 0; j < 4; j++) piece(rgA, 0, 0, j);
     issue(rgB, 1);
     __syncthreads();
-    // two tiles per trip (the register sets and the stages alternate); an odd count runs one tile of zeros
+    {
+        const u32x4 *fa = lds4 + sa, *fb = lds4 + sb;
+#pragma unroll
+        for (int i = 0; i < 2; i++) fA0[i] = fa[i * 8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fB0[j] = fb[j * 8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fB1[j] = fb[W4_PLANE + j * 8];
+    }
+#if PN_W4_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);       // the second-dispatched half loses every arbitration otherwise
+#endif
+    // two tiles per trip (register sets, stages and the b fragment arrays alternate); an odd count runs one tile of zeros
 #pragma unroll 1
     for (int64_t i = 0; i < my_tiles; i += 2) {
+        W4_STAMP(((int)i - 8) * 5);
         issue(rgA, i + 2);
         wait_vm<4>(rgB[0], rgB[1], rgB[2], rgB[3]);         // tile i + 1 has arrived (the four loads just issued may be out)
-        step(0, rgB, i + 1);
-        __syncthreads();
+        step(0, fA0, fA1, fB0, fB1, rgB, i + 1);
+        W4_STAMP(((int)i + 1 - 8) * 5);
         issue(rgB, i + 3);
         wait_vm<4>(rgA[0], rgA[1], rgA[2], rgA[3]);
-        step(1, rgA, i + 2);
-        __syncthreads();
+        step(1, fA0, fA1, fB1, fB0, rgA, i + 2);
     }
     wait_vm<0>(rgA[0], rgA[1], rgA[2], rgA[3]);     // drain the trailing (clamped) loads
     wait_vm<0>(rgB[0], rgB[1], rgB[2], rgB[3]);
+    __syncthreads();        // (the bias sums below reuse the stages)
 #undef W4_FENCE
     float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
 #pragma unroll
