@@ -61,6 +61,10 @@ using namespace pn;
 #ifndef PN_BWD_REVERSE
 #define PN_BWD_REVERSE 1
 #endif
+#ifndef PN_SEQ_PRIO
+#define PN_SEQ_PRIO 0       // 1: s_setprio 1 while a wave is in its MFMA phase, 2: while it is in its cell phase (two or three
+                            // workgroups share a SIMD; issue arbitration is by priority, then age)
+#endif
 #ifndef PN_FWD_RB
 #define PN_FWD_RB 1         // row blocks of 32 paths per WAVE of the forward.  2: each weight fragment is used for two MFMAs, the
                             // L2 -> CU fragment stream per path halves; one workgroup of 512-register waves per CU.  Correct
@@ -1052,6 +1056,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (RB > 1 ? 1 : fwd_waves<H, RG>())
         //      are re-fetched into their own registers as soon as the MFMAs that read them are issued (2/3 of a k-step
         //      ahead).  vmcnt is in order: [P0(s) P1(s) P2(s) P0(s+1)] in flight at the top of k-step s.
         //      Step 0 has h_{-1} = 0: it stops after the x half of K.
+        if (PN_SEQ_PRIO) __builtin_amdgcn_s_setprio(PN_SEQ_PRIO == 1 ? 1 : 0);
         {
             const int nsteps = t == 0 ? KX : KS;
             // wave-uniform stream base in SGPRs, one VGPR of lane offset (pn_kernels.h: async_load_frags)
@@ -1124,6 +1129,7 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, (RB > 1 ? 1 : fwd_waves<H, RG>())
                 wait_frag<0, G>(P2);
             }
         }
+        if (PN_SEQ_PRIO) __builtin_amdgcn_s_setprio(PN_SEQ_PRIO == 1 ? 0 : 1);
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
         PN_STAMP(4 * t + 2);
 
@@ -1800,10 +1806,12 @@ __global__ __launch_bounds__(H / 32 * 64 * RG, H == 32 && RG == 1 ? 1 : PN_BWD_W
             wait_frag<0, NF>(P1);
             wait_frag<0, NF>(P2);
         };
+        if (PN_SEQ_PRIO) __builtin_amdgcn_s_setprio(PN_SEQ_PRIO == 1 ? 1 : 0);
         if (t > 0)
             mfma_phase(std::integral_constant<int, 2>{});
         else
             mfma_phase(std::integral_constant<int, 1>{});
+        if (PN_SEQ_PRIO) __builtin_amdgcn_s_setprio(PN_SEQ_PRIO == 1 ? 0 : 1);
         __syncthreads();
         PN_STAMP(4 * (p.L - 1 - t) + 2);
 
