@@ -61,6 +61,12 @@ using namespace pn;
 #ifndef PN_BWD_REVERSE
 #define PN_BWD_REVERSE 1
 #endif
+#ifndef PN_POOL_ATT_ATOMIC
+#define PN_POOL_ATT_ATOMIC 0    // 1: the pooling backward adds its attention-weight terms with atomics (A/B builds)
+#endif
+#ifndef PN_POOL_BWD_UNROLL
+#define PN_POOL_BWD_UNROLL 4    // members per trip of the pooling backward's per-path loop (loads of a trip are in flight together)
+#endif
 #ifndef PN_SEQ_PRIO
 #define PN_SEQ_PRIO 0       // 1: s_setprio 1 while a wave is in its MFMA phase, 2: while it is in its cell phase (two or three
                             // workgroups share a SIMD; issue arbitration is by priority, then age)
@@ -1465,7 +1471,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 ego_acc[i] = 0.0f;
             }
         };
-#pragma unroll 4
+#pragma unroll PN_POOL_BWD_UNROLL
         for (int mem = 0; mem < W; mem++) {
             const int64_t s = (int64_t)g * W + mem;
             const float ds = dsc[mem], cf = s_coef[mem];
@@ -2508,6 +2514,7 @@ WsLayout ws_layout(const Dims &d) {
     w.dl1 = take(Sb * 2 * H * 4 + 1024);
     w.gx = take(d.generic ? Pb * 2 * H * 4 : 0);        // [dx_t | dh_{t-1}] of a step of the generic recurrence
     w.gout = take(Sb * (size_t)d.C * 4);                // d loss / d logits of a micro-batch (pn_pagg_train_step)
+    w.datt = take(((Sb + 3) / 4) * (2 * H + 4) * 4);    // per-workgroup attention-weight terms of the pooling backward
     w.flags = take(d.compact ? N * L + 16 : 0);
     w.rank = take(d.compact ? N * L * 4 : 0);
     w.list = take(d.compact ? (size_t)d.ZR * 4 : 0);
@@ -2528,7 +2535,6 @@ WsLayout ws_layout(const Dims &d) {
         w.cpart = take(((K + DET_CHUNK - 1) / DET_CHUNK) * 2 * H * 4);
         w.dsel = take(Sb * H * 4);
         w.dds = take(Pb * 4);
-        w.datt = take(((Sb + 3) / 4) * (2 * H + 4) * 4);
         w.dgemm = take(std::max({det_gemm_floats(C, 2 * H), det_gemm_floats(d.compact ? H : L * H, H), det_gemm_floats(H, F)}) * 4);
     }
     w.total = at;
@@ -3238,10 +3244,12 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             // attention gradients are optional outputs: fall back to scratch so the kernel needs no branches
             pp.g_att_w = a->g_att_w ? a->g_att_w : scratch;
             pp.g_att_b = a->g_att_b ? a->g_att_b : scratch + 2 * H;
+            // the attention-weight terms always go through per-workgroup partials + an ordered reduce: 325 workgroups adding
+            // to the same 2H + 1 addresses with atomics serialise (PN_POOL_ATT_ATOMIC=1 builds keep the atomics for A/B)
+            if (d.det || !PN_POOL_ATT_ATOMIC) pp.det_att = c.at<float>(c.w.datt);
             if (d.det) {
                 pp.det_sel = c.at<float>(c.w.dsel);
                 pp.det_ds = c.at<float>(c.w.dds);
-                pp.det_att = c.at<float>(c.w.datt);
             }
             const size_t lds_bytes = (size_t)(4 * (2 * d.W + H) + 8 * H + 8 * d.W) * sizeof(float);
             StageTimer tm(ctx, ST_POOL_BWD, stream);
@@ -3252,18 +3260,18 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 hipLaunchKernelGGL(pool_bwd_kernel<16>, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
             }
             PN_CHECK_HIP(hipGetLastError());
+            if (has_att && pp.det_att) {        // the attention weights' terms in workgroup order
+                hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, (Sb + 3) / 4, H,
+                                   pp.g_att_w, pp.g_att_b);
+                PN_CHECK_HIP(hipGetLastError());
+            }
             if (d.det) {
-                // the ego half of d layer1 onto the masked nodes' rows of dXh; the attention-ego term onto the ego rows;
-                // the attention weights' terms in workgroup order
+                // the ego half of d layer1 onto the masked nodes' rows of dXh; the attention-ego term onto the ego rows
                 if (int rc = run_det_scatter(c, pp.sel, Sb, d.N - 1, pp.det_sel, nullptr, nullptr, dXh)) return rc;
-                if (has_att) {
+                if (has_att)
                     if (int rc = run_det_scatter(c, pp.egoidx, Pb, homo ? d.ZR - 1 : (int64_t)d.N - 1, nullptr, pp.det_ds,
                                                  a->att_w + H, pp.dego))
                         return rc;
-                    hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, (Sb + 3) / 4, H,
-                                       pp.g_att_w, pp.g_att_b);
-                    PN_CHECK_HIP(hipGetLastError());
-                }
             }
         }
 
