@@ -64,9 +64,6 @@ using namespace pn;
 #ifndef PN_POOL_ATT_ATOMIC
 #define PN_POOL_ATT_ATOMIC 0    // 1: the pooling backward adds its attention-weight terms with atomics (A/B builds)
 #endif
-#ifndef PN_POOL_BWD_UNROLL
-#define PN_POOL_BWD_UNROLL 4    // members per trip of the pooling backward's per-path loop (loads of a trip are in flight together)
-#endif
 #ifndef PN_SEQ_PRIO
 #define PN_SEQ_PRIO 0       // 1: s_setprio 1 while a wave is in its MFMA phase, 2: while it is in its cell phase (two or three
                             // workgroups share a SIMD; issue arbitration is by priority, then age)
@@ -310,13 +307,26 @@ struct Gemm3Params {
     int64_t ldc;
     const float *bias;
     int M, N, K;
+    // node-level GEMMs over row lists (the compact distance bank, GEMM_IND_A_ROWS / GEMM_IND_C_ROWS as in gemm_kernel: the
+    // row count lives in device memory, M bounds it), a ReLU gate on A (element kept where gate > 0, same indexing as A),
+    // ReLU on the result, C += instead of C =
+    const float *gate;
+    const int32_t *seg, *list;
+    int relu, add;
 };
 
+template <int IND, bool GATE>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[6 * G3_PLANE];     // A planes 0..2 | B planes 0..2
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * G3_BM, n0 = blockIdx.x * G3_BN;
+    int pM = p.M, ib = 0;
+    if (IND != GEMM_IND_NONE) {         // (block-uniform)
+        ib = p.seg[0];
+        pM = min(pM, p.seg[1] - ib);
+        if (m0 >= pM) return;
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -327,22 +337,34 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Params p) {
     // staging: thread -> rows lr + 32 i (i < 4) of the tile, floats lk .. lk + 3 of the K tile (rows past M / N: clamped,
     // their results are never stored)
     const int lr = tid >> 3, lk = 4 * (tid & 7);
-    const float *ap[4], *bp[4];
+    const float *ap[4], *bp[4], *gp[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        ap[i] = p.A + (int64_t)min(m0 + lr + 32 * i, p.M - 1) * p.lda + lk;
+        int arow = min(m0 + lr + 32 * i, pM - 1);
+        if (IND == GEMM_IND_A_ROWS) arow = p.list[ib + arow];
+        else if (IND == GEMM_IND_C_ROWS) arow += ib;
+        ap[i] = p.A + (int64_t)arow * p.lda + lk;
+        gp[i] = GATE ? p.gate + (int64_t)arow * p.lda + lk : nullptr;
         bp[i] = p.B + (int64_t)min(n0 + lr + 32 * i, p.N - 1) * p.ldb + lk;
     }
-    f32x4 ra[4], rb[4];
+    f32x4 ra[4], rb[4], rgt[GATE ? 4 : 1];
     auto issue = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             async_load_b128(ra[i], ap[i] + k0);
+            if constexpr (GATE) async_load_b128(rgt[i], gp[i] + k0);
             async_load_b128(rb[i], bp[i] + k0);
         }
     };
     auto commit = [&]() {
         wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);
+        if constexpr (GATE) {       // (a second wait names the gate registers: nothing may read them before it)
+            wait_vm<0>(rgt[0], rgt[1], rgt[2], rgt[3]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) ra[i][e] = rgt[i][e] > 0.0f ? ra[i][e] : 0.0f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             unsigned char *da = lds + (lr + 32 * i) * G3_PITCH + 2 * lk, *db = da + 3 * G3_PLANE;
@@ -389,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Params p) {
         __syncthreads();
     }
     wait_vm<0>(ra[0], ra[1], ra[2], ra[3], rb[0], rb[1], rb[2], rb[3]);
+    if constexpr (GATE) wait_vm<0>(rgt[0], rgt[1], rgt[2], rgt[3]);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int col = n0 + wn * 64 + j * 32 + li;
@@ -399,19 +422,57 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(Gemm3Params p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (row < p.M) p.C[(int64_t)row * p.ldc + col] = acc[i][j][r] + bias;
+                if (row >= pM) continue;
+                const int crow = IND == GEMM_IND_A_ROWS ? ib + row : IND == GEMM_IND_C_ROWS ? p.list[ib + row] : row;
+                float v = acc[i][j][r] + bias;
+                if (p.relu) v = fmaxf(v, 0.0f);
+                float *dst = p.C + (int64_t)crow * p.ldc + col;
+                if (p.add)
+                    *dst += v;
+                else
+                    *dst = v;
             }
     }
 }
 
 int launch_gemm3(hipStream_t stream, const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc,
-                 const float *bias, int M, int N, int K) {
+                 const float *bias, int M, int N, int K, int relu = 0, int add = 0, const float *gate = nullptr,
+                 int ind = GEMM_IND_NONE, const int32_t *seg = nullptr, const int32_t *list = nullptr) {
     if (M <= 0 || N <= 0) return PN_OK;
     if (K < G3_KT || K % G3_KT != 0) PN_FAIL(PN_ERR_ARG, "gemm3: K=%d is not a multiple of %d", K, G3_KT);
-    Gemm3Params p{A, lda, B, ldb, C, ldc, bias, M, N, K};
-    hipLaunchKernelGGL(gemm3_kernel, dim3((N + G3_BN - 1) / G3_BN, (M + G3_BM - 1) / G3_BM), dim3(256), 0, stream, p);
+    Gemm3Params p{A, lda, B, ldb, C, ldc, bias, M, N, K, gate, seg, list, relu, add};
+    const dim3 grid((N + G3_BN - 1) / G3_BN, (M + G3_BM - 1) / G3_BM);
+    if (ind == GEMM_IND_A_ROWS && !gate)
+        hipLaunchKernelGGL((gemm3_kernel<GEMM_IND_A_ROWS, false>), grid, dim3(256), 0, stream, p);
+    else if (ind == GEMM_IND_C_ROWS && gate)
+        hipLaunchKernelGGL((gemm3_kernel<GEMM_IND_C_ROWS, true>), grid, dim3(256), 0, stream, p);
+    else if (ind == GEMM_IND_C_ROWS)
+        hipLaunchKernelGGL((gemm3_kernel<GEMM_IND_C_ROWS, false>), grid, dim3(256), 0, stream, p);
+    else if (ind == GEMM_IND_NONE && gate)
+        hipLaunchKernelGGL((gemm3_kernel<GEMM_IND_NONE, true>), grid, dim3(256), 0, stream, p);
+    else if (ind == GEMM_IND_NONE)
+        hipLaunchKernelGGL((gemm3_kernel<GEMM_IND_NONE, false>), grid, dim3(256), 0, stream, p);
+    else
+        PN_FAIL(PN_ERR_ARG, "gemm3: unsupported indirection %d", ind);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
+}
+
+// weights [R][C] -> [C][R] (the dX GEMMs of the node-level backward want the reduction index contiguous)
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, int R, int C, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)R * C) return;
+    const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
+    out[(int64_t)c * R + r] = in[i];
+}
+
+// the bf16 x 3 GEMM pays once its 128 x 128 tiles fill the GPU (the fp32-input MFMA kernel has 64 x 64 tiles and a split-K
+// front end for the small shapes); K must be a multiple of 32
+enum { G3_FC0 = 1, G3_BANK = 2, G3_BANK_DX = 4 };
+inline bool gemm3_pays(int64_t M, int64_t N, int K, int which) {
+    if (const char *e = getenv("PN_NODE_GEMM3"))        // bit mask of G3_*: A/B runs and tests (default: all)
+        if (!(atoi(e) & which)) return false;
+    return K >= G3_KT && K % G3_KT == 0 && ((M + G3_BM - 1) / G3_BM) * ((N + G3_BN - 1) / G3_BN) >= 384;
 }
 
 // ---- deterministic split-K for the STORE / ADD GEMMs -------------------------------------------------------------
@@ -1471,7 +1532,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
                 ego_acc[i] = 0.0f;
             }
         };
-#pragma unroll PN_POOL_BWD_UNROLL
+#pragma unroll 4
         for (int mem = 0; mem < W; mem++) {
             const int64_t s = (int64_t)g * W + mem;
             const float ds = dsc[mem], cf = s_coef[mem];
@@ -2458,7 +2519,7 @@ struct WsLayout {
     size_t Xh, Z;                                                        // node tables (first: reuse_tables relies on it)
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
-    size_t xh, keep, dG, dhn, dl1, gx, gout;                             // per micro-batch, saved / backward
+    size_t xh, keep, dG, dhn, dl1, gx, gout, bankT;                      // per micro-batch, saved / backward
     size_t flags, rank, list, seg, bsum;                                 // touched-row compaction (Dims.compact)
     size_t dx, keys, iota, skey, ssrc, stmp, cpart, dsel, dds, datt, dgemm;  // deterministic backward (Dims.det)
     size_t stmp_bytes;
@@ -2515,6 +2576,7 @@ WsLayout ws_layout(const Dims &d) {
     w.gx = take(d.generic ? Pb * 2 * H * 4 : 0);        // [dx_t | dh_{t-1}] of a step of the generic recurrence
     w.gout = take(Sb * (size_t)d.C * 4);                // d loss / d logits of a micro-batch (pn_pagg_train_step)
     w.datt = take(((Sb + 3) / 4) * (2 * H + 4) * 4);    // per-workgroup attention-weight terms of the pooling backward
+    w.bankT = take(L * H * H * 4);                      // transposed bank weights (the dX GEMM on the bf16 x 3 kernel)
     w.flags = take(d.compact ? N * L + 16 : 0);
     w.rank = take(d.compact ? N * L * 4 : 0);
     w.list = take(d.compact ? (size_t)d.ZR * 4 : 0);
@@ -2878,8 +2940,11 @@ int run_tables(const Call &c, JoinGuard &joiner) {
         // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
         if (!a->Xh_in) {
             StageTimer tm(ctx, ST_FC0, stream);
-            if (int rc = launch_gemm_split(stream, a->X, d.F, 1, nullptr, a->fc0_w, d.F, 1, c.at<float>(c.w.Xh), H,
-                                           a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart)))
+            if (gemm3_pays(d.N, H, d.F, G3_FC0)) {          // large graphs: fp32 results from the bf16 matrix pipe (six MFMAs per product)
+                if (int rc = launch_gemm3(stream, a->X, d.F, a->fc0_w, d.F, c.at<float>(c.w.Xh), H, a->fc0_b, d.N, H, d.F, homo))
+                    return rc;
+            } else if (int rc = launch_gemm_split(stream, a->X, d.F, 1, nullptr, a->fc0_w, d.F, 1, c.at<float>(c.w.Xh), H,
+                                                  a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart)))
                 return rc;
         }
     }
@@ -2888,16 +2953,24 @@ int run_tables(const Call &c, JoinGuard &joiner) {
         // (the touched set belongs to this batch: reuse_tables keeps the projected features only)
         StageTimer tm(ctx, ST_BANK, stream);
         const int mmax = (int)std::min<int64_t>(d.N, d.ZR);
-        for (int code = 0; code < L; code++)
-            if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w + (size_t)code * H * H, H, 1, c.Z, H,
-                                     a->bank_b + (size_t)code * H, mmax, H, H, homo, GEMM_STORE, 1, nullptr, GEMM_IND_A_ROWS,
-                                     c.at<const int32_t>(c.w.seg) + code, c.at<const int32_t>(c.w.list)))
+        for (int code = 0; code < L; code++) {
+            if (gemm3_pays(mmax, H, H, G3_BANK)) {
+                if (int rc = launch_gemm3(stream, c.Xh, H, a->bank_w + (size_t)code * H * H, H, c.Z, H, a->bank_b + (size_t)code * H,
+                                          mmax, H, H, homo, 0, nullptr, GEMM_IND_A_ROWS, c.at<const int32_t>(c.w.seg) + code,
+                                          c.at<const int32_t>(c.w.list)))
+                    return rc;
+            } else if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w + (size_t)code * H * H, H, 1, c.Z, H,
+                                            a->bank_b + (size_t)code * H, mmax, H, H, homo, GEMM_STORE, 1, nullptr,
+                                            GEMM_IND_A_ROWS, c.at<const int32_t>(c.w.seg) + code, c.at<const int32_t>(c.w.list)))
                 return rc;
+        }
     } else if (!a->reuse_tables) {
         // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
         StageTimer tm(ctx, ST_BANK, stream);
-        if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
-                                 L * H, H, homo, GEMM_STORE, 1))
+        if (gemm3_pays(d.N, L * H, H, G3_BANK)) {
+            if (int rc = launch_gemm3(stream, c.Xh, H, a->bank_w, H, c.Z, (int64_t)L * H, a->bank_b, d.N, L * H, H, homo)) return rc;
+        } else if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
+                                        L * H, H, homo, GEMM_STORE, 1))
             return rc;
     }
     return joiner.join();       // the recurrence needs the plan and the packed weights
@@ -3371,9 +3444,21 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (a->g_bank_b && !a->g_bank_w) PN_FAIL(PN_ERR_ARG, "pn_pagg_backward: compact rows need g_bank_w with g_bank_b");
         const int mmax = (int)std::min<int64_t>(d.N, d.ZR);
         const int32_t *seg = c.at<const int32_t>(c.w.seg), *list = c.at<const int32_t>(c.w.list);
+        // (measured at the 10 M-node shape: the 128 x 128 tiles' read-modify-write of scattered dXh rows at two workgroups
+        //  per CU is slower than the 64 x 64 kernel's, 24.1 vs 21.6 ms for the stage; PN_NODE_GEMM3 bit 3 switches it on)
+        const bool g3 = getenv("PN_NODE_GEMM3") && (atoi(getenv("PN_NODE_GEMM3")) & 8) && gemm3_pays(mmax, H, H, G3_BANK_DX);
+        float *bankT = c.at<float>(c.w.bankT);
+        if (g3)             // bank_w[code] [out, in] -> [in, out]: the reduction index (out) contiguous
+            for (int code = 0; code < L; code++)
+                hipLaunchKernelGGL(transpose_kernel, dim3((H * H + 255) / 256), dim3(256), 0, stream, a->bank_w + (size_t)code * H * H,
+                                   H, H, bankT + (size_t)code * H * H);
         for (int code = 0; code < L; code++) {
-            if (int rc = launch_gemm(stream, dZ, H, 1, zgate, a->bank_w + (size_t)code * H * H, 1, H, dXh, H, nullptr, mmax, H,
-                                     H, 0, GEMM_ADD, 1, nullptr, GEMM_IND_C_ROWS, seg + code, list))
+            if (g3) {
+                if (int rc = launch_gemm3(stream, dZ, H, bankT + (size_t)code * H * H, H, dXh, H, nullptr, mmax, H, H, 0, 1, zgate,
+                                          GEMM_IND_C_ROWS, seg + code, list))
+                    return rc;
+            } else if (int rc = launch_gemm(stream, dZ, H, 1, zgate, a->bank_w + (size_t)code * H * H, 1, H, dXh, H, nullptr, mmax,
+                                            H, H, 0, GEMM_ADD, 1, nullptr, GEMM_IND_C_ROWS, seg + code, list))
                 return rc;
             if (a->g_bank_w && d.det) {
                 if (int rc = launch_gemm_det(stream, dZ, 1, H, zgate, Xh, 1, H, a->g_bank_w + (size_t)code * H * H, H, H, H, mmax,
@@ -3387,8 +3472,13 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                     return rc;
         }
     } else {
-    if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, d.N, H, L * H,
-                                   0, GEMM_ADD, c.at<float>(c.w.gpart)))
+    if (gemm3_pays(d.N, H, L * H, G3_BANK_DX)) {        // bank_w [L*H, H] -> [H, L*H]
+        float *bankT = c.at<float>(c.w.bankT);
+        hipLaunchKernelGGL(transpose_kernel, dim3((L * H * H + 255) / 256), dim3(256), 0, stream, a->bank_w, L * H, H, bankT);
+        if (int rc = launch_gemm3(stream, dZ, (int64_t)L * H, bankT, (int64_t)L * H, dXh, H, nullptr, d.N, H, L * H, 0, 1, zgate))
+            return rc;
+    } else if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, d.N, H, L * H,
+                                          0, GEMM_ADD, c.at<float>(c.w.gpart)))
         return rc;
     if (a->g_bank_w && d.det) {
         if (int rc = launch_gemm_det(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, L * H, H, d.N,
