@@ -114,6 +114,10 @@ __device__ __forceinline__ void wait_vm_all(float (&a)[8], float (&b)[8], float 
                    "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
 }
 template <int N>
+__device__ __forceinline__ void wait_vm(float &r0, float &r1, float &r2, float &r3) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "i"(N));
+}
+template <int N>
 __device__ __forceinline__ void wait_vm(f32x4 &r0) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0) : "i"(N));
 }

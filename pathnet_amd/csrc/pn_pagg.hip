@@ -3465,6 +3465,10 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                                              (mmax + 255) / 256, a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, dgemm,
                                              GEMM_IND_K, seg + code, list))
                     return rc;
+            } else if (a->g_bank_w && rgrad_pays(mmax, H, H)) {         // large graphs: the bf16 x 3 row-reduction kernel
+                const RgradParams rp{dZ, zgate, Xh, H, H, mmax, H, H, a->g_bank_w + (size_t)code * H * H, H,
+                                     a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, seg + code, list};
+                if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
             } else if (a->g_bank_w)
                 if (int rc = launch_gemm(stream, dZ, 1, H, zgate, Xh, 1, H, a->g_bank_w + (size_t)code * H * H, H, nullptr, H,
                                          H, mmax, 0, GEMM_ATOMIC, (mmax + 255) / 256,
@@ -3484,6 +3488,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (int rc = launch_gemm_det(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, L * H, H, d.N,
                                      (d.N + 255) / 256, a->g_bank_b, dgemm))
             return rc;
+    } else if (a->g_bank_w && rgrad_pays(d.N, L * H, H)) {
+        const RgradParams rp{dZ, zgate, Xh, (int64_t)L * H, H, d.N, L * H, H, a->g_bank_w, H, a->g_bank_b, nullptr, nullptr};
+        if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
     } else if (a->g_bank_w) {       // g_bank_b rides along as the row sums of the same (gated) A operand
         if (int rc = launch_gemm(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, nullptr, L * H, H, d.N,
                                  0, GEMM_ATOMIC, (d.N + 255) / 256, a->g_bank_b))
@@ -3502,6 +3509,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (int rc = launch_gemm_det(stream, dXh, 1, H, xgate, a->X, 1, d.F, a->g_fc0_w, d.F, H, d.F, d.N, (d.N + 255) / 256,
                                      a->g_fc0_b, dgemm))
             return rc;
+    } else if (a->g_fc0_w && d.F % 4 == 0 && rgrad_pays(d.N, H, d.F)) {
+        const RgradParams rp{dXh, xgate, a->X, H, d.F, d.N, H, d.F, a->g_fc0_w, d.F, a->g_fc0_b, nullptr, nullptr};
+        if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
     } else if (a->g_fc0_w) {
         if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, d.F, a->g_fc0_w, d.F, nullptr, H, d.F, d.N, 0,
                                  GEMM_ATOMIC, (d.N + 255) / 256, a->g_fc0_b))

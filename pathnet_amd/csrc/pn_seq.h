@@ -57,6 +57,22 @@ struct WgradParams {
     float *part_b;     // [nsplit, GH]
 };
 
+// ---- pn_rgrad.hip: C [M, N] += A^T . B over the rows of a large graph (node-level weight gradients) ----------------------
+struct RgradParams {
+    const float *A;         // [., lda]: reduction rows x M columns (d Z' or d Xh)
+    const float *gate;      // same indexing as A, or null: an element of A counts where gate > 0 (ReLU backward)
+    const float *B;         // [., ldb]: reduction rows x N columns (Xh or X)
+    int64_t lda, ldb;
+    int64_t R;              // reduction rows (an upper bound when seg is set)
+    int M, N;               // multiples of 4
+    float *C;               // [M, ldc] +=  (atomics)
+    int64_t ldc;
+    float *rowsum;          // [M] += column sums of the gated A (the bias gradient), or null
+    const int32_t *seg, *list;      // compact rows: A row = seg[0] + k, B row = list[seg[0] + k], k < seg[1] - seg[0]; or both null
+};
+bool rgrad_pays(int64_t R, int M, int N);       // the kernel's 128 x 128 tiles and K tiles of 32 rows want >= ~50 000 rows
+int launch_rgrad(pn_context *ctx, void *stream, const RgradParams &p);
+
 // ---- pn_seq4.hip: the recurrent kernels with 128 paths per workgroup -------------------------------------------------
 // which of the three kernels take the 128-row path for this shape (bit 0: forward, bit 1: BPTT, bit 2: weight gradient);
 // 0 when the shape is outside what they are built for.  PN_SEQ4 in the environment (a bit mask) narrows it.

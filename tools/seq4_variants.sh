@@ -14,7 +14,7 @@ for spec in "$@"; do
   defs=""
   for kv in $spec; do defs="$defs -DPN_$kv"; done
   ( hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $defs -c pn_seq4.hip -o _variants/seq4_$n.o && \
-    hipcc -shared --offload-arch=gfx950 -o _variants/lib_$n.so _obj/pn_host.o _obj/pn_sampler.o _obj/pn_pagg.o _obj/pn_train.o _obj/pn_merw.o _obj/pn_context.o _obj/pn_sort.o _variants/seq4_$n.o && rm _variants/seq4_$n.o ) &
+    hipcc -shared --offload-arch=gfx950 -o _variants/lib_$n.so _obj/pn_host.o _obj/pn_sampler.o _obj/pn_pagg.o _obj/pn_train.o _obj/pn_merw.o _obj/pn_context.o _obj/pn_sort.o _obj/pn_rgrad.o _variants/seq4_$n.o && rm _variants/seq4_$n.o ) &
   echo "$n $spec" >> _variants/specs.txt
   n=$((n+1))
 done

@@ -12,13 +12,14 @@ hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -c pn_merw.hip -o _obj/pn_merw.
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -c pn_context.hip -o _obj/pn_context.o
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -c pn_seq4.hip -o _obj/pn_seq4.o
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -c pn_sort.hip -o _obj/pn_sort.o
+hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -c pn_rgrad.hip -o _obj/pn_rgrad.o
 n=0
 : > _variants/specs.txt
 for spec in "$@"; do
   defs=""
   for kv in $spec; do defs="$defs -DPN_$kv"; done
   ( hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $defs -c pn_pagg.hip -o _variants/pagg_$n.o && \
-    hipcc -shared --offload-arch=gfx950 -o _variants/lib_$n.so _obj/pn_host.o _obj/pn_sampler.o _obj/pn_train.o _obj/pn_merw.o _obj/pn_context.o _obj/pn_seq4.o _obj/pn_sort.o _variants/pagg_$n.o && rm _variants/pagg_$n.o ) &
+    hipcc -shared --offload-arch=gfx950 -o _variants/lib_$n.so _obj/pn_host.o _obj/pn_sampler.o _obj/pn_train.o _obj/pn_merw.o _obj/pn_context.o _obj/pn_seq4.o _obj/pn_sort.o _obj/pn_rgrad.o _variants/pagg_$n.o && rm _variants/pagg_$n.o ) &
   echo "$n $spec" >> _variants/specs.txt
   n=$((n+1))
 done
