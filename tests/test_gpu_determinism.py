@@ -173,3 +173,29 @@ def test_sharded_step_single_rank_is_bitwise_reproducible():
         outs.append({k: v.grad.detach().clone() for k, v in m.named_parameters()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_deterministic_backward_captured_in_a_hip_graph_replays_the_same_bits():
+    """the sorted scatter (rocPRIM radix sort included) records into a hipGraph: a replay gives the eager run's bits"""
+    m, X, ids, codes, sel, G = _case("homo", 200, 12, 4, N=500, F=40, C=5, drop=0.0)
+    m.deterministic = True
+    params = list(m.parameters())
+
+    def step():
+        out = m(X, ids, ids.shape[1], ids.shape[2], sel, codes, None)
+        return torch.autograd.grad(out, params, G)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ref = step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ref = [r.clone() for r in ref]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = step()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
