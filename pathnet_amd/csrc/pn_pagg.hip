@@ -1581,6 +1581,149 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
     if (lane == 0 && active) atomicAdd(p.g_att_b, gab);
 }
 
+// ---- the same with a workgroup per group: the W members of a group split over the four waves.  One wave per group runs
+//      its ~50 dependent memory round trips alone on its SIMD (1 299 waves on 1 024 SIMDs at the headline shape); four
+//      times the waves hide them.  (Round 2 had rejected this layout for quadrupling the atomics on the 2H + 1
+//      attention-weight addresses; those now go through per-workgroup partials, det_att: [groups][2H + 4].)
+template <int HI>
+__global__ __launch_bounds__(256) void pool_bwd_wg_kernel(PoolBwdParams p) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int H = p.H, W = p.W;
+    float *dco = lds;                        // [W] d coef
+    float *dsc = dco + W;                    // [W] d score
+    float *dp = dsc + W;                     // [H] d pooled / W
+    float *red = dp + H;                     // [4][2H] per-wave attention-weight partials; before that [4][H] ego partials
+    int *s_erow = reinterpret_cast<int *>(red + 8 * H);    // [W] ego rows of the group
+    float *s_coef = reinterpret_cast<float *>(s_erow + W);  // [W]
+    float *s_tot = s_coef + W;               // [4] hetero: partial sums of coef * d coef
+    const int g = blockIdx.x;
+    const float inv_w = 1.0f / (float)W;
+    for (int mem = tid; mem < W; mem += 256) {
+        const int64_t s = (int64_t)g * W + mem;
+        s_erow[mem] = p.variant == PN_VARIANT_PAGG ? 0 : p.egoidx[s];
+        s_coef[mem] = p.coef[s];
+    }
+    for (int j = tid; j < H; j += 256) {
+        float a = 0.0f, b = 0.0f;
+        for (int c = 0; c < p.C; c++) {
+            const float go = p.g_out[(int64_t)g * p.C + c];
+            a += go * p.fc2_w[(int64_t)c * 2 * H + j];
+            b += go * p.fc2_w[(int64_t)c * 2 * H + H + j];
+        }
+        const uint64_t gg = (uint64_t)(p.goff + g);
+        if (p.mask) {
+            a *= p.mask[gg * 2 * H + j];
+            b *= p.mask[gg * 2 * H + H + j];
+        } else if (p.p_drop > 0.0f) {
+            const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
+            a *= dropout1(seed, gg * 2 * H + j, 2u, p.p_drop);
+            b *= dropout1(seed, gg * 2 * H + H + j, 2u, p.p_drop);
+        }
+        if (p.det_sel)
+            p.det_sel[(int64_t)g * H + j] = a;
+        else
+            atomicAdd(&p.dXh[(int64_t)min(max(p.sel[g], 0), p.N - 1) * H + j], a);
+        dp[j] = b * inv_w;
+    }
+    __syncthreads();
+    {       // d coef[mem] = hn[mem] . d pooled / W: eight lanes per member, 32 members per pass
+        const int m32 = tid >> 3, part = tid & 7, jw = H / 8;
+        for (int m0 = 0; m0 < W; m0 += 32) {
+            const int mem = m0 + m32;
+            const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + ((int64_t)g * W + min(mem, W - 1)) * H + part * jw);
+            float acc = 0.0f;
+            for (int j = 0; j < jw / 4; j++) {
+                const float4 hv = h4[j];
+                const float *d = dp + part * jw + 4 * j;
+                acc += hv.x * d[0] + hv.y * d[1] + hv.z * d[2] + hv.w * d[3];
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (part == 0 && mem < W) dco[mem] = acc;
+        }
+    }
+    __syncthreads();
+    if (p.variant == PN_VARIANT_HETERO) {
+        float tot = 0.0f;
+        for (int mem = tid; mem < W; mem += 256) tot += s_coef[mem] * dco[mem];
+        tot = wave_sum(tot);
+        if (lane == 0) s_tot[wave] = tot;
+        __syncthreads();
+        tot = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+        for (int mem = tid; mem < W; mem += 256) {
+            const int64_t s = (int64_t)g * W + mem;
+            dsc[mem] = s_coef[mem] * (dco[mem] - tot) * (p.rawsc[s] > 0.0f ? 1.0f : 0.01f);
+        }
+    } else {
+        for (int mem = tid; mem < W; mem += 256) dsc[mem] = p.variant == PN_VARIANT_HOMO ? dco[mem] : 0.0f;
+    }
+    __syncthreads();
+    // per member: d h_n, the attention-weight terms and the attention-ego term; wave w takes members w, w + 4, ...
+    float gaw_h[HI], gaw_e[HI], ego_acc[HI], gab = 0.0f;
+#pragma unroll
+    for (int i = 0; i < HI; i++) gaw_h[i] = gaw_e[i] = ego_acc[i] = 0.0f;
+    const bool has_att = p.variant != PN_VARIANT_PAGG;
+    // the members' ego rows: usually one row for the whole group (HOMO: all W paths of a node start at the node) -- then the
+    // waves' sums meet in LDS and the group flushes once; otherwise (HETERO, or paths that start elsewhere) a row per
+    // member, flushed as it comes
+    int same = 1;
+    for (int mem = tid; mem < W; mem += 256) same &= s_erow[mem] == s_erow[0];
+    const bool one_row = __syncthreads_and(same) != 0;
+#pragma unroll 2
+    for (int mem = wave; mem < W; mem += 4) {
+        const int64_t s = (int64_t)g * W + mem;
+        const float ds = dsc[mem], cf = s_coef[mem];
+        const int64_t erow = (int64_t)s_erow[mem] * H;
+#pragma unroll
+        for (int i = 0; i < HI; i++) {
+            const int j = lane + 64 * i;
+            if (j < H) {
+                float dh = cf * dp[j];
+                if (has_att) {
+                    dh += ds * p.att_w[j];
+                    gaw_h[i] += ds * p.hn[s * H + j];
+                    gaw_e[i] += ds * p.ego_tab[erow + j];
+                    const float eg = ds * p.att_w[H + j];
+                    if (one_row)
+                        ego_acc[i] += eg;
+                    else if (!p.det_ds)
+                        atomicAdd(&p.dego[erow + j], eg);
+                }
+                p.dhn[s * H + j] = dh;
+            }
+        }
+        gab += ds;
+        if (p.det_ds && lane == 0) p.det_ds[s] = ds;
+    }
+    if (!has_att) return;       // block-uniform
+    if (one_row && !p.det_ds) {
+#pragma unroll
+        for (int i = 0; i < HI; i++) {
+            const int j = lane + 64 * i;
+            if (j < H) red[wave * H + j] = ego_acc[i];
+        }
+        __syncthreads();
+        const int64_t erow = (int64_t)s_erow[0] * H;
+        for (int j = tid; j < H; j += 256)
+            atomicAdd(&p.dego[erow + j], (red[j] + red[H + j]) + (red[2 * H + j] + red[3 * H + j]));
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < HI; i++) {
+        const int j = lane + 64 * i;
+        if (j < H) {
+            red[wave * 2 * H + j] = gaw_h[i];
+            red[wave * 2 * H + H + j] = gaw_e[i];
+        }
+    }
+    __syncthreads();
+    float *out = p.det_att + (int64_t)blockIdx.x * (2 * H + 4);
+    for (int j = tid; j < 2 * H; j += 256) out[j] = red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j];
+    if (lane == 0) out[2 * H + wave] = gab;
+}
+
 // ---- BPTT through the recurrent cell, fused with the gather-backward scatter ---------------------
 // (SeqBwdParams: pn_seq.h)
 
@@ -2575,7 +2718,7 @@ WsLayout ws_layout(const Dims &d) {
     w.dl1 = take(Sb * 2 * H * 4 + 1024);
     w.gx = take(d.generic ? Pb * 2 * H * 4 : 0);        // [dx_t | dh_{t-1}] of a step of the generic recurrence
     w.gout = take(Sb * (size_t)d.C * 4);                // d loss / d logits of a micro-batch (pn_pagg_train_step)
-    w.datt = take(((Sb + 3) / 4) * (2 * H + 4) * 4);    // per-workgroup attention-weight terms of the pooling backward
+    w.datt = take(Sb * (2 * H + 4) * 4);                // per-workgroup attention-weight terms of the pooling backward
     w.bankT = take(L * H * H * 4);                      // transposed bank weights (the dX GEMM on the bf16 x 3 kernel)
     w.flags = take(d.compact ? N * L + 16 : 0);
     w.rank = take(d.compact ? N * L * 4 : 0);
@@ -3326,7 +3469,19 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             }
             const size_t lds_bytes = (size_t)(4 * (2 * d.W + H) + 8 * H + 8 * d.W) * sizeof(float);
             StageTimer tm(ctx, ST_POOL_BWD, stream);
-            if (H <= 256) {
+            // a workgroup per group (four waves share its members) unless PN_POOL_BWD_WG=0; it needs the partials buffer
+            const char *e_wg = getenv("PN_POOL_BWD_WG");
+            const bool wg = (!has_att || pp.det_att) && !(e_wg && atoi(e_wg) == 0);
+            int att_blocks = (Sb + 3) / 4;
+            if (wg) {
+                att_blocks = Sb;
+                if (H <= 256) {
+                    hipLaunchKernelGGL(pool_bwd_wg_kernel<4>, dim3(Sb), dim3(256), lds_bytes, stream, pp);
+                } else {
+                    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_bwd_wg_kernel<16>), (int)lds_bytes)) return rc;
+                    hipLaunchKernelGGL(pool_bwd_wg_kernel<16>, dim3(Sb), dim3(256), lds_bytes, stream, pp);
+                }
+            } else if (H <= 256) {
                 hipLaunchKernelGGL(pool_bwd_kernel<4>, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
             } else {
                 if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_bwd_kernel<16>), (int)lds_bytes)) return rc;
@@ -3334,7 +3489,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             }
             PN_CHECK_HIP(hipGetLastError());
             if (has_att && pp.det_att) {        // the attention weights' terms in workgroup order
-                hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, (Sb + 3) / 4, H,
+                hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, att_blocks, H,
                                    pp.g_att_w, pp.g_att_b);
                 PN_CHECK_HIP(hipGetLastError());
             }
