@@ -101,9 +101,13 @@ def main():
     grad1 = (F * H + H + L * (H * H + H) + 2 * (4 * H * H + 4 * H) + 2 * H + 1 + 2 * H * C + C) * 4
     out.append(("configs[1] Cora-shaped block per rank (weak)", "efficiency",
                 model(b["stages_ms"], b["ms_per_step"], 2708, H, grad1, True, a.link_GBs, a.latency_us)))
-    out.append(("configs[1], bank over touched rows only", "efficiency",
+    import math
+    # a rank's 51 960 paths x 4 steps land on the whole R x 2708-node graph (bench.workload draws ONE graph over all
+    # nodes): expected distinct (node, code) rows = rows x (1 - exp(-steps / rows)) -- nearly all of them up to 8 ranks
+    steps1 = 1299 * 40 * L
+    out.append(("configs[1], bank over the rows a rank's paths touch (uniform estimate)", "efficiency",
                 model(b["stages_ms"], b["ms_per_step"], 2708, H, grad1, True, a.link_GBs, a.latency_us,
-                      touched_frac=lambda R: 1.0 / R + 0.05)))
+                      touched_frac=lambda R: 1.0 - math.exp(-steps1 / (R * 2708.0 * L)))))
     if "bgp_scale_step" in b:
         g = b["bgp_scale_step"]
         F3, C3 = 287, 8
