@@ -53,6 +53,11 @@ def collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes=0):
     return ag + rs + ar + ix, {"all_gather_Xh": ag, "reduce_scatter_dXh": rs, "all_reduce_grads": ar, "all_gather_indices": ix}
 
 
+BANK_MS_PER_NODE = 6.2e-6    # measured slope of bank + bank backward over the node count at L = 4, hid = 128: 0.058 ms at 2708
+                             # nodes, 0.174 ms at 8 x 2708 (tools/emulate_rank_work.py): small GEMMs are
+                             # latency-bound, the replicated bank does NOT cost R times the single-block time
+
+
 def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, idx_bytes=0, touched_frac=None, replicated=False):
     """-> rows (R, t_ms, speedup_or_efficiency, parts).  stages: single-GPU per-stage ms; total_ms: single-GPU wall per
     step (the part not covered by the stage timers -- loss, Adam, torch glue -- is carried as `other`, per rank)."""
@@ -62,12 +67,12 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
     for R in (1, 2, 4, 8):
         if weak:        # per-rank paths and rows stay, the graph grows: the replicated bank grows with it
             n_total = n_total_1 * R
-            sh, own, rep = s, o, r * R
+            sh, own, rep = s, o, r + BANK_MS_PER_NODE * n_total_1 * (R - 1)
         else:           # one graph: paths and rows shrink, the replicated bank does not
             n_total = n_total_1
             sh, own, rep = s / R, o / R, r
         if touched_frac is not None:    # compaction: the bank runs over the rows this rank's paths touch
-            rep = min(rep, (r * (R if weak else 1)) * min(1.0, touched_frac(R)))
+            rep = min(rep, rep * min(1.0, touched_frac(R)))
         coll, parts = collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes)
         if replicated:      # dist.ReplicatedAggregator: all of X on every rank, fc0 over all rows, no exchange of Xh / d Xh
             own = o * (R if weak else 1)
