@@ -36,12 +36,14 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 5 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
+#define PN_ABI_VERSION 6 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
                           * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
                           *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
                           *    offsets throughout; pn_clock_probe
                           * 5: pn_pagg_shape gained deterministic; pn_linear_backward gained workspace / workspace_bytes;
-                          *    pn_pagg_train_step */
+                          *    pn_pagg_train_step
+                          * 6: pn_pagg_shape gained compact / seq_math (decisions that shape the workspace travel with the
+                          *    shape, not with the environment); pn_pagg_args.reuse_tables = 2; pn_pagg_shape_info */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -254,7 +256,26 @@ typedef struct pn_pagg_shape {
      * (pn_pagg_workspace_bytes accounts for it: ~600 B per path step at H = 128) and time; the
      * forward computes the same values either way. */
     int32_t deterministic;
+    /* Touched-row compaction of the distance bank (Z / dZ hold only the (node, code) rows this call's paths gather,
+     * DESIGN.md section 3): 0 = the library decides from the shape (when the path steps cannot touch half of the N * L
+     * rows), 1 = always, 2 = never.  The decision is part of the workspace layout, so pn_pagg_workspace_bytes, the
+     * forward and the backward of one call must be given the same value. */
+    int32_t compact;
+    /* Arithmetic of the three recurrent GEMMs (hidden size <= 256; inputs, outputs and accumulation are fp32 either way):
+     *   0 / PN_SEQ_MATH_F16X2: every fp32 product as THREE fp16 MFMAs over two-plane splits of both operands
+     *       (a = a_hi + a_lo, |a_lo| <= 2^-12 |a|; a.b = a_hi b_hi + a_hi b_lo + a_lo b_hi + O(2^-24 |a||b|)), each operand
+     *       scaled by a power of two taken from its largest magnitude so that the planes sit at the top of fp16's range;
+     *   PN_SEQ_MATH_BF16X3: SIX bf16 MFMAs over three-plane splits, no scaling (rounds 1-3).
+     * Both are as accurate as an fp32 FMA chain for operands whose magnitudes span less than ~2^16 below the largest
+     * (DESIGN.md section 4); the bf16 mode keeps that for any span.  Explicit dropout masks must satisfy |m| <= 16. */
+    int32_t seq_math;
 } pn_pagg_shape;
+#define PN_SEQ_MATH_DEFAULT 0
+#define PN_SEQ_MATH_BF16X3 1
+#define PN_SEQ_MATH_F16X2 2
+#define PN_COMPACT_AUTO 0
+#define PN_COMPACT_ON 1
+#define PN_COMPACT_OFF 2
 #define PN_CELL_DEFAULT 0
 #define PN_CELL_LSTM 1
 #define PN_CELL_RNN 2
@@ -308,9 +329,12 @@ typedef struct pn_pagg_args {
     /* inference: non-zero skips writing the saved-for-backward tensors (gates, cell states, [x|h] rows --
      * ~3.6 KB per path step); pn_pagg_backward must not follow such a forward. */
     int32_t no_save;
-    /* non-zero: Xh and Z = bank(Xh) of the previous pn_pagg_forward on this workspace are still valid (same X, same
-     * fc0 / bank weights, same N, H, L): skip fc0 and the bank.  The validation and test forwards of an epoch
-     * (PathNet_run.py:362, :378) share them this way.  The caller vouches for the precondition. */
+    /* 1: Xh AND the dense Z = bank(Xh) [N * L, H] of the previous pn_pagg_forward on this workspace are still valid (same
+     * X, same fc0 / bank weights, same N, H, L, and that forward was NOT compact): skip fc0 and the bank.
+     * 2: only Xh is valid (the previous forward ran over compact rows, whose Z belongs to its own batch): skip fc0,
+     * compute the bank.  A compact call always computes its own rows of the bank, whatever the value.
+     * The validation and test forwards of an epoch (PathNet_run.py:362, :378) share the tables this way; the caller
+     * vouches for the precondition -- pn_pagg_shape_info tells whether a shape runs compact. */
     int32_t reuse_tables;
     /* non-zero: ids / codes / sel hold only the rows of this call's slice ([S, W, L] / [S]: rows group_begin ..
      * group_begin + S of the batch) instead of the whole batch.  HOMO / PAGG only (a group reads nothing but its own
@@ -322,6 +346,9 @@ typedef struct pn_pagg_args {
 } pn_pagg_args;
 
 int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes);
+/* What the library decides from a shape: out[0] = 1 when the call runs over compact rows of the distance bank, out[1] =
+ * rows of Z / dZ, out[2] = micro-batches, out[3] = PN_SEQ_MATH_* the recurrent GEMMs will use (0: the shape has none). */
+int pn_pagg_shape_info(const pn_pagg_shape *shape, int64_t out[4]);
 /* out = forward(...).  Leaves what backward needs in the workspace. */
 int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 /* Gradients of sum(out * g_out) w.r.t. every parameter (overwritten, not accumulated) and X.

@@ -13,9 +13,11 @@ PN_OK = 0
 PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
-ABI_VERSION = 5               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
+ABI_VERSION = 6               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
 CELL_DEFAULT, CELL_LSTM, CELL_RNN, CELL_GRU, CELL_MEAN, CELL_SUM = 0, 1, 2, 3, 4, 5
+SEQ_MATH_DEFAULT, SEQ_MATH_BF16X3, SEQ_MATH_F16X2 = 0, 1, 2     # pn_pagg_shape.seq_math
+COMPACT_AUTO, COMPACT_ON, COMPACT_OFF = 0, 1, 2                 # pn_pagg_shape.compact
 LINEAR_SPLIT_MAX = 8          # PN_LINEAR_SPLIT_MAX: workspace floats per output element of pn_linear_forward
 LINEAR_BWD_SPLIT_MAX = 32     # PN_LINEAR_BWD_SPLIT_MAX: chunk sums of pn_linear_backward's deterministic weight gradient
 
@@ -50,7 +52,8 @@ class PaggShape(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int32), ("N", ctypes.c_int32), ("F", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("C", ctypes.c_int32), ("S", ctypes.c_int32), ("W", ctypes.c_int32), ("L", ctypes.c_int32),
                 ("S_total", ctypes.c_int32), ("group_begin", ctypes.c_int32), ("batch_groups", ctypes.c_int32),
-                ("cell", ctypes.c_int32), ("deterministic", ctypes.c_int32)]
+                ("cell", ctypes.c_int32), ("deterministic", ctypes.c_int32), ("compact", ctypes.c_int32),
+                ("seq_math", ctypes.c_int32)]
 
 
 class PaggArgs(ctypes.Structure):
@@ -104,6 +107,7 @@ SIGNATURES = {
     "pn_paths_write_bin": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_u8p, ctypes.c_int64, ctypes.c_int32]),
     "pn_paths_read_bin": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i32p, c_u8p, ctypes.c_int64, c_i64p]),
     "pn_pagg_workspace_bytes": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
+    "pn_pagg_shape_info": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
     "pn_pagg_forward": (ctypes.c_int, [vp, ctypes.POINTER(PaggArgs), vp]),
     "pn_pagg_backward": (ctypes.c_int, [vp, ctypes.POINTER(PaggArgs), vp]),
     "pn_pagg_gather": (ctypes.c_int, [vp, ctypes.POINTER(PaggShape), vp, vp, vp, vp, vp]),

@@ -49,6 +49,44 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t &p0, uint32_t 
     p2 = cvt_pk_bf16(ra, rb);
 }
 
+// ---- fp32 products on the fp16 matrix pipe: two planes, three MFMAs ------------------------------------------------------
+// a = a_hi + a_lo with a_hi = fp16(a) (round to nearest, 11 significant bits) and a_lo = fp16(a - a_hi) (the subtraction
+// is exact): while a_lo is a normal fp16 number, |a - a_hi - a_lo| <= 2^-24 |a| -- the pair carries fp32's 24 bits.
+//   a.b = a_hi b_hi + (a_hi b_lo + a_lo b_hi) + O(2^-24 |a||b|):  THREE fp16 MFMAs with fp32 accumulation per product
+// instead of the six of the bf16 three-plane form above, and two planes instead of three in LDS and in the weight stream.
+// What fp16 lacks is bf16's range.  Every operand tensor is therefore multiplied by a power of two (exact) that puts its
+// largest magnitude into [2^14, 2^15) -- scale_exp() of a maximum the kernels find in device memory or compute for their
+// own tile -- and the product of the two scales is divided out of the accumulator.  With the maximum at 2^14 an element
+// needs |a| >= 2^-2, i.e. >= 2^-16 of the maximum, for a_lo to stay normal; below that a_lo loses bits and the element's
+// absolute error stops shrinking at 2^-25 = 2^-39 of the tensor's maximum (an fp32 FMA chain: 2^-24 of the element).
+// gfx950's fp16 MFMA does not flush denormal inputs.  Known-answer tests: tests/test_gpu_seqh.py.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// (a, b) -> packed fp16 pairs hi = {fp16(a), fp16(b)}, lo = {fp16(a - hi.a), fp16(b - hi.b)}   (v_cvt_pk_f16_f32 x 2,
+// two v_cvt_f32_f16, one v_pk_add_f32)
+__device__ __forceinline__ void split2h(float a, float b, uint32_t &hi, uint32_t &lo) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+    const f32x2 back = __builtin_convertvector(h, f32x2);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a - back[0], b - back[1]}, f16x2));
+}
+// e with vmax * 2^e in [2^14, 2^15), clamped to [-100, 100]; 0 for vmax = 0, negative or not finite
+__device__ __forceinline__ int scale_exp(float vmax) {
+    const int be = (int)((__float_as_uint(vmax) >> 23) & 255u);
+    if (be == 255 || !(vmax > 0.0f)) return 0;
+    const int e = 14 - (be - 127);          // (a subnormal maximum: be = 0, clamped below)
+    return e > 100 ? 100 : e < -100 ? -100 : e;
+}
+// 2^e as a float: 0 below the normal range, 2^127 above
+__device__ __forceinline__ float exp2i(int e) {
+    if (e < -126) return 0.0f;
+    return __uint_as_float((uint32_t)((e > 127 ? 127 : e) + 127) << 23);
+}
+
 // ---- weight-fragment loads the compiler must not re-schedule -------------------------------------------
 // hipcc sinks ordinary loads of loop-invariant-addressable data next to their first use (it re-issues the
 // load instead of carrying registers around the loop), which turns a software prefetch into a load -> wait ->

@@ -2556,6 +2556,7 @@ struct Dims {
     bool det;           // pn_pagg_shape.deterministic: the backward adds in a fixed order (no floating-point atomics)
     bool compact;       // the bank runs over the (node, code) rows this call's paths touch (compact_rows)
     int64_t ZR;         // rows of Z / dZ: N * L, or the bound of the touched rows
+    int math;           // PN_SEQ_MATH_F16X2 / PN_SEQ_MATH_BF16X3 for the fused recurrent kernels, 0 when the call has none
 };
 
 // K chunks a split node-level GEMM is cut into (1 = not split): aim at ~2 workgroups per CU, at least two K tiles each
@@ -2645,13 +2646,15 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     d.P_total = (int64_t)S_total * s.W;
     d.det = s.deterministic != 0;
     {
-        // compaction pays when the path steps of this call cannot touch half of the N * L rows (PN_COMPACT=1 / 0 forces it
-        // on / off: tests, A/B); the hetero class reads paths of the whole batch, a slice marks the whole batch's steps
+        // compaction pays when the path steps of this call cannot touch half of the N * L rows (pn_pagg_shape.compact forces
+        // it on / off: tests, A/B); the hetero class reads paths of the whole batch, a slice marks the whole batch's steps
         const int64_t steps = (int64_t)(d.variant == PN_VARIANT_HETERO ? S_total : s.S) * s.W * s.L, rows = (int64_t)s.N * s.L;
-        const char *e = getenv("PN_COMPACT");
-        d.compact = d.G >= 0 && s.S > 0 && (e ? atoi(e) != 0 : 2 * steps < rows);
+        if (s.compact < 0 || s.compact > PN_COMPACT_OFF) PN_FAIL(PN_ERR_ARG, "unknown compact mode %d", s.compact);
+        d.compact = s.S > 0 && (s.compact == PN_COMPACT_AUTO ? 2 * steps < rows : s.compact == PN_COMPACT_ON);
         d.ZR = d.compact ? std::min(rows, steps) : rows;
     }
+    if (s.seq_math < 0 || s.seq_math > PN_SEQ_MATH_F16X2) PN_FAIL(PN_ERR_ARG, "unknown seq_math %d", s.seq_math);
+    d.math = (d.G > 0 && !d.generic) ? (s.seq_math == PN_SEQ_MATH_BF16X3 ? PN_SEQ_MATH_BF16X3 : PN_SEQ_MATH_F16X2) : 0;
     // rows of one micro-batch's [Pb * L, .] tensors are counted in int32 inside the kernels
     if ((int64_t)d.Sb * s.W * s.L > 2000000000LL)
         PN_FAIL(PN_ERR_ARG, "%lld path steps in one micro-batch exceed int32: set batch_groups", (long long)d.Sb * s.W * s.L);
@@ -2659,7 +2662,7 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
 }
 
 struct WsLayout {
-    size_t Xh, Z;                                                        // node tables (first: reuse_tables relies on it)
+    size_t Xh, Z, range;                                                 // node tables (first: reuse_tables relies on it)
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
     size_t xh, keep, dG, dhn, dl1, gx, gout, bankT;                      // per micro-batch, saved / backward
@@ -2683,6 +2686,7 @@ WsLayout ws_layout(const Dims &d) {
     };
     w.Xh = take(N * H * 4);
     w.Z = take((size_t)d.ZR * H * 4);
+    w.range = take(sizeof(SeqRange));       // operand ranges of the fp16 recurrent kernels; range.x belongs to Z
     w.Wp = take(G * H * 3 * H * 4);          // (G = 0, the mean / sum encoders: no recurrent weights, no saved gates)
     w.biasc = take(G * H * 4);
     w.WpT = take(G * H * 3 * H * 4);
@@ -2934,6 +2938,12 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
         PN_CHECK_HIP(hipGetLastError());
         return PN_OK;
     }
+    if (d.math == PN_SEQ_MATH_F16X2) {      // two fp16 planes, scaled by the weights' own maxima (pn_seqh.hip)
+        SeqRange *rg = c.at<SeqRange>(c.w.range);
+        if (int rc = launch_range_w(s, c.a->w_ih, c.a->w_hh, (int64_t)d.Gw * d.H * d.H, rg)) return rc;
+        return launch_pack_fwdh(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg,
+                                c.at<void>(c.w.Wp), c.at<float>(c.w.biasc));
+    }
     if (seq4_select(d.H, d.G, d.L) & SEQ4_FWD)      // the 128-path kernel reads its own fragment order (pn_seq4.hip)
         return launch_pack_fwd4(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0,
                                 c.at<void>(c.w.Wp), c.at<float>(c.w.biasc));
@@ -2975,6 +2985,12 @@ int run_seq_reduce(const Call &c, int b, bool backward) {
     return PN_OK;
 }
 
+// bound of the factor the sequence dropout applies to a gathered row: 1 / (1 - p), or 16 for explicit masks (the contract
+// of pn_pagg_shape.seq_math)
+inline float seq_xmul(const pn_pagg_args *a) {
+    return a->mask_seq ? 16.0f : a->p_seq > 0.0f ? 1.0f / (1.0f - a->p_seq) : 1.0f;
+}
+
 int run_seq_fwd(const Call &c, int b, bool save) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
@@ -2998,6 +3014,11 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     sp.dyn = a->step_state;
     sp.mask = a->mask_seq;
     StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
+    if (d.math == PN_SEQ_MATH_F16X2) {
+        sp.range = c.at<SeqRange>(c.w.range);
+        sp.xmul = seq_xmul(a);
+        return launch_seq_fwdh(c.ctx, c.stream, d.H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp);
+    }
     if (seq4_select(d.H, d.G, d.L) & SEQ4_FWD) {
         sp.xh = c.at<float>(c.w.xh);        // h_t travels to the next step through these rows, saved or not
         sp.store_x = save ? 1 : 0;
@@ -3107,13 +3128,21 @@ int run_tables(const Call &c, JoinGuard &joiner) {
                                             GEMM_IND_A_ROWS, c.at<const int32_t>(c.w.seg) + code, c.at<const int32_t>(c.w.list)))
                 return rc;
         }
-    } else if (!a->reuse_tables) {
+    } else if (a->reuse_tables != 1) {      // (1: the dense Z of the previous forward is still valid; 2: only Xh is)
         // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
         StageTimer tm(ctx, ST_BANK, stream);
         if (gemm3_pays(d.N, L * H, H, G3_BANK)) {
             if (int rc = launch_gemm3(stream, c.Xh, H, a->bank_w, H, c.Z, (int64_t)L * H, a->bank_b, d.N, L * H, H, homo)) return rc;
         } else if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
                                         L * H, H, homo, GEMM_STORE, 1))
+            return rc;
+    }
+    // the fp16 recurrence scales the gathered rows by a power of two taken from the largest |Z| of the rows just computed
+    // (a reused dense Z keeps its record: it sits next to Z in the workspace)
+    if (d.math == PN_SEQ_MATH_F16X2 && (d.compact || a->reuse_tables != 1)) {
+        StageTimer tm(ctx, ST_BANK, stream);
+        if (int rc = launch_range_rows(stream, c.Z, d.ZR, H, d.compact ? c.at<const int32_t>(c.w.seg) + L : nullptr,
+                                       c.at<SeqRange>(c.w.range)))
             return rc;
     }
     return joiner.join();       // the recurrence needs the plan and the packed weights
@@ -3150,6 +3179,17 @@ int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes) {
     Dims d;
     if (int rc = make_dims(*shape, d)) return rc;
     *bytes = (int64_t)ws_layout(d).total;
+    return PN_OK;
+}
+
+int pn_pagg_shape_info(const pn_pagg_shape *shape, int64_t out[4]) {
+    if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_shape_info: null");
+    Dims d;
+    if (int rc = make_dims(*shape, d)) return rc;
+    out[0] = d.compact ? 1 : 0;
+    out[1] = d.ZR;
+    out[2] = d.nb;
+    out[3] = d.math;
     return PN_OK;
 }
 
@@ -3371,7 +3411,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (int rc = run_tables(c, joiner)) return rc;
     // (per-stage timings are taken serially; so is the deterministic mode, whose stages share scratch buffers)
     const bool side_ok = !profiling_every_stage(ctx) && !d.det;
-    const int seq4 = seq4_select(H, G, L);
+    const bool f16 = d.math == PN_SEQ_MATH_F16X2;
+    const int seq4 = f16 ? 0 : seq4_select(H, G, L);
+    SeqRange *range = c.at<SeqRange>(c.w.range);
     float *dgemm = d.det ? c.at<float>(c.w.dgemm) : nullptr;
     if (d.det) {        // the identity the BPTT kernels index the contribution buffer with
         const int64_t n = std::max<int64_t>((int64_t)d.Sb * d.W * L, d.Sb);
@@ -3380,7 +3422,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     }
     if (G > 0 && !d.generic) {
         StageTimer tm(ctx, ST_PLAN_PACK, stream);      // (its own bracket: ST_SEQ_BWD times the BPTT kernel alone)
-        if (seq4 & SEQ4_BWD) {
+        if (f16) {      // (the weights' ranges are the forward's: same workspace, same weights)
+            if (int rc = launch_pack_bwdh(stream, a->w_ih, a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, range, c.at<void>(c.w.WpT))) return rc;
+        } else if (seq4 & SEQ4_BWD) {
             if (int rc = launch_pack_bwd4(stream, a->w_ih, a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<void>(c.w.WpT))) return rc;
         } else {
             hipLaunchKernelGGL(pack_bwd3_kernel, dim3((unsigned)((GH * H / 4 + 255) / 256)), dim3(256), 0, stream, a->w_ih,
@@ -3528,7 +3572,10 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             sp.mask = a->mask_seq;
             sp.merge0 = d.variant != PN_VARIANT_HETERO && !d.det;   // (the hetero plan's step-0 rows are other paths' far ends: no runs)
             if (d.det) sp.rowidx = c.at<int32_t>(c.w.iota), sp.dZ = c.at<float>(c.w.dx);     // (see det_scatter_kernel)
-            if (seq4 & SEQ4_BWD) {
+            sp.range = range;
+            if (f16) {
+                if (int rc = launch_seq_bwdh(ctx, stream, H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp)) return rc;
+            } else if (seq4 & SEQ4_BWD) {
                 if (int rc = launch_seq_bwd4(ctx, stream, d.cell == CELL_GRU ? 3 : 4, sp)) return rc;
             } else if (int rc = (d.cell == CELL_GRU    ? dispatch_seq_bwd<3>(ctx, stream, H, sp)
                                  : d.cell == CELL_LSTM ? dispatch_seq_bwd<4>(ctx, stream, H, sp)
@@ -3567,7 +3614,13 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             {
                 StageTimer tm(ctx, ST_WGRAD, wstream);
                 int nz_red = nz_used;
-                if (seq4 & SEQ4_WGRAD) {        // two-stage pipeline over K tiles of 16 rows (pn_seq4.hip)
+                wp.range = range;
+                wp.xmul = seq_xmul(a);
+                if (f16 && !d.generic) {        // the two-stage pipeline on fp16 planes (pn_seqh.hip)
+                    const int64_t nt16 = (wp.R + 15) / 16;
+                    nz_red = (int)(nt16 < nz ? nt16 : nz);
+                    if (int rc = launch_wgradh(ctx, wstream, wp, H, nz_red)) return rc;
+                } else if (seq4 & SEQ4_WGRAD) {        // two-stage pipeline over K tiles of 16 rows (pn_seq4.hip)
                     const int64_t nt16 = (wp.R + 15) / 16;
                     nz_red = (int)(nt16 < nz ? nt16 : nz);
                     if (int rc = launch_wgrad4(ctx, wstream, wp, nz_red)) return rc;

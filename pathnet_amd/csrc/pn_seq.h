@@ -8,6 +8,15 @@
 
 namespace pn {
 
+// ---- operand ranges of the fp16 two-plane kernels (pn_seqh.hip) --------------------------------------------------------
+// Largest magnitudes, kept in DEVICE memory as the bit patterns of non-negative floats (atomicMax on uint32 orders them);
+// every kernel derives its power-of-two operand scales from them when it runs -- no host round trip, capturable.
+struct SeqRange {
+    uint32_t x;             // max |Z| over the bank rows a call gathers from (range_rows_kernel, after the bank)
+    uint32_t w_ih, w_hh;    // max |W_ih|, max |W_hh|                          (range_w_kernel, before the weight packing)
+    uint32_t dg;            // max |dG| of the BPTT launch the weight-gradient GEMM follows (seq_bwdh_kernel)
+};
+
 struct SeqFwdParams {
     const float *Z;         // [N*L, H] bank output (post activation)
     const int32_t *rowidx;  // [P, L]
@@ -29,6 +38,8 @@ struct SeqFwdParams {
     const pn_step_state *dyn;   // seed in device memory when set (hipGraph replay)
     const float *mask;      // [L, Pmask, H] explicit mask (reference order: original slot q) or null
     int store_x;            // seq_fwd4_kernel: keep x_t (after dropout) in xh for the weight-gradient GEMM
+    const SeqRange *range;  // fp16 kernels: operand ranges (device)
+    float xmul;             // fp16 kernels: bound of the factor dropout applies to a gathered row (1 / (1 - p), or 16 for explicit masks)
 };
 
 struct SeqBwdParams {
@@ -45,6 +56,7 @@ struct SeqBwdParams {
     float p_drop;
     uint64_t seed;
     const float *mask;
+    SeqRange *range;        // fp16 kernels: reads w_ih / w_hh, leaves max |dG| in dg
 };
 
 struct WgradParams {
@@ -55,6 +67,8 @@ struct WgradParams {
     int64_t rows_per_split;
     float *part_w;     // [nsplit, GH, 2H]
     float *part_b;     // [nsplit, GH]
+    const SeqRange *range;  // fp16 kernel: x (with xmul) and dg give the operand scales
+    float xmul;
 };
 
 // ---- pn_rgrad.hip: C [M, N] += A^T . B over the rows of a large graph (node-level weight gradients) ----------------------
@@ -87,5 +101,18 @@ int launch_seq_fwd4(pn_context *ctx, void *stream, int gc, const SeqFwdParams &s
 int launch_seq_bwd4(pn_context *ctx, void *stream, int gc, const SeqBwdParams &sp);
 // the weight-gradient GEMM; nsplit row splits as laid out by the caller (part_w / part_b hold nsplit partials)
 int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nsplit);
+
+
+// ---- pn_seqh.hip: the recurrent kernels on the fp16 matrix pipe (three MFMAs per fp32 product, two planes) ------------
+// every multiple of 32 up to 256 as hidden size; gc: 4 = LSTM, 1 = tanh RNN, 3 = GRU on the LSTM's four gate slots
+int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, SeqRange *range);
+// range->x = max |rows[r, :]| over r < (count ? *count : rows): zeroes the slot first (same stream)
+int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, const int32_t *count, SeqRange *range);
+int launch_pack_fwdh(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
+                     int gru, const SeqRange *range, void *Wp, float *biasc);
+int launch_pack_bwdh(void *stream, const float *w_ih, const float *w_hh, int H, int G, int gru, const SeqRange *range, void *WpT);
+int launch_seq_fwdh(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
+int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp);
+int launch_wgradh(pn_context *ctx, void *stream, const WgradParams &wp, int H, int nsplit);
 
 }  // namespace pn

@@ -306,7 +306,14 @@ class ShardedAggregator:
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb, seed=seed,
                    S_total=S_total, group_begin=begin, index_rows_local=local_rows and multi, cell=m._cell_kind,
                    mask_seq=None, mask_cls=None,
-                   deterministic=M.deterministic_default() if m.deterministic is None else bool(m.deterministic))
+                   deterministic=M.deterministic_default() if m.deterministic is None else bool(m.deterministic),
+                   compact=M.compact_default(),
+                   seq_math=M.seq_math_default() if m.seq_math is None else M._SEQ_MATH[m.seq_math])
+        if m.hidden_size % 32:
+            # (the single-GPU module zero-pads such a hidden size through differentiable pads of its parameters,
+            #  modules._padded_param_inputs; the sharded runner hands the kernels the parameters themselves)
+            raise ValueError("ShardedAggregator: hidden size %d is not a multiple of 32 -- use ReplicatedAggregator (which "
+                             "runs the module itself) or a padded hidden size" % m.hidden_size)
         if not multi:
             cfg["S_total"], cfg["group_begin"] = 0, 0
         if m.training and (self.mask_seq is not None or self.mask_cls is not None):
@@ -314,7 +321,9 @@ class ShardedAggregator:
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["batch_groups"] = M.pick_batch_groups(m.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
                                                   cfg["L"], m.workspace_budget, cell=m._cell_kind,
-                                                  deterministic=cfg["deterministic"]) if isinstance(self.ops, HipOps) else 0
+                                                  deterministic=cfg["deterministic"], S_total=cfg["S_total"],
+                                                  group_begin=cfg["group_begin"], compact=cfg["compact"],
+                                                  seq_math=cfg["seq_math"]) if isinstance(self.ops, HipOps) else 0
         return _ShardedFn.apply(self, cfg, X_loc.contiguous().float(), ids, codes, sel, *params)
 
     def set_batch_counts(self, counts):

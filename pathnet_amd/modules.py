@@ -48,9 +48,40 @@ def default_budget(device=None):
         return WORKSPACE_BUDGET_BYTES
 
 
-def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None, deterministic=False):
+_SEQ_MATH = {None: _lib.SEQ_MATH_DEFAULT, "": _lib.SEQ_MATH_DEFAULT, "f16x2": _lib.SEQ_MATH_F16X2, "bf16x3": _lib.SEQ_MATH_BF16X3}
+
+
+def compact_default():
+    """pn_pagg_shape.compact when a call does not say: PN_COMPACT=1 / 0 in the environment forces the touched-row
+    compaction of the distance bank on / off (tests, A/B runs); otherwise the library decides from the shape.  Read when a
+    call is set up -- the value then travels with the call's shape through workspace size, forward and backward."""
+    e = os.environ.get("PN_COMPACT")
+    if e is None or e == "":
+        return _lib.COMPACT_AUTO
+    return _lib.COMPACT_ON if int(e) != 0 else _lib.COMPACT_OFF
+
+
+def seq_math_default():
+    """pn_pagg_shape.seq_math when a module does not say: PN_SEQ_MATH=bf16x3 selects rounds 1-3's six-MFMA bf16 products
+    for the recurrent GEMMs, the default (f16x2) is three fp16 MFMAs over scaled two-plane splits (include/pathnet_hip.h)."""
+    e = os.environ.get("PN_SEQ_MATH", "").strip().lower()
+    if e not in _SEQ_MATH:
+        raise ValueError("PN_SEQ_MATH=%r: f16x2 or bf16x3" % e)
+    return _SEQ_MATH[e]
+
+
+def _shape(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None, deterministic=False,
+           compact=None, seq_math=None):
     return _lib.PaggShape(_VARIANT[variant], N, F, H, C, S, W, L, S_total, group_begin, batch_groups, _CELL[cell],
-                          1 if deterministic else 0)
+                          1 if deterministic else 0, compact_default() if compact is None else int(compact),
+                          seq_math_default() if seq_math is None else int(seq_math))
+
+
+def shape_info(sh):
+    """(compact, rows of Z, micro-batches, seq_math) the library derives from a pn_pagg_shape"""
+    out = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.load().pn_pagg_shape_info(ctypes.byref(sh), out))
+    return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
 
 
 def deterministic_default():
@@ -62,22 +93,31 @@ def deterministic_default():
 def _cfg_shape(cfg):
     return _shape(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
                   cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"),
-                  cfg.get("deterministic", False))
+                  cfg.get("deterministic", False), cfg.get("compact"), cfg.get("seq_math"))
 
 
-def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None, deterministic=False):
+def workspace_bytes(variant, N, F, H, C, S, W, L, S_total=0, group_begin=0, batch_groups=0, cell=None, deterministic=False,
+                    compact=None, seq_math=None):
     n = ctypes.c_int64(0)
-    sh = _shape(variant, N, F, H, C, S, W, L, S_total, group_begin, batch_groups, cell, deterministic)
+    sh = _shape(variant, N, F, H, C, S, W, L, S_total, group_begin, batch_groups, cell, deterministic, compact, seq_math)
     _lib.check(_lib.load().pn_pagg_workspace_bytes(ctypes.byref(sh), ctypes.byref(n)))
     return n.value
 
 
-def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, device=None, deterministic=False):
+def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, device=None, deterministic=False,
+                      S_total=0, group_begin=0, compact=None, seq_math=None):
     """0 when the whole batch fits the workspace budget, else the largest micro-batch (in masked nodes) that does.
     budget=None: default_budget(device) -- queried only when the batch needs more than MIN_BATCH_BYTES, so that ordinary
-    steps make no runtime call."""
-    kw = dict(cell=cell, deterministic=deterministic)
-    need = workspace_bytes(variant, N, F, H, C, S, W, L, **kw) if S > 1 else 0
+    steps make no runtime call.
+    The workspace of a call that runs b masked nodes at a time is fixed(S) + b * per_group: the node tables -- whose rows
+    depend on the WHOLE call's S (and S_total for a slice of a hetero batch) when the bank runs over compact rows -- plus
+    the per-path tensors of one micro-batch.  Both terms are measured on this call's own shape (batch_groups = 1 and
+    1 + step), and the pick is checked against the budget afterwards."""
+    kw = dict(cell=cell, deterministic=deterministic, S_total=S_total, group_begin=group_begin, compact=compact, seq_math=seq_math)
+
+    def ws(bg):
+        return workspace_bytes(variant, N, F, H, C, S, W, L, batch_groups=bg, **kw)
+    need = ws(0) if S > 1 else 0
     floor = MIN_BATCH_BYTES if budget is None else 0       # an explicit budget is kept to the byte
     if budget is None:
         if need <= MIN_BATCH_BYTES:
@@ -86,16 +126,22 @@ def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, devi
     budget = int(budget)
     if S <= 1 or need <= budget:
         return 0
-    fixed = workspace_bytes(variant, N, F, H, C, 1, W, L, **kw)          # the node tables: needed whatever the batch
-    per_group = max((workspace_bytes(variant, N, F, H, C, 1025, W, L, **kw) - fixed) // 1024, 1)
-    avail = max(budget - fixed, floor)       # default budget: graphs whose tables alone exceed it still get real batches
-    return int(max(1, min(S, avail // per_group if avail > 0 else 1)))
+    step = min(1024, S - 1)
+    w1 = ws(1)
+    per_group = max((ws(1 + step) - w1) // step, 1) if step > 0 else max(need, 1)
+    fixed = w1 - per_group                  # the node tables (and the compact-row arrays): needed whatever the micro-batch
+    avail = max(budget - fixed, floor)      # default budget: graphs whose tables alone exceed it still get real batches
+    bg = int(max(1, min(S, avail // per_group if avail > 0 else 1)))
+    if floor == 0:                          # an explicit budget: shrink until the real layout fits (alignment, rounding)
+        while bg > 1 and ws(bg) > budget:
+            bg = max(1, min(bg - 1, int(bg * 0.98)))
+    return bg
 
 
 def _cfg_workspace_bytes(cfg):
     return workspace_bytes(cfg["variant"], cfg["N"], cfg["F"], cfg["H"], cfg["C"], cfg["S"], cfg["W"], cfg["L"],
                            cfg.get("S_total", 0), cfg.get("group_begin", 0), cfg.get("batch_groups", 0), cfg.get("cell"),
-                           cfg.get("deterministic", False))
+                           cfg.get("deterministic", False), cfg.get("compact"), cfg.get("seq_math"))
 
 
 def _split_params(params, L):
@@ -143,7 +189,7 @@ class _PaggFunction(torch.autograd.Function):
             a.out = out.data_ptr()
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             a.no_save = 0 if cfg.get("grad", True) else 1       # torch.no_grad() forwards skip the saved tensors
-            a.reuse_tables = 1 if cfg.get("reuse_tables") else 0
+            a.reuse_tables = int(cfg.get("reuse_tables") or 0)     # 1: Xh and the dense bank are valid, 2: Xh only
             if cfg["S"] > 0:
                 _lib.check(lib.pn_pagg_forward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
         ctx.cfg, ctx.ws = cfg, ws
@@ -240,6 +286,7 @@ class _PaggLossFunction(torch.autograd.Function):
         return loss, out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_loss, _g_out):
         # (the context lets go of the tensors: with a second owner alive autograd's AccumulateGrad would copy every
         #  gradient into a fresh tensor instead of adopting it -- 18 copy launches per step)
@@ -247,7 +294,9 @@ class _PaggLossFunction(torch.autograd.Function):
         ctx.grads = ctx.flat = None
         if grads is None:
             raise RuntimeError("forward_loss: the gradients were handed out already (backward twice)")
-        flat.mul_(g_loss)                       # (d loss' / d loss: 1 for loss.backward())
+        # (d loss' / d loss: 1 for loss.backward().  The gradients were computed once, in forward(): a single backward, no
+        #  double backward -- once_differentiable says so to autograd; a second backward raises above)
+        flat.mul_(g_loss)
         if grads[0] is not None:
             grads[0].mul_(g_loss)
         return (None, grads[0], None, None, None, None) + tuple(grads[1:])
@@ -309,6 +358,7 @@ class _Aggregator(nn.Module):
         self.step_state = None            # pathnet_amd.StepState: dropout seed read from device memory (hipGraph replay)
         self.workspace_budget = None      # bytes; None = modules.WORKSPACE_BUDGET_BYTES (see pick_batch_groups)
         self.deterministic = None         # True / False: fixed-order backward or not; None: deterministic_default()
+        self.seq_math = None              # "f16x2" / "bf16x3": arithmetic of the recurrent GEMMs; None: seq_math_default()
         self._mask_seq = None     # test hook: explicit dropout masks (reference order)
         self._mask_cls = None
         self._bank_flat = (None, None)
@@ -446,6 +496,8 @@ class _Aggregator(nn.Module):
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
                    step_state=self.step_state, cell=self._cell_kind,
                    deterministic=deterministic_default() if self.deterministic is None else bool(self.deterministic),
+                   # decisions that shape the workspace are taken once per call and travel with its shape
+                   compact=compact_default(), seq_math=seq_math_default() if self.seq_math is None else _SEQ_MATH[self.seq_math],
                    seed=(int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
                    if (p > 0 and self.step_state is None) else 0)
         if batch_position is not None:
@@ -478,20 +530,28 @@ class _Aggregator(nn.Module):
         cfg["grad"] = torch.is_grad_enabled()
         cfg["batch_groups"] = pick_batch_groups(self.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
                                                 cfg["L"], self.workspace_budget, cell=self._cell_kind, device=dev,
-                                                deterministic=cfg["deterministic"])
+                                                deterministic=cfg["deterministic"], S_total=cfg.get("S_total", 0),
+                                                group_begin=cfg.get("group_begin", 0), compact=cfg["compact"],
+                                                seq_math=cfg["seq_math"])
         if not cfg["grad"]:
             need = _cfg_workspace_bytes(cfg)
             fits = self._ws_eval is not None and self._ws_eval.numel() >= need and self._ws_eval.device == dev
             key = self._tables_key(X, cfg["L"])
-            if reuse_tables and not (fits and self._ws_tables == key):
-                reuse_tables = False        # nothing (valid) to reuse: compute the tables as usual
+            compact_now = shape_info(_cfg_shape(cfg))[0]
+            # what the workspace holds: (key, dense) -- Xh for `key`, and with dense also the distance bank over all N * L
+            # rows.  A compact call leaves only ITS batch's rows of the bank behind (a later dense call must not
+            # read them as the full table), so it hands on Xh alone.
+            have_key, have_dense = self._ws_tables if self._ws_tables is not None else (None, False)
+            mode = 0
+            if reuse_tables and fits and have_key == key:
+                mode = 1 if (have_dense and not compact_now) else 2
             if not fits:
                 with torch.cuda.device(dev):
                     self._ws_eval = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
             cfg["workspace"] = self._ws_eval
-            cfg["reuse_tables"] = bool(reuse_tables)
+            cfg["reuse_tables"] = mode
             # the tables are in the workspace after this call only if it computes (or keeps) them: S = 0 returns early
-            self._ws_tables = key if S > 0 else None
+            self._ws_tables = (key, not compact_now) if S > 0 else None
         elif reuse_tables:
             raise RuntimeError("reuse_tables is for no-grad (inference) forwards")
         else:

@@ -245,6 +245,36 @@ def test_validation_and_test_forwards_share_the_projected_tables():
         m(X, torch.as_tensor(it2.reshape(30, -1)), W, L, mt2, torch.as_tensor(ct2), None, reuse_tables=True)
 
 
+def test_reused_tables_after_a_compact_forward():
+    """a validation forward small enough to run over compact rows of the distance bank leaves only ITS
+    rows of Z in the workspace; the test forward of the same epoch (PathNet_run.py:362, :378), large enough to run dense,
+    must not read them as the full table.  The module hands on Xh alone after a compact call (reuse_tables = 2)."""
+    from pathnet_amd import modules
+    torch.manual_seed(67)
+    rng = np.random.default_rng(67)
+    N, F, H, C, W, L = 2000, 32, 128, 5, 4, 4
+    m = build_module("homo", F, H, C, L, N, None).eval()
+    X = torch.rand(N, F).cuda()
+    mv, sv, iv, cv = random_case(rng, N, 100, W, L)         # 2 * 100 * 4 * 4 path steps < 2000 * 4 rows: compact
+    mt, st, it, ct = random_case(rng, N, 600, W, L)         # 2 * 600 * 4 * 4 >= 8000: dense
+    assert modules.shape_info(modules._shape("homo", N, F, H, C, 100, W, L))[0]
+    assert not modules.shape_info(modules._shape("homo", N, F, H, C, 600, W, L))[0]
+    with torch.no_grad():
+        want_t = run_module(m, X, it, ct, mt, W, L).clone()
+        want_v = run_module(m, X, iv, cv, mv, W, L).clone()
+        # dense first (the workspace is large enough for both afterwards), then compact, then dense with reuse
+        run_module(m, X, it, ct, mt, W, L)
+        got_v = m(X, torch.as_tensor(iv.reshape(100, -1)), W, L, mv, torch.as_tensor(cv), None, reuse_tables=True)
+        assert torch.equal(got_v, want_v)
+        assert m._ws_tables is not None and m._ws_tables[1] is False        # Xh only from here on
+        got_t = m(X, torch.as_tensor(it.reshape(600, -1)), W, L, mt, torch.as_tensor(ct), None, reuse_tables=True)
+        assert torch.equal(got_t, want_t)
+        assert m._ws_tables[1] is True
+        # and once a dense forward has run, the next dense one reuses the bank as well
+        got_t = m(X, torch.as_tensor(it.reshape(600, -1)), W, L, mt, torch.as_tensor(ct), None, reuse_tables=True)
+        assert torch.equal(got_t, want_t)
+
+
 def test_two_contexts_two_host_threads_one_device():
     """No process-global state: two host threads drive the same GPU through two pn_context handles on
     two streams at the same time; a NULL context works too (single stream); a context of another device is refused."""

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _restore_env():
-    old = {k: os.environ.get(k) for k in ("PN_SEQ4", "PN_B4_WIDE")}
+    old = {k: os.environ.get(k) for k in ("PN_SEQ4", "PN_B4_WIDE", "PN_SEQ_MATH")}
+    os.environ["PN_SEQ_MATH"] = "bf16x3"        # these kernels are bf16 x 3 variants: the fp16 default never dispatches them
     yield
     for k, v in old.items():
         if v is None:
