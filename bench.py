@@ -33,9 +33,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak, same guide (fp32-input MFMA: 157.3)
-# The recurrent GEMMs evaluate every fp32 product as six bf16 MFMAs on three-plane splits of both operands
-# (pn_kernels.h): the ceiling for fp32-accurate flops on this pipe is the bf16 peak / 6.
+# The recurrent GEMMs evaluate every fp32 product on the 16-bit matrix pipe (pn_kernels.h; fp16 and bf16 MFMAs run at the
+# same rate): THREE fp16 MFMAs over scaled two-plane splits (pn_pagg_shape.seq_math = f16x2, the default since round 4) or
+# SIX bf16 MFMAs over three-plane splits (bf16x3, rounds 1-3).  The ceiling for fp32-accurate flops is the pipe's dense
+# peak divided by the MFMAs one product takes.
+MFMAS_PER_PRODUCT = {"f16x2": 3, "bf16x3": 6}
 F32_ON_BF16_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6.0
+
+
+def seq_math_name():
+    return os.environ.get("PN_SEQ_MATH", "").strip().lower() or "f16x2"
 
 
 def synthetic_graph(n, seed, avg_und_deg=3.9):
@@ -119,25 +126,40 @@ def seq_flops(P, L, H, G=4):
     return survey * (2 * L - 1) / (2 * L), survey
 
 
-def roofline_block(dominant, dom_ms, launches, P, L, H, traffic):
+def roofline_block(dominant, dom_ms, launches, P, L, H, traffic, math=None):
     alg, survey = seq_flops(P, L, H)
+    math = math or seq_math_name()
     if dominant in ("seq_fwd", "seq_bwd", "wgrad"):
+        per = MFMAS_PER_PRODUCT[math]
+        peak = BF16_MFMA_PEAK_TFLOPS / per
         achieved = alg / (dom_ms * 1e-3) / 1e12
-        return {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
-                "peak": round(F32_ON_BF16_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / F32_ON_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
-                "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(launches),
-                "algorithmic_flops_per_launch": alg,
-                "survey_8d_flops_per_launch": survey,
-                "frac_with_survey_8d_flops": round(survey / (dom_ms * 1e-3) / 1e12 / F32_ON_BF16_PEAK_TFLOPS, 4),
-                "mfma_flops_issued_per_launch": 6 * alg,
-                "ceilings_TFLOPs": {"bf16_pipe_over_6": round(F32_ON_BF16_PEAK_TFLOPS, 1), "f32_input_mfma": 157.3},
-                "frac_of_f32_input_mfma_peak": round(achieved / 157.3, 4),
-                "note": "fp32 results (1e-5 parity; measured 3e-7 against float64) from the bf16 matrix pipe: fp32 = 3 "
-                        "bf16 planes, 6 MFMAs per product, fp32 accumulate; peak = 2.5 PFLOP/s dense bf16 / 6.  achieved "
-                        "counts ALGORITHMIC fp32 flops = (2L-1)*8*H^2 per path, i.e. 7/8 (L=4) of SURVEY.md 8d's "
-                        "L*16*H^2 (the step-0 products with h_{-1} = 0 are not charged); frac_with_survey_8d_flops "
-                        "charges all of it"}
+        blk = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
+               "peak": round(peak, 1), "unit": "TFLOP/s",
+               "frac": round(achieved / peak, 4), "traffic": traffic,
+               "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(launches),
+               "seq_math": math,
+               "algorithmic_flops_per_launch": alg,
+               "survey_8d_flops_per_launch": survey,
+               "frac_with_survey_8d_flops": round(survey / (dom_ms * 1e-3) / 1e12 / peak, 4),
+               "mfma_flops_issued_per_launch": per * alg,
+               "ceilings_TFLOPs": {"f16_pipe_over_3": round(BF16_MFMA_PEAK_TFLOPS / 3, 1),
+                                   "bf16_pipe_over_6": round(F32_ON_BF16_PEAK_TFLOPS, 1), "f32_input_mfma": 157.3},
+               "frac_of_bf16_pipe_over_6": round(achieved / F32_ON_BF16_PEAK_TFLOPS, 4),
+               "frac_of_f32_input_mfma_peak": round(achieved / 157.3, 4),
+               "note": "fp32 results (1e-5 parity; measured ~3e-7 against float64) from the 16-bit matrix pipe: %s; peak = "
+                       "2.5 PFLOP/s dense / %d.  achieved counts ALGORITHMIC fp32 flops = (2L-1)*8*H^2 per path, i.e. 7/8 "
+                       "(L=4) of SURVEY.md 8d's L*16*H^2 (the step-0 products with h_{-1} = 0 are not charged); "
+                       "frac_with_survey_8d_flops charges all of it.  With three MFMAs per product the kernel's saved-tensor "
+                       "traffic is the co-bound: see hbm_side" %
+                       ("fp32 = 2 scaled fp16 planes, 3 MFMAs per product, fp32 accumulate" if per == 3 else
+                        "fp32 = 3 bf16 planes, 6 MFMAs per product, fp32 accumulate", per)}
+        if traffic:
+            tbs = traffic / (dom_ms * 1e-3) / 1e12
+            blk["hbm_side"] = {"traffic_bytes_per_launch": traffic, "TB_per_s": round(tbs, 3),
+                               "frac_of_hbm_peak": round(tbs * 1e3 / HBM_PEAK_GBS, 4),
+                               "note": "PMC HBM bytes of the same launch / its duration: what the design's saved tensors (gates, "
+                                       "cell states, [x|h] rows, gate gradients) cost, beside the matrix-pipe fraction above"}
+        return blk
     return {"kernel": dominant, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None, "traffic": traffic, "avg_launch_ms": round(dom_ms, 4)}
 
@@ -549,6 +571,20 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
                                    "bank, recurrence, pooling, classifier; the training forward also draws the dropout masks "
                                    "and writes the tensors the backward reads"}
 
+    # ---- the same headline step with the other arithmetic of the recurrent GEMMs (report both) -------------------
+    other = "bf16x3" if seq_math_name() == "f16x2" else "f16x2"
+    old_math = sr.model.seq_math
+    sr.model.seq_math = other
+    try:
+        mo = measure(sr, lib, ctx, names, max(5, args.steps // 2), 3, torch.cuda.synchronize)
+        steps_o = max(5, args.steps // 2)
+        out["headline_step_" + other] = {
+            "seq_math": other, "ms_per_step": mo["elapsed"] / steps_o * 1e3, "value": sr.S * W / (mo["elapsed"] / steps_o),
+            "unit": "paths/s", "steps": steps_o, "stages_ms": mo["stages_ms"],
+            "roofline": roofline_block(mo["dominant"], mo["dom_ms"], mo["dom_launches"], sr.S * W, L, H, None, math=other)}
+    finally:
+        sr.model.seq_math = old_math
+
     # ---- configs[2]: Pubmed-scale full training step (on-GPU MERW sampler + PAGG fwd/bwd + Adam) ---------------------
     pw = pubmed_workload()
     t0 = time.time()
@@ -618,7 +654,7 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
     out["hid512_step"] = {
         "config": "bench graph, hid=512 (generic recurrence: one bf16x3 MFMA GEMM per step + cell kernels), %d paths/step" % Ph,
         "value": Ph / (mh["elapsed"] / steps_h), "unit": "paths/s", "ms_per_step": mh["elapsed"] / steps_h * 1e3,
-        "steps": steps_h, "roofline": roofline_block(mh["dominant"], mh["dom_ms"], mh["dom_launches"], Ph, L, 512, None),
+        "steps": steps_h, "roofline": roofline_block(mh["dominant"], mh["dom_ms"], mh["dom_launches"], Ph, L, 512, None, math="bf16x3"),
         "stages_ms": mh["stages_ms"]}
     del hsr
 
@@ -790,8 +826,10 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong" if args.workload == "bgp" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "dtype_note": "fp32 in, fp32 out, fp32 accumulation; the recurrent GEMM products run as 3-plane bf16 splits "
-                      "(6 bf16 MFMAs per fp32 product), everything else in fp32",
+        "dtype_note": "fp32 in, fp32 out, fp32 accumulation; the recurrent GEMM products run as %s, everything else in fp32"
+                      % ("scaled 2-plane fp16 splits (3 fp16 MFMAs per fp32 product)" if seq_math_name() == "f16x2" else
+                         "3-plane bf16 splits (6 bf16 MFMAs per fp32 product)"),
+        "seq_math": seq_math_name(),
         "config": {"workload": {"cora": "Cora-shaped synthetic (configs[1])", "pubmed": "Pubmed-shaped synthetic (configs[2])",
                                 "bgp": "BGP-sized synthetic, hetero class (configs[3])"}[args.workload] + ": N=%d F=%d C=%d hid=%d path_num=%d path_len=%d, "
                                "%d masked nodes = %d paths/step, %s, dropout 0.7, Adam" %

@@ -27,11 +27,37 @@ using namespace pn;
 #ifndef PN_FWDH_WAVES
 #define PN_FWDH_WAVES 3     // waves per SIMD the forward is compiled for at H <= 128 (= workgroups per CU at H = 128)
 #endif
+#ifndef PN_FWDH_RB
+#define PN_FWDH_RB 1        // row blocks of 32 paths per wave of the forward at H = 64 / 128 (see seq_fwdh_kernel)
+#endif
+#ifndef PN_FWDH_RB2_PP
+#define PN_FWDH_RB2_PP 0    // RB = 2: a second register set for the hi-plane fragments (ping-pong)
+#endif
 #ifndef PN_BWDH_WAVES
 #define PN_BWDH_WAVES 2
 #endif
+#ifndef PN_BWDH_TOUCH
+#define PN_BWDH_TOUCH 0     // > 0: the BPTT pulls the saved rows of its NEXT step into L2 while the current step runs (LDS-DMA touches)
+#endif
+#ifndef PN_BWDH_CARRY
+#define PN_BWDH_CARRY 1     // 1: c_{t-1}, loaded for step t, stays in registers as step t-1's c_t
+#endif
 #ifndef PN_BWD_REVERSE
 #define PN_BWD_REVERSE 1
+#endif
+
+#ifndef PN_TRACE_H
+#define PN_TRACE_H 0        // 1: tuning builds only -- wave 0 of every workgroup stamps the cycle counter at phase boundaries
+#endif
+#if PN_TRACE_H
+__device__ long long *g_trace_h = nullptr;      // [blocks][64] stamps, set with pn_debug_set_trace_h
+#define HSTAMP(slot)                                                                                      \
+    do {                                                                                                  \
+        if (g_trace_h && threadIdx.x == 0 && (slot) < 64)                                                 \
+            g_trace_h[(size_t)blockIdx.x * 64 + (slot)] = (long long)__builtin_readcyclecounter();        \
+    } while (0)
+#else
+#define HSTAMP(slot) do { } while (0)
 #endif
 
 namespace {
@@ -81,6 +107,17 @@ __device__ __forceinline__ FwdScales fwd_scales(const SeqRange *rg, float xmul) 
     return FwdScales{exp2i(ES - e_ih), exp2i(ES - e_hh), exp2i(ES), exp2i(-ES)};
 }
 
+// One 4-byte LDS-DMA per lane: lane l's dword at g goes to LDS byte (lds_wave_base + 4 l).  No register destination -- used to
+// pull cache lines towards the CU ahead of time, the LDS target being a scratch nobody reads (pn cdna_hip_programming.md 5.7:
+// M0 is written in the statement that reads it and restored).
+__device__ __forceinline__ void touch_dma4(const void *g, uint32_t lds_wave_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_wave_base)
+                 : "memory");
+}
+
 __device__ __forceinline__ int gru_weight_row(int slot, int j, int H) { return (slot < 2 ? slot : 2) * H + j; }
 
 // =====================================================================================================================
@@ -127,22 +164,26 @@ __global__ void pack_fwdh_kernel(const float *__restrict__ w_ih, const float *__
     dst[G * 64] = q1;
 }
 
-template <int H>
-constexpr int fwdh_waves() { return H == 32 ? 1 : H > 128 ? 2 : PN_FWDH_WAVES; }
+// RB: row blocks of 32 paths per wave.  RB = 2: a wave keeps two accumulator sets and every weight fragment feeds two MFMAs --
+// the fragment stream per path, which bounds the k loop (35 B/clk/CU through the vector-memory return path: 14.7 k cycles
+// per step where the matrix pipe needs 6.1 k, profiles/r04_phase_trace.txt), halves.  With two fp16 planes the 64-row tile
+// is 68 KB: two workgroups per CU (the bf16 form of this needed 101 KB, one workgroup per CU, and was slower).
+template <int H, int RB>
+constexpr int fwdh_waves() { return H == 32 && RB == 1 ? 1 : (H > 128 || RB > 1) ? 2 : PN_FWDH_WAVES; }
 
 // GC: 4 = LSTM, 1 = tanh RNN, 3 = GRU
-template <int H, int GC>
-__global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(SeqFwdParams p) {
+template <int H, int GC, int RB>
+__global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_kernel(SeqFwdParams p) {
     constexpr int G = GC == 3 ? 4 : GC;
     constexpr bool GRU = GC == 3;
-    constexpr int MT = 32;
+    constexpr int MT = 32 * RB;
     constexpr int NW = H / 32, NT = NW * 64, SV = (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
     constexpr int PB = 4 * H + 16;            // row pitch of a plane of the tile [x | h], bytes: conflict-free ds_read_b128
     constexpr int PLANE = MT * PB;
     // three workgroups per CU: no register room for the x_{t+1} rows or a second hi-plane fragment set, the third
     // workgroup covers those latencies instead (as in seq_fwd3_kernel)
-    constexpr bool PREFETCH_X = fwdh_waves<H>() < 3, PING_PONG = fwdh_waves<H>() < 3;
+    constexpr bool PREFETCH_X = RB == 1 && fwdh_waves<H, RB>() < 3, PING_PONG = fwdh_waves<H, RB>() < 3 && (RB == 1 || PN_FWDH_RB2_PP);
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 2 * PLANE);  // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
@@ -155,9 +196,11 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
     for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
 
     const FwdScales sc = fwd_scales(p.range, p.xmul);
-    f32x16 cst;
+    f32x16 cst[RB];
 #pragma unroll
-    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
+    for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) cst[rb][r] = 0.0f;
     const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     const bool builtin_drop = !p.mask && p.p_drop > 0.0f;
     const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
@@ -171,7 +214,7 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
 
     // ---- coalesced row gather of x_{t+1} (H*4 bytes per row), dropout keep bits drawn behind the loads, mask and
     //      scale applied when the rows are committed to LDS
-    constexpr int NLD = 4;        // float4 per thread = MT * (H/4) / NT
+    constexpr int NLD = 4 * RB;   // float4 per thread = MT * (H/4) / NT
     f32x4 xr[NLD];
     uint32_t keepbits = 0;        // 4 bits per row of this thread
     int tid_g = tid;              // re-derived per step (fresh_lane): offsets derived from it must not live across the MFMA loop
@@ -197,7 +240,10 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
         keepbits = bits;
     };
     auto gather_commit = [&](int t) {
-        wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
+        if constexpr (RB == 1)
+            wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
+        else
+            wait_vm<0>(xr[0], xr[1], xr[2], xr[3], xr[4 % NLD], xr[5 % NLD], xr[6 % NLD], xr[7 % NLD]);
 #pragma unroll
         for (int i = 0; i < NLD; i++) {
             const int idx = tid_g + NT * i;
@@ -237,15 +283,18 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
     __syncthreads();
 
     for (int t = 0; t < p.L; t++) {
+        HSTAMP(4 * t + 0);
         tid_g = wave_u * 64 + fresh_lane();
         if (PREFETCH_X && t + 1 < p.L) gather_issue(t + 1);
 
-        f32x16 acc[G];
+        f32x16 acc[RB][G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const float bias = p.biasc[g * H + col] * sc.S;
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[g][r] = bias;
+            for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[rb][g][r] = bias;
         }
 
         // ---- [x_t ; h_{t-1}] x [W_ih ; W_hh]^T.  Per k-step the products run  a_lo.B_hi, a_hi.B_hi | a_hi.B_lo : the lo
@@ -262,11 +311,18 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
             auto load = [&](u32x4 (&B)[G], int s, int pl) {
                 async_load_frags<G>(B, wb + (size_t)(s * 2 + pl) * (G * 1024), voff);
             };
-            u32x4 a[2];
-            auto aread = [&](int s, int pl) { return *reinterpret_cast<const u32x4 *>(arow + 32 * s + pl * PLANE); };
+            u32x4 a[RB][2];
+            auto areads = [&](int s, int pl) {
+#pragma unroll
+                for (int rb = 0; rb < RB; rb++)
+                    a[rb][pl] = *reinterpret_cast<const u32x4 *>(arow + rb * 32 * PB + 32 * s + pl * PLANE);
+            };
+            // all RB row blocks of a product before the next product: every weight fragment feeds RB MFMAs
             auto prod = [&](int pa, u32x4 (&B)[G]) {
 #pragma unroll
-                for (int g = 0; g < G; g++) acc[g] = mfma_f16(a[pa], B[g], acc[g]);
+                for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) acc[rb][g] = mfma_f16(a[rb][pa], B[g], acc[rb][g]);
             };
             // vmcnt (in order) at the top of k-step s: PING_PONG [Bh(s) Bl(s)] + the Bh(s+1) just issued; else [Bh(s) Bl(s)]
             auto kstep = [&](int s, u32x4 (&Bh)[G], u32x4 (&Bhnext)[G]) {
@@ -274,16 +330,16 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
                 if (PING_PONG) load(Bhnext, sn, 0);
                 wait_frag<(PING_PONG ? 2 : 1) * G, G>(Bh);
                 prod(1, Bh);
-                a[1] = aread(sn, 1);
+                areads(sn, 1);
                 prod(0, Bh);
                 if (!PING_PONG) load(Bh, sn, 0);
                 wait_frag<G, G>(Bl);
                 prod(0, Bl);
-                a[0] = aread(sn, 0);
+                areads(sn, 0);
                 load(Bl, sn, 1);
             };
-            a[0] = aread(0, 0);
-            a[1] = aread(0, 1);
+            areads(0, 0);
+            areads(0, 1);
             load(Bha, 0, 0);
             load(Bl, 0, 1);
 #pragma unroll 1
@@ -299,43 +355,47 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
             wait_frag<0, G>(Bha);                         // drain (harmless re-loads of the last k-step)
             wait_frag<0, G>(Bl);
         }
+        HSTAMP(4 * t + 1);
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
+        HSTAMP(4 * t + 2);
 
         // ---- cell update in registers; h_t goes back to LDS (scaled, split) for the next step ----------------------
         const int lane_o = fresh_lane();    // row offsets are re-derived in every step: hoisted out of the t loop they spill
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
         float hv[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int row = acc_row(r, lane_o);
+            const int row = 32 * rb + acc_row(r, lane_o);
             const int q = q0 + row;
             float h;
             if (GRU) {
                 // saved: r, z, n, the pre-activation W_hn h + b_hn, h_{t-1}
-                const float rg = sigmoidf_(acc[0][r] * sc.inv_S);
-                const float zg = sigmoidf_(acc[G > 1 ? 1 : 0][r] * sc.inv_S);
-                const float nh = acc[G > 3 ? 3 : 0][r] * sc.inv_S;
-                const float ng = tanhf_(acc[G > 2 ? 2 : 0][r] * sc.inv_S + rg * nh);
-                const float hp = cst[r];
+                const float rg = sigmoidf_(acc[rb][0][r] * sc.inv_S);
+                const float zg = sigmoidf_(acc[rb][G > 1 ? 1 : 0][r] * sc.inv_S);
+                const float nh = acc[rb][G > 3 ? 3 : 0][r] * sc.inv_S;
+                const float ng = tanhf_(acc[rb][G > 2 ? 2 : 0][r] * sc.inv_S + rg * nh);
+                const float hp = cst[rb][r];
                 h = (1.0f - zg) * ng + zg * hp;
-                cst[r] = h;
+                cst[rb][r] = h;
                 if (saved_t && q < p.P) {
                     float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
                     sv[0] = rg; sv[H] = zg; sv[2 * H] = ng; sv[3 * H] = nh; sv[4 * H] = hp;
                 }
             } else if (G == 4) {
-                const float ig = sigmoidf_(acc[0][r] * sc.inv_S);
-                const float fg = sigmoidf_(acc[G > 1 ? 1 : 0][r] * sc.inv_S);
-                const float gg = tanhf_(acc[G > 2 ? 2 : 0][r] * sc.inv_S);
-                const float og = sigmoidf_(acc[G > 3 ? 3 : 0][r] * sc.inv_S);
-                const float c = fg * cst[r] + ig * gg;
-                cst[r] = c;
+                const float ig = sigmoidf_(acc[rb][0][r] * sc.inv_S);
+                const float fg = sigmoidf_(acc[rb][G > 1 ? 1 : 0][r] * sc.inv_S);
+                const float gg = tanhf_(acc[rb][G > 2 ? 2 : 0][r] * sc.inv_S);
+                const float og = sigmoidf_(acc[rb][G > 3 ? 3 : 0][r] * sc.inv_S);
+                const float c = fg * cst[rb][r] + ig * gg;
+                cst[rb][r] = c;
                 h = og * tanhf_(c);
                 if (saved_t && q < p.P) {
                     float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
                     sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
                 }
             } else {
-                h = tanhf_(acc[0][r] * sc.inv_S);
+                h = tanhf_(acc[rb][0][r] * sc.inv_S);
                 if (saved_t && q < p.P) at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)H + col) * 4u) = h;
             }
             hv[r] = h;
@@ -351,17 +411,21 @@ __global__ __launch_bounds__(H / 32 * 64, fwdh_waves<H>()) void seq_fwdh_kernel(
             for (int r = 0; r < 16; r += 2) {       // accumulator registers r, r+1 are tile rows row, row+1
                 uint32_t h0, h1;
                 split2h(hv[r] * sc.s_h, hv[r + 1] * sc.s_h, h0, h1);
-                unsigned char *d = ldsb + acc_row(r, lane_o) * PB + 2 * (H + col);
+                unsigned char *d = ldsb + (32 * rb + acc_row(r, lane_o)) * PB + 2 * (H + col);
                 *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
                 *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
                 *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
                 *reinterpret_cast<uint16_t *>(d + PLANE + PB) = (uint16_t)(h1 >> 16);
             }
+        }
+        }
+        if (t + 1 < p.L) {
             tid_g = wave_u * 64 + fresh_lane();
             if (!PREFETCH_X) gather_issue(t + 1);
             gather_commit(t + 1);     // (every wave is past its reads of x_t)
             __syncthreads();
         }
+        HSTAMP(4 * t + 3);
     }
 }
 
@@ -422,6 +486,9 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
     float *s_max = reinterpret_cast<float *>(s_slotof + MT);     // [8] wave maxima of |dG_t|
     uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_max + 8);    // [2][MT][H/4] dropout keep bits of step t (t & 1)
+    [[maybe_unused]] const uint32_t touch_lds =                  // [NW][256 B] landing area of the touches (never read)
+        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(s_keep + 2 * MT * (H / 4)) +
+                                       256u * (uint32_t)(threadIdx.x >> 6));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
     const int q0 = (PN_BWD_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * MT;
     const int col = 32 * wave + li;
@@ -442,6 +509,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     const float *dhn_t = p.dhn + (size_t)q0 * H;
     const int rows_here = min(MT, p.P - q0);            // >= 1
     f32x16 dh, dc;
+    [[maybe_unused]] f32x16 cnext;      // PN_BWDH_CARRY: c_t of the step processed next (= c_{t-1} now)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = acc_row(r, lane);
@@ -449,6 +517,8 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         const float dh0 = at_bytes(dhn_t, ((uint32_t)rc * (uint32_t)H + col) * 4u);     // unconditional load, select afterwards
         dh[r] = row < rows_here ? dh0 : 0.0f;
         dc[r] = 0.0f;
+        if (PN_BWDH_CARRY && G == 4 && !GRU)
+            cnext[r] = at_bytes(saved_t, ((((uint32_t)rc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col) * 4u);
     }
     float launch_max = 0.0f;        // largest |dG| this workgroup has seen (wave-uniform after each step)
 
@@ -456,6 +526,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         // (row numbers are re-derived from an opaque copy of the lane id in every step: as loop invariants the
         //  per-row offsets would occupy ~40 registers across the MFMA loop and spill)
         const int lane_t = fresh_lane();
+        HSTAMP(6 * (p.L - 1 - t) + 0);
         if (p.keep) {      // this step's keep bytes (MT rows x H/4) -> LDS, read by the scatter phase below
             const int tid_t = wave_u * 64 + lane_t;
             for (int i = tid_t; i < MT * (H / 16); i += NT) {
@@ -484,7 +555,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     vi[r] = sv[0]; vf[r] = sv[H]; vg[r] = sv[2 * H];
                     vo[r] = sv[3 * H];
                     vc[r] = t > 0 ? sv[-H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
-                    vn[r] = sv[4 * H];                              // c_t
+                    vn[r] = PN_BWDH_CARRY ? cnext[r] : sv[4 * H];   // c_t
                 } else {
                     vi[r] = sv[0];                                   // h_t
                 }
@@ -523,6 +594,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     float a_o = d_o * og * (1.0f - og);
                     if (!ok) a_i = a_f = a_g = a_o = 0.0f;
                     dc[r] = dct * fg;
+                    if (PN_BWDH_CARRY) cnext[r] = cprev;
                     dgv[0][r] = a_i; dgv[G > 1 ? 1 : 0][r] = a_f; dgv[G > 2 ? 2 : 0][r] = a_g; dgv[G > 3 ? 3 : 0][r] = a_o;
                     if (ok) {
                         d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
@@ -539,7 +611,24 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         }
         vmax = wave_max(vmax);
         if (lane_t == 0) s_max[wave_u] = vmax;
+        HSTAMP(6 * (p.L - 1 - t) + 1);
         __syncthreads();        // the wave maxima are in place; every wave is past the previous step's k loop
+        HSTAMP(6 * (p.L - 1 - t) + 2);
+        if (PN_BWDH_TOUCH && t > 0) {
+            // the next step's saved rows, one lane per 128-byte line: row (0..31) x array (i f g o [c]) x segment (H/32)
+            constexpr int NARR = G == 4 ? (PN_BWDH_TOUCH < 5 ? PN_BWDH_TOUCH : 5) : 1, LINES = MT * NARR * NW;
+            const int tid_x = wave_u * 64 + lane_t;
+#pragma unroll
+            for (int e0 = 0; e0 < LINES; e0 += NT) {
+                const int e = e0 + tid_x;
+                if (e < LINES) {
+                    const int row = e / (NARR * NW), rem = e - row * (NARR * NW), k = rem / NW, j = rem - k * NW;
+                    const uint32_t rc = (uint32_t)min(row, rows_here - 1);
+                    touch_dma4(&at_bytes(saved_t, ((rc * (uint32_t)p.L + (uint32_t)(t - 1)) * (uint32_t)(SV * H) + (uint32_t)(k * H + 32 * j)) * 4u),
+                               touch_lds);
+                }
+            }
+        }
         float tmax = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; w++) tmax = fmaxf(tmax, s_max[w]);
@@ -560,6 +649,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                 *reinterpret_cast<uint16_t *>(d + PLANE + PB) = (uint16_t)(x1 >> 16);
             }
         __syncthreads();
+        HSTAMP(6 * (p.L - 1 - t) + 3);
 
         // ---- [dx_t ; dh_{t-1}] = dG_t . [W_ih | W_hh]; the dh half is not needed at t = 0 ------------------------
         f32x16 acc[2];
@@ -622,6 +712,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
             mfma_phase(std::integral_constant<int, 2>{});
         else
             mfma_phase(std::integral_constant<int, 1>{});
+        HSTAMP(6 * (p.L - 1 - t) + 4);
         const float inv_x = exp2i(-(e_g + e_ih)), inv_h = exp2i(-(e_g + e_hh));
 
         // ---- gather backward: dZ[row(q, t)] += mask * dx.  Step 0 is the last one of the kernel and its rows are the
@@ -678,6 +769,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                 dh[r] = GRU ? acc[1][r] * inv_h + dc[r] : acc[1][r] * inv_h;
             }
         }
+        HSTAMP(6 * (p.L - 1 - t) + 5);
     }
     if (tid == 0 && launch_max > 0.0f) atomicMax(&p.range->dg, __float_as_uint(launch_max));
 }
@@ -843,9 +935,10 @@ __global__ __launch_bounds__(WH_THREADS, 2) void wgradh_kernel(WgradParams p, in
 
 template <int H, int GC>
 int launch_fwdh_t(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
-    constexpr int MT = 32;
+    constexpr int RB = (H == 64 || H == 128) ? PN_FWDH_RB : 1;     // (two workgroups of 68 KB tiles per CU at H = 128)
+    constexpr int MT = 32 * RB;
     const size_t lds_bytes = (size_t)2 * MT * (4 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
-    auto kern = seq_fwdh_kernel<H, GC>;
+    auto kern = seq_fwdh_kernel<H, GC, RB>;
     if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
     hipLaunchKernelGGL(kern, dim3((sp.P + MT - 1) / MT), dim3(H / 32 * 64), lds_bytes, stream, sp);
     PN_CHECK_HIP(hipGetLastError());
@@ -854,7 +947,8 @@ int launch_fwdh_t(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
 template <int H, int GC>
 int launch_bwdh_t(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int MT = 32, G = GC == 3 ? 4 : GC;
-    const size_t lds_bytes = (size_t)2 * MT * (2 * G * H + 16) + (size_t)(MT * sp.L + MT) * 4 + 32 + (size_t)2 * MT * (H / 4);
+    const size_t lds_bytes = (size_t)2 * MT * (2 * G * H + 16) + (size_t)(MT * sp.L + MT) * 4 + 32 + (size_t)2 * MT * (H / 4) +
+                             (PN_BWDH_TOUCH ? (size_t)(H / 32) * 256 : 0);
     auto kern = seq_bwdh_kernel<H, GC>;
     if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
     hipLaunchKernelGGL(kern, dim3((sp.P + MT - 1) / MT), dim3(H / 32 * 64), lds_bytes, stream, sp);
@@ -891,6 +985,12 @@ int dispatch_bwdh(pn_context *ctx, hipStream_t s, int H, const SeqBwdParams &sp)
 }
 
 }  // namespace
+
+#if PN_TRACE_H
+extern "C" int pn_debug_set_trace_h(long long *dev_buf) {     // tuning builds only; not part of the ABI
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_h), &dev_buf, sizeof dev_buf) == hipSuccess ? 0 : -4;
+}
+#endif
 
 namespace pn {
 

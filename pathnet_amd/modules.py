@@ -132,9 +132,13 @@ def pick_batch_groups(variant, N, F, H, C, S, W, L, budget=None, cell=None, devi
     fixed = w1 - per_group                  # the node tables (and the compact-row arrays): needed whatever the micro-batch
     avail = max(budget - fixed, floor)      # default budget: graphs whose tables alone exceed it still get real batches
     bg = int(max(1, min(S, avail // per_group if avail > 0 else 1)))
-    if floor == 0:                          # an explicit budget: shrink until the real layout fits (alignment, rounding)
-        while bg > 1 and ws(bg) > budget:
+    if floor == 0:                          # an explicit budget is kept to the byte: settle on the real layout (alignment,
+        while bg > 1 and ws(bg) > budget:   # terms that are not linear in the micro-batch such as the sort's scratch)
             bg = max(1, min(bg - 1, int(bg * 0.98)))
+        for _ in range(16):
+            if bg >= S or ws(bg + 1) > budget:
+                break
+            bg += 1
     return bg
 
 

@@ -66,9 +66,8 @@ def test_fused_step_is_the_three_calls(variant, S, W, L, H, cell, micro):
     if micro:
         Hk = -(-H // 32) * 32
         kw = dict(cell=m._cell_kind, deterministic=True)
-        fixed = M.workspace_bytes(variant, 900, 40, Hk, 5, 1, W, L, **kw)
-        per = (M.workspace_bytes(variant, 900, 40, Hk, 5, 1025, W, L, **kw) - fixed) // 1024
-        m.workspace_budget = fixed + micro * per
+        # the workspace of this call when it runs b masked nodes at a time is fixed(S) + b * per (pick_batch_groups)
+        m.workspace_budget = M.workspace_bytes(variant, 900, 40, Hk, 5, S, W, L, batch_groups=micro, **kw)
         assert M.pick_batch_groups(variant, 900, 40, Hk, 5, S, W, L, m.workspace_budget, **kw) == micro
     l0, o0, g0 = _separate(case)
     l1, o1, g1 = _fused(case)
