@@ -403,7 +403,9 @@ int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, cons
  * A is CSR on the device (row_off [n+1], col [nnz], val [nnz] or NULL for all ones).  Power iteration on A + I in fp64,
  * deterministic; converged when |A x - lambda x| <= tol (lambda + 1) (tol <= 0: 1e-13; max_iter < 1: 100000).
  * Outputs: p dev [nnz], psi dev [n] (unit 2-norm, positive), *lambda and *iters on the host.  Fails with the residual in
- * pn_last_error() when it does not converge (disconnected graph: the reference's own output is noise there). */
+ * pn_last_error() when it does not converge.  Call it per CONNECTED component: on a disconnected graph the reference's one
+ * eigenpair is exact on the dominant component only and eigensolver noise elsewhere (the negative and > 1 "probabilities" of
+ * the shipped cora.in / citeseer.in); pathnet_amd/merw_init.py splits the graph and documents what it writes there. */
 int pn_merw_workspace_bytes(int32_t n, int64_t *bytes);
 int pn_merw_probabilities(int32_t n, int64_t nnz, const int64_t *row_off, const int32_t *col, const double *val,
                           double *p, double *psi, double *lambda, int32_t max_iter, double tol, int32_t *iters,

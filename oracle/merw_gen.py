@@ -8,7 +8,9 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Reference behaviour restated
       "u v P[u,v]" and "v u P[v,u]" (edge_index of a symmetric graph already holds both directions, so every row of
       the file appears twice -- the shipped .in files do).
 Pinned against the reference function itself, imported from /root/reference on synthetic graphs
-(tests/golden/make_golden_merwgen.py -> tests/golden/merwgen_*.npz).  Parity is to 1e-9 (two different eigensolvers),
+(tests/golden/make_golden_merwgen.py -> tests/golden/merwgen_*.npz).  Also pinned on what the reference SHIPS: edge_input/cornell.in and Nba.in are
+reproduced row for row (2e-13) from the adjacency recovered from them (tests/golden/merwfile_*.npz,
+tests/test_merw_gen.py).  Parity is to 1e-9 (two different eigensolvers),
 on connected non-bipartite graphs -- elsewhere the reference's own output is not well defined (eigsh's "largest
 magnitude" may return -lambda on a bipartite graph, and the eigenvector is noise on the smaller components, which is
 where the negative and > 1 "probabilities" of the shipped cora/citeseer files come from).
@@ -16,10 +18,12 @@ where the negative and > 1 "probabilities" of the shipped cora/citeseer files co
 import numpy as np
 
 
-def adjacency_dense(n, edge_index):
-    """init_rw.py:63-68: csr_matrix((ones, (row, col)), shape=(n, n)) -- duplicates accumulate."""
+def adjacency_dense(n, edge_index, weights=None):
+    """init_rw.py:63-68: csr_matrix((ones, (row, col)), shape=(n, n)) -- duplicates accumulate.  weights: per column
+    instead of ones (the shipped cornell.in / Nba.in come from matrices whose self loops weigh 2,
+    tests/golden/make_golden_merw_shipped.py)."""
     A = np.zeros((n, n), np.float64)
-    np.add.at(A, (np.asarray(edge_index[0]), np.asarray(edge_index[1])), 1.0)
+    np.add.at(A, (np.asarray(edge_index[0]), np.asarray(edge_index[1])), 1.0 if weights is None else np.asarray(weights, np.float64))
     return A
 
 
@@ -40,6 +44,14 @@ def edge_rows(n, edge_index, P):
     ru = np.stack([u, v], 1).reshape(-1)
     rv = np.stack([v, u], 1).reshape(-1)
     return ru.astype(np.int32), rv.astype(np.int32), P[ru, rv]
+
+
+def edge_rows_from(edge_index, p_uv, p_vu):
+    """the same rows from per-column probabilities"""
+    u, v = np.asarray(edge_index[0]), np.asarray(edge_index[1])
+    ru = np.stack([u, v], 1).reshape(-1)
+    rv = np.stack([v, u], 1).reshape(-1)
+    return ru.astype(np.int32), rv.astype(np.int32), np.stack([p_uv, p_vu], 1).reshape(-1)
 
 
 def format_edge_file(n, ru, rv, rp):

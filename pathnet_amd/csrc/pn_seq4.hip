@@ -27,6 +27,13 @@ using namespace pn;
 
 // tuning builds only (tools/seq4_variants.sh): ablations of the forward kernel (results are wrong, times are the point) and
 // s_memtime stamps of waves 0 and 4 of every workgroup at the phase boundaries of each k-step
+// The forward and BPTT kernels of this file measured SLOWER than the fused ones of pn_pagg.hip (DESIGN.md section 2, round-3
+// finding 1) and are not part of the shipped library: they build only with -DPN_EXPERIMENTAL=1 (tools/seq4_variants.sh,
+// tests/test_gpu_seq4.py runs them when PN_LIB_PATH names such a build).  The weight-gradient GEMM below is the bf16 x 3
+// mode's default at hidden size 128.
+#ifndef PN_EXPERIMENTAL
+#define PN_EXPERIMENTAL 0
+#endif
 #ifndef PN_F4_NODMA
 #define PN_F4_NODMA 0
 #endif
@@ -100,9 +107,9 @@ constexpr int T4_SLOTS = 512;
 
 namespace {
 
-constexpr int H4 = 128, G4 = 4, NW4 = H4 / 32;      // hidden size, gate slots, unit blocks of 32 hidden units
-constexpr int MT4 = 128, NT4 = 512;                 // paths and threads per workgroup (8 waves: 2 row groups x 4 unit blocks)
-constexpr int SV4 = 5;                              // saved values per (path, step, unit): i f g o c / r z n nh h_prev
+[[maybe_unused]] constexpr int H4 = 128, G4 = 4, NW4 = H4 / 32;      // hidden size, gate slots, unit blocks of 32 hidden units
+[[maybe_unused]] constexpr int MT4 = 128, NT4 = 512;                 // paths and threads per workgroup (8 waves: 2 row groups x 4 unit blocks)
+[[maybe_unused]] constexpr int SV4 = 5;                              // saved values per (path, step, unit): i f g o c / r z n nh h_prev
 
 // LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to `lds_wave_base + lane * 16` (wave-uniform base)
 __device__ __forceinline__ void dma16(const void *gsrc_lane, unsigned char *lds_wave_base) {
@@ -110,6 +117,7 @@ __device__ __forceinline__ void dma16(const void *gsrc_lane, unsigned char *lds_
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+#if PN_EXPERIMENTAL      // the 128-path forward and the 64 / 128-path BPTT: measured experiments, not product (see above)
 // =====================================================================================================================
 // forward recurrence
 //   k-step s of step t: gates[128, 4H] += A[128, 16] . B[16, 4H];  A = columns 16s.. of [x_t | h_{t-1}], B = rows of
@@ -880,6 +888,8 @@ __global__ __launch_bounds__(256 * NRG, 2) void seq_bwd4_kernel(SeqBwdParams p) 
 }
 
 
+#endif  // PN_EXPERIMENTAL
+
 // =====================================================================================================================
 // weight gradient:  [g_W_ih | g_W_hh] [G*H, 2H] = dG^T [G*H, R] . XH [R, 2H]   (R = P*L rows; colsum(dG) = bias gradient)
 //   Same decomposition as wgrad3_kernel (pn_pagg.hip): 256 x 256 output tile per workgroup (8 waves, 64 x 128 each),
@@ -1089,9 +1099,10 @@ int seq4_select(int H, int G, int L) {
     // opt-in (PN_SEQ4 = bit mask, 0 = every fused kernel)
     int mask = SEQ4_WGRAD;
     if (const char *e = getenv("PN_SEQ4")) mask = atoi(e);
-    return mask & (SEQ4_FWD | SEQ4_BWD | SEQ4_WGRAD);
+    return mask & (PN_EXPERIMENTAL ? (SEQ4_FWD | SEQ4_BWD | SEQ4_WGRAD) : SEQ4_WGRAD);
 }
 
+#if PN_EXPERIMENTAL
 int launch_pack_fwd4(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
                      int gru, void *Wp, float *biasc) {
     if (H != H4 || G != G4) PN_FAIL(PN_ERR_ARG, "pack_fwd4: shape");
@@ -1151,6 +1162,17 @@ int launch_seq_bwd4(pn_context *ctx, void *stream, int gc, const SeqBwdParams &s
 }
 
 
+#else   // the shipped library: seq4_select never selects them
+int launch_pack_fwd4(void *, const float *, const float *, const float *, const float *, int, int, int, void *, float *) {
+    PN_FAIL(PN_ERR_ARG, "seq_fwd4: not in this build (PN_EXPERIMENTAL)");
+}
+int launch_seq_fwd4(pn_context *, void *, int, const SeqFwdParams &) { PN_FAIL(PN_ERR_ARG, "seq_fwd4: not in this build (PN_EXPERIMENTAL)"); }
+int launch_pack_bwd4(void *, const float *, const float *, int, int, int, void *) {
+    PN_FAIL(PN_ERR_ARG, "seq_bwd4: not in this build (PN_EXPERIMENTAL)");
+}
+int launch_seq_bwd4(pn_context *, void *, int, const SeqBwdParams &) { PN_FAIL(PN_ERR_ARG, "seq_bwd4: not in this build (PN_EXPERIMENTAL)"); }
+#endif
+
 int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nsplit) {
     if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(wgrad4_kernel), W4_LDS_BYTES)) return rc;
     hipLaunchKernelGGL(wgrad4_kernel, dim3((wp.H2 + W4_BN - 1) / W4_BN, (wp.GH + W4_BM - 1) / W4_BM, nsplit), dim3(W4_THREADS),
@@ -1160,3 +1182,6 @@ int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nspl
 }
 
 }  // namespace pn
+
+// which of the 128-path kernels this build holds (bit mask of SEQ4_*): tests skip what is not there; not part of the ABI
+extern "C" int pn_debug_seq4_kernels(void) { return PN_EXPERIMENTAL ? 7 : 4; }

@@ -42,6 +42,9 @@ using namespace pn;
 #ifndef PN_BWDH_CARRY
 #define PN_BWDH_CARRY 1     // 1: c_{t-1}, loaded for step t, stays in registers as step t-1's c_t
 #endif
+#ifndef PN_ABL
+#define PN_ABL 0            // tuning builds only (wrong results, times are the point): bit 0 the forward does not store x_t, bit 1
+#endif                      // forward and BPTT skip the o gate's saved value, bit 2 the BPTT does not store dG
 #ifndef PN_BWD_REVERSE
 #define PN_BWD_REVERSE 1
 #endif
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
             if (xh4_t && q < p.P) {
                 float4 *xo = &at_bytes(xh4_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4) * 16u);
-                xo[0] = v;
+                if (!(PN_ABL & 1)) xo[0] = v;
                 if (t == 0) xo[H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 h = og * tanhf_(c);
                 if (saved_t && q < p.P) {
                     float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
-                    sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+                    sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; if (!(PN_ABL & 2)) sv[3 * H] = og; sv[4 * H] = c;
                 }
             } else {
                 h = tanhf_(acc[rb][0][r] * sc.inv_S);
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     vn[r] = 0.0f;
                 } else if (G == 4) {
                     vi[r] = sv[0]; vf[r] = sv[H]; vg[r] = sv[2 * H];
-                    vo[r] = sv[3 * H];
+                    vo[r] = (PN_ABL & 2) ? 0.5f : sv[3 * H];
                     vc[r] = t > 0 ? sv[-H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
                     vn[r] = PN_BWDH_CARRY ? cnext[r] : sv[4 * H];   // c_t
                 } else {
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     dc[r] = dct * fg;
                     if (PN_BWDH_CARRY) cnext[r] = cprev;
                     dgv[0][r] = a_i; dgv[G > 1 ? 1 : 0][r] = a_f; dgv[G > 2 ? 2 : 0][r] = a_g; dgv[G > 3 ? 3 : 0][r] = a_o;
-                    if (ok) {
+                    if (ok && !(PN_ABL & 4)) {
                         d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
                     }
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a_i), fabsf(a_f))), fmaxf(fabsf(a_g), fabsf(a_o)));

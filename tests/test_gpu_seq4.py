@@ -27,6 +27,14 @@ def _restore_env():
             os.environ[k] = v
 
 
+def _built():
+    """bit mask of the 128-path kernels the loaded library holds: the shipped one has the weight-gradient GEMM only (bit 2),
+    a -DPN_EXPERIMENTAL=1 build (tools/seq4_variants.sh, PN_LIB_PATH) the forward and the BPTT as well"""
+    import ctypes
+    from pathnet_amd import _lib
+    return int(ctypes.CDLL(_lib.LIB_PATH).pn_debug_seq4_kernels())
+
+
 def _case(variant, S, W, L, cell=None, drop=0.5, N=400, F=48, C=5, seed=0):
     import pathnet_amd
     g = torch.Generator().manual_seed(seed)
@@ -65,6 +73,8 @@ def _run(case, mask, wide=0, seed=7):
 ])
 @pytest.mark.parametrize("mask,wide", [(1, 0), (2, 0), (2, 1), (4, 0), (7, 0), (7, 1)])
 def test_seq4_kernels_match_the_fused_kernels(variant, S, W, L, cell, drop, mask, wide):
+    if mask & ~_built():
+        pytest.skip("the 128-path forward / BPTT are experiments outside the shipped library (PN_EXPERIMENTAL build)")
     case = _case(variant, S, W, L, cell, drop)
     ref_out, ref_g = _run(case, 0)
     out, g = _run(case, mask, wide)
@@ -91,7 +101,7 @@ def test_seq4_kernels_match_the_oracle():
     mask_seq = (torch.rand(L, S * W, H, generator=g) < keep).float() / keep
     mask_cls = (torch.rand(S, 2 * H, generator=g) < keep).float() / keep
     m._mask_seq, m._mask_cls = mask_seq.cuda(), mask_cls.cuda()
-    os.environ["PN_SEQ4"] = "7"
+    os.environ["PN_SEQ4"] = str(7 & _built())
     mask = np.zeros(N, bool)
     mask[sel] = True
     out = m(X.cuda(), torch.as_tensor(ids.reshape(S, W * L).astype(np.int64)), W, L, mask,

@@ -95,3 +95,87 @@ def test_edge_file_writer_prints_what_the_reference_prints(tmp_path):
     n2, u2, v2, p2 = sampler.read_edge_file(f)
     ru, rv, rp = mg.edge_rows(n, ei, P)
     assert n2 == n and (u2 == ru).all() and (v2 == rv).all() and (p2 == rp).all()
+
+
+# ---- the edge files the reference ships: f-2 pinned on reference-held artefacts --------------------------
+SHIPPED = golden_files("merwfile_*.npz")
+
+
+def _giant_oracle(g):
+    """P of the dominant component from the oracle's dense eigensolver, per edge column (NaN elsewhere)"""
+    n, ei, w = int(g["n"]), g["edge_index"], g["weights"]
+    big = g["in_giant"]
+    nodes = np.unique(ei[:, big])
+    pos = np.full(n, -1)
+    pos[nodes] = np.arange(len(nodes))
+    A = mg.adjacency_dense(len(nodes), pos[ei[:, big]], w[big])
+    P, psi, lam = mg.merw_matrix(A)
+    a, b = pos[ei[0, big]], pos[ei[1, big]]
+    return P[a, b], P[b, a], lam
+
+
+@pytest.mark.parametrize("name", [f for f in SHIPPED if "cora" not in f])
+def test_oracle_reproduces_the_shipped_edge_files(name):
+    """edge_input/cornell.in and Nba.in, every row: the oracle on the adjacency recovered from the file itself"""
+    g = golden(name)
+    p_uv, p_vu, lam = _giant_oracle(g)
+    big = g["in_giant"]
+    assert abs(lam - float(g["lam"])) < 1e-9
+    assert np.abs(p_uv - g["p_uv"][big]).max() < TOL and np.abs(p_vu - g["p_vu"][big]).max() < TOL
+    # single nodes outside the dominant component: A[u,u] / lambda (psi cancels in compute_merw.py:118)
+    s_ = g["single"]
+    assert np.abs(g["weights"][s_] / lam - g["p_uv"][s_]).max(initial=0.0) < TOL
+    assert (big | s_).all()                                      # i.e. every row of these two files is reproduced
+    if "cornell" in name:                                        # connected: the file itself, where repr(float) agrees
+        n, ei = int(g["n"]), g["edge_index"]
+        P = mg.merw_matrix(mg.adjacency_dense(n, ei, g["weights"]))[0]
+        got = mg.format_edge_file(n, *mg.edge_rows(n, ei, P)).split("\n")
+        want = mg.format_edge_file(n, *mg.edge_rows_from(ei, g["p_uv"], g["p_vu"])).split("\n")
+        assert got[0] == want[0] and len(got) == len(want)
+        # same rows in the same order; the printed probabilities agree to 12 significant digits (two eigensolvers: the
+        # 17-digit repr itself coincides on 28 of the 1474 rows)
+        assert all(a.split()[:2] == b.split()[:2] for a, b in zip(got[1:-1], want[1:-1]))
+        assert all(abs(float(a.split()[2]) - float(b.split()[2])) <= 1e-12 * abs(float(b.split()[2]))
+                   for a, b in zip(got[1:-1], want[1:-1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SHIPPED)
+def test_hip_generator_reproduces_the_shipped_edge_files(name):
+    from pathnet_amd import merw_init as mi
+    g = golden(name)
+    n, ei = int(g["n"]), g["edge_index"].astype(np.int64)
+    r = mi.merw_probabilities(n, ei, weights=g["weights"])
+    big, s_ = g["in_giant"], g["single"]
+    # cora.in: the reference's own eigensolver (ARPACK, default tolerance) is 1.6e-5 away from the exact dominant pair
+    tol = 5e-5 if "cora" in name else TOL
+    assert abs(r["lam"] - float(g["lam"])) < (1e-4 if "cora" in name else 1e-9)
+    assert np.abs(r["p_uv"][big] - g["p_uv"][big]).max() < tol and np.abs(r["p_vu"][big] - g["p_vu"][big]).max() < tol
+    assert np.abs(r["p_uv"][s_] - g["p_uv"][s_]).max(initial=0.0) < tol
+    assert (r["reference_defined"] == (big | s_)).all()
+    assert r["components"] == len(np.unique(mi.component_labels(n, ei[0], ei[1])))
+    # whatever the component, a node's probabilities sum to one -- except single nodes outside the dominant component,
+    # where the reference's A[u,u] / lambda is kept
+    ro, col, val, k_uv, _ = mi.adjacency_csr(n, ei, g["weights"])
+    tot = np.zeros(n)
+    first = np.unique(k_uv, return_index=True)[1]                # one column per stored entry
+    np.add.at(tot, ei[0][first], r["p_uv"][first])
+    lone = np.zeros(n, bool)
+    lone[ei[0][s_]] = True
+    assert np.abs(tot[~lone] - 1.0).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_disconnected_graph_policy(tmp_path):
+    """cora.in's graph has 78 components: the default computes every component (the dominant one as the reference does),
+    disconnected='error' and the CLI's --strict refuse it with a clear message"""
+    from pathnet_amd import merw_init as mi
+    g = golden("merwfile_cora.npz")
+    n, ei = int(g["n"]), g["edge_index"].astype(np.int64)
+    with pytest.raises(ValueError, match="connected components"):
+        mi.merw_probabilities(n, ei, disconnected="error")
+    np.save(os.path.join(tmp_path, "ei.npy"), ei)
+    assert mi.main([os.path.join(tmp_path, "ei.npy"), str(n), "-o", os.path.join(tmp_path, "cora.in"), "--strict"]) == 1
+    assert mi.main([os.path.join(tmp_path, "ei.npy"), str(n), "-o", os.path.join(tmp_path, "cora.in")]) == 0
+    head = open(os.path.join(tmp_path, "cora.in")).readline().split()
+    assert head == [str(n), str(2 * ei.shape[1])]
