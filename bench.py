@@ -395,6 +395,7 @@ class StepRunner:
         self.fused = os.environ.get("PN_BENCH_FUSED", "0") not in ("", "0")
         Y = torch.from_numpy(wl["Y"]).to(dev)
         self.runner = None
+        self.overlap = os.environ.get("PN_BENCH_OVERLAP", "1") not in ("", "0")    # collectives on their own stream (dist.py)
         if not sharded:
             self.X = torch.from_numpy(wl["X"]).to(dev)
             self.sel = torch.from_numpy(np.flatnonzero(wl["mask"]).astype(np.int64)).to(dev)
@@ -410,6 +411,7 @@ class StepRunner:
             self.sel = torch.from_numpy(np.flatnonzero(loc_mask).astype(np.int64)).to(dev)        # local row ids
             self.sel32 = (self.sel + self.node_begin).to(torch.int32)                             # global node ids
             self.comm = pdist.Comm(timing=timing_comm)
+            self.comm.overlap = self.overlap
             self.runner = pdist.ShardedAggregator(self.model, n_total=n, row_begin=self.node_begin, row_count=n_loc,
                                                   comm=self.comm)
             # the mask is fixed: every rank knows every rank's count (no per-step exchange of counts)
@@ -426,6 +428,8 @@ class StepRunner:
         import pathnet_amd
         wl = self.wl
         W, L = wl["W"], wl["L"]
+        if self.runner is not None and hasattr(self.runner, "begin_step") and self.overlap:
+            self.runner.begin_step(self.X)      # fc0 of the rank's rows + the all-gather of Xh start now, under the sampler
         if self.state is not None:
             self.state.advance()        # (one tiny launch: epoch + 1, Adam step + 1, the step's dropout seed)
             self.smp.sample(W, 0, nodes=self.sel32, draw_source=pathnet_amd.DRAW_PHILOX, check=False,
@@ -788,6 +792,16 @@ def main():
             sr.step(7000 + e)
         sr.comm.timing = False
         mine = {kk: round(v / k * 1e3, 4) for kk, v in sr.comm.seconds.items()}
+        # and what the overlapped step actually waits for: per collective, from the moment the compute stream needs the
+        # result to the collective's end (events on both streams; zero when it is hidden)
+        sr.comm.measure_exposed = True
+        for e in range(k):
+            sr.step(8000 + e)
+        torch.cuda.synchronize()
+        exposed = {kk: round(v / k, 4) for kk, v in sr.comm.exposed_ms().items()}
+        sr.comm.measure_exposed = False
+        gathered_exposed = [None] * world
+        dist.all_gather_object(gathered_exposed, exposed)
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
         # every rank contributes a one through the backend the step used (backend "nccl" IS RCCL on ROCm) and names the
@@ -800,8 +814,13 @@ def main():
         collectives = {"rccl_ranks_seen": int(one.item()), "backend": "rccl" if backend == "nccl" else backend,
                        "distinct_devices": len(set(devs)),
                        "ms_per_step_by_rank": gathered,
-                       "note": "each collective bracketed by torch.cuda.synchronize (serialised: an upper bound on what "
-                               "the overlapped step pays)",
+                       "exposed_ms_per_step_by_rank": gathered_exposed,
+                       "overlap": bool(sr.overlap),
+                       "note": "ms_per_step_by_rank: each collective bracketed by torch.cuda.synchronize (serialised: an upper "
+                               "bound).  exposed_ms_per_step_by_rank: the timed step runs the all-gather of Xh on a communication "
+                               "stream under the sampler + index plan + weight packing and the reduce-scatter of dXh (+ fc0's "
+                               "backward) under the recurrent / bank weight-gradient GEMMs; exposed = time from the compute "
+                               "stream needing the result to the collective's end, 0 when hidden (PN_BENCH_OVERLAP=0 disables)",
                        "bytes_per_step": {"all_gather_Xh": n * H * 4, "reduce_scatter_dXh": n * H * 4,
                                           "all_reduce_grads": sum(q.numel() for q in sr.model.parameters()) * 4}}
     else:

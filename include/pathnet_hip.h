@@ -43,7 +43,8 @@ extern "C" {
                           * 5: pn_pagg_shape gained deterministic; pn_linear_backward gained workspace / workspace_bytes;
                           *    pn_pagg_train_step
                           * 6: pn_pagg_shape gained compact / seq_math (decisions that shape the workspace travel with the
-                          *    shape, not with the environment); pn_pagg_args.reuse_tables = 2; pn_pagg_shape_info */
+                          *    shape, not with the environment); pn_pagg_args.reuse_tables = 2; pn_pagg_shape_info; pn_pagg_args gained
+                          *    Xh_ready / g_Xh_ready (events that let the node-sharded path overlap its collectives) */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -326,6 +327,13 @@ typedef struct pn_pagg_args {
      * finished with pn_linear_backward) instead of g_fc0_* / g_X. */
     const float *Xh_in;
     float *g_Xh;
+    /* Overlap of those two collectives with the library's own work (both may be NULL; hipEvent_t handles, not captured into
+     * graphs).  Xh_ready: recorded by the caller on ITS communication stream after the all-gather -- the forward makes `stream`
+     * wait for it only where Xh_in is first read (the distance bank), so the touched-row marking, the index plan and the
+     * weight packing run under the all-gather.  g_Xh_ready: recorded by the backward on `stream` as soon as g_Xh is complete
+     * -- before the distance bank's and the recurrent weight gradients, which then run under the caller's reduce-scatter. */
+    void *Xh_ready;
+    void *g_Xh_ready;
     /* inference: non-zero skips writing the saved-for-backward tensors (gates, cell states, [x|h] rows --
      * ~3.6 KB per path step); pn_pagg_backward must not follow such a forward. */
     int32_t no_save;

@@ -65,7 +65,8 @@ class PaggArgs(ctypes.Structure):
                  ("g_out", vp), ("g_X", vp)] +
                 [("g_" + k, vp) for k in ("fc0_w", "fc0_b", "bank_w", "bank_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w",
                                           "att_b", "fc2_w", "fc2_b")] +
-                [("Xh_in", vp), ("g_Xh", vp), ("no_save", ctypes.c_int32), ("reuse_tables", ctypes.c_int32),
+                [("Xh_in", vp), ("g_Xh", vp), ("Xh_ready", vp), ("g_Xh_ready", vp), ("no_save", ctypes.c_int32),
+                 ("reuse_tables", ctypes.c_int32),
                  ("index_rows_local", ctypes.c_int32), ("step_state", vp)])
 
 

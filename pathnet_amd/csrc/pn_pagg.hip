@@ -3112,6 +3112,9 @@ int run_tables(const Call &c, JoinGuard &joiner) {
                 return rc;
         }
     }
+    // node-sharded path: the caller's all-gather of Xh runs on its own stream; this one waits for it here, where Xh is first
+    // read -- everything above (touched rows, plan, packing) has been enqueued under it
+    if (a->Xh_in && a->Xh_ready) PN_CHECK_HIP(hipStreamWaitEvent(stream, (hipEvent_t)a->Xh_ready, 0));
     if (d.compact) {
         // distance bank over the touched rows: code by code, Z[compact row] = act(Xh[node] . bank_w[code]^T + bank_b[code])
         // (the touched set belongs to this batch: reuse_tables keeps the projected features only)
@@ -3399,7 +3402,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (int rc = zero(a->g_b_ih, (size_t)GwH)) return rc;
         if (int rc = zero(a->g_b_hh, (size_t)GwH)) return rc;
         if (int rc = zero(a->g_X, (size_t)d.N * d.F)) return rc;
-        return flush_zero();
+        if (int rc = flush_zero()) return rc;
+        if (a->Xh_in && a->g_Xh_ready) PN_CHECK_HIP(hipEventRecord((hipEvent_t)a->g_Xh_ready, stream));    // (zeros: complete)
+        return PN_OK;
     }
     // (the fused step clears them after the forward of its first micro-batch instead: the forward's gigabyte of saved
     //  tensors would push the freshly zeroed dZ out of the caches the scatter atomics want it in)
@@ -3660,6 +3665,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             for (int code = 0; code < L; code++)
                 hipLaunchKernelGGL(transpose_kernel, dim3((H * H + 255) / 256), dim3(256), 0, stream, a->bank_w + (size_t)code * H * H,
                                    H, H, bankT + (size_t)code * H * H);
+        // first every code's contribution to d Xh (what a sharded caller's reduce-scatter waits for), then the weight gradients
         for (int code = 0; code < L; code++) {
             if (g3) {
                 if (int rc = launch_gemm3(stream, dZ, H, bankT + (size_t)code * H * H, H, dXh, H, nullptr, mmax, H, H, 0, 1, zgate,
@@ -3668,6 +3674,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             } else if (int rc = launch_gemm(stream, dZ, H, 1, zgate, a->bank_w + (size_t)code * H * H, 1, H, dXh, H, nullptr, mmax,
                                             H, H, 0, GEMM_ADD, 1, nullptr, GEMM_IND_C_ROWS, seg + code, list))
                 return rc;
+        }
+        if (a->Xh_in && a->g_Xh_ready) PN_CHECK_HIP(hipEventRecord((hipEvent_t)a->g_Xh_ready, stream));
+        for (int code = 0; code < L; code++) {
             if (a->g_bank_w && d.det) {
                 if (int rc = launch_gemm_det(stream, dZ, 1, H, zgate, Xh, 1, H, a->g_bank_w + (size_t)code * H * H, H, H, H, mmax,
                                              (mmax + 255) / 256, a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, dgemm,
@@ -3692,6 +3701,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     } else if (int rc = launch_gemm_split(stream, dZ, (int64_t)L * H, 1, zgate, a->bank_w, 1, H, dXh, H, nullptr, d.N, H, L * H,
                                           0, GEMM_ADD, c.at<float>(c.w.gpart)))
         return rc;
+    if (a->Xh_in && a->g_Xh_ready) PN_CHECK_HIP(hipEventRecord((hipEvent_t)a->g_Xh_ready, stream));
     if (a->g_bank_w && d.det) {
         if (int rc = launch_gemm_det(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, L * H, H, d.N,
                                      (d.N + 255) / 256, a->g_bank_b, dgemm))

@@ -53,6 +53,35 @@ class Comm:
         self.timing = timing
         self.always = always        # run the collectives even in a one-rank group (exercises RCCL on a single GPU)
         self.seconds = {"all_gather_Xh": 0.0, "reduce_scatter_dXh": 0.0, "all_reduce_grads": 0.0, "all_gather_index": 0.0}
+        # overlap: the two big collectives of a step run on a stream of their own, ordered against the compute stream by
+        # events (ShardedAggregator.begin_step / _ShardedFn).  measure_exposed: keep, per kind, the time the compute stream
+        # would have to wait for the collective -- from the moment it needs the result to the collective's end (timed events,
+        # read back by exposed_ms(); only what the overlap does not hide shows up here)
+        self.overlap = True
+        self.measure_exposed = False
+        self._streams = {}
+        self._exposed = []          # (kind, event the consumer was ready at, event the collective ended at)
+
+    def stream(self, device):
+        """this Comm's communication stream on `device`"""
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        st = self._streams.get(key)
+        if st is None:
+            st = self._streams[key] = torch.cuda.Stream(device=key)
+        return st
+
+    def note_exposed(self, kind, need_ev, done_ev):
+        if self.measure_exposed:
+            self._exposed.append((kind, need_ev, done_ev))
+
+    def exposed_ms(self):
+        """-> {kind: summed milliseconds the consumers were (or would have been) stalled}; clears the record.  Synchronises."""
+        out = {}
+        for kind, need, done in self._exposed:
+            done.synchronize()
+            out[kind] = out.get(kind, 0.0) + max(0.0, need.elapsed_time(done))
+        self._exposed = []
+        return out
 
     def world(self):
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -167,27 +196,32 @@ class HipOps:
         a.mask_cls = mc.data_ptr() if mc is not None else None
         return a
 
-    def forward(self, cfg, Xh, ids, codes, sel, p):
+    def forward(self, cfg, Xh, ids, codes, sel, p, ready=None):
+        """ready: torch.cuda.Event recorded after the all-gather of Xh on the communication stream, or None (Xh is complete
+        in stream order)"""
         lib = _lib.load()
         dev = Xh.device
         with torch.cuda.device(dev):
             out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
             ws = torch.empty(max(M._cfg_workspace_bytes(cfg), 1), dtype=torch.uint8, device=dev)
             a = self._args(cfg, Xh, ids, codes, sel, p)
+            a.Xh_ready = ready.cuda_event if ready is not None else None
             a.out = out.data_ptr()
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             if cfg["S"] > 0:
                 _lib.check(lib.pn_pagg_forward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
         return out, (cfg, Xh, ids, codes, sel, p, ws)
 
-    def backward(self, state, g_out):
+    def backward(self, state, g_out, ready=None):
         """-> (g_Xh [N,H], grads): grads maps the head parameter names (without fc0) to tensors and
-        "bank_w"/"bank_b" to the stacked [L,H,H] / [L,H] gradients."""
+        "bank_w"/"bank_b" to the stacked [L,H,H] / [L,H] gradients.  ready: a torch.cuda.Event the library records as soon
+        as g_Xh is complete (the weight gradients follow it), or None."""
         lib = _lib.load()
         cfg, Xh, ids, codes, sel, p, ws = state
         dev = Xh.device
         with torch.cuda.device(dev):
             a = self._args(cfg, Xh, ids, codes, sel, p)
+            a.g_Xh_ready = ready.cuda_event if ready is not None else None
             a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
             g_out = g_out.contiguous().float()
             a.g_out = g_out.data_ptr()
@@ -221,14 +255,31 @@ class HipOps:
         return g_w, g_b
 
 
+def _new_event(device, timing=False):
+    """an event whose handle exists (torch creates it at the first record) -- the library records / waits on the raw handle"""
+    ev = torch.cuda.Event(enable_timing=timing)
+    ev.record(torch.cuda.current_stream(device))
+    return ev
+
+
 class _ShardedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, cfg, X_loc, ids, codes, sel, *params):
         p = M._split_params(params, cfg["L"])
         ops, comm = runner.ops, runner.comm
-        Xh_loc = ops.project(cfg["variant"], X_loc, p["fc0_w"], p["fc0_b"])
-        Xh = comm.all_gather_rows(Xh_loc) if comm.active() else Xh_loc      # the one forward collective
-        out, state = ops.forward(cfg, Xh, ids, codes, sel, p)
+        pre = runner._take_prefetched(X_loc, p["fc0_w"], p["fc0_b"])
+        if pre is not None:             # begin_step projected and gathered already, on the communication stream
+            Xh_loc, Xh, ready = pre
+        else:
+            Xh_loc, Xh, ready = runner._project_and_gather(cfg["variant"], X_loc, p["fc0_w"], p["fc0_b"])
+        if ready is not None and comm.measure_exposed:
+            need = torch.cuda.Event(enable_timing=True)
+            need.record()
+            comm.note_exposed("all_gather_Xh", need, runner._ag_done)
+        if ready is not None and not isinstance(ops, HipOps):      # a checker backend: plain stream order
+            torch.cuda.current_stream(X_loc.device).wait_event(ready)
+            ready = None
+        out, state = ops.forward(cfg, Xh, ids, codes, sel, p, ready) if isinstance(ops, HipOps) else ops.forward(cfg, Xh, ids, codes, sel, p)
         ctx.runner, ctx.state, ctx.cfg = runner, state, cfg
         ctx.save_for_backward(X_loc, Xh_loc, p["fc0_w"])
         ctx.present = [t is not None for t in params]
@@ -239,10 +290,34 @@ class _ShardedFn(torch.autograd.Function):
         runner, cfg = ctx.runner, ctx.cfg
         ops, comm = runner.ops, runner.comm
         X_loc, Xh_loc, fc0_w = ctx.saved_tensors
-        g_Xh, grads = ops.backward(ctx.state, g_out)
-        g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0]) if comm.active() else g_Xh   # the one backward collective
-        grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w,
-                                                             deterministic=cfg.get("deterministic", False))
+        dev = X_loc.device
+        overlap = comm.active() and comm.overlap and X_loc.is_cuda and isinstance(ops, HipOps)
+        if not overlap:
+            g_Xh, grads = ops.backward(ctx.state, g_out)
+            g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0]) if comm.active() else g_Xh   # the one backward collective
+            grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w,
+                                                                 deterministic=cfg.get("deterministic", False))
+        else:
+            # the library records `ready` as soon as d Xh is complete; its weight-gradient GEMMs then run under the
+            # reduce-scatter and fc0's backward, which follow on the communication stream
+            cur, cst = torch.cuda.current_stream(dev), comm.stream(dev)
+            ready = _new_event(dev, timing=comm.measure_exposed)
+            g_Xh, grads = ops.backward(ctx.state, g_out, ready)
+            g_Xh.record_stream(cst)
+            with torch.cuda.stream(cst):
+                cst.wait_event(ready)
+                g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0])
+                grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w,
+                                                                     deterministic=cfg.get("deterministic", False))
+                done = torch.cuda.Event(enable_timing=comm.measure_exposed)
+                done.record(cst)
+            if comm.measure_exposed:        # the compute stream needs fc0's gradients when the library's own work is over
+                need = torch.cuda.Event(enable_timing=True)
+                need.record(cur)
+                comm.note_exposed("reduce_scatter_dXh+fc0_bwd", need, done)
+            cur.wait_event(done)
+            for t in (g_loc, grads["fc0_w"], grads["fc0_b"]):
+                t.record_stream(cur)
         L = cfg["L"]
         head = tuple(grads.get(k) if pres else None for k, pres in zip(M._HEAD_PARAMS, ctx.present[:10]))
         return (None, None, None, None, None, None) + head + tuple(grads["bank_w"][d] for d in range(L)) + tuple(
@@ -273,6 +348,51 @@ class ShardedAggregator:
         self._seed_gen = torch.Generator()
         self._seed_gen.manual_seed(int(dropout_seed))
         self.mask_seq = self.mask_cls = None    # test hook: explicit dropout masks of the WHOLE batch
+        self._prefetched = None
+        self._ag_done = None
+
+    # ---- forward collective, overlapped ------------------------------------------------------------------------------
+    def _project_and_gather(self, variant, X_loc, fc0_w, fc0_b):
+        """Xh_loc = fc0(X_loc) on the current stream, then the all-gather of Xh on the communication stream.
+        -> (Xh_loc, Xh, ready): `ready` is the event the consumer of Xh has to wait for (None: plain stream order)."""
+        ops, comm = self.ops, self.comm
+        Xh_loc = ops.project(variant, X_loc, fc0_w, fc0_b)
+        if not comm.active():
+            return Xh_loc, Xh_loc, None
+        if not (comm.overlap and X_loc.is_cuda):
+            return Xh_loc, comm.all_gather_rows(Xh_loc), None
+        dev = X_loc.device
+        cur, cst = torch.cuda.current_stream(dev), comm.stream(dev)
+        projected = torch.cuda.Event()
+        projected.record(cur)
+        Xh_loc.record_stream(cst)
+        with torch.cuda.stream(cst):
+            cst.wait_event(projected)
+            Xh = comm.all_gather_rows(Xh_loc)
+            ready = torch.cuda.Event(enable_timing=comm.measure_exposed)
+            ready.record(cst)
+        Xh.record_stream(cur)
+        self._ag_done = ready
+        return Xh_loc, Xh, ready
+
+    def begin_step(self, X_loc):
+        """Start the step's projection and all-gather NOW, before the paths of the step are sampled: the walker (and, inside
+        the aggregator call, the touched-row marking, the index plan and the weight packing) then run under the all-gather.
+        Optional -- without it the call itself projects and gathers, and only the library's own preamble overlaps.
+        Valid for the next call with the same X_loc and unchanged fc0 parameters; no-grad bookkeeping only: the autograd
+        graph is that of the call (fc0's backward runs on X_loc as always)."""
+        m = self.module
+        with torch.no_grad():
+            pre = self._project_and_gather(m.variant, X_loc.contiguous().float(), m.fc0.weight, m.fc0.bias)
+        self._prefetched = ((X_loc.data_ptr(), X_loc._version, m.fc0.weight.data_ptr(), m.fc0.weight._version,
+                             m.fc0.bias._version), pre)
+
+    def _take_prefetched(self, X_loc, fc0_w, fc0_b):
+        pre, self._prefetched = self._prefetched, None
+        if pre is None:
+            return None
+        key = (X_loc.data_ptr(), X_loc._version, fc0_w.data_ptr(), fc0_w._version, fc0_b._version)
+        return pre[1] if pre[0] == key else None
 
     def __call__(self, X_loc, neis, num_w, walk_len, sel_global, layer_type):
         """X_loc [row_count, F]; sel_global: global node ids of this rank's masked nodes (inside its block);
@@ -405,6 +525,25 @@ class ReplicatedAggregator(ShardedAggregator):
         self._seed_gen = torch.Generator()
         self._seed_gen.manual_seed(int(dropout_seed))
         self.mask_seq = self.mask_cls = None
+        self.compact_nodes = None       # True / False: run on the rows of X the call's paths can touch; None: when they are few
+
+    def _touched_rows(self, X, ids, sel):
+        """(X', ids', sel'): the call restricted to the nodes its paths and masked nodes name.  A rank's share of the batch
+        touches a fraction of a large graph (12 500 masked nodes x 40 paths x 6 steps reach ~26 % of the 10 M nodes of
+        configs[4]); without this every rank projects, zero-fills and flags ALL N rows each step -- the terms that do not
+        shrink with the number of ranks (tools/scale_model.py).  Rows keep their relative order; every row's arithmetic
+        is unchanged (the projection of a row does not depend on the other rows)."""
+        N = X.shape[0]
+        steps = ids.numel() + sel.numel()
+        on = self.compact_nodes if self.compact_nodes is not None else 2 * steps < N
+        if not on or steps == 0:
+            return X, ids, sel
+        flags = torch.zeros(N, dtype=torch.bool, device=X.device)
+        flags[ids.reshape(-1).long()] = True
+        flags[sel.long()] = True
+        nodes = torch.nonzero(flags).flatten()                      # (one host round trip for the count)
+        rank = torch.cumsum(flags, 0, dtype=torch.int32) - 1
+        return X.index_select(0, nodes), rank[ids.long()], rank[sel.long()]
 
     @staticmethod
     def cheaper_than_sharding(n_total, in_features, hidden, world, link_GBs=50.0, gemm_TFLOPs=50.0):
@@ -422,6 +561,7 @@ class ReplicatedAggregator(ShardedAggregator):
         ids, codes, sel, S = M._as_index_tensors(neis, layer_type, sel_global, num_w, walk_len, dev, n_nodes=self.n_total)
         if not comm.active():
             self.batch_counts = [S]
+            X, ids, sel = self._touched_rows(X, ids, sel)
             return m._run(X, ids, num_w, walk_len, sel, codes)
         if self._fixed_counts is not None:
             counts = self._fixed_counts
@@ -439,7 +579,9 @@ class ReplicatedAggregator(ShardedAggregator):
         try:
             if m.variant == "hetero":
                 ids, codes, sel = (comm.all_gather_ragged(t, counts) for t in (ids, codes, sel))
+                X, ids, sel = self._touched_rows(X, ids, sel)
                 return m._run(X, ids, num_w, walk_len, sel, codes, group_slice=(begin, S), seed=seed)
+            X, ids, sel = self._touched_rows(X, ids, sel)
             return m._run(X, ids, num_w, walk_len, sel, codes, batch_position=(S_total, begin), seed=seed)
         finally:
             m._mask_seq, m._mask_cls = old

@@ -55,14 +55,20 @@ def worker(rank, world, port, variant, ret, empty_rank1=False, mode="sharded"):
         n_loc = case["N"] // world
         lo = rank * n_loc
         mine = (case["sel"] >= lo) & (case["sel"] < lo + n_loc)
-        if mode == "replicated":        # every rank holds all of X: plain data parallelism over the masked nodes
+        if mode.startswith("replicated"):   # every rank holds all of X: plain data parallelism over the masked nodes
             runner = pdist.ReplicatedAggregator(m, case["N"], comm=pdist.Comm())
+            runner.compact_nodes = mode == "replicated_touched"     # ... restricted to the rows of X its paths touch
             X_in = case["X"].cuda()
         else:
             runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, comm=pdist.Comm())      # ops = HipOps (default); gloo: staged
             assert isinstance(runner.ops, pdist.HipOps)
             X_in = case["X"][lo:lo + n_loc].cuda()
         assert runner.distributed
+        if mode == "sharded_serial":        # collectives on the compute stream, as before round 4
+            runner.comm.overlap = False
+        if mode == "sharded_begin":         # projection + all-gather started ahead of the call (under the sampler, in a step)
+            runner.comm.measure_exposed = True
+            runner.begin_step(X_in)
         ms, mc = masks(case)
         runner.mask_seq, runner.mask_cls = ms.cuda(), mc.cuda()         # the whole batch's masks
         out = runner(X_in,
@@ -72,6 +78,9 @@ def worker(rank, world, port, variant, ret, empty_rank1=False, mode="sharded"):
         (out * case["G"][mine].cuda()).sum().backward()
         runner.allreduce_grads(average=False)
         torch.cuda.synchronize()
+        if mode == "sharded_begin":
+            ex = runner.comm.exposed_ms()
+            assert set(ex) == {"all_gather_Xh", "reduce_scatter_dXh+fc0_bwd"} and all(v >= 0.0 for v in ex.values()), ex
         ret[rank] = (out.detach().cpu().numpy(), {k: v.grad.cpu().numpy().copy() for k, v in m.named_parameters()},
                      np.flatnonzero(mine))
     finally:
@@ -86,15 +95,17 @@ def free_port():
     return port
 
 
-@pytest.mark.parametrize("variant,empty_rank1", [("homo", False), ("hetero", False), ("pagg", False),
-                                                 ("homo", True), ("hetero", True)])
-def test_two_ranks_hip_ops_match_the_single_process_module(variant, empty_rank1):
+@pytest.mark.parametrize("variant,empty_rank1,mode", [("homo", False, "sharded"), ("hetero", False, "sharded"), ("pagg", False, "sharded"),
+                                                      ("homo", True, "sharded"), ("hetero", True, "sharded"),
+                                                      ("homo", False, "sharded_begin"), ("hetero", True, "sharded_begin"),
+                                                      ("homo", False, "sharded_serial")])
+def test_two_ranks_hip_ops_match_the_single_process_module(variant, empty_rank1, mode):
     """empty_rank1: rank 1 has no masked node -- its aggregator calls run with S = 0 (empty index arrays, NULL pointers) and must
     still take part in the collectives with zero gradients"""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1, mode), nprocs=world, join=True)
     case = make_case(empty_rank1=empty_rank1)
     m = build(variant, case).train()
     ms, mc = masks(case)
@@ -116,14 +127,15 @@ def test_two_ranks_hip_ops_match_the_single_process_module(variant, empty_rank1)
             assert np.abs(grads[k] - ref).max() < 3e-5 * max(1.0, np.abs(ref).max()), (rank, k)
 
 
+@pytest.mark.parametrize("mode", ["replicated", "replicated_touched"])
 @pytest.mark.parametrize("variant,empty_rank1", [("homo", False), ("hetero", False), ("pagg", False), ("homo", True)])
-def test_two_ranks_replicated_features_match_the_single_process_module(variant, empty_rank1):
+def test_two_ranks_replicated_features_match_the_single_process_module(variant, empty_rank1, mode):
     """dist.ReplicatedAggregator: all of X on every rank, each rank aggregates its own masked nodes, the flat gradient
     all-reduce is the only collective of the homo / PAGG classes (the hetero class also gathers the batch's index arrays)"""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1, "replicated"), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1, mode), nprocs=world, join=True)
     case = make_case(empty_rank1=empty_rank1)
     m = build(variant, case).train()
     ms, mc = masks(case)
