@@ -17,9 +17,16 @@ Model, per rank and step, R ranks:
                  block per link): t = latency + block_bytes / link_rate.  All-reduce of the flat gradient buffer
                  (G bytes): 2 (R - 1) / R x G / (links x link_rate) + latency.  The hetero class adds the all-gather of
                  the batch's index arrays (5 bytes per path step).
-  overlap        none assumed (dist.py issues the collectives on the compute stream).
-  replicated     dist.ReplicatedAggregator: every rank holds all of X and runs fc0 over all rows (own rows x R); the only
-                 collective is the gradient all-reduce (plus the hetero class's index arrays).
+  overlap        (round 4, dist.py) the all-gather of Xh runs on a communication stream from begin_step on: under the sampler
+                 and the aggregator's preamble (plan_pack); the reduce-scatter of dXh + fc0's backward on the rank's rows
+                 run under the weight gradients that follow d Xh in the library's backward -- the recurrent one on its
+                 own stream and half of the bank backward stage (its weight-gradient GEMMs; the other half, d Xh itself,
+                 precedes the event).  What a collective costs the step is max(0, its time - the stage time it hides
+                 under); the gradient all-reduce stays exposed.  overlap=False charges every collective in full (round 3).
+  replicated     dist.ReplicatedAggregator: every rank holds all of X; the only collective is the gradient all-reduce (plus
+                 the hetero class's index arrays).  Round 4: the call is restricted to the rows of X the rank's paths touch
+                 (touched_nodes: their expected fraction), so fc0 and its backward run over those rows only -- before,
+                 every rank projected all N rows each step, the term that capped configs[4] at 5.4 x on 8 ranks.
 
 weak scaling (configs[1]: every rank owns a 2708-node block of an R x 2708-node graph, bench.py --gpus R):
   efficiency = t(1) / t(R).  strong scaling (configs[3], configs[4]: one graph): speed-up = t(1) / t(R).
@@ -58,9 +65,12 @@ BANK_MS_PER_NODE = 6.2e-6    # measured slope of bank + bank backward over the n
                              # latency-bound, the replicated bank does NOT cost R times the single-block time
 
 
-def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, idx_bytes=0, touched_frac=None, replicated=False):
+def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, idx_bytes=0, touched_frac=None, replicated=False,
+          overlap=False, touched_nodes=None):
     """-> rows (R, t_ms, speedup_or_efficiency, parts).  stages: single-GPU per-stage ms; total_ms: single-GPU wall per
-    step (the part not covered by the stage timers -- loss, Adam, torch glue -- is carried as `other`, per rank)."""
+    step (the part not covered by the stage timers -- loss, Adam, torch glue -- is carried as `other`, per rank).
+    overlap: collectives hide under the stages named in the module docstring.  touched_nodes(R): fraction of the graph's
+    nodes a rank's paths name (replicated mode: fc0 over those rows only)."""
     s, o, r, rest = split(stages)
     other = max(total_ms - (s + o + r + rest), 0.0) + rest
     rows = []
@@ -68,17 +78,30 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
         if weak:        # per-rank paths and rows stay, the graph grows: the replicated bank grows with it
             n_total = n_total_1 * R
             sh, own, rep = s, o, r + BANK_MS_PER_NODE * n_total_1 * (R - 1)
+            scale = 1.0
         else:           # one graph: paths and rows shrink, the replicated bank does not
             n_total = n_total_1
             sh, own, rep = s / R, o / R, r
+            scale = 1.0 / R
         if touched_frac is not None:    # compaction: the bank runs over the rows this rank's paths touch
             rep = min(rep, rep * min(1.0, touched_frac(R)))
         coll, parts = collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes)
-        if replicated:      # dist.ReplicatedAggregator: all of X on every rank, fc0 over all rows, no exchange of Xh / d Xh
+        if replicated:      # dist.ReplicatedAggregator: all of X on every rank, no exchange of Xh / d Xh
             own = o * (R if weak else 1)
+            if touched_nodes is not None:
+                own *= min(1.0, touched_nodes(R)) / min(1.0, touched_nodes(1))
             if R > 1:
                 coll = parts["all_reduce_grads"] + parts["all_gather_indices"]
                 parts = dict(parts, all_gather_Xh=0.0, reduce_scatter_dXh=0.0)
+        elif overlap and R > 1:
+            hide_ag = (stages.get("sampler_walk", 0.0) + stages.get("sampler_fill", 0.0) + stages.get("plan_pack", 0.0)) * scale
+            hide_rs = max(stages.get("wgrad", 0.0) * scale, 0.5 * stages.get("bank_bwd", 0.0) * (rep / r if r > 0 else 1.0))
+            own_bwd = stages.get("fc0_bwd", 0.0) * (scale if not weak else 1.0)      # fc0's backward rides on the communication stream
+            ag = max(0.0, parts["all_gather_Xh"] - hide_ag)
+            rs = max(0.0, parts["reduce_scatter_dXh"] + own_bwd - hide_rs)
+            own = own - own_bwd
+            coll = ag + rs + parts["all_reduce_grads"] + parts["all_gather_indices"]
+            parts = dict(parts, all_gather_Xh=ag, reduce_scatter_dXh=rs)
         t = sh + own + rep + other + coll
         rows.append((R, t, dict(sharded=sh, own_rows=own, replicated_bank=rep, other=other, collectives=coll, **parts)))
     t1 = rows[0][1]
@@ -93,8 +116,9 @@ def main():
     ap.add_argument("--md", action="store_true")
     a = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = a.bench or next(p for p in (os.path.join(root, "profiles", "r03_bench_final.json"), os.path.join(root, "BENCH_r02.json"))
-                           if os.path.exists(p))
+    path = a.bench or next(p for p in (os.path.join(root, "profiles", "r04_bench_final.json"),
+                                       os.path.join(root, "profiles", "r04_bench_f16_v1.json"),
+                                       os.path.join(root, "profiles", "r03_bench_final.json")) if os.path.exists(p))
     b = json.load(open(path))
     b = b.get("bench", b) if "stages_ms" not in b else b
     if "stages_ms" not in b:            # the driver's record wraps the line
@@ -104,8 +128,10 @@ def main():
     # configs[1]: weak scaling of the Cora-shaped block (bench.py --gpus R)
     F, C, L = 1433, 7, 4
     grad1 = (F * H + H + L * (H * H + H) + 2 * (4 * H * H + 4 * H) + 2 * H + 1 + 2 * H * C + C) * 4
-    out.append(("configs[1] Cora-shaped block per rank (weak)", "efficiency",
+    out.append(("configs[1] Cora-shaped block per rank (weak), collectives charged in full (no overlap)", "efficiency",
                 model(b["stages_ms"], b["ms_per_step"], 2708, H, grad1, True, a.link_GBs, a.latency_us)))
+    out.append(("configs[1] Cora-shaped block per rank (weak), collectives overlapped (dist.py, round 4)", "efficiency",
+                model(b["stages_ms"], b["ms_per_step"], 2708, H, grad1, True, a.link_GBs, a.latency_us, overlap=True)))
     import math
     # a rank's 51 960 paths x 4 steps land on the whole R x 2708-node graph (bench.workload draws ONE graph over all
     # nodes): expected distinct (node, code) rows = rows x (1 - exp(-steps / rows)) -- nearly all of them up to 8 ranks
@@ -118,8 +144,11 @@ def main():
         F3, C3 = 287, 8
         grad3 = (F3 * H + H + L * (H * H + H) + 2 * (4 * H * H + 4 * H) + 2 * H + 1 + 2 * H * C3 + C3) * 4
         idx = 30708 * 40 * 4 * 5 + 30708 * 4
-        out.append(("configs[3] BGP-sized, hetero class (strong)", "speed-up",
+        out.append(("configs[3] BGP-sized, hetero class (strong), no overlap", "speed-up",
                     model(g["stages_ms"], g["ms_per_step"], 63977, H, grad3, False, a.link_GBs, a.latency_us, idx_bytes=idx)))
+        out.append(("configs[3] BGP-sized, hetero class (strong), collectives overlapped", "speed-up",
+                    model(g["stages_ms"], g["ms_per_step"], 63977, H, grad3, False, a.link_GBs, a.latency_us, idx_bytes=idx,
+                          overlap=True)))
     if "configs4_one_gpu_step" in b and b["configs4_one_gpu_step"].get("stage_ms_per_step"):
         g = b["configs4_one_gpu_step"]
         st = g["stage_ms_per_step"]
@@ -135,9 +164,19 @@ def main():
             out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over the touched rows (as measured)",
                         "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
                                           touched_frac=lambda R: uniq(R) / uniq(1))))
-            out.append(("configs[4], all of X on every rank (dist.ReplicatedAggregator): fc0 over all rows, gradient all-reduce only",
+            out.append(("configs[4] node-sharded, collectives overlapped (the exchange of Xh / dXh does not fit under anything)",
+                        "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
+                                          touched_frac=lambda R: uniq(R) / uniq(1), overlap=True)))
+            out.append(("configs[4], all of X on every rank (dist.ReplicatedAggregator): fc0 over all rows (round 3), gradient all-reduce only",
                         "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
                                           touched_frac=lambda R: uniq(R) / uniq(1), replicated=True)))
+            nodes, nsteps = 10e6, 100_000 * (40 * 6 + 1)
+            tn = lambda R: 1.0 - math.exp(-nsteps / (R * nodes))       # expected fraction of the nodes a rank's paths name
+            out.append(("configs[4], all of X on every rank, the call restricted to the rows its paths touch (round 4: fc0 over %.0f %% "
+                        "of the nodes on one rank, %.0f %% on each of 8)" % (100 * tn(1), 100 * tn(8)),
+                        "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
+                                          touched_frac=lambda R: uniq(R) / uniq(1), replicated=True,
+                                          touched_nodes=lambda R: tn(R) / 1.0)))
         else:
             out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over all 60 M rows", "speed-up",
                         model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us)))
