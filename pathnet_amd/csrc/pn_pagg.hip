@@ -914,7 +914,7 @@ __global__ void gen_pack_kernel(const float *__restrict__ w_ih, const float *__r
     float v = k < H ? w_ih[(int64_t)row * H + k] : w_hh[(int64_t)row * H + (k - H)];
     if (gru && ((slot == 2 && k >= H) || (slot == 3 && k < H))) v = 0.0f;
     Wcat[i] = v;
-    WcatT[(int64_t)k * G * H + m] = v;      // [2H, GH]: the BPTT's GEMM wants its B operand K-contiguous too
+    if (WcatT) WcatT[(int64_t)k * G * H + m] = v;      // [2H, GH]: the BPTT's GEMM wants its B operand K-contiguous too
 }
 
 // (SeqFwdParams: pn_seq.h)
@@ -2940,7 +2940,9 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
     }
     if (d.math == PN_SEQ_MATH_F16X2) {      // two fp16 planes, scaled by the weights' own maxima (pn_seqh.hip)
         SeqRange *rg = c.at<SeqRange>(c.w.range);
-        if (int rc = launch_range_w(s, c.a->w_ih, c.a->w_hh, (int64_t)d.Gw * d.H * d.H, rg)) return rc;
+        // (it also clears the slots this call's atomicMax launches add to; a reused dense bank keeps its range.x)
+        if (int rc = launch_range_w(s, c.a->w_ih, c.a->w_hh, (int64_t)d.Gw * d.H * d.H, d.compact || c.a->reuse_tables != 1, rg))
+            return rc;
         return launch_pack_fwdh(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg,
                                 c.at<void>(c.w.Wp), c.at<float>(c.w.biasc));
     }
@@ -2985,6 +2987,19 @@ int run_seq_reduce(const Call &c, int b, bool backward) {
     return PN_OK;
 }
 
+// Inference without dropout on the fp16 kernels: the input half of the gates is applied to the rows of the bank once
+// (ZW = Z . W_ih^T + b, seq_fwdzw_kernel in pn_seqh.hip) when the table fits the slot the saved gates would take.
+// PN_EVAL_ZW=0 switches it off (A/B runs, tests of the plain inference path).
+inline bool use_zw(const Call &c) {
+    const Dims &d = c.d;
+    const pn_pagg_args *a = c.a;
+    if (d.math != PN_SEQ_MATH_F16X2 || !a->no_save || a->p_seq > 0.0f || a->mask_seq) return false;
+    if (const char *e = getenv("PN_EVAL_ZW"))
+        if (atoi(e) == 0) return false;
+    const size_t need = (size_t)d.ZR * d.G * d.H * 4, have = (size_t)d.Sb * d.W * d.L * d.SV * d.H * 4;
+    return need <= have && need <= ((size_t)2 << 30);
+}
+
 // bound of the factor the sequence dropout applies to a gathered row: 1 / (1 - p), or 16 for explicit masks (the contract
 // of pn_pagg_shape.seq_math)
 inline float seq_xmul(const pn_pagg_args *a) {
@@ -3014,6 +3029,11 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     sp.dyn = a->step_state;
     sp.mask = a->mask_seq;
     StageTimer tm(c.ctx, ST_SEQ_FWD, c.stream);
+    if (!save && use_zw(c)) {
+        sp.range = c.at<SeqRange>(c.w.range);
+        sp.ZW = c.at<const float>(c.w.saved);
+        return launch_seq_fwdzw(c.ctx, c.stream, d.H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp);
+    }
     if (d.math == PN_SEQ_MATH_F16X2) {
         sp.range = c.at<SeqRange>(c.w.range);
         sp.xmul = seq_xmul(a);
@@ -3142,13 +3162,33 @@ int run_tables(const Call &c, JoinGuard &joiner) {
     }
     // the fp16 recurrence scales the gathered rows by a power of two taken from the largest |Z| of the rows just computed
     // (a reused dense Z keeps its record: it sits next to Z in the workspace)
+    if (int rc = joiner.join()) return rc;      // the recurrence needs the plan and the packed weights
+    // (after the join: the packing stream's range_w_kernel cleared the slot this launch adds to)
     if (d.math == PN_SEQ_MATH_F16X2 && (d.compact || a->reuse_tables != 1)) {
         StageTimer tm(ctx, ST_BANK, stream);
         if (int rc = launch_range_rows(stream, c.Z, d.ZR, H, d.compact ? c.at<const int32_t>(c.w.seg) + L : nullptr,
                                        c.at<SeqRange>(c.w.range)))
             return rc;
     }
-    return joiner.join();       // the recurrence needs the plan and the packed weights
+    if (use_zw(c)) {
+        // ZW [rows of Z, G*H] = Z . W_ih^T + (b_ih + b_hh)  (GRU: its four slots): Wcat in the slot of the backward's packed
+        // weights, the table in the slot of the saved gates -- neither is used by an inference forward
+        StageTimer tm(ctx, ST_BANK, stream);
+        const int GH = d.G * H;
+        const int64_t n = (int64_t)GH * 2 * H;
+        float *Wcat = c.at<float>(c.w.WpT);
+        hipLaunchKernelGGL(gen_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a->w_ih, a->w_hh, a->b_ih,
+                           a->b_hh, H, d.G, d.cell == CELL_GRU ? 1 : 0, Wcat, (float *)nullptr, c.at<float>(c.w.biasc));
+        PN_CHECK_HIP(hipGetLastError());
+        const int M = (int)d.ZR;
+        const bool g3 = H % G3_KT == 0 && (int64_t)((M + G3_BM - 1) / G3_BM) * ((GH + G3_BN - 1) / G3_BN) >= 256;
+        if (g3) {
+            if (int rc = launch_gemm3(stream, c.Z, H, Wcat, 2 * H, c.at<float>(c.w.saved), GH, c.at<float>(c.w.biasc), M, GH, H)) return rc;
+        } else if (int rc = launch_gemm(stream, c.Z, H, 1, nullptr, Wcat, 2 * H, 1, c.at<float>(c.w.saved), GH, c.at<float>(c.w.biasc), M,
+                                        GH, H, 0, GEMM_STORE, 1))
+            return rc;
+    }
+    return PN_OK;
 }
 
 // dst[clamp(keys[i])] += contribution i (rows[i] or scal[i] * vec) for i < K, in the order of i (deterministic mode)

@@ -40,6 +40,7 @@ struct SeqFwdParams {
     int store_x;            // seq_fwd4_kernel: keep x_t (after dropout) in xh for the weight-gradient GEMM
     const SeqRange *range;  // fp16 kernels: operand ranges (device)
     float xmul;             // fp16 kernels: bound of the factor dropout applies to a gathered row (1 / (1 - p), or 16 for explicit masks)
+    const float *ZW;        // seq_fwdzw_kernel: [rows of Z, G*H] = Z . W_ih^T + b (inference without dropout)
 };
 
 struct SeqBwdParams {
@@ -105,13 +106,16 @@ int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nspl
 
 // ---- pn_seqh.hip: the recurrent kernels on the fp16 matrix pipe (three MFMAs per fp32 product, two planes) ------------
 // every multiple of 32 up to 256 as hidden size; gc: 4 = LSTM, 1 = tanh RNN, 3 = GRU on the LSTM's four gate slots
-int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, SeqRange *range);
-// range->x = max |rows[r, :]| over r < (count ? *count : rows): zeroes the slot first (same stream)
+// range->w_ih / w_hh = the maxima (one workgroup, stores); clears range->dg and, with clear_x, range->x for the launches below
+int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, int clear_x, SeqRange *range);
+// range->x = max(range->x, |rows[r, :]|) over r < (count ? *count : rows); ordered after the launch_range_w that cleared it
 int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, const int32_t *count, SeqRange *range);
 int launch_pack_fwdh(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
                      int gru, const SeqRange *range, void *Wp, float *biasc);
 int launch_pack_bwdh(void *stream, const float *w_ih, const float *w_hh, int H, int G, int gru, const SeqRange *range, void *WpT);
 int launch_seq_fwdh(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
+// inference forward over pre-projected rows (sp.ZW): only the W_hh half of the products remains
+int launch_seq_fwdzw(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
 int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp);
 int launch_wgradh(pn_context *ctx, void *stream, const WgradParams &wp, int H, int nsplit);
 

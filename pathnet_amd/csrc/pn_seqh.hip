@@ -68,19 +68,28 @@ namespace {
 __device__ __forceinline__ uint32_t fbits_abs(float v) { return __float_as_uint(v) & 0x7fffffffu; }
 
 // ---- operand ranges ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void range_w_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int64_t n4,
-                                                      SeqRange *__restrict__ range) {
+// One workgroup: max |W_ih|, max |W_hh| stored (no atomics, nothing to clear beforehand); it also clears the slots the
+// atomicMax kernels of this call add to -- x unless the call keeps the bank of an earlier one, and dg -- so that a step
+// issues no memset launch of its own.  Runs ahead of the weight packing, on the stream that packs.
+__global__ __launch_bounds__(1024) void range_w_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int64_t n4,
+                                                       int clear_x, SeqRange *__restrict__ range) {
+    __shared__ float red[2][16];
     float m0 = 0.0f, m1 = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
         const float4 a = reinterpret_cast<const float4 *>(w_ih)[i], b = reinterpret_cast<const float4 *>(w_hh)[i];
         m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
         m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
     }
     m0 = wave_max(m0);
     m1 = wave_max(m1);
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&range->w_ih, __float_as_uint(m0));
-        atomicMax(&range->w_hh, __float_as_uint(m1));
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = m0, red[1][threadIdx.x >> 6] = m1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) m0 = fmaxf(m0, red[0][w]), m1 = fmaxf(m1, red[1][w]);
+        range->w_ih = __float_as_uint(m0);
+        range->w_hh = __float_as_uint(m1);
+        range->dg = 0u;
+        if (clear_x) range->x = 0u;
     }
 }
 
@@ -429,6 +438,139 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             __syncthreads();
         }
         HSTAMP(4 * t + 3);
+    }
+}
+
+// =====================================================================================================================
+// Inference forward with the input half of the gates applied BEFORE the gather.  Without dropout x_t is the gathered bank
+// row itself, so W_ih x_t + b depends on (node, code) only -- the argument that put the distance bank before the gather
+//  applies once more: ZW[row] = Z[row] . W_ih^T + b is ONE GEMM over the rows of the bank (the caller:
+// pn_pagg.hip, run_tables), a path step gathers its G*H pre-activations straight into the accumulator layout, and the
+// recurrence keeps only the W_hh half of its products -- half the MFMAs and half the weight-fragment stream per step, no x
+// tile in LDS, no step-0 products at all.  The validation and test forwards of an epoch (PathNet_run.py:359-362, :378) are
+// two of its three forwards.
+//   acc = S ZW[row] + (s_h h) . (2^e_hh W_hh)^T   with S = s_h 2^e_hh as in seq_fwdh_kernel; the weights are the same
+//   packed planes, of which only the k-steps KX .. KS-1 (the h half) are read.
+// =====================================================================================================================
+template <int H, int GC>
+__global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, 1>())) void seq_fwdzw_kernel(SeqFwdParams p) {
+    constexpr int G = GC == 3 ? 4 : GC;
+    constexpr bool GRU = GC == 3;
+    constexpr int MT = 32, NW = H / 32, NT = NW * 64, GH = G * H;
+    constexpr int KS = H / 8, KX = KS / 2, KH = KS - KX;      // k-steps of 16 over [x | h]: the last KH walk h
+    constexpr int PB = 2 * H + 16, PLANE = MT * PB;           // the tile holds h_{t-1} only
+    constexpr bool PING_PONG = fwdh_waves<H, 1>() < 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+    int *s_rowidx = reinterpret_cast<int *>(ldsb + 2 * PLANE);  // [MT][L] gather rows of this tile
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
+    const int q0 = blockIdx.x * MT;
+    const int col = 32 * wave + li;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = q0 + i / p.L < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
+    const FwdScales sc = fwd_scales(p.range, 1.0f);
+    f32x16 cst;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
+    float *hn_t = p.hn + (size_t)q0 * H;
+    __syncthreads();
+
+    for (int t = 0; t < p.L; t++) {
+        const int lane_k = fresh_lane();
+        // ---- the gathered pre-activations, in accumulator layout (rows past P read the table's row 0)
+        f32x16 acc[G];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float *zw = p.ZW + (size_t)(uint32_t)s_rowidx[acc_row(r, lane_k) * p.L + t] * GH + col;
+#pragma unroll
+            for (int g = 0; g < G; g++) acc[g][r] = zw[g * H] * sc.S;
+        }
+        if (t > 0) {
+            const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.Wp) + (size_t)wave_u * (KS * 2 * G * 1024) +
+                                      (size_t)KX * 2 * (G * 1024);
+            const uint32_t voff = lane_k * 16;
+            const unsigned char *arow = ldsb + (lane_k & 31) * PB + 16 * (lane_k >> 5);
+            u32x4 Bha[G], Bhb[G], Bl[G];
+            auto load = [&](u32x4 (&B)[G], int s, int pl) {
+                async_load_frags<G>(B, wb + (size_t)(s * 2 + pl) * (G * 1024), voff);
+            };
+            u32x4 a[2];
+            auto aread = [&](int s, int pl) { return *reinterpret_cast<const u32x4 *>(arow + 32 * s + pl * PLANE); };
+            auto prod = [&](int pa, u32x4 (&B)[G]) {
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = mfma_f16(a[pa], B[g], acc[g]);
+            };
+            auto kstep = [&](int s, u32x4 (&Bh)[G], u32x4 (&Bhnext)[G]) {       // (the pipeline of seq_fwdh_kernel)
+                const int sn = min(s + 1, KH - 1);
+                if (PING_PONG) load(Bhnext, sn, 0);
+                wait_frag<(PING_PONG ? 2 : 1) * G, G>(Bh);
+                prod(1, Bh);
+                a[1] = aread(sn, 1);
+                prod(0, Bh);
+                if (!PING_PONG) load(Bh, sn, 0);
+                wait_frag<G, G>(Bl);
+                prod(0, Bl);
+                a[0] = aread(sn, 0);
+                load(Bl, sn, 1);
+            };
+            a[0] = aread(0, 0);
+            a[1] = aread(0, 1);
+            load(Bha, 0, 0);
+            load(Bl, 0, 1);
+#pragma unroll 1
+            for (int s = 0; s < KH; s += 2) {
+                if (PING_PONG) {
+                    kstep(s, Bha, Bhb);
+                    if (KH % 2 == 0 || s + 1 < KH) kstep(s + 1, Bhb, Bha);
+                } else {
+                    kstep(s, Bha, Bha);
+                    if (KH % 2 == 0 || s + 1 < KH) kstep(s + 1, Bha, Bha);
+                }
+            }
+            wait_frag<0, G>(Bha);
+            if (PING_PONG) wait_frag<0, G>(Bhb);
+            wait_frag<0, G>(Bl);
+            __syncthreads();  // every wave is done reading h_{t-1}
+        }
+        const int lane_o = fresh_lane();
+        float hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float h;
+            if (GRU) {
+                const float rg = sigmoidf_(acc[0][r] * sc.inv_S);
+                const float zg = sigmoidf_(acc[G > 1 ? 1 : 0][r] * sc.inv_S);
+                const float nh = acc[G > 3 ? 3 : 0][r] * sc.inv_S;
+                const float ng = tanhf_(acc[G > 2 ? 2 : 0][r] * sc.inv_S + rg * nh);
+                h = (1.0f - zg) * ng + zg * cst[r];
+                cst[r] = h;
+            } else if (G == 4) {
+                const float ig = sigmoidf_(acc[0][r] * sc.inv_S);
+                const float fg = sigmoidf_(acc[G > 1 ? 1 : 0][r] * sc.inv_S);
+                const float gg = tanhf_(acc[G > 2 ? 2 : 0][r] * sc.inv_S);
+                const float og = sigmoidf_(acc[G > 3 ? 3 : 0][r] * sc.inv_S);
+                const float c = fg * cst[r] + ig * gg;
+                cst[r] = c;
+                h = og * tanhf_(c);
+            } else {
+                h = tanhf_(acc[0][r] * sc.inv_S);
+            }
+            hv[r] = h;
+            const int row = acc_row(r, lane_o);
+            if (t == p.L - 1 && q0 + row < p.P) at_bytes(hn_t, ((uint32_t)row * (uint32_t)H + col) * 4u) = h;
+        }
+        if (t + 1 < p.L) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                uint32_t h0, h1;
+                split2h(hv[r] * sc.s_h, hv[r + 1] * sc.s_h, h0, h1);
+                unsigned char *d = ldsb + acc_row(r, lane_o) * PB + 2 * col;
+                *reinterpret_cast<uint16_t *>(d) = (uint16_t)h0;
+                *reinterpret_cast<uint16_t *>(d + PB) = (uint16_t)(h0 >> 16);
+                *reinterpret_cast<uint16_t *>(d + PLANE) = (uint16_t)h1;
+                *reinterpret_cast<uint16_t *>(d + PLANE + PB) = (uint16_t)(h1 >> 16);
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -958,6 +1100,30 @@ int launch_bwdh_t(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
+template <int H, int GC>
+int launch_fwdzw_t(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
+    constexpr int MT = 32;
+    const size_t lds_bytes = (size_t)2 * MT * (2 * H + 16) + (size_t)(MT * sp.L) * 4;
+    auto kern = seq_fwdzw_kernel<H, GC>;
+    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
+    hipLaunchKernelGGL(kern, dim3((sp.P + MT - 1) / MT), dim3(H / 32 * 64), lds_bytes, stream, sp);
+    PN_CHECK_HIP(hipGetLastError());
+    return PN_OK;
+}
+template <int GC>
+int dispatch_fwdzw(pn_context *ctx, hipStream_t s, int H, const SeqFwdParams &sp) {
+    switch (H) {
+        case 32: return launch_fwdzw_t<32, GC>(ctx, s, sp);
+        case 64: return launch_fwdzw_t<64, GC>(ctx, s, sp);
+        case 96: return launch_fwdzw_t<96, GC>(ctx, s, sp);
+        case 128: return launch_fwdzw_t<128, GC>(ctx, s, sp);
+        case 160: return launch_fwdzw_t<160, GC>(ctx, s, sp);
+        case 192: return launch_fwdzw_t<192, GC>(ctx, s, sp);
+        case 224: return launch_fwdzw_t<224, GC>(ctx, s, sp);
+        case 256: return launch_fwdzw_t<256, GC>(ctx, s, sp);
+    }
+    PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
+}
 template <int GC>
 int dispatch_fwdh(pn_context *ctx, hipStream_t s, int H, const SeqFwdParams &sp) {
     switch (H) {
@@ -997,19 +1163,14 @@ extern "C" int pn_debug_set_trace_h(long long *dev_buf) {     // tuning builds o
 
 namespace pn {
 
-int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, SeqRange *range) {
-    hipStream_t s = (hipStream_t)stream;
-    PN_CHECK_HIP(hipMemsetAsync(&range->w_ih, 0, 2 * sizeof(uint32_t), s));
-    const int64_t n4 = n_each / 4;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, (n4 + 255) / 256));
-    hipLaunchKernelGGL(range_w_kernel, dim3(blocks), dim3(256), 0, s, w_ih, w_hh, n4, range);
+int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, int clear_x, SeqRange *range) {
+    hipLaunchKernelGGL(range_w_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_ih, w_hh, n_each / 4, clear_x, range);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
 
 int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, const int32_t *count, SeqRange *range) {
-    hipStream_t s = (hipStream_t)stream;
-    PN_CHECK_HIP(hipMemsetAsync(&range->x, 0, sizeof(uint32_t), s));
+    hipStream_t s = (hipStream_t)stream;        // (range->x was cleared by launch_range_w, ordered before this launch)
     const int64_t n4 = nrows * (H / 4);
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (n4 + 2047) / 2048));
     hipLaunchKernelGGL(range_rows_kernel, dim3(blocks), dim3(256), 0, s, rows, nrows, H / 4, count, range);
@@ -1038,10 +1199,15 @@ int launch_seq_fwdh(pn_context *ctx, void *stream, int H, int gc, const SeqFwdPa
     return gc == 3 ? dispatch_fwdh<3>(ctx, s, H, sp) : gc == 4 ? dispatch_fwdh<4>(ctx, s, H, sp) : dispatch_fwdh<1>(ctx, s, H, sp);
 }
 
+int launch_seq_fwdzw(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp) {
+    if (!sp.range || !sp.ZW) PN_FAIL(PN_ERR_ARG, "seq_fwdzw: operand ranges / ZW missing");
+    hipStream_t s = (hipStream_t)stream;
+    return gc == 3 ? dispatch_fwdzw<3>(ctx, s, H, sp) : gc == 4 ? dispatch_fwdzw<4>(ctx, s, H, sp) : dispatch_fwdzw<1>(ctx, s, H, sp);
+}
+
 int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp) {
     if (!sp.range) PN_FAIL(PN_ERR_ARG, "seq_bwdh: operand ranges missing");
-    hipStream_t s = (hipStream_t)stream;
-    PN_CHECK_HIP(hipMemsetAsync(&sp.range->dg, 0, sizeof(uint32_t), s));
+    hipStream_t s = (hipStream_t)stream;        // (range->dg was cleared by the forward's launch_range_w)
     return gc == 3 ? dispatch_bwdh<3>(ctx, s, H, sp) : gc == 4 ? dispatch_bwdh<4>(ctx, s, H, sp) : dispatch_bwdh<1>(ctx, s, H, sp);
 }
 

@@ -228,3 +228,30 @@ def test_shape_info_reports_the_arithmetic():
     assert modules.shape_info(sh)[3] == 0
     sh = modules._shape("homo", 300, 16, 128, 3, 10, 5, 4, cell="mean")
     assert modules.shape_info(sh)[3] == 0
+
+
+@pytest.mark.parametrize("variant,H,cell,L", [("homo", 128, None, 4), ("hetero", 128, None, 4), ("pagg", 128, None, 4),
+                                              ("homo", 128, "gru", 4), ("homo", 64, None, 6), ("pagg", 96, "lstm", 4),
+                                              ("hetero", 256, None, 4), ("homo", 32, "rnn", 1)])
+def test_inference_forward_with_the_input_gates_applied_before_the_gather(variant, H, cell, L, monkeypatch):
+    """eval-mode no-grad forwards run seq_fwdzw_kernel (ZW = Z . W_ih^T + b once per bank row, only the W_hh products per
+    step; PathNet_run.py:359-362, :378): same logits as the plain inference path (PN_EVAL_ZW=0) and as the CPU oracle"""
+    import pathnet_amd
+    W = 9
+    m, X, sel, ids, codes, ms, mc, G = _oracle_case(variant, H, 70, W, L, cell=cell)
+    m.eval()
+    S, N = len(sel), X.shape[0]
+    mask = np.zeros(N, bool)
+    mask[sel] = True
+    args = (X.cuda(), torch.as_tensor(ids.reshape(S, W * L).astype(np.int64)), W, L, mask, torch.as_tensor(codes.astype(np.int64)), None)
+    with torch.no_grad():
+        monkeypatch.setenv("PN_EVAL_ZW", "0")
+        plain = m(*args).clone()
+        monkeypatch.setenv("PN_EVAL_ZW", "1")
+        got = m(*args).clone()
+        again = m(*args, reuse_tables=True).clone()         # the test forward of an epoch: tables reused, ZW rebuilt
+    params = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want = po.forward(variant, params, X, ids, codes, sel, W, L, cell=cell)
+    assert (got - plain).abs().max().item() <= 2e-6
+    assert torch.equal(got, again)
+    assert (got.cpu() - want).abs().max().item() < 1e-5
