@@ -285,11 +285,33 @@ __global__ __launch_bounds__(kWalkThreads) void merw_walk_kernel(WalkParams p) {
 // length of a real path, i.e. an upper bound.  The backward search is depth-limited by the best bound found so
 // far (best - 1 - RF), which for L <= RF + 2 (L = 4) means no search at all and for L = 6 two levels.
 // A hub whose 2-ball overflows the table falls back to RF = 1 or 0 (deeper backward search, still exact).
+//
+// Round 4 -- the LAST level of that search is where the time went at L = 6 (configs[4]: a walk node at step 5 is hardly
+// ever inside the 2-ball, so all 16 in-neighbours and all their 256 in-neighbours were looked up, for nothing: 195 M
+// paths/s against 17 G at L = 4).  Scanning the in-neighbours cc of a node c at the last allowed level can only succeed if
+// some cc lies in the ball, i.e. if c is an out-neighbour of a ball node; for c outside the ball that means c is an
+// out-neighbour of a LEVEL-2 node.  Those are recorded once per source node in a Bloom filter (32 Kbit, two hashes: no false
+// negatives) and a last-level scan is entered only on "maybe" -- a false positive costs one wasted scan, never a wrong code.
+// A node c found inside the ball is not expanded either: the best path through it is k + df(c), already recorded.
 // =================================================================================================
-constexpr int kOtfWaves = 4;                  // source nodes per workgroup
+#ifndef PN_OTF_ABL
+#define PN_OTF_ABL 0     // tuning builds only: 1 = no Bloom filter (round 3's search), 2 = no backward search at all (wrong codes)
+#endif
+constexpr int kOtfWaves = 2;                  // source nodes per workgroup (16 KB of LDS each: five workgroups per CU)
 constexpr int kOtfCap = 2048;                 // hash slots per wave (8 KB)
 constexpr uint32_t kOtfEmpty = 0xFFFFFFFFu;
 constexpr int kOtfMaxDepth = 8;
+constexpr int kOtfBloomWords = 1024;          // 32 Kbit per wave
+__device__ __forceinline__ void otf_bloom_bits(int32_t node, uint32_t &b0, uint32_t &b1, uint32_t &b2) {
+    b0 = ((uint32_t)node * 0x9E3779B1u) >> 17;         // 15 bits each
+    b1 = ((uint32_t)node * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 17;
+    b2 = ((uint32_t)node * 0xC2B2AE35u + 0x165667B1u) >> 17;
+}
+__device__ __forceinline__ bool otf_bloom_maybe(const uint32_t *bloom, int32_t node) {
+    uint32_t b0, b1, b2;
+    otf_bloom_bits(node, b0, b1, b2);
+    return ((bloom[b0 >> 5] >> (b0 & 31)) & (bloom[b1 >> 5] >> (b1 & 31)) & (bloom[b2 >> 5] >> (b2 & 31)) & 1u) != 0;
+}
 
 struct OtfParams {
     WalkParams w;
@@ -330,11 +352,14 @@ template <int DRAW>
 __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams op) {
     __shared__ uint32_t s_tab[kOtfWaves][kOtfCap];
     __shared__ int s_cnt[kOtfWaves];
-    __shared__ uint32_t s_cur[kOtfWaves][kOtfMaxDepth][64];   // per lane DFS cursor / end per level (CSR positions)
-    __shared__ uint32_t s_end[kOtfWaves][kOtfMaxDepth][64];
+    __shared__ uint32_t s_stack[kOtfWaves][2][kOtfMaxDepth][64];   // per lane DFS cursor / end per level (CSR positions);
+                                                                    // before the walks: the list of the ball's level-2 nodes
+    __shared__ uint32_t s_bloom[kOtfWaves][kOtfBloomWords];
     const WalkParams &p = op.w;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int st_l = blockIdx.x * kOtfWaves + wave;
+#define CUR(d_) s_stack[wave][0][d_][lane]
+#define END(d_) s_stack[wave][1][d_][lane]
     if (st_l >= p.node_count) return;                       // wave-uniform; no block barriers below
     const int32_t st = p.node_list ? min(max(p.node_list[st_l], 0), p.n - 1) : p.node_begin + st_l;
     uint32_t *tab = s_tab[wave];
@@ -377,6 +402,45 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
     }
     __builtin_amdgcn_wave_barrier();
 
+    // ---- out-neighbours of the ball's level-2 nodes -> Bloom filter (only when a search can happen: L >= rf + 3) ----------
+    uint32_t *bloom = s_bloom[wave];
+    bool bloom_ok = false;
+    if (rf == 2 && p.L >= 5 && PN_OTF_ABL != 1) {
+        uint32_t *list = &s_stack[wave][0][0][0];             // 2 * kOtfMaxDepth * 64 = 1024 entries: the table is at most half full
+        for (int i = lane; i < kOtfBloomWords; i += 64) bloom[i] = 0u;
+        if (lane == 0) s_cnt[wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < kOtfCap; i += 64) {
+            const uint32_t v = tab[i];
+            if (v != kOtfEmpty && (v & 7u) == 2u) list[atomicAdd(&s_cnt[wave], 1)] = v >> 3;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int n2 = s_cnt[wave];
+        // a lane per level-2 node: its out-neighbours, three bits each; the list bounds of a lane's NEXT node are fetched
+        // while it walks the current one
+        int64_t kb_n = 0, ke_n = 0;
+        if (lane < n2) kb_n = op.adj_off[(int32_t)list[lane]], ke_n = op.adj_off[(int32_t)list[lane] + 1];
+        for (int i = lane; i < n2; i += 64) {
+            const int64_t kb = kb_n, ke = ke_n;
+            if (i + 64 < n2) kb_n = op.adj_off[(int32_t)list[i + 64]], ke_n = op.adj_off[(int32_t)list[i + 64] + 1];
+            for (int64_t k = kb; k < ke; k += 4) {       // four loads in flight (the tail repeats the last entry)
+                int32_t nb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) nb[u] = op.adj[min(k + u, ke - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    uint32_t b0, b1, b2;
+                    otf_bloom_bits(nb[u], b0, b1, b2);
+                    atomicOr(&bloom[b0 >> 5], 1u << (b0 & 31));
+                    atomicOr(&bloom[b1 >> 5], 1u << (b1 & 31));
+                    atomicOr(&bloom[b2 >> 5], 1u << (b2 & 31));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        bloom_ok = true;
+    }
+
     // ---- walks: lane = walk index (loop when W > 64), all epochs of the window -------------------------
     const int64_t epoch_begin = p.dyn ? p.dyn->epoch : p.epoch_begin;
     const uint64_t seed = p.dyn ? p.dyn->seed : p.seed;
@@ -399,25 +463,78 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
                     const int d0 = otf_lookup(tab, x);
                     if (d0 >= 0 && d0 < best) best = d0;
                     // depth-limited DFS over in-neighbour chains; a level k can only help while k <= best - 1 - rf
-                    if (best - 1 - rf >= 1) {
+                    if (PN_OTF_ABL != 2 && bloom_ok && best - 1 - rf <= 2) {
+                        // the common case (L <= 7 with the full 2-ball): at most two levels, written as two loops with the
+                        // in-neighbour ids fetched four at a time -- same candidates as the generic search below
+                        // Level 1 for every lane first; the in-neighbours that pass the filter are only NOTED (a lane's
+                        // 16 stack slots), and expanded afterwards, each lane walking its own short list: a wavefront runs
+                        // a level-2 scan whenever ANY of its lanes has one, so expanding inside the level-1 loop cost the
+                        // wave one scan per level-1 position (1 - 0.95^40 = 87 % of them) instead of one per list entry.
+                        int n_cand = 0;
+                        if (best - 1 - rf == 2 || (best - 1 - rf == 1 && otf_bloom_maybe(bloom, x))) {
+                            const uint32_t e1 = (uint32_t)op.radj_off[x + 1];
+                            for (uint32_t j = (uint32_t)op.radj_off[x]; j < e1; j += 4) {
+                                int32_t c[4];
+#pragma unroll
+                                for (int u = 0; u < 4; u++) c[u] = op.radj[min(j + u, e1 - 1)];
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    const int dc = otf_lookup(tab, c[u]);
+                                    if (dc >= 0) {
+                                        if (1 + dc < best) best = 1 + dc;
+                                    } else if (best - 1 - rf == 2 && j + u < e1 && otf_bloom_maybe(bloom, c[u])) {
+                                        if (n_cand < 2 * kOtfMaxDepth) {
+                                            s_stack[wave][n_cand >> 3][n_cand & 7][lane] = (uint32_t)c[u];
+                                            n_cand++;
+                                        } else {        // (list full: expand right here)
+                                            const uint32_t e2 = (uint32_t)op.radj_off[c[u] + 1];
+                                            for (uint32_t i2 = (uint32_t)op.radj_off[c[u]]; i2 < e2 && best - 1 - rf == 2; i2++) {
+                                                const int d2 = otf_lookup(tab, op.radj[i2]);
+                                                if (d2 >= 0 && 2 + d2 < best) best = 2 + d2;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        // c may be an out-neighbour of a level-2 ball node: dist(st, c) = 3 iff one of ITS in-neighbours is one
+                        for (int q = 0; q < n_cand && best - 1 - rf == 2; q++) {
+                            const int32_t c = (int32_t)s_stack[wave][q >> 3][q & 7][lane];
+                            const uint32_t e2 = (uint32_t)op.radj_off[c + 1];
+                            for (uint32_t i2 = (uint32_t)op.radj_off[c]; i2 < e2 && best - 1 - rf == 2; i2 += 4) {
+                                int32_t cc[4];
+#pragma unroll
+                                for (int w2 = 0; w2 < 4; w2++) cc[w2] = op.radj[min(i2 + w2, e2 - 1)];
+#pragma unroll
+                                for (int w2 = 0; w2 < 4; w2++) {
+                                    const int d2 = otf_lookup(tab, cc[w2]);
+                                    if (d2 >= 0 && 2 + d2 < best) best = 2 + d2;
+                                }
+                            }
+                        }
+                    } else if (PN_OTF_ABL != 2 && best - 1 - rf >= 1 && !(bloom_ok && best - 1 - rf == 1 && !otf_bloom_maybe(bloom, x))) {
                         int d = 0;
-                        s_cur[wave][0][lane] = (uint32_t)op.radj_off[x];
-                        s_end[wave][0][lane] = (uint32_t)op.radj_off[x + 1];
+                        CUR(0) = (uint32_t)op.radj_off[x];
+                        END(0) = (uint32_t)op.radj_off[x + 1];
                         while (d >= 0) {
-                            const uint32_t cur = s_cur[wave][d][lane];
-                            if (cur >= s_end[wave][d][lane] || d + 1 > best - 1 - rf) {
+                            const uint32_t cur = CUR(d);
+                            if (cur >= END(d) || d + 1 > best - 1 - rf) {
                                 d--;
                                 continue;
                             }
-                            s_cur[wave][d][lane] = cur + 1;
+                            CUR(d) = cur + 1;
                             const int32_t c = op.radj[cur];
                             const int k = d + 1;
                             const int dc = otf_lookup(tab, c);
                             if (dc >= 0 && k + dc < best) best = k + dc;
-                            if (k + 1 <= best - 1 - rf && d + 1 < kOtfMaxDepth) {
+                            // expand c (scan ITS in-neighbours at level k + 1)?  Not when c is in the ball (k + df(c) is the
+                            // best any path through c can do); at the last allowed level only when c can be an out-
+                            // neighbour of a level-2 ball node at all
+                            if (dc < 0 && k + 1 <= best - 1 - rf && d + 1 < kOtfMaxDepth &&
+                                !(bloom_ok && k + 1 == best - 1 - rf && !otf_bloom_maybe(bloom, c))) {
                                 d++;
-                                s_cur[wave][d][lane] = (uint32_t)op.radj_off[c];
-                                s_end[wave][d][lane] = (uint32_t)op.radj_off[c + 1];
+                                CUR(d) = (uint32_t)op.radj_off[c];
+                                END(d) = (uint32_t)op.radj_off[c + 1];
                             }
                         }
                     }
@@ -443,6 +560,8 @@ __global__ __launch_bounds__(kOtfWaves * 64) void merw_walk_otf_kernel(OtfParams
             }
         }
     }
+#undef CUR
+#undef END
 }
 
 }  // namespace

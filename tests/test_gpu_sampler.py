@@ -211,7 +211,7 @@ def hub_and_directed_graph(n, seed):
     return n, src, dst, p
 
 
-@pytest.mark.parametrize("L,W", [(4, 40), (6, 12), (3, 5)])
+@pytest.mark.parametrize("L,W", [(4, 40), (6, 12), (3, 5), (5, 9), (8, 6)])
 def test_otf_hop_codes_match_dense_on_hubs_and_directed_edges(L, W):
     from pathnet_amd import DRAW_PHILOX, MerwSampler
     n, u, v, p = hub_and_directed_graph(4000, 9)
