@@ -533,6 +533,21 @@ def time_launches(fn, reps, warm=3):
     return ev0.elapsed_time(ev1) * 1e-3 / reps
 
 
+def deterministic_line(sr, lib, ctx, names, steps, W):
+    """the same step with module.deterministic = True: ms per step and the stages that change"""
+    old = sr.model.deterministic
+    sr.model.deterministic = True
+    try:
+        m = measure(sr, lib, ctx, names, steps, 3, torch.cuda.synchronize)
+        return {"deterministic_ms_per_step": m["elapsed"] / steps * 1e3, "value": sr.S * W / (m["elapsed"] / steps),
+                "unit": "paths/s", "steps": steps,
+                "stages_ms": {k: v for k, v in m["stages_ms"].items() if k in ("pool_bwd", "seq_bwd", "wgrad", "bank_bwd", "fc0_bwd", "fc2_grad")},
+                "note": "seq_bwd is bracketed twice in this mode (the BPTT, then the sorted segmented reduce of its rows): the "
+                        "stage figure is the mean of the two brackets"}
+    finally:
+        sr.model.deterministic = old
+
+
 def extras_single_gpu(lib, ctx, names, dev, sr, args):
     """Untimed extras of the N = 1 report: the other single-GPU configurations and the HBM-side microbenchmarks."""
     import pathnet_amd
@@ -588,6 +603,8 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
             "roofline": roofline_block(mo["dominant"], mo["dom_ms"], mo["dom_launches"], sr.S * W, L, H, None, math=other)}
     finally:
         sr.model.seq_math = old_math
+    # ---- and with the fixed-order backward (pn_pagg_shape.deterministic: bitwise reproducible gradients, no fp32 atomics) ------
+    out["headline_step_deterministic"] = deterministic_line(sr, lib, ctx, names, max(5, args.steps // 2), W)
 
     # ---- configs[2]: Pubmed-scale full training step (on-GPU MERW sampler + PAGG fwd/bwd + Adam) ---------------------
     pw = pubmed_workload()
@@ -607,6 +624,7 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
                   (pw["n"], pw["F"], pw["C"], H, W, L, psr.S, Pp, pw["n"] ** 2 >> 20),
         "value": Pp / (m["elapsed"] / steps_p), "unit": "paths/s", "ms_per_step": m["elapsed"] / steps_p * 1e3,
         "steps": steps_p, "roofline": rb, "stages_ms": m["stages_ms"], "sampler_setup_s": round(setup_s, 2)}
+    out["pubmed_scale_step"]["deterministic"] = deterministic_line(psr, lib, ctx, names, max(3, args.steps // 4), W)
     # sampler at Pubmed size: dense 389 MB table (beyond the Infinity Cache) and exact on-the-fly hop codes
     ids_p = torch.empty((4, pw["n"], W, L), dtype=torch.int32, device=dev)
     codes_p = torch.empty((4, pw["n"], W, L), dtype=torch.uint8, device=dev)

@@ -3593,7 +3593,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         }
 
         // BPTT + gather-backward scatter (mean / sum encoders: the scatter alone)
-        if (d.det) PN_CHECK_HIP(hipMemsetAsync(c.at<float>(c.w.dx), 0, (size_t)Pb * L * H * sizeof(float), stream));
+        // (the fp16 BPTT stores its rows outright; the other kernels add into a zero-filled buffer)
+        if (d.det && !(f16 && G > 0 && !d.generic))
+            PN_CHECK_HIP(hipMemsetAsync(c.at<float>(c.w.dx), 0, (size_t)Pb * L * H * sizeof(float), stream));
         if (G == 0) {
             if (int rc = run_seq_reduce(c, b, true)) return rc;
         } else if (d.generic) {
@@ -3618,6 +3620,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             sp.merge0 = d.variant != PN_VARIANT_HETERO && !d.det;   // (the hetero plan's step-0 rows are other paths' far ends: no runs)
             if (d.det) sp.rowidx = c.at<int32_t>(c.w.iota), sp.dZ = c.at<float>(c.w.dx);     // (see det_scatter_kernel)
             sp.range = range;
+            sp.store_dx = d.det && f16;
             if (f16) {
                 if (int rc = launch_seq_bwdh(ctx, stream, H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp)) return rc;
             } else if (seq4 & SEQ4_BWD) {

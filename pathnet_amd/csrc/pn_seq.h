@@ -58,6 +58,7 @@ struct SeqBwdParams {
     uint64_t seed;
     const float *mask;
     SeqRange *range;        // fp16 kernels: reads w_ih / w_hh, leaves max |dG| in dg
+    int store_dx;           // fp16 kernel, deterministic mode: rowidx is the identity -- mask * dx is STORED (no zero-fill, no atomics)
 };
 
 struct WgradParams {

@@ -909,7 +909,11 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                         dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col];
                     else if (p.keep)
                         dx = (s_keep[((t & 1) * MT + row) * (H / 4) + (col >> 2)] >> (col & 3)) & 1 ? dx * keep_scale : 0.0f;
-                    atomicAdd(p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col), dx);
+                    float *dst = p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col);
+                    if (p.store_dx)
+                        *dst = dx;          // deterministic mode: a row of its own per path step (det_scatter_kernel adds them up)
+                    else
+                        atomicAdd(dst, dx);
                 }
                 dh[r] = GRU ? acc[1][r] * inv_h + dc[r] : acc[1][r] * inv_h;
             }

@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/final}
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --maxfail=10 > $OUT/tests.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --maxfail=10 > $OUT/tests.log 2>&1
 tail -3 $OUT/tests.log
 timeout 420 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -2 $OUT/bench.err

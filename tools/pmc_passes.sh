@@ -5,7 +5,7 @@
 # (stamped with the library's source hash: bench.py quotes it only for the same build).
 set -u
 OUT=${1:-gpurun_out/pmc}
-RE="seq_fwd3|seq_bwd3|wgrad3_kernel|wgrad4_kernel|gather_kernel|merw_walk"
+RE="seq_fwdh|seq_bwdh|wgradh_kernel|seq_fwd3|seq_bwd3|wgrad3_kernel|wgrad4_kernel|gather_kernel|merw_walk"
 export TMPDIR=/tmp
 mkdir -p $OUT
 run_set() {   # workload, pass number, counters...

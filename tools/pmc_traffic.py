@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-STAGE = {"seq_fwd3_kernel": "seq_fwd", "seq_bwd3_kernel": "seq_bwd", "wgrad3_kernel": "wgrad", "wgrad4_kernel": "wgrad", "gather_kernel": "gather",
+STAGE = {"seq_fwdh_kernel": "seq_fwd", "seq_bwdh_kernel": "seq_bwd", "wgradh_kernel": "wgrad", "seq_fwd3_kernel": "seq_fwd", "seq_bwd3_kernel": "seq_bwd", "wgrad3_kernel": "wgrad", "wgrad4_kernel": "wgrad", "gather_kernel": "gather",
          "merw_walk_kernel": "sampler_walk", "merw_walk_otf_kernel": "sampler_walk"}
 
 
