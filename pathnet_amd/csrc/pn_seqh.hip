@@ -36,6 +36,9 @@ using namespace pn;
 #ifndef PN_BWDH_WAVES
 #define PN_BWDH_WAVES 2
 #endif
+#ifndef PN_WGRADH_PAIR
+#define PN_WGRADH_PAIR 0    // 1: the two gate-column blocks of a K split on one XCD (see wgradh_kernel; measured neutral, 0.183 = 0.183 ms)
+#endif
 #ifndef PN_BWDH_TOUCH
 #define PN_BWDH_TOUCH 0     // > 0: the BPTT pulls the saved rows of its NEXT step into L2 while the current step runs (LDS-DMA touches)
 #endif
@@ -942,10 +945,20 @@ __global__ __launch_bounds__(WH_THREADS, 2) void wgradh_kernel(WgradParams p, in
     extern __shared__ __attribute__((aligned(16))) u32x4 ldsw[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * WH_BM, n0 = blockIdx.x * WH_BN;
+    // The two 256-row blocks of gate columns (blockIdx.y) of one K split read the SAME [x | h] rows.  Workgroups are dealt to
+    // the eight XCDs round robin by their linear id, so neighbours (y, z), (y + 1, z) sit on different L2s and both fetch the
+    // rows from memory (PMC: 8.6 row-widths per path step where 6 are needed).  With two column blocks and a multiple of
+    // eight splits the pair is re-mapped eight ids apart -- same XCD, the second read is an L2 hit.
+    unsigned by = blockIdx.y, bz = blockIdx.z;
+    if (PN_WGRADH_PAIR && gridDim.x == 1 && gridDim.y == 2 && gridDim.z % 8 == 0) {
+        const unsigned id = blockIdx.y + 2u * blockIdx.z, blk = id >> 4, r = id & 15u;
+        by = r >> 3;
+        bz = blk * 8u + (r & 7u);
+    }
+    const int m0 = by * WH_BM, n0 = blockIdx.x * WH_BN;
     const int64_t ntiles = (p.R + WH_KT - 1) / WH_KT;
     const int64_t nz = gridDim.z;
-    const int64_t my_tiles = blockIdx.z < ntiles ? (ntiles - blockIdx.z + nz - 1) / nz : 0;
+    const int64_t my_tiles = bz < ntiles ? (ntiles - bz + nz - 1) / nz : 0;
     if (my_tiles == 0) return;      // block-uniform
     f32x16 acc[2][4];
 #pragma unroll
@@ -964,7 +977,7 @@ __global__ __launch_bounds__(WH_THREADS, 2) void wgradh_kernel(WgradParams p, in
     const float *srcc = src + (c_ok ? c0 : 0);
     const float sc_op = exp2i(op == 0 ? e_g : c0 < H ? e_x : e_h);       // (4 | H: a thread's four columns share a half)
     f32x4 rgA[4], rgB[4];
-    auto row0_of = [&](int64_t i) { return (blockIdx.z + min(i, my_tiles - 1) * nz) * WH_KT; };     // (clamped: harmless re-load)
+    auto row0_of = [&](int64_t i) { return (bz + min(i, my_tiles - 1) * nz) * WH_KT; };     // (clamped: harmless re-load)
     auto issue = [&](f32x4 (&rg)[4], int64_t i) {
         const int64_t k0 = row0_of(i);
 #pragma unroll
@@ -1055,7 +1068,7 @@ __global__ __launch_bounds__(WH_THREADS, 2) void wgradh_kernel(WgradParams p, in
     wait_vm<0>(rgB[0], rgB[1], rgB[2], rgB[3]);
     __syncthreads();        // (the bias sums below reuse the stages)
 #undef WH_FENCE
-    float *pw = p.part_w + (int64_t)blockIdx.z * p.GH * p.H2;
+    float *pw = p.part_w + (int64_t)bz * p.GH * p.H2;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1078,7 +1091,7 @@ __global__ __launch_bounds__(WH_THREADS, 2) void wgradh_kernel(WgradParams p, in
     }
     __syncthreads();
     if (tid < WH_BM && m0 + tid < p.GH)
-        p.part_b[(int64_t)blockIdx.z * p.GH + m0 + tid] =
+        p.part_b[(int64_t)bz * p.GH + m0 + tid] =
             (fl[tid] + fl[WH_BM + tid]) + (fl[2 * WH_BM + tid] + fl[3 * WH_BM + tid]);
 }
 
