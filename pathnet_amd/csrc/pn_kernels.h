@@ -87,6 +87,26 @@ __device__ __forceinline__ float exp2i(int e) {
     return __uint_as_float((uint32_t)((e > 127 ? 127 : e) + 127) << 23);
 }
 
+// ---- the LSTM's four gate values of one (path step, unit) in 96 bits (fp16 kernels' saved-for-backward layout) --------------
+// i, f, o in [0, 1] and g in [-1, 1] as 24-bit fixed point: steps of 2^-24 / 2^-23, i.e. the ABSOLUTE precision fp32 itself
+// has for values near 1.  The BPTT multiplies them into gradients whose own fp32 rounding is of that size; what is lost is
+// relative precision of gates below ~2^-8, whose products i (1 - i), ... are then small in absolute terms.  Three dwords
+// instead of four per element: -0.11 GB each way at the headline shape.  (The forward's own recurrence uses the unrounded
+// values; NaN packs as a finite value -- the forward's h and the loss still carry it.)
+__device__ __forceinline__ uint3 pack_gates(float i, float f, float g, float o) {
+    const uint32_t qi = (uint32_t)fminf(fmaf(i, 16777216.0f, 0.5f), 16777215.0f);
+    const uint32_t qf = (uint32_t)fminf(fmaf(f, 16777216.0f, 0.5f), 16777215.0f);
+    const uint32_t qo = (uint32_t)fminf(fmaf(o, 16777216.0f, 0.5f), 16777215.0f);
+    const uint32_t qg = (uint32_t)fminf(fmaf(g + 1.0f, 8388608.0f, 0.5f), 16777215.0f);
+    return make_uint3(qi | (qf << 24), (qf >> 8) | (qg << 16), (qg >> 16) | (qo << 8));
+}
+__device__ __forceinline__ void unpack_gates(uint3 w, float &i, float &f, float &g, float &o) {
+    i = (float)(w.x & 0xffffffu) * (1.0f / 16777216.0f);
+    f = (float)((w.x >> 24) | ((w.y & 0xffffu) << 8)) * (1.0f / 16777216.0f);
+    g = (float)((w.y >> 16) | ((w.z & 0xffu) << 16)) * (1.0f / 8388608.0f) - 1.0f;
+    o = (float)(w.z >> 8) * (1.0f / 16777216.0f);
+}
+
 // ---- weight-fragment loads the compiler must not re-schedule -------------------------------------------
 // hipcc sinks ordinary loads of loop-invariant-addressable data next to their first use (it re-issues the
 // load instead of carrying registers around the loop), which turns a software prefetch into a load -> wait ->

@@ -42,6 +42,9 @@ using namespace pn;
 #ifndef PN_BWDH_TOUCH
 #define PN_BWDH_TOUCH 0     // > 0: the BPTT pulls the saved rows of its NEXT step into L2 while the current step runs (LDS-DMA touches)
 #endif
+#ifndef PN_SEQH_PACK
+#define PN_SEQH_PACK 1      // the LSTM's saved gates as 3 dwords per element (pn_kernels.h: pack_gates) instead of 4
+#endif
 #ifndef PN_BWDH_CARRY
 #define PN_BWDH_CARRY 1     // 1: c_{t-1}, loaded for step t, stays in registers as step t-1's c_t
 #endif
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
     constexpr int G = GC == 3 ? 4 : GC;
     constexpr bool GRU = GC == 3;
     constexpr int MT = 32 * RB;
-    constexpr int NW = H / 32, NT = NW * 64, SV = (G == 4 ? 5 : 1);
+    constexpr bool PACKED = GC == 4 && PN_SEQH_PACK;      // LSTM: gates as 3 dwords + c (pack_gates): 4 H dwords per path step
+    constexpr int NW = H / 32, NT = NW * 64, SV = PACKED ? 4 : (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
     constexpr int PB = 4 * H + 16;            // row pitch of a plane of the tile [x | h], bytes: conflict-free ds_read_b128
     constexpr int PLANE = MT * PB;
@@ -406,8 +410,14 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 cst[rb][r] = c;
                 h = og * tanhf_(c);
                 if (saved_t && q < p.P) {
-                    float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
-                    sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; if (!(PN_ABL & 2)) sv[3 * H] = og; sv[4 * H] = c;
+                    const uint32_t base = ((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H);
+                    if constexpr (PACKED) {
+                        *reinterpret_cast<uint3 *>(&at_bytes(saved_t, (base + 3u * col) * 4u)) = pack_gates(ig, fg, gg, og);
+                        at_bytes(saved_t, (base + 3u * H + col) * 4u) = c;
+                    } else {
+                        float *sv = &at_bytes(saved_t, (base + col) * 4u);
+                        sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; if (!(PN_ABL & 2)) sv[3 * H] = og; sv[4 * H] = c;
+                    }
                 }
             } else {
                 h = tanhf_(acc[rb][0][r] * sc.inv_S);
@@ -626,7 +636,8 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     constexpr int G = GC == 3 ? 4 : GC;         // GC: 4 = LSTM, 1 = tanh RNN, 3 = GRU on the LSTM's four gate slots
     constexpr bool GRU = GC == 3;
     constexpr int MT = 32, NW = H / 32;
-    constexpr int NT = NW * 64, GH = G * H, SV = (G == 4 ? 5 : 1);
+    constexpr bool PACKED = GC == 4 && PN_SEQH_PACK;            // (the forward's layout: pack_gates)
+    constexpr int NT = NW * 64, GH = G * H, SV = PACKED ? 4 : (G == 4 ? 5 : 1);
     constexpr int PB = 2 * GH + 16, PLANE = MT * PB;            // plane row pitch / plane size, bytes
     constexpr int NU = GH / 32;                                 // units of two k-steps
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
@@ -666,7 +677,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         dh[r] = row < rows_here ? dh0 : 0.0f;
         dc[r] = 0.0f;
         if (PN_BWDH_CARRY && G == 4 && !GRU)
-            cnext[r] = at_bytes(saved_t, ((((uint32_t)rc * (uint32_t)p.L + (p.L - 1)) * SV + 4) * (uint32_t)H + col) * 4u);
+            cnext[r] = at_bytes(saved_t, ((((uint32_t)rc * (uint32_t)p.L + (p.L - 1)) * SV + (PACKED ? 3 : 4)) * (uint32_t)H + col) * 4u);
     }
     float launch_max = 0.0f;        // largest |dG| this workgroup has seen (wave-uniform after each step)
 
@@ -694,7 +705,14 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
             for (int r = 0; r < 16; r++) {
                 const int rc = min(acc_row(r, lane_t), rows_here - 1);
                 const float *sv = &at_bytes(saved_t, (((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
-                if (GRU) {
+                if constexpr (PACKED) {
+                    const uint32_t base = ((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H);
+                    const uint3 w = *reinterpret_cast<const uint3 *>(&at_bytes(saved_t, (base + 3u * col) * 4u));
+                    unpack_gates(w, vi[r], vf[r], vg[r], vo[r]);
+                    const float *cp = &at_bytes(saved_t, (base + 3u * H + col) * 4u);
+                    vc[r] = t > 0 ? cp[-(SV * H)] : 0.0f;           // c_{t-1}: the c slot of step t-1
+                    vn[r] = PN_BWDH_CARRY ? cnext[r] : cp[0];       // c_t
+                } else if (GRU) {
                     vi[r] = sv[0]; vf[r] = sv[H]; vg[r] = sv[2 * H];     // r, z, n
                     vo[r] = sv[3 * H];                                    // W_hn h + b_hn
                     vc[r] = sv[4 * H];                                    // h_{t-1}
@@ -762,7 +780,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         HSTAMP(6 * (p.L - 1 - t) + 1);
         __syncthreads();        // the wave maxima are in place; every wave is past the previous step's k loop
         HSTAMP(6 * (p.L - 1 - t) + 2);
-        if (PN_BWDH_TOUCH && t > 0) {
+        if (PN_BWDH_TOUCH && !PACKED && t > 0) {
             // the next step's saved rows, one lane per 128-byte line: row (0..31) x array (i f g o [c]) x segment (H/32)
             constexpr int NARR = G == 4 ? (PN_BWDH_TOUCH < 5 ? PN_BWDH_TOUCH : 5) : 1, LINES = MT * NARR * NW;
             const int tid_x = wave_u * 64 + lane_t;
