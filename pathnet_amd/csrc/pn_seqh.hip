@@ -42,6 +42,9 @@ using namespace pn;
 #ifndef PN_BWDH_TOUCH
 #define PN_BWDH_TOUCH 0     // > 0: the BPTT pulls the saved rows of its NEXT step into L2 while the current step runs (LDS-DMA touches)
 #endif
+#ifndef PN_BWDH_PIPE
+#define PN_BWDH_PIPE 1      // the BPTT requests step t-1's saved values before step t's scatter (see load_saved)
+#endif
 #ifndef PN_SEQH_PACK
 #define PN_SEQH_PACK 1      // the LSTM's saved gates as 3 dwords per element (pn_kernels.h: pack_gates) instead of 4
 #endif
@@ -681,6 +684,43 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     }
     float launch_max = 0.0f;        // largest |dG| this workgroup has seen (wave-uniform after each step)
 
+    // ---- the saved values of one step, as loaded (PN_BWDH_PIPE: those of step t - 1 are requested right after step t's k
+    //      loop, ahead of its scatter -- ordinary loads, which the compiler cannot sink below the scatter's atomics -- so their
+    //      latency runs under the atomics instead of in front of the next cell backward).  All loads of a step are issued
+    //      together, unconditionally (padded rows read a clamped row and are zeroed afterwards).
+    constexpr int NRAW = PACKED ? 4 : (G == 4 || GRU) ? 5 : 1;
+    uint32_t raw[NRAW][16];                 // (the packed gates as three dword loads: a dwordx3 load wants three CONSECUTIVE
+                                            //  registers, and the allocator spilled half of the sixteen triples)
+    [[maybe_unused]] float raw_cn[16];      // c_t when it is not carried in registers
+    auto load_saved = [&](int t, int lane_x) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rc = min(acc_row(r, lane_x), rows_here - 1);
+            const uint32_t base = ((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H);
+            if constexpr (PACKED) {
+                const uint32_t *gq = reinterpret_cast<const uint32_t *>(&at_bytes(saved_t, (base + 3u * col) * 4u));
+                raw[0][r] = gq[0]; raw[1][r] = gq[1]; raw[2][r] = gq[2];
+                const float *cp = &at_bytes(saved_t, (base + 3u * H + col) * 4u);
+                raw[3][r] = __float_as_uint(cp[t > 0 ? -(SV * H) : 0]);       // c_{t-1}: the c slot of step t-1 (t = 0: unused)
+                if (!PN_BWDH_CARRY) raw_cn[r] = cp[0];
+            } else {
+                const float *sv = &at_bytes(saved_t, (base + col) * 4u);
+                if constexpr (GRU) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) raw[k][r] = __float_as_uint(sv[k * H]);    // r, z, n, W_hn h + b_hn, h_{t-1}
+                } else if constexpr (G == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) raw[k][r] = __float_as_uint(sv[k * H]);
+                    raw[NRAW - 1][r] = __float_as_uint(sv[t > 0 ? -H : 4 * H]);            // c_{t-1} = slot 4 of step t-1
+                    if (!PN_BWDH_CARRY) raw_cn[r] = sv[4 * H];
+                } else {
+                    raw[0][r] = __float_as_uint(sv[0]);                                    // h_t
+                }
+            }
+        }
+    };
+    if (PN_BWDH_PIPE) load_saved(p.L - 1, lane);
+
     for (int t = p.L - 1; t >= 0; t--) {
         // (row numbers are re-derived from an opaque copy of the lane id in every step: as loop invariants the
         //  per-row offsets would occupy ~40 registers across the MFMA loop and spill)
@@ -695,46 +735,39 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     at_bytes(reinterpret_cast<const uint32_t *>(keep_t), (rc * (uint32_t)p.L + t) * (uint32_t)(H / 4) + 4u * w);
             }
         }
-        // ---- cell backward into registers.  All loads are issued together (unconditionally, padded rows read a clamped
-        //      row and are zeroed afterwards): one memory round trip per step.
+        // ---- cell backward into registers
         float dgv[G][16];
         float vmax = 0.0f;
+        if (!PN_BWDH_PIPE) load_saved(t, lane_t);
         {
-            float vi[16], vf[16], vg[16], vo[16], vc[16], vn[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int rc = min(acc_row(r, lane_t), rows_here - 1);
-                const float *sv = &at_bytes(saved_t, (((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
+                // (unpacked element by element: a second set of arrays beside `raw` would not fit the register file)
+                float vi_, vf_ = 0.f, vg_ = 0.f, vo_ = 0.f, vc_ = 0.f, vn_ = 0.f;
                 if constexpr (PACKED) {
-                    const uint32_t base = ((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H);
-                    const uint3 w = *reinterpret_cast<const uint3 *>(&at_bytes(saved_t, (base + 3u * col) * 4u));
-                    unpack_gates(w, vi[r], vf[r], vg[r], vo[r]);
-                    const float *cp = &at_bytes(saved_t, (base + 3u * H + col) * 4u);
-                    vc[r] = t > 0 ? cp[-(SV * H)] : 0.0f;           // c_{t-1}: the c slot of step t-1
-                    vn[r] = PN_BWDH_CARRY ? cnext[r] : cp[0];       // c_t
+                    unpack_gates(make_uint3(raw[0][r], raw[NRAW > 1 ? 1 : 0][r], raw[NRAW > 2 ? 2 : 0][r]), vi_, vf_, vg_, vo_);
+                    vc_ = t > 0 ? __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]) : 0.0f;
+                    vn_ = PN_BWDH_CARRY ? cnext[r] : raw_cn[r];
                 } else if (GRU) {
-                    vi[r] = sv[0]; vf[r] = sv[H]; vg[r] = sv[2 * H];     // r, z, n
-                    vo[r] = sv[3 * H];                                    // W_hn h + b_hn
-                    vc[r] = sv[4 * H];                                    // h_{t-1}
-                    vn[r] = 0.0f;
+                    vi_ = __uint_as_float(raw[0][r]); vf_ = __uint_as_float(raw[NRAW > 1 ? 1 : 0][r]); vg_ = __uint_as_float(raw[NRAW > 2 ? 2 : 0][r]);
+                    vo_ = __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]);
+                    vc_ = __uint_as_float(raw[NRAW > 4 ? 4 : 0][r]);
                 } else if (G == 4) {
-                    vi[r] = sv[0]; vf[r] = sv[H]; vg[r] = sv[2 * H];
-                    vo[r] = (PN_ABL & 2) ? 0.5f : sv[3 * H];
-                    vc[r] = t > 0 ? sv[-H] : 0.0f;                  // c_{t-1} = slot 4 of step t-1
-                    vn[r] = PN_BWDH_CARRY ? cnext[r] : sv[4 * H];   // c_t
+                    vi_ = __uint_as_float(raw[0][r]); vf_ = __uint_as_float(raw[NRAW > 1 ? 1 : 0][r]);
+                    vg_ = __uint_as_float(raw[NRAW > 2 ? 2 : 0][r]);
+                    vo_ = (PN_ABL & 2) ? 0.5f : __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]);
+                    vc_ = t > 0 ? __uint_as_float(raw[NRAW - 1][r]) : 0.0f;
+                    vn_ = PN_BWDH_CARRY ? cnext[r] : raw_cn[r];
                 } else {
-                    vi[r] = sv[0];                                   // h_t
+                    vi_ = __uint_as_float(raw[0][r]);
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
                 const int row = acc_row(r, lane_t);
                 const bool ok = row < rows_here;
                 float *d = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col) * 4u);
                 if (GRU) {
                     // h = (1 - z) n + z h_prev,  n = tanh(nx + r nh):  gradients of the four slots r, z, nx, nh; the direct
                     // path d h_t / d h_{t-1} = z is carried in dc[] across the GEMM and added to its dh output
-                    const float rg = vi[r], zg = vf[r], ng = vg[r], nh = vo[r], hp = vc[r];
+                    const float rg = vi_, zg = vf_, ng = vg_, nh = vo_, hp = vc_;
                     const float dhv = dh[r];
                     const float dnp = dhv * (1.0f - zg) * (1.0f - ng * ng);
                     float a_r = dnp * nh * rg * (1.0f - rg);
@@ -749,8 +782,8 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     }
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a_r), fabsf(a_z))), fmaxf(fabsf(a_nx), fabsf(a_nh)));
                 } else if (G == 4) {
-                    const float ig = vi[r], fg = vf[r], gg = vg[r], og = vo[r], cprev = vc[r];
-                    const float tc = tanhf_(vn[r]);
+                    const float ig = vi_, fg = vf_, gg = vg_, og = vo_, cprev = vc_;
+                    const float tc = tanhf_(vn_);
                     const float dhv = dh[r];
                     const float d_o = dhv * tc;
                     const float dct = dc[r] + dhv * og * (1.0f - tc * tc);
@@ -767,7 +800,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     }
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a_i), fabsf(a_f))), fmaxf(fabsf(a_g), fabsf(a_o)));
                 } else {
-                    const float h = vi[r];
+                    const float h = vi_;
                     const float a = ok ? dh[r] * (1.0f - h * h) : 0.0f;
                     dgv[0][r] = a;
                     if (ok) d[0] = a;
@@ -880,6 +913,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
             mfma_phase(std::integral_constant<int, 1>{});
         HSTAMP(6 * (p.L - 1 - t) + 4);
         const float inv_x = exp2i(-(e_g + e_ih)), inv_h = exp2i(-(e_g + e_hh));
+        if (PN_BWDH_PIPE) load_saved(max(t - 1, 0), lane_t);        // (dgv is dead: these take its registers; t = 0: a harmless re-load)
 
         // ---- gather backward: dZ[row(q, t)] += mask * dx.  Step 0 is the last one of the kernel and its rows are the
         //      paths' own start nodes: the wave parks its 32 x 32 block in the (then dead) plane region and each half-wave
