@@ -42,6 +42,9 @@ using namespace pn;
 #ifndef PN_BWDH_TOUCH
 #define PN_BWDH_TOUCH 0     // > 0: the BPTT pulls the saved rows of its NEXT step into L2 while the current step runs (LDS-DMA touches)
 #endif
+#ifndef PN_FWDH_EARLYX
+#define PN_FWDH_EARLYX 0    // 1: see seq_fwdh_kernel, EARLY_X (measured slower: 0.249 vs 0.242 ms -- the 16 registers cost a spill at 168)
+#endif
 #ifndef PN_BWDH_PIPE
 #define PN_BWDH_PIPE 1      // the BPTT requests step t-1's saved values before step t's scatter (see load_saved)
 #endif
@@ -261,8 +264,35 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         asm volatile("" : "+v"(bits));      // drawn here, not sunk to the commit
         keepbits = bits;
     };
+    // EARLY_X (three workgroups per CU, where nothing is prefetched across the k loop): the rows of x_{t+1} are requested with
+    // ORDINARY loads right behind the barrier that ends the k loop, ahead of the cell update -- whose stores the compiler cannot
+    // prove distinct from the table, so the loads stay where they are written -- and committed after it: their latency runs
+    // under the cell math and its stores instead of behind them.
+    constexpr bool EARLY_X = !PREFETCH_X && RB == 1 && PN_FWDH_EARLYX;
+    [[maybe_unused]] float4 xe[NLD];
+    auto gather_early = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = tid_g + NT * i;
+            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+            xe[i] = *reinterpret_cast<const float4 *>(p.Z + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (H / 4) + c4) * 4);
+        }
+        uint32_t bits = 0;
+        if (builtin_drop) {
+#pragma unroll
+            for (int i = 0; i < NLD; i++) {
+                const int idx = tid_g + NT * i;
+                const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+                const float4 m = dropout4(seed, ((uint64_t)t * p.Pmask + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
+                bits |= ((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) |
+                         (m.w != 0.f ? 8u : 0u)) << (4 * i);
+            }
+        }
+        keepbits = bits;
+    };
     auto gather_commit = [&](int t) {
-        if constexpr (RB == 1)
+        if constexpr (EARLY_X) {
+        } else if constexpr (RB == 1)
             wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
         else
             wait_vm<0>(xr[0], xr[1], xr[2], xr[3], xr[4 % NLD], xr[5 % NLD], xr[6 % NLD], xr[7 % NLD]);
@@ -271,7 +301,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             const int idx = tid_g + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
             const int q = q0 + row;
-            float4 v = make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
+            float4 v = EARLY_X ? xe[i] : make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
             if (q >= p.P) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.mask) {
                 if (q < p.P) {
@@ -300,7 +330,10 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             }
         }
     };
-    gather_issue(0);
+    if (EARLY_X)
+        gather_early(0);
+    else
+        gather_issue(0);
     gather_commit(0);
     __syncthreads();
 
@@ -380,6 +413,10 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         HSTAMP(4 * t + 1);
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
         HSTAMP(4 * t + 2);
+        if (EARLY_X && t + 1 < p.L) {
+            tid_g = wave_u * 64 + fresh_lane();
+            gather_early(t + 1);
+        }
 
         // ---- cell update in registers; h_t goes back to LDS (scaled, split) for the next step ----------------------
         const int lane_o = fresh_lane();    // row offsets are re-derived in every step: hoisted out of the t loop they spill
@@ -448,8 +485,8 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         }
         }
         if (t + 1 < p.L) {
-            tid_g = wave_u * 64 + fresh_lane();
-            if (!PREFETCH_X) gather_issue(t + 1);
+            if (!EARLY_X) tid_g = wave_u * 64 + fresh_lane();
+            if (!PREFETCH_X && !EARLY_X) gather_issue(t + 1);
             gather_commit(t + 1);     // (every wave is past its reads of x_t)
             __syncthreads();
         }
