@@ -1278,7 +1278,9 @@ int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n
 int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, const int32_t *count, SeqRange *range) {
     hipStream_t s = (hipStream_t)stream;        // (range->x was cleared by launch_range_w, ordered before this launch)
     const int64_t n4 = nrows * (H / 4);
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (n4 + 2047) / 2048));
+    // (on the step's critical path between the bank and the recurrence: one or two 16-byte loads per thread, 11 -> ~4 us at
+    //  the headline shape's 5.5 MB)
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (n4 + 511) / 512));
     hipLaunchKernelGGL(range_rows_kernel, dim3(blocks), dim3(256), 0, s, rows, nrows, H / 4, count, range);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
