@@ -171,7 +171,7 @@ int pn_profile_stage_count(void) { return pn::ST_COUNT; }
 const char *pn_profile_stage_name(int32_t stage) {
     static const char *const names[pn::ST_COUNT] = {"sampler_glibc_fill", "sampler_walk", "gather",    "fc0",      "bank",
                                                     "plan_pack",          "seq_fwd",      "pool_fwd",  "fc2_grad", "pool_bwd",
-                                                    "seq_bwd",            "wgrad",        "bias_grad", "bank_bwd", "fc0_bwd"};
+                                                    "seq_bwd",            "wgrad",        "bias_grad", "bank_bwd", "fc0_bwd", "zero_fill"};
     return (stage >= 0 && stage < pn::ST_COUNT) ? names[stage] : "?";
 }
 int pn_profile_read(pn_context *ctx, double *ms_sum, int64_t *count) try {

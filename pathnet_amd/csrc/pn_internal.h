@@ -42,7 +42,7 @@ GlibcState glibc_seed_state(uint32_t seed);
 // ---- pn_context: the only state that outlives a call (pn_context.hip) ------------------------------------
 enum Stage {
     ST_SAMPLER_FILL = 0, ST_SAMPLER_WALK, ST_GATHER, ST_FC0, ST_BANK, ST_PLAN_PACK, ST_SEQ_FWD, ST_POOL_FWD,
-    ST_FC2_GRAD, ST_POOL_BWD, ST_SEQ_BWD, ST_WGRAD, ST_BIAS_GRAD, ST_BANK_BWD, ST_FC0_BWD, ST_COUNT
+    ST_FC2_GRAD, ST_POOL_BWD, ST_SEQ_BWD, ST_WGRAD, ST_BIAS_GRAD, ST_BANK_BWD, ST_FC0_BWD, ST_ZERO_FILL, ST_COUNT
 };
 // true while pn_profile_configure(ctx, 1, ...) brackets every stage: stages then run back to back on one stream
 bool profiling_every_stage(const pn_context *ctx);

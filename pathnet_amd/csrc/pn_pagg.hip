@@ -3414,6 +3414,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     };
     auto flush_zero = [&]() -> int {
         if (zl.n) {
+            StageTimer tm(ctx, ST_ZERO_FILL, stream);       // (d Z and d Xh are the bulk: rows of the graph, not paths)
             hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, stream, zl);
             PN_CHECK_HIP(hipGetLastError());
             zl.n = 0;

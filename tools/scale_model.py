@@ -23,6 +23,9 @@ Model, per rank and step, R ranks:
                  own stream and half of the bank backward stage (its weight-gradient GEMMs; the other half, d Xh itself,
                  precedes the event).  What a collective costs the step is max(0, its time - the stage time it hides
                  under); the gradient all-reduce stays exposed.  overlap=False charges every collective in full (round 3).
+  zero fill      (round 4: its own stage) the backward clears d Z and d Xh every step -- rows of the graph, not paths: d Z
+                 (fraction zero_dz of the stage) follows the bank's rows (all N x L, or the rows the rank's paths touch when
+                 the bank is compact), d Xh follows the nodes (all N; the touched ones in the restricted replicated mode).
   replicated     dist.ReplicatedAggregator: every rank holds all of X; the only collective is the gradient all-reduce (plus
                  the hetero class's index arrays).  Round 4: the call is restricted to the rows of X the rank's paths touch
                  (touched_nodes: their expected fraction), so fc0 and its backward run over those rows only -- before,
@@ -45,7 +48,7 @@ def split(stages):
     s = sum(v for k, v in stages.items() if k in SHARDED)
     o = sum(v for k, v in stages.items() if k in OWN_ROWS)
     r = sum(v for k, v in stages.items() if k in REPLICATED)
-    rest = sum(v for k, v in stages.items() if k not in SHARDED + OWN_ROWS + REPLICATED)
+    rest = sum(v for k, v in stages.items() if k not in SHARDED + OWN_ROWS + REPLICATED + ("zero_fill",))
     return s, o, r, rest
 
 
@@ -66,13 +69,14 @@ BANK_MS_PER_NODE = 6.2e-6    # measured slope of bank + bank backward over the n
 
 
 def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, idx_bytes=0, touched_frac=None, replicated=False,
-          overlap=False, touched_nodes=None):
+          overlap=False, touched_nodes=None, zero_dz=0.8):
     """-> rows (R, t_ms, speedup_or_efficiency, parts).  stages: single-GPU per-stage ms; total_ms: single-GPU wall per
     step (the part not covered by the stage timers -- loss, Adam, torch glue -- is carried as `other`, per rank).
     overlap: collectives hide under the stages named in the module docstring.  touched_nodes(R): fraction of the graph's
     nodes a rank's paths name (replicated mode: fc0 over those rows only)."""
     s, o, r, rest = split(stages)
-    other = max(total_ms - (s + o + r + rest), 0.0) + rest
+    z = stages.get("zero_fill", 0.0)
+    other = max(total_ms - (s + o + r + rest + z), 0.0) + rest
     rows = []
     for R in (1, 2, 4, 8):
         if weak:        # per-rank paths and rows stay, the graph grows: the replicated bank grows with it
@@ -102,8 +106,14 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
             own = own - own_bwd
             coll = ag + rs + parts["all_reduce_grads"] + parts["all_gather_indices"]
             parts = dict(parts, all_gather_Xh=ag, reduce_scatter_dXh=rs)
-        t = sh + own + rep + other + coll
-        rows.append((R, t, dict(sharded=sh, own_rows=own, replicated_bank=rep, other=other, collectives=coll, **parts)))
+        # zero fill of d Z (with the bank's rows) and d Xh (with the nodes)
+        grow = R if weak else 1
+        z_dz = z * zero_dz * grow * (min(1.0, touched_frac(R)) if touched_frac is not None else 1.0)
+        z_dx = z * (1.0 - zero_dz) * grow
+        if replicated and touched_nodes is not None:
+            z_dx *= min(1.0, touched_nodes(R)) / min(1.0, touched_nodes(1))
+        t = sh + own + rep + other + z_dz + z_dx + coll
+        rows.append((R, t, dict(sharded=sh, own_rows=own, replicated_bank=rep, other=other + z_dz + z_dx, collectives=coll, **parts)))
     t1 = rows[0][1]
     return [(R, t, (t1 / t) if weak else (t1 / t), p) for R, t, p in rows]
 
@@ -157,26 +167,27 @@ def main():
         tot = g["seconds_per_step"] * 1e3
         import math
         rows, steps = 60e6, 100_000 * 40 * 6
+        ZDZ4 = 24e6 / (24e6 + 10e6)      # d Z holds min(rows, path steps) = 24 M rows of the zero fill, d Xh 10 M
         uniq = lambda R: rows * (1.0 - math.exp(-steps / (R * rows)))      # expected distinct (node, code) rows of a rank's steps
         if g.get("compact_rows", True):
             # the measured step already runs the bank over the rows its 24 M path steps touch (19.8 M of 60 M expected);
             # a rank's share of the paths touches uniq(R) of them
             out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over the touched rows (as measured)",
                         "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
-                                          touched_frac=lambda R: uniq(R) / uniq(1))))
+                                          touched_frac=lambda R: uniq(R) / uniq(1), zero_dz=ZDZ4)))
             out.append(("configs[4] node-sharded, collectives overlapped (the exchange of Xh / dXh does not fit under anything)",
                         "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
-                                          touched_frac=lambda R: uniq(R) / uniq(1), overlap=True)))
+                                          touched_frac=lambda R: uniq(R) / uniq(1), overlap=True, zero_dz=ZDZ4)))
             out.append(("configs[4], all of X on every rank (dist.ReplicatedAggregator): fc0 over all rows (round 3), gradient all-reduce only",
                         "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
-                                          touched_frac=lambda R: uniq(R) / uniq(1), replicated=True)))
+                                          touched_frac=lambda R: uniq(R) / uniq(1), replicated=True, zero_dz=ZDZ4)))
             nodes, nsteps = 10e6, 100_000 * (40 * 6 + 1)
             tn = lambda R: 1.0 - math.exp(-nsteps / (R * nodes))       # expected fraction of the nodes a rank's paths name
             out.append(("configs[4], all of X on every rank, the call restricted to the rows its paths touch (round 4: fc0 over %.0f %% "
                         "of the nodes on one rank, %.0f %% on each of 8)" % (100 * tn(1), 100 * tn(8)),
                         "speed-up", model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us,
                                           touched_frac=lambda R: uniq(R) / uniq(1), replicated=True,
-                                          touched_nodes=lambda R: tn(R) / 1.0)))
+                                          touched_nodes=lambda R: tn(R) / 1.0, zero_dz=ZDZ4)))
         else:
             out.append(("configs[4] 10 M nodes, L = 6, 100 000 masked nodes (strong), bank over all 60 M rows", "speed-up",
                         model(st, tot, 10_000_000, H, grad4, False, a.link_GBs, a.latency_us)))
