@@ -529,6 +529,10 @@ class _Aggregator(nn.Module):
                 P = torch.nn.functional.pad
                 ms = P(ms, (0, Hk - H)).contiguous() if ms is not None else None
                 mc = P(mc.view(mc.shape[0], 2, H), (0, Hk - H)).reshape(mc.shape[0], 2 * Hk).contiguous() if mc is not None else None
+            if ms is not None and cfg["seq_math"] != _lib.SEQ_MATH_BF16X3 and float(ms.abs().max()) > 16.0:
+                # (test hook only: one device round trip) the fp16 kernels scale the gathered rows for masks up to 16 = 1 / (1 - 0.9375)
+                raise ValueError("explicit sequence masks must satisfy |m| <= 16 with seq_math f16x2 (include/pathnet_hip.h); "
+                                 "use seq_math='bf16x3' for others")
             cfg["mask_seq"], cfg["mask_cls"] = ms, mc
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["grad"] = torch.is_grad_enabled()

@@ -15,6 +15,9 @@ DB=$(find $OUT/kt -name "*.db" | head -1)
 CSV=$(find $OUT/kt -name "*kernel_stats.csv" | head -1)
 [ -n "$CSV" ] && cp $CSV $OUT/kernel_stats.csv
 PMC_TIMEOUT=240 bash tools/pmc_passes.sh $OUT/pmc
+# the traffic stamp of THIS build now exists: a second (short) bench line carries roofline.traffic / hbm_side
+cp $OUT/pmc/pmc_traffic.json profiles/pmc_traffic.json
+timeout 200 python bench.py --no-extras --no-cpu-baseline > $OUT/bench_traffic.json 2> $OUT/bench_traffic.err
 PN_BENCH_FORCE_SHARDED=1 timeout 200 python bench.py --workload bgp --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $OUT/bgp_sharded_path.json 2> $OUT/bgp_sharded_path.err
 tail -1 $OUT/bgp_sharded_path.err
 ls $OUT $OUT/pmc
