@@ -218,8 +218,9 @@ def test_all_zero_inputs_and_gradients():
         assert torch.isfinite(g[k]).all() and g[k].abs().max().item() == 0.0, k
 
 
-def test_shape_info_reports_the_arithmetic():
+def test_shape_info_reports_the_arithmetic(monkeypatch):
     from pathnet_amd import _lib, modules
+    monkeypatch.delenv("PN_SEQ_MATH", raising=False)     # (the suite also runs with PN_SEQ_MATH=bf16x3: profiles/r04_pytest_gpu_bf16x3.txt)
     sh = modules._shape("homo", 300, 16, 128, 3, 10, 5, 4)
     assert modules.shape_info(sh)[3] == _lib.SEQ_MATH_F16X2
     sh = modules._shape("homo", 300, 16, 128, 3, 10, 5, 4, seq_math=_lib.SEQ_MATH_BF16X3)
