@@ -396,6 +396,7 @@ class StepRunner:
         Y = torch.from_numpy(wl["Y"]).to(dev)
         self.runner = None
         self.overlap = os.environ.get("PN_BENCH_OVERLAP", "1") not in ("", "0")    # collectives on their own stream (dist.py)
+        self.seed_backward = os.environ.get("PN_BENCH_PLAIN_BACKWARD", "0") in ("", "0")
         if not sharded:
             self.X = torch.from_numpy(wl["X"]).to(dev)
             self.sel = torch.from_numpy(np.flatnonzero(wl["mask"]).astype(np.int64)).to(dev)
@@ -451,7 +452,10 @@ class StepRunner:
             if self.loss_scale != 1.0:
                 loss = loss * self.loss_scale
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        if self.seed_backward:
+            pathnet_amd.backward(loss)      # loss.backward() without autograd's ones_like fill and the multiply by it (optim.py)
+        else:
+            loss.backward()
         if self.runner is not None:
             self.runner.allreduce_grads(average=True)
         self.opt.step()

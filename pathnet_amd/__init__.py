@@ -11,7 +11,7 @@ Everything computes through csrc/libpathnet_hip.so (C ABI: include/pathnet_hip.h
 """
 from . import _lib  # noqa: F401
 from .modules import PAGG, PathNet, PathNet_homo  # noqa: F401
-from .optim import Adam, CrossEntropyLoss, StepState, cross_entropy  # noqa: F401
+from .optim import Adam, CrossEntropyLoss, StepState, backward, cross_entropy  # noqa: F401
 from .sampler import DRAW_GLIBC_REPLAY, DRAW_PHILOX, MerwSampler, UniformSampler  # noqa: F401
 
 __version__ = "0.1.0"

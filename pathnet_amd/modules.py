@@ -300,9 +300,12 @@ class _PaggLossFunction(torch.autograd.Function):
             raise RuntimeError("forward_loss: the gradients were handed out already (backward twice)")
         # (d loss' / d loss: 1 for loss.backward().  The gradients were computed once, in forward(): a single backward, no
         #  double backward -- once_differentiable says so to autograd; a second backward raises above)
-        flat.mul_(g_loss)
-        if grads[0] is not None:
-            grads[0].mul_(g_loss)
+        from . import optim
+        one = optim._UNIT.get(g_loss.device)
+        if one is None or g_loss.data_ptr() != one.data_ptr():       # (optim.backward(loss) seeds with the cached 1.0: nothing to scale)
+            flat.mul_(g_loss)
+            if grads[0] is not None:
+                grads[0].mul_(g_loss)
         return (None, grads[0], None, None, None, None) + tuple(grads[1:])
 
 

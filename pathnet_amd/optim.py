@@ -32,7 +32,35 @@ class _CrossEntropy(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        return (ctx.g * grad_out if ctx.g is not None else None), None
+        if ctx.g is None:
+            return None, None
+        # loss.backward() hands a freshly filled ones tensor down and costs a multiply by it: two launches for nothing.
+        # optim.backward(loss) passes the cached tensor of `unit()` instead, recognised here by identity
+        one = _UNIT.get(grad_out.device)
+        if one is not None and grad_out.data_ptr() == one.data_ptr():
+            return ctx.g, None
+        return ctx.g * grad_out, None
+
+
+_UNIT = {}
+
+
+def unit(device):
+    """the cached scalar 1.0 on `device` that `backward(loss)` seeds autograd with"""
+    dev = torch.device(device)
+    if dev.type == "cuda" and dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = _UNIT.get(dev)
+    if t is None:
+        t = _UNIT[dev] = torch.ones((), dtype=torch.float32, device=dev)
+    return t
+
+
+def backward(loss):
+    """``loss.backward()`` for a scalar loss of this module's cross entropy without the two launches autograd spends on the
+    seed gradient (a ones_like fill, and the multiply by it in the loss's backward): the seed is a cached tensor that the
+    loss recognises.  Same gradients, bit for bit."""
+    loss.backward(unit(loss.device))
 
 
 def cross_entropy(logits, target):

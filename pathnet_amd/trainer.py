@@ -92,7 +92,7 @@ def train_fixed_indices(X, Y, num_classes, data_name, train_indices, val_indices
         ids_tr, codes_tr = paths_of(tr32, epoch, check=(epoch == 0))
         loss, out = model.forward_loss(X, ids_tr, num_w, walk_len, tr32, codes_tr, Y[tr], fused=fused_step)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        optim.backward(loss)        # = loss.backward(), minus the seed gradient's fill and multiply
         opt.step()
         with torch.no_grad():
             model.eval()

@@ -54,3 +54,32 @@ def test_adam_rejects_cpu_parameters():
     p.grad = torch.ones(4)
     with pytest.raises(RuntimeError):
         pathnet_amd.Adam([p]).step()
+
+
+def test_seeded_backward_equals_loss_backward():
+    """pathnet_amd.backward(loss) = loss.backward() without the ones_like fill and the multiply by it: same gradients, bit for
+    bit, through the three-call step and through the fused one (deterministic backward: run-to-run bits are comparable)"""
+    import pathnet_amd
+    torch.manual_seed(5)
+    N, F, H, C, S, W, L = 150, 24, 64, 4, 40, 6, 4
+    m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.5).cuda().train()
+    m.deterministic = True
+    X = torch.rand(N, F, device="cuda")
+    sel = torch.randperm(N)[:S].sort().values.to(torch.int32).cuda()
+    ids = torch.randint(0, N, (S, W, L), dtype=torch.int32, device="cuda")
+    ids[:, :, 0] = sel[:, None]
+    codes = torch.randint(0, L, (S, W, L), dtype=torch.uint8, device="cuda")
+    y = torch.randint(0, C, (S,), device="cuda")
+    for fused in (False, True):
+        got = []
+        for seeded in (False, True):
+            torch.manual_seed(9)
+            m.zero_grad(set_to_none=True)
+            loss, _ = m.forward_loss(X, ids, W, L, sel, codes, y, fused=fused)
+            if seeded:
+                pathnet_amd.backward(loss)
+            else:
+                loss.backward()
+            got.append({k: v.grad.clone() for k, v in m.named_parameters()})
+        for k in got[0]:
+            assert torch.equal(got[0][k], got[1][k]), (fused, k)
