@@ -67,8 +67,9 @@ struct StageTimer {
 
 // softmax cross entropy of `rows` rows (pn_train.hip): loss[0] += scale * sum of the rows' losses, g_logits (or null) =
 // (softmax - onehot) * scale.  pn_cross_entropy = zero-fill + this with scale = 1 / rows.
+// overwrite: loss[0] = ... instead of += (the zero fill, when one is needed at all, is issued here)
 int launch_cross_entropy(const float *logits, const int64_t *target, int rows, int classes, float scale, float *loss,
-                         float *g_logits, void *stream);
+                         float *g_logits, void *stream, bool overwrite = false);
 
 // ---- stable radix sort of (int32 key, int32 value) pairs (pn_sort.hip; the deterministic backward) ----------------
 size_t sort_temp_reserve(int64_t n);        // bytes of temporary storage to reserve for n pairs (no device needed)

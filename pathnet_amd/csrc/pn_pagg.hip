@@ -2691,9 +2691,17 @@ WsLayout ws_layout(const Dims &d) {
     w.biasc = take(G * H * 4);
     w.WpT = take(G * H * 3 * H * 4);
     {
-        // split of the Pb*L rows of the weight-gradient GEMM: one 8-wave workgroup per CU
+        // split of the Pb*L rows of the weight-gradient GEMM: one 8-wave workgroup per CU.  Such a workgroup takes the CU's
+        // whole register file: with one on every CU the node-level GEMMs of the main stream (bank / fc0 backward) cannot
+        // start until the launch is over, whatever stream they are on.  A short launch (a Cora-sized batch: 0.17 ms against
+        // ~0.07 ms of launch-bound GEMMs) therefore leaves an eighth of the CUs free -- the kernel is HBM-bound enough to
+        // lose 3 % on 224 CUs, the step wins 2.8 % (0.988 -> 0.959 ms); where the weight gradient is 6-12x the GEMM chain
+        // (Pubmed, BGP size: +10 % on the kernel for nothing hidden) it keeps every CU.  profiles/r04_wgrad_cus_ab.txt
         const size_t rows = Pb * L, tiles = std::max<size_t>(1, ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN));
-        size_t nz = (256 + tiles - 1) / tiles;
+        const double wg_flops = 2.0 * (double)rows * (double)(G * H) * (double)(2 * H);
+        size_t cus = (!d.det && wg_flops <= 1.2e11) ? 224 : 256;        // (deterministic mode runs its stages serially)
+        if (const char *e = getenv("PN_WGRAD_CUS")) cus = (size_t)std::max(8, atoi(e));        // tuning / A-B runs
+        size_t nz = (cus + tiles - 1) / tiles;
         const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
         if (nz > max_nz) nz = max_nz;
         if (nz < 1) nz = 1;
@@ -2943,8 +2951,14 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
         // (it also clears the slots this call's atomicMax launches add to; a reused dense bank keeps its range.x)
         if (int rc = launch_range_w(s, c.a->w_ih, c.a->w_hh, (int64_t)d.Gw * d.H * d.H, d.compact || c.a->reuse_tables != 1, rg))
             return rc;
-        return launch_pack_fwdh(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg,
-                                c.at<void>(c.w.Wp), c.at<float>(c.w.biasc));
+        if (int rc = launch_pack_fwdh(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg,
+                                      c.at<void>(c.w.Wp), c.at<float>(c.w.biasc)))
+            return rc;
+        // a training forward also packs the BPTT's planes here, on the side stream under fc0 / the bank: the backward that
+        // follows on this workspace then starts on its first real kernel (an inference forward uses that slot for Wcat)
+        if (!c.a->no_save)
+            return launch_pack_bwdh(s, c.a->w_ih, c.a->w_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg, c.at<void>(c.w.WpT));
+        return PN_OK;
     }
     if (seq4_select(d.H, d.G, d.L) & SEQ4_FWD)      // the 128-path kernel reads its own fragment order (pn_seq4.hip)
         return launch_pack_fwd4(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0,
@@ -3382,7 +3396,8 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     if (fused) {
         if (d.S > 0)
             if (int rc = check_forward_args(c, "pn_pagg_train_step")) return rc;
-        PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
+        // (one micro-batch: the loss kernel overwrites -- launch_cross_entropy zero-fills only if it needs several workgroups)
+        if (d.nb > 1 || d.S == 0) PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
     }
     // (S == 0 -- a rank of a sharded batch without masked nodes: its index arrays and g_out are empty tensors, i.e. NULL;
     //  the call still zero-fills every gradient it was given)
@@ -3468,8 +3483,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     }
     if (G > 0 && !d.generic) {
         StageTimer tm(ctx, ST_PLAN_PACK, stream);      // (its own bracket: ST_SEQ_BWD times the BPTT kernel alone)
-        if (f16) {      // (the weights' ranges are the forward's: same workspace, same weights)
-            if (int rc = launch_pack_bwdh(stream, a->w_ih, a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, range, c.at<void>(c.w.WpT))) return rc;
+        if (f16) {
+            // (packed by the forward that left its saved tensors on this workspace -- run_pack_fwd; the fused step's
+            //  run_tables above did the same)
         } else if (seq4 & SEQ4_BWD) {
             if (int rc = launch_pack_bwd4(stream, a->w_ih, a->w_hh, H, G, d.cell == CELL_GRU ? 1 : 0, c.at<void>(c.w.WpT))) return rc;
         } else {
@@ -3495,7 +3511,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             if (int rc = run_pool_fwd(c, b, out_b)) return rc;
             if (fused)
                 if (int rc = launch_cross_entropy(out_b, target + (size_t)b * d.Sb, Sb, d.C, grad_scale, loss,
-                                                  c.at<float>(c.w.gout), stream))
+                                                  c.at<float>(c.w.gout), stream, d.nb == 1))
                     return rc;
             if (fused && b == 0)
                 if (int rc = flush_zero()) return rc;

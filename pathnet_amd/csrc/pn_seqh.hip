@@ -71,8 +71,16 @@ __device__ long long *g_trace_h = nullptr;      // [blocks][64] stamps, set with
         if (g_trace_h && threadIdx.x == 0 && (slot) < 64)                                                 \
             g_trace_h[(size_t)blockIdx.x * 64 + (slot)] = (long long)__builtin_readcyclecounter();        \
     } while (0)
+// (the cycle counters are per CU and not aligned with each other: the dispatch timeline of a launch -- when workgroups
+//  start and end relative to each other -- is taken from the 100 MHz device-wide counter, slots 62 / 63)
+#define HSTAMP_RT(slot)                                                                                   \
+    do {                                                                                                  \
+        if (g_trace_h && threadIdx.x == 0)                                                                \
+            g_trace_h[(size_t)blockIdx.x * 64 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime();    \
+    } while (0)
 #else
 #define HSTAMP(slot) do { } while (0)
+#define HSTAMP_RT(slot) do { } while (0)
 #endif
 
 namespace {
@@ -345,6 +353,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
     __syncthreads();
 
     for (int t = 0; t < p.L; t++) {
+        if (t == 0) HSTAMP_RT(62);
         HSTAMP(4 * t + 0);
         tid_g = wave_u * 64 + fresh_lane();
         if (PREFETCH_X && t + 1 < p.L) gather_issue(t + 1);
@@ -499,6 +508,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         }
         HSTAMP(4 * t + 3);
     }
+    HSTAMP_RT(63);
 }
 
 // =====================================================================================================================
@@ -769,6 +779,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         // (row numbers are re-derived from an opaque copy of the lane id in every step: as loop invariants the
         //  per-row offsets would occupy ~40 registers across the MFMA loop and spill)
         const int lane_t = fresh_lane();
+        if (t == p.L - 1) HSTAMP_RT(62);
         HSTAMP(6 * (p.L - 1 - t) + 0);
         if (p.keep) {      // this step's keep bytes (MT rows x H/4) -> LDS, read by the scatter phase below
             const int tid_t = wave_u * 64 + lane_t;
@@ -1019,6 +1030,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         }
         HSTAMP(6 * (p.L - 1 - t) + 5);
     }
+    HSTAMP_RT(63);
     if (tid == 0 && launch_max > 0.0f) atomicMax(&p.range->dg, __float_as_uint(launch_max));
 }
 

@@ -18,7 +18,7 @@ namespace {
 __global__ __launch_bounds__(1024) void cross_entropy_kernel(const float *__restrict__ logits,
                                                              const int64_t *__restrict__ target, int rows, int classes,
                                                              float inv_rows, float *__restrict__ loss,
-                                                             float *__restrict__ g_logits) {
+                                                             float *__restrict__ g_logits, int store) {
     __shared__ float part[16];
     float mine = 0.0f;
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) {
@@ -42,7 +42,10 @@ __global__ __launch_bounds__(1024) void cross_entropy_kernel(const float *__rest
     if (threadIdx.x == 0) {
         float s = 0.0f;
         for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += part[w];
-        atomicAdd(loss, s * inv_rows);      // (one workgroup -- up to CE_ONE_BLOCK_ROWS rows -- or two: an exact, order-free sum)
+        if (store)
+            *loss = s * inv_rows;           // one workgroup computes the whole loss: no zero-fill launch ahead of it
+        else
+            atomicAdd(loss, s * inv_rows);  // (several workgroups, or a loss that accumulates over micro-batches)
     }
 }
 
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamList a) {
 namespace pn {
 // loss[0] += scale * sum over rows of (logsumexp - logit[target]);  g_logits = (softmax - onehot) * scale
 int launch_cross_entropy(const float *logits, const int64_t *target, int rows, int classes, float scale, float *loss,
-                         float *g_logits, void *stream_) {
+                         float *g_logits, void *stream_, bool overwrite) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (rows < 1) return PN_OK;
     // Up to CE_ONE_BLOCK_ROWS rows one workgroup of 1024 threads walks them all (a few microseconds) and the loss is a
@@ -107,8 +110,9 @@ int launch_cross_entropy(const float *logits, const int64_t *target, int rows, i
     constexpr int CE_ONE_BLOCK_ROWS = 32768;
     const int threads = rows <= CE_ONE_BLOCK_ROWS ? 1024 : 256;
     const int blocks = rows <= CE_ONE_BLOCK_ROWS ? 1 : ((rows + 255) / 256 < 256 ? (rows + 255) / 256 : 256);
+    if (overwrite && blocks > 1) PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
     hipLaunchKernelGGL(cross_entropy_kernel, dim3(blocks), dim3(threads), 0, stream, logits, target, rows, classes, scale,
-                       loss, g_logits);
+                       loss, g_logits, overwrite && blocks == 1 ? 1 : 0);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -121,8 +125,7 @@ int pn_cross_entropy(const float *logits, const int64_t *target, int32_t rows, i
     if (!logits || !target || !loss) PN_FAIL(PN_ERR_ARG, "pn_cross_entropy: null argument");
     if (rows < 1 || classes < 1) PN_FAIL(PN_ERR_ARG, "pn_cross_entropy: rows=%d classes=%d", rows, classes);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    PN_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
-    return pn::launch_cross_entropy(logits, target, rows, classes, 1.0f / (float)rows, loss, g_logits, stream);
+    return pn::launch_cross_entropy(logits, target, rows, classes, 1.0f / (float)rows, loss, g_logits, stream, true);
 }
 
 int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,

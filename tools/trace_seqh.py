@@ -58,6 +58,22 @@ for which, per, names in (("fwd", 4, ["k loop", "barrier", "cell + commit"]),
     span = t.max() - t.min()
     print("%s: %d workgroups, life %.0f cycles mean, kernel span %.0f cycles, mean concurrency %.1f workgroups"
           % (which, len(t), life.mean(), span, life.sum() / span))
+    # dispatch timeline from the device-wide 100 MHz counter (slots 62 / 63; the cycle counters are per CU).  "drain" = the
+    # moment the last workgroup started: from there on the launch only empties -- the tail a launch cannot avoid when its
+    # workgroup count is not a multiple of the resident slots
+    rt = buf.cpu().numpy().astype(np.float64)[ok][:, 62:64] * 10.0e-3        # us
+    st, en = rt[:, 0], rt[:, 1]
+    t0, t1, drain = st.min(), en.max(), st.max()
+    busy_tail = np.clip(en - np.maximum(st, drain), 0, None).sum()
+    busy_head = (en - st).sum() - busy_tail
+    print("  timeline: first start -> last end %.1f us; last dispatch at %.1f us, %.1f us (%.0f %%) before the end; workgroups "
+          "in flight: %.0f before, %.0f after; workgroup life %.1f us mean, %.1f us for the last 5 %% dispatched"
+          % (t1 - t0, drain - t0, t1 - drain, 100 * (t1 - drain) / (t1 - t0), busy_head / max(drain - t0, 1e-9),
+             busy_tail / max(t1 - drain, 1e-9), (en - st).mean(), (en - st)[np.argsort(st)[-len(st) // 20:]].mean()))
+    edges = np.linspace(t0, t1, 11)
+    print("  in flight per tenth of the launch: " + " ".join(
+        "%.0f" % (np.clip(np.minimum(en, edges[i + 1]) - np.maximum(st, edges[i]), 0, None).sum() / (edges[i + 1] - edges[i]))
+        for i in range(10)))
     for s in range(L):
         parts = ["%s %.0f" % (names[i], (t[:, s, i + 1] - t[:, s, i]).mean()) for i in range(per - 1)]
         gap = (t[:, s + 1, 0] - t[:, s, per - 1]).mean() if s + 1 < L else 0.0
