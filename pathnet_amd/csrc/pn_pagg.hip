@@ -2661,6 +2661,7 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     return PN_OK;
 }
 
+constexpr int WGRAD_CUS_SHARED = 224;   // CUs of the weight-gradient launch when something is meant to run beside it (of 256)
 struct WsLayout {
     size_t Xh, Z, range;                                                 // node tables (first: reuse_tables relies on it)
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
@@ -2669,7 +2670,7 @@ struct WsLayout {
     size_t flags, rank, list, seg, bsum;                                 // touched-row compaction (Dims.compact)
     size_t dx, keys, iota, skey, ssrc, stmp, cpart, dsel, dds, datt, dgemm;  // deterministic backward (Dims.det)
     size_t stmp_bytes;
-    int wgrad_split;
+    int wgrad_split, wgrad_tiles;
     size_t total;
 };
 
@@ -2699,13 +2700,14 @@ WsLayout ws_layout(const Dims &d) {
         // (Pubmed, BGP size: +10 % on the kernel for nothing hidden) it keeps every CU.  profiles/r04_wgrad_cus_ab.txt
         const size_t rows = Pb * L, tiles = std::max<size_t>(1, ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN));
         const double wg_flops = 2.0 * (double)rows * (double)(G * H) * (double)(2 * H);
-        size_t cus = (!d.det && wg_flops <= 1.2e11) ? 224 : 256;        // (deterministic mode runs its stages serially)
+        size_t cus = (!d.det && wg_flops <= 1.2e11) ? WGRAD_CUS_SHARED : 256;        // (deterministic mode runs its stages serially)
         if (const char *e = getenv("PN_WGRAD_CUS")) cus = (size_t)std::max(8, atoi(e));        // tuning / A-B runs
         size_t nz = (cus + tiles - 1) / tiles;
         const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
         if (nz > max_nz) nz = max_nz;
         if (nz < 1) nz = 1;
         w.wgrad_split = (int)nz;
+        w.wgrad_tiles = (int)tiles;
         w.wpart = take(nz * (G * H * 2 * H + G * H) * 4);
     }
     {
@@ -3664,7 +3666,10 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             wp.R = Pb * L;
             wp.GH = GH;
             wp.H2 = 2 * H;
-            const int nz = c.w.wgrad_split;
+            int nz = c.w.wgrad_split;
+            // a node-sharded caller runs its reduce-scatter of d Xh (RCCL's kernels) and fc0's backward under this launch
+            // (g_Xh_ready): they need CUs whose registers are not all taken, whatever the launch's length
+            if (a->Xh_in && a->g_Xh_ready) nz = std::min(nz, std::max(1, (WGRAD_CUS_SHARED + c.w.wgrad_tiles - 1) / c.w.wgrad_tiles));
             int64_t rps = (wp.R + nz - 1) / nz;
             rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
             wp.rows_per_split = rps;
