@@ -360,8 +360,9 @@ int pn_pagg_shape_info(const pn_pagg_shape *shape, int64_t out[4]);
 /* out = forward(...).  Leaves what backward needs in the workspace. */
 int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 /* Gradients of sum(out * g_out) w.r.t. every parameter (overwritten, not accumulated) and X.
- * Must follow a pn_pagg_forward on the same args/workspace (the saved tensors, the index plan and -- fp16 mode -- the operand
- * ranges of the weights live there). */
+ * Must follow a pn_pagg_forward (no_save = 0) on the same args/workspace with the same weights: the saved tensors, the index
+ * plan and -- fp16 mode -- the weights' operand ranges and their packed planes for the BPTT (written by the forward's packing
+ * stream, off the backward's critical path) live there. */
 int pn_pagg_backward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 /* One call for the aggregator's part of a training step (PathNet_run.py:343-351: forward, CrossEntropyLoss, backward):
  *   out [S, C] = forward(...);  loss[0] = grad_scale * sum over the S rows of softmax-cross-entropy(out[r], target[r]);
