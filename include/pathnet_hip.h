@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 6 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
+#define PN_ABI_VERSION 7 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
                           * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
                           *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
                           *    offsets throughout; pn_clock_probe
@@ -44,7 +44,9 @@ extern "C" {
                           *    pn_pagg_train_step
                           * 6: pn_pagg_shape gained compact / seq_math (decisions that shape the workspace travel with the
                           *    shape, not with the environment); pn_pagg_args.reuse_tables = 2; pn_pagg_shape_info; pn_pagg_args gained
-                          *    Xh_ready / g_Xh_ready (events that let the node-sharded path overlap its collectives) */
+                          *    Xh_ready / g_Xh_ready (events that let the node-sharded path overlap its collectives)
+                          * 7: pn_context_set_knob / pn_context_get_knob: the kernel-selection knobs are part of the context (read
+                          *    from the environment once, when it is created); no call reads the environment any more */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -75,6 +77,13 @@ int pn_device_query(pn_device_info *out);
 typedef struct pn_context pn_context;
 int pn_context_create(pn_context **out);
 int pn_context_destroy(pn_context *ctx);
+/* Kernel-selection knobs for A/B measurements and tests (none changes a result beyond rounding): PN_NODE_GEMM3, PN_EVAL_ZW,
+ * PN_POOL_BWD_WG, PN_NODE_RGRAD, PN_SAMPLER_STAGE, PN_SEQ4, PN_B4_WIDE, PN_SEQH_TAIL (pn_internal.h: struct Knobs).  A context
+ * takes its values from the environment variables of the same names ONCE, in pn_context_create; afterwards only these two
+ * calls read or change them -- device entry points never call getenv, so a captured step keeps its selection and a setenv
+ * on another thread cannot race a launch.  get accepts ctx = NULL (the defaults a NULL context runs with). */
+int pn_context_set_knob(pn_context *ctx, const char *name, int32_t value);
+int pn_context_get_knob(const pn_context *ctx, const char *name, int32_t *value);
 
 /* Per-step values kept in DEVICE memory, so that a whole training step captured into a hipGraph (every launch below is
  * capturable: no allocation, no synchronisation, the second stream joins the capture through its fork / join events) can

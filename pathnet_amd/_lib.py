@@ -13,7 +13,7 @@ PN_OK = 0
 PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
-ABI_VERSION = 6               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
+ABI_VERSION = 7               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
 CELL_DEFAULT, CELL_LSTM, CELL_RNN, CELL_GRU, CELL_MEAN, CELL_SUM = 0, 1, 2, 3, 4, 5
 SEQ_MATH_DEFAULT, SEQ_MATH_BF16X3, SEQ_MATH_F16X2 = 0, 1, 2     # pn_pagg_shape.seq_math
@@ -83,6 +83,8 @@ SIGNATURES = {
     "pn_device_query": (ctypes.c_int, [ctypes.POINTER(DeviceInfo)]),
     "pn_context_create": (ctypes.c_int, [ctypes.POINTER(vp)]),
     "pn_context_destroy": (ctypes.c_int, [vp]),
+    "pn_context_set_knob": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int32]),
+    "pn_context_get_knob": (ctypes.c_int, [vp, ctypes.c_char_p, c_i32p]),
     "pn_clock_probe": (ctypes.c_int, [c_f64p, vp]),
     "pn_step_state_advance": (ctypes.c_int, [vp, vp]),
     "pn_edges_read_text": (ctypes.c_int, [ctypes.c_char_p, c_i32p, c_i64p, c_i32p, c_i32p, c_f64p, ctypes.c_int64]),
@@ -176,6 +178,21 @@ def context(device):
             import atexit
             atexit.register(_destroy_contexts)
     return ctx
+
+
+def set_knob(name, value, device="cuda"):
+    """pn_context_set_knob on this process's context for `device`: the kernel-selection knobs (PN_EVAL_ZW, PN_SEQ4, ...) are
+    read from the environment once, when the context is created; afterwards this is the only way to change them.
+    Returns the previous value."""
+    old = get_knob(name, device)
+    check(load().pn_context_set_knob(context(device), name.encode(), int(value)))
+    return old
+
+
+def get_knob(name, device="cuda"):
+    v = ctypes.c_int32()
+    check(load().pn_context_get_knob(context(device), name.encode(), ctypes.byref(v)))
+    return v.value
 
 
 def _destroy_contexts():

@@ -3,6 +3,8 @@
 // an opaque handle").
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <new>
 #include <vector>
@@ -21,6 +23,9 @@ struct pn_context {
     std::vector<Rec> recs;
     std::vector<hipEvent_t> free_events;
     std::map<const void *, int> lds_attr;      // kernel -> dynamic LDS bytes already granted on this device
+    std::map<const void *, int> slots;         // kernel -> resident workgroups per CU (at the LDS size it is launched with)
+    int cus = 0;
+    pn::Knobs knobs;
 };
 
 namespace {
@@ -64,9 +69,49 @@ hipEvent_t take_event(pn_context *ctx) {
 
 }  // namespace
 
+namespace {
+
+struct KnobName {
+    const char *name;
+    int pn::Knobs::*field;
+};
+const KnobName kKnobs[] = {{"PN_NODE_GEMM3", &pn::Knobs::node_gemm3}, {"PN_EVAL_ZW", &pn::Knobs::eval_zw},
+                           {"PN_POOL_BWD_WG", &pn::Knobs::pool_bwd_wg}, {"PN_NODE_RGRAD", &pn::Knobs::node_rgrad},
+                           {"PN_SAMPLER_STAGE", &pn::Knobs::sampler_stage}, {"PN_SEQ4", &pn::Knobs::seq4},
+                           {"PN_B4_WIDE", &pn::Knobs::b4_wide}, {"PN_SEQH_TAIL", &pn::Knobs::seqh_tail}};
+
+}  // namespace
+
 namespace pn {
 
+const Knobs &knobs_of(const pn_context *ctx) {
+    static const Knobs defaults;
+    return ctx ? ctx->knobs : defaults;
+}
+
 bool profiling_every_stage(const pn_context *ctx) { return ctx && ctx->prof_mode == 1; }
+
+int resident_slots(pn_context *ctx, const void *kernel, int threads, size_t lds_bytes, int *slots, int *cus) {
+    if (ctx) {
+        auto it = ctx->slots.find(kernel);
+        if (it != ctx->slots.end() && ctx->cus > 0) {
+            *slots = it->second * ctx->cus;
+            *cus = ctx->cus;
+            return PN_OK;
+        }
+    }
+    int dev = 0, n_cu = 0, per_cu = 0;
+    PN_CHECK_HIP(hipGetDevice(&dev));
+    PN_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    PN_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes));
+    if (ctx) {
+        ctx->slots[kernel] = per_cu;
+        ctx->cus = n_cu;
+    }
+    *slots = per_cu * n_cu;
+    *cus = n_cu;
+    return PN_OK;
+}
 
 int context_check_device(const pn_context *ctx) {
     if (!ctx) return PN_OK;
@@ -127,6 +172,8 @@ int pn_context_create(pn_context **out) try {
         (void)pn_context_destroy(c);
         return PN_ERR_HIP;
     };
+    for (const KnobName &k : kKnobs)
+        if (const char *v = std::getenv(k.name)) c->knobs.*(k.field) = std::atoi(v);
     hipError_t e = hipGetDevice(&c->device);
     if (e != hipSuccess) return fail(e, "hipGetDevice");
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
@@ -158,6 +205,25 @@ int pn_context_destroy(pn_context *c) {
     delete c;
     if (rc != PN_OK) pn::set_error("pn_context_destroy: the context's stream reported an error");
     return rc;
+}
+
+int pn_context_set_knob(pn_context *ctx, const char *name, int32_t value) {
+    if (!ctx || !name) PN_FAIL(PN_ERR_ARG, "pn_context_set_knob: null");
+    for (const KnobName &k : kKnobs)
+        if (std::strcmp(k.name, name) == 0) {
+            ctx->knobs.*(k.field) = value;
+            return PN_OK;
+        }
+    PN_FAIL(PN_ERR_ARG, "pn_context_set_knob: no knob named %s", name);
+}
+int pn_context_get_knob(const pn_context *ctx, const char *name, int32_t *value) {
+    if (!name || !value) PN_FAIL(PN_ERR_ARG, "pn_context_get_knob: null");
+    for (const KnobName &k : kKnobs)
+        if (std::strcmp(k.name, name) == 0) {
+            *value = pn::knobs_of(ctx).*(k.field);
+            return PN_OK;
+        }
+    PN_FAIL(PN_ERR_ARG, "pn_context_get_knob: no knob named %s", name);
 }
 
 int pn_profile_configure(pn_context *ctx, int32_t mode, int32_t stage) {

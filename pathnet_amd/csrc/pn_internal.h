@@ -39,6 +39,27 @@ GlibcState glibc_apply(const GlibcPoly &p, const GlibcState &st);
 // state whose s[0] >> 1 is the first rand() after srand(seed)
 GlibcState glibc_seed_state(uint32_t seed);
 
+// ---- kernel-selection knobs (A/B runs, tests): part of the context, read from the environment ONCE when the context is
+// created (pn_context_create) and changed afterwards only through pn_context_set_knob -- no call reads the environment,
+// so a concurrent setenv cannot race a launch and a captured step replays the selection it was captured with.
+// A NULL context runs the defaults.
+#ifndef PN_SEQH_TAIL_DEFAULT
+#define PN_SEQH_TAIL_DEFAULT 1
+#endif
+struct Knobs {
+    int node_gemm3 = 7;         // PN_NODE_GEMM3: bit mask -- 1 fc0, 2 distance bank, 4 dense bank dX on the bf16 x 3 GEMM when its
+                                //                tiles fill the GPU; 8: the compact bank dX as well (measured slower)
+    int eval_zw = 1;            // PN_EVAL_ZW: inference forwards apply W_ih to the bank rows before the gather
+    int pool_bwd_wg = 1;        // PN_POOL_BWD_WG: pooling backward as a workgroup per node
+    int node_rgrad = 1;         // PN_NODE_RGRAD: row-reduction kernel for the node-level weight gradients of large graphs
+    int sampler_stage = -1;     // PN_SAMPLER_STAGE: first-hop tables in LDS (-1: by launch size)
+    int seq4 = 4;               // PN_SEQ4: which 128-path kernels of pn_seq4.hip serve the bf16 mode (bit 2: weight gradient)
+    int b4_wide = 0;            // PN_B4_WIDE (experimental builds)
+    int seqh_tail = PN_SEQH_TAIL_DEFAULT;   // PN_SEQH_TAIL: 0 = 32-path tiles only; 1 = the remainder round of the fp16 recurrent
+                                //                launches in smaller tiles, one per CU; 8 / 16 / 24 = that size, always
+};
+const Knobs &knobs_of(const pn_context *ctx);
+
 // ---- pn_context: the only state that outlives a call (pn_context.hip) ------------------------------------
 enum Stage {
     ST_SAMPLER_FILL = 0, ST_SAMPLER_WALK, ST_GATHER, ST_FC0, ST_BANK, ST_PLAN_PACK, ST_SEQ_FWD, ST_POOL_FWD,
@@ -56,6 +77,8 @@ int context_join(pn_context *ctx, void *stream);
 // hipFuncSetAttribute(kernel, MaxDynamicSharedMemorySize, bytes), remembered per context (= per device) so that the
 // steady state issues no runtime call besides the launches (a captured step must not)
 int ensure_dynamic_lds(pn_context *ctx, const void *kernel, int bytes);
+// resident workgroups of `kernel` on the whole device (occupancy x compute units), remembered per context like the above
+int resident_slots(pn_context *ctx, const void *kernel, int threads, size_t lds_bytes, int *slots, int *cus);
 // RAII bracket: records a start event now and a stop event at scope exit when the context's profiling selects `stage`
 struct StageTimer {
     StageTimer(pn_context *ctx, int stage, void *stream);

@@ -469,9 +469,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // the bf16 x 3 GEMM pays once its 128 x 128 tiles fill the GPU (the fp32-input MFMA kernel has 64 x 64 tiles and a split-K
 // front end for the small shapes); K must be a multiple of 32
 enum { G3_FC0 = 1, G3_BANK = 2, G3_BANK_DX = 4 };
-inline bool gemm3_pays(int64_t M, int64_t N, int K, int which) {
-    if (const char *e = getenv("PN_NODE_GEMM3"))        // bit mask of G3_*: A/B runs and tests (default: all)
-        if (!(atoi(e) & which)) return false;
+inline bool gemm3_pays(const pn_context *ctx, int64_t M, int64_t N, int K, int which) {
+    if (!(knobs_of(ctx).node_gemm3 & which)) return false;      // bit mask of G3_*: A/B runs and tests (default: all)
     return K >= G3_KT && K % G3_KT == 0 && ((M + G3_BM - 1) / G3_BM) * ((N + G3_BN - 1) / G3_BN) >= 384;
 }
 
@@ -2965,7 +2964,7 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
             return launch_pack_bwdh(s, c.a->w_ih, c.a->w_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg, c.at<void>(c.w.WpT));
         return PN_OK;
     }
-    if (seq4_select(d.H, d.G, d.L) & SEQ4_FWD)      // the 128-path kernel reads its own fragment order (pn_seq4.hip)
+    if (seq4_select(c.ctx, d.H, d.G, d.L) & SEQ4_FWD)      // the 128-path kernel reads its own fragment order (pn_seq4.hip)
         return launch_pack_fwd4(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0,
                                 c.at<void>(c.w.Wp), c.at<float>(c.w.biasc));
     hipLaunchKernelGGL(pack_fwd3_kernel, dim3((unsigned)((d.G * d.H * d.H / 4 + 255) / 256)), dim3(256), 0, s, c.a->w_ih,
@@ -3013,8 +3012,7 @@ inline bool use_zw(const Call &c) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
     if (d.math != PN_SEQ_MATH_F16X2 || !a->no_save || a->p_seq > 0.0f || a->mask_seq) return false;
-    if (const char *e = getenv("PN_EVAL_ZW"))
-        if (atoi(e) == 0) return false;
+    if (knobs_of(c.ctx).eval_zw == 0) return false;
     const size_t need = (size_t)d.ZR * d.G * d.H * 4, have = (size_t)d.Sb * d.W * d.L * d.SV * d.H * 4;
     return need <= have && need <= ((size_t)2 << 30);
 }
@@ -3058,7 +3056,7 @@ int run_seq_fwd(const Call &c, int b, bool save) {
         sp.xmul = seq_xmul(a);
         return launch_seq_fwdh(c.ctx, c.stream, d.H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp);
     }
-    if (seq4_select(d.H, d.G, d.L) & SEQ4_FWD) {
+    if (seq4_select(c.ctx, d.H, d.G, d.L) & SEQ4_FWD) {
         sp.xh = c.at<float>(c.w.xh);        // h_t travels to the next step through these rows, saved or not
         sp.store_x = save ? 1 : 0;
         return launch_seq_fwd4(c.ctx, c.stream, d.cell == CELL_GRU ? 3 : 4, sp);
@@ -3143,7 +3141,7 @@ int run_tables(const Call &c, JoinGuard &joiner) {
         // fc0 (+ReLU for HOMO): Xh = X . fc0_w^T + fc0_b
         if (!a->Xh_in) {
             StageTimer tm(ctx, ST_FC0, stream);
-            if (gemm3_pays(d.N, H, d.F, G3_FC0)) {          // large graphs: fp32 results from the bf16 matrix pipe (six MFMAs per product)
+            if (gemm3_pays(c.ctx, d.N, H, d.F, G3_FC0)) {          // large graphs: fp32 results from the bf16 matrix pipe (six MFMAs per product)
                 if (int rc = launch_gemm3(stream, a->X, d.F, a->fc0_w, d.F, c.at<float>(c.w.Xh), H, a->fc0_b, d.N, H, d.F, homo))
                     return rc;
             } else if (int rc = launch_gemm_split(stream, a->X, d.F, 1, nullptr, a->fc0_w, d.F, 1, c.at<float>(c.w.Xh), H,
@@ -3160,7 +3158,7 @@ int run_tables(const Call &c, JoinGuard &joiner) {
         StageTimer tm(ctx, ST_BANK, stream);
         const int mmax = (int)std::min<int64_t>(d.N, d.ZR);
         for (int code = 0; code < L; code++) {
-            if (gemm3_pays(mmax, H, H, G3_BANK)) {
+            if (gemm3_pays(c.ctx, mmax, H, H, G3_BANK)) {
                 if (int rc = launch_gemm3(stream, c.Xh, H, a->bank_w + (size_t)code * H * H, H, c.Z, H, a->bank_b + (size_t)code * H,
                                           mmax, H, H, homo, 0, nullptr, GEMM_IND_A_ROWS, c.at<const int32_t>(c.w.seg) + code,
                                           c.at<const int32_t>(c.w.list)))
@@ -3173,7 +3171,7 @@ int run_tables(const Call &c, JoinGuard &joiner) {
     } else if (a->reuse_tables != 1) {      // (1: the dense Z of the previous forward is still valid; 2: only Xh is)
         // distance bank over every node: Z[v, d, :] = act(Xh[v] . bank_w[d]^T + bank_b[d])
         StageTimer tm(ctx, ST_BANK, stream);
-        if (gemm3_pays(d.N, L * H, H, G3_BANK)) {
+        if (gemm3_pays(c.ctx, d.N, L * H, H, G3_BANK)) {
             if (int rc = launch_gemm3(stream, c.Xh, H, a->bank_w, H, c.Z, (int64_t)L * H, a->bank_b, d.N, L * H, H, homo)) return rc;
         } else if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
                                         L * H, H, homo, GEMM_STORE, 1))
@@ -3478,7 +3476,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     // (per-stage timings are taken serially; so is the deterministic mode, whose stages share scratch buffers)
     const bool side_ok = !profiling_every_stage(ctx) && !d.det;
     const bool f16 = d.math == PN_SEQ_MATH_F16X2;
-    const int seq4 = f16 ? 0 : seq4_select(H, G, L);
+    const int seq4 = f16 ? 0 : seq4_select(ctx, H, G, L);
     SeqRange *range = c.at<SeqRange>(c.w.range);
     float *dgemm = d.det ? c.at<float>(c.w.dgemm) : nullptr;
     if (d.det) {        // the identity the BPTT kernels index the contribution buffer with
@@ -3581,8 +3579,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             const size_t lds_bytes = (size_t)(4 * (2 * d.W + H) + 8 * H + 8 * d.W) * sizeof(float);
             StageTimer tm(ctx, ST_POOL_BWD, stream);
             // a workgroup per group (four waves share its members) unless PN_POOL_BWD_WG=0; it needs the partials buffer
-            const char *e_wg = getenv("PN_POOL_BWD_WG");
-            const bool wg = (!has_att || pp.det_att) && !(e_wg && atoi(e_wg) == 0);
+            const bool wg = (!has_att || pp.det_att) && knobs_of(ctx).pool_bwd_wg != 0;
             int att_blocks = (Sb + 3) / 4;
             if (wg) {
                 att_blocks = Sb;
@@ -3727,7 +3724,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         const int32_t *seg = c.at<const int32_t>(c.w.seg), *list = c.at<const int32_t>(c.w.list);
         // (measured at the 10 M-node shape: the 128 x 128 tiles' read-modify-write of scattered dXh rows at two workgroups
         //  per CU is slower than the 64 x 64 kernel's, 24.1 vs 21.6 ms for the stage; PN_NODE_GEMM3 bit 3 switches it on)
-        const bool g3 = getenv("PN_NODE_GEMM3") && (atoi(getenv("PN_NODE_GEMM3")) & 8) && gemm3_pays(mmax, H, H, G3_BANK_DX);
+        const bool g3 = (knobs_of(ctx).node_gemm3 & 8) && gemm3_pays(ctx, mmax, H, H, G3_BANK_DX);
         float *bankT = c.at<float>(c.w.bankT);
         if (g3)             // bank_w[code] [out, in] -> [in, out]: the reduction index (out) contiguous
             for (int code = 0; code < L; code++)
@@ -3750,7 +3747,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                                              (mmax + 255) / 256, a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, dgemm,
                                              GEMM_IND_K, seg + code, list))
                     return rc;
-            } else if (a->g_bank_w && rgrad_pays(mmax, H, H)) {         // large graphs: the bf16 x 3 row-reduction kernel
+            } else if (a->g_bank_w && rgrad_pays(ctx, mmax, H, H)) {         // large graphs: the bf16 x 3 row-reduction kernel
                 const RgradParams rp{dZ, zgate, Xh, H, H, mmax, H, H, a->g_bank_w + (size_t)code * H * H, H,
                                      a->g_bank_b ? a->g_bank_b + (size_t)code * H : nullptr, seg + code, list};
                 if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
@@ -3761,7 +3758,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                     return rc;
         }
     } else {
-    if (gemm3_pays(d.N, H, L * H, G3_BANK_DX)) {        // bank_w [L*H, H] -> [H, L*H]
+    if (gemm3_pays(c.ctx, d.N, H, L * H, G3_BANK_DX)) {        // bank_w [L*H, H] -> [H, L*H]
         float *bankT = c.at<float>(c.w.bankT);
         hipLaunchKernelGGL(transpose_kernel, dim3((L * H * H + 255) / 256), dim3(256), 0, stream, a->bank_w, L * H, H, bankT);
         if (int rc = launch_gemm3(stream, dZ, (int64_t)L * H, bankT, (int64_t)L * H, dXh, H, nullptr, d.N, H, L * H, 0, 1, zgate))
@@ -3774,7 +3771,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (int rc = launch_gemm_det(stream, dZ, 1, (int64_t)L * H, zgate, Xh, 1, H, a->g_bank_w, H, L * H, H, d.N,
                                      (d.N + 255) / 256, a->g_bank_b, dgemm))
             return rc;
-    } else if (a->g_bank_w && rgrad_pays(d.N, L * H, H)) {
+    } else if (a->g_bank_w && rgrad_pays(ctx, d.N, L * H, H)) {
         const RgradParams rp{dZ, zgate, Xh, (int64_t)L * H, H, d.N, L * H, H, a->g_bank_w, H, a->g_bank_b, nullptr, nullptr};
         if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
     } else if (a->g_bank_w) {       // g_bank_b rides along as the row sums of the same (gated) A operand
@@ -3795,7 +3792,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (int rc = launch_gemm_det(stream, dXh, 1, H, xgate, a->X, 1, d.F, a->g_fc0_w, d.F, H, d.F, d.N, (d.N + 255) / 256,
                                      a->g_fc0_b, dgemm))
             return rc;
-    } else if (a->g_fc0_w && d.F % 4 == 0 && rgrad_pays(d.N, H, d.F)) {
+    } else if (a->g_fc0_w && d.F % 4 == 0 && rgrad_pays(ctx, d.N, H, d.F)) {
         const RgradParams rp{dXh, xgate, a->X, H, d.F, d.N, H, d.F, a->g_fc0_w, d.F, a->g_fc0_b, nullptr, nullptr};
         if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
     } else if (a->g_fc0_w) {

@@ -217,9 +217,8 @@ __global__ __launch_bounds__(R_THREADS, 2) void rgrad_kernel(RgradParams p) {
 
 namespace pn {
 
-bool rgrad_pays(int64_t R, int M, int N) {
-    if (const char *e = getenv("PN_NODE_RGRAD"))        // 0: never (A/B runs, tests)
-        if (atoi(e) == 0) return false;
+bool rgrad_pays(const pn_context *ctx, int64_t R, int M, int N) {
+    if (knobs_of(ctx).node_rgrad == 0) return false;    // 0: never (A/B runs, tests)
     return R >= 49152 && M % 4 == 0 && N % 4 == 0;
 }
 

@@ -635,9 +635,9 @@ int pn_sample_paths(pn_context *ctx, const pn_sampler_tables *tb, int32_t W, int
     wp.node_list = node_list;
     {
         // a node range was always staged (round 2's rates); a node list only when the launch has workgroups to overlap with
-        const char *e = getenv("PN_SAMPLER_STAGE");
+        const int forced = pn::knobs_of(ctx).sampler_stage;
         const int64_t walks = (int64_t)epoch_count * node_count * W;
-        wp.stage = e ? atoi(e) != 0 : (!node_list || walks >= (int64_t)kWalkThreads * 1024);
+        wp.stage = forced >= 0 ? forced != 0 : (!node_list || walks >= (int64_t)kWalkThreads * 1024);
     }
 
     if (draw_source == PN_DRAW_GLIBC_REPLAY) {

@@ -17,6 +17,15 @@ struct SeqRange {
     uint32_t dg;            // max |dG| of the BPTT launch the weight-gradient GEMM follows (seq_bwdh_kernel)
 };
 
+// tile geometry of the fp16 recurrent kernels (pn_seqh.hip "tile geometry"): n_big tiles of 32 paths and n_small tiles of
+// small_rows (8 / 16 / 24; 0 = every tile has 32) -- the small ones after the big ones, or before them (small_first)
+struct SeqTiling {
+    int n_big, n_small, small_rows, small_first;
+};
+struct SeqTile {
+    int q0, rows;
+};
+
 struct SeqFwdParams {
     const float *Z;         // [N*L, H] bank output (post activation)
     const int32_t *rowidx;  // [P, L]
@@ -41,6 +50,7 @@ struct SeqFwdParams {
     const SeqRange *range;  // fp16 kernels: operand ranges (device)
     float xmul;             // fp16 kernels: bound of the factor dropout applies to a gathered row (1 / (1 - p), or 16 for explicit masks)
     const float *ZW;        // seq_fwdzw_kernel: [rows of Z, G*H] = Z . W_ih^T + b (inference without dropout)
+    SeqTiling tiling;       // fp16 kernels: filled in by the launcher
 };
 
 struct SeqBwdParams {
@@ -59,6 +69,7 @@ struct SeqBwdParams {
     const float *mask;
     SeqRange *range;        // fp16 kernels: reads w_ih / w_hh, leaves max |dG| in dg
     int store_dx;           // fp16 kernel, deterministic mode: rowidx is the identity -- mask * dx is STORED (no zero-fill, no atomics)
+    SeqTiling tiling;       // fp16 kernels: filled in by the launcher
 };
 
 struct WgradParams {
@@ -86,14 +97,14 @@ struct RgradParams {
     float *rowsum;          // [M] += column sums of the gated A (the bias gradient), or null
     const int32_t *seg, *list;      // compact rows: A row = seg[0] + k, B row = list[seg[0] + k], k < seg[1] - seg[0]; or both null
 };
-bool rgrad_pays(int64_t R, int M, int N);       // the kernel's 128 x 128 tiles and K tiles of 32 rows want >= ~50 000 rows
+bool rgrad_pays(const pn_context *ctx, int64_t R, int M, int N);       // the kernel's 128 x 128 tiles and K tiles of 32 rows want >= ~50 000 rows
 int launch_rgrad(pn_context *ctx, void *stream, const RgradParams &p);
 
 // ---- pn_seq4.hip: the recurrent kernels with 128 paths per workgroup -------------------------------------------------
 // which of the three kernels take the 128-row path for this shape (bit 0: forward, bit 1: BPTT, bit 2: weight gradient);
 // 0 when the shape is outside what they are built for.  PN_SEQ4 in the environment (a bit mask) narrows it.
 enum { SEQ4_FWD = 1, SEQ4_BWD = 2, SEQ4_WGRAD = 4 };
-int seq4_select(int H, int G, int L);
+int seq4_select(const pn_context *ctx, int H, int G, int L);
 // weight packing for seq_fwd4_kernel / seq_bwd4_kernel (same workspace slots and sizes as pack_fwd3 / pack_bwd3)
 int launch_pack_fwd4(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
                      int gru, void *Wp, float *biasc);

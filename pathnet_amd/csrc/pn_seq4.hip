@@ -1092,13 +1092,12 @@ extern "C" int pn_debug_set_trace4(long long *dev_buf) {     // tuning builds on
 
 namespace pn {
 
-int seq4_select(int H, int G, int L) {
+int seq4_select(const pn_context *ctx, int H, int G, int L) {
     if (H != H4 || G != G4 || L < 1 || L > 8) return 0;      // (LDS: the index arrays of a 128-path tile)
     // default: the weight-gradient GEMM of this file (commit of the next K tile between the MFMA groups of the current
     // one: 0.278 vs 0.297 ms, A/B in one session); its forward and BPTT measured slower than the fused kernels and stay
     // opt-in (PN_SEQ4 = bit mask, 0 = every fused kernel)
-    int mask = SEQ4_WGRAD;
-    if (const char *e = getenv("PN_SEQ4")) mask = atoi(e);
+    const int mask = knobs_of(ctx).seq4;
     return mask & (PN_EXPERIMENTAL ? (SEQ4_FWD | SEQ4_BWD | SEQ4_WGRAD) : SEQ4_WGRAD);
 }
 
@@ -1154,8 +1153,7 @@ static int launch_seq_bwd4_t(pn_context *ctx, hipStream_t stream, const SeqBwdPa
 
 int launch_seq_bwd4(pn_context *ctx, void *stream, int gc, const SeqBwdParams &sp) {
     // PN_B4_WIDE=1: 128 paths per workgroup (one workgroup per CU); default: 64 paths, two workgroups per CU
-    const char *e = getenv("PN_B4_WIDE");
-    const bool wide = e && atoi(e) != 0;
+    const bool wide = knobs_of(ctx).b4_wide != 0;
     hipStream_t st = (hipStream_t)stream;
     if (wide) return gc == 3 ? launch_seq_bwd4_t<3, 2, 2>(ctx, st, sp) : launch_seq_bwd4_t<4, 2, 2>(ctx, st, sp);
     return gc == 3 ? launch_seq_bwd4_t<3, 1, 1>(ctx, st, sp) : launch_seq_bwd4_t<4, 1, 1>(ctx, st, sp);

@@ -60,6 +60,12 @@ using namespace pn;
 #ifndef PN_BWD_REVERSE
 #define PN_BWD_REVERSE 1
 #endif
+#ifndef PN_BWDH_SKIPZ
+#define PN_BWDH_SKIPZ 0     // 1: the scatter issues no atomic for an element dropout zeroed (dx == 0: adding it changes nothing)
+#endif
+#ifndef PN_SEQH_PLANAR
+#define PN_SEQH_PLANAR 0    // 1: the three dwords of the packed gates as three [H] planes per path step instead of [H][3]: every
+#endif                      // load of the BPTT is then one full line per half-wave (the [H][3] form touches each line three times)
 
 #ifndef PN_TRACE_H
 #define PN_TRACE_H 0        // 1: tuning builds only -- wave 0 of every workgroup stamps the cycle counter at phase boundaries
@@ -86,6 +92,86 @@ __device__ long long *g_trace_h = nullptr;      // [blocks][64] stamps, set with
 namespace {
 
 __device__ __forceinline__ uint32_t fbits_abs(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
+// the scatter's add (PN_ABL bit 3: none at all, timing only)
+__device__ __forceinline__ void scatter_add(float *dst, float v) {
+#if PN_ABL & 8
+    (void)dst; (void)v;
+#else
+    atomicAdd(dst, v);
+#endif
+}
+
+// ---- tile geometry ------------------------------------------------------------------------------------------------
+// A launch of T = ceil(P / 32) tiles on S resident workgroup slots runs as ceil(T / S) synchronised rounds (every tile costs
+// the same): at the headline shape 1624 tiles on 768 (forward) / 512 (BPTT) slots, and the last 20 % / 14 % of the launch
+// keeps 143 / 78 workgroups in flight (profiles/r04_tail_experiments.txt).  A lone workgroup's step is bound by its memory
+// phases and by the weight-fragment stream, not by the matrix pipe, so the remainder round is cut into SMALLER tiles --
+// small_rows = 8, 16 or 24 paths, the accumulator registers of the missing rows are whole-wave dead (acc_row: rows < 8k are
+// registers r < 4k) and their stores / atomics never issue -- one per CU instead of a 32-path tile on a third of the CUs.
+// Tile j < n_big * (1 - small_first):  paths [32 j, 32 j + 32);  the small ones follow (forward) or come first (BPTT,
+// whose dispatch order is descending: its remainder round is the START of the path range).
+__device__ __forceinline__ SeqTile seq_tile_of(const SeqTiling tg, int j, int MT, int P) {
+    SeqTile t;
+    if (tg.small_rows == 0) {
+        t.q0 = j * MT;
+        t.rows = min(MT, P - t.q0);
+    } else if (tg.small_first) {
+        if (j < tg.n_small) {
+            t.q0 = j * tg.small_rows;
+            t.rows = min(tg.small_rows, P - t.q0);
+        } else {
+            t.q0 = tg.n_small * tg.small_rows + (j - tg.n_small) * MT;
+            t.rows = min(MT, P - t.q0);
+        }
+    } else {
+        if (j < tg.n_big) {
+            t.q0 = j * MT;
+            t.rows = MT;
+        } else {
+            t.q0 = tg.n_big * MT + (j - tg.n_big) * tg.small_rows;
+            t.rows = min(tg.small_rows, P - t.q0);
+        }
+    }
+    t.q0 = __builtin_amdgcn_readfirstlane(t.q0);
+    t.rows = __builtin_amdgcn_readfirstlane(t.rows);
+    return t;
+}
+
+// host side: the split of P paths into n_big tiles of MT and n_small of small_rows for a kernel with `slots` resident
+// workgroups on `cus` compute units.  Pure arithmetic (tests/test_abi.py drives it through pn_debug_seq_tiling).
+void seq_tiling_for(int64_t P, int MT, int slots, int cus, int mode, bool small_first, SeqTiling *tg, int *blocks) {
+    *tg = SeqTiling{0, 0, 0, small_first ? 1 : 0};
+    const int64_t T = (P + MT - 1) / MT;
+    *blocks = (int)T;
+    if (mode == 0 || MT != 32 || slots <= 0 || cus <= 0 || P <= 0) return;
+    const int64_t full = T / slots * slots;             // tiles of the full rounds
+    const int64_t rem_paths = P - full * MT;            // what the remainder round holds
+    if (rem_paths <= 0) return;
+    int rows = mode >= 8 ? mode : (int)((rem_paths + (int64_t)cus * 8 - 1) / ((int64_t)cus * 8)) * 8;      // one tile per CU
+    if (rows >= MT) return;                             // the remainder round fills the CUs as it is
+    const int64_t n_small = (rem_paths + rows - 1) / rows;
+    if (small_first) {
+        const int64_t rest = P - n_small * rows;
+        tg->n_small = (int)n_small;
+        tg->n_big = (int)(rest > 0 ? (rest + MT - 1) / MT : 0);
+    } else {
+        tg->n_big = (int)full;
+        tg->n_small = (int)n_small;
+    }
+    tg->small_rows = rows;
+    *blocks = tg->n_big + tg->n_small;
+}
+
+int plan_tiling(pn_context *ctx, const void *kernel, int threads, size_t lds_bytes, int64_t P, int MT, bool small_first,
+                SeqTiling *tg, int *blocks) {
+    int slots = 0, cus = 0;
+    const int mode = knobs_of(ctx).seqh_tail;
+    if (mode != 0)
+        if (int rc = resident_slots(ctx, kernel, threads, lds_bytes, &slots, &cus)) return rc;
+    seq_tiling_for(P, MT, slots, cus, mode, small_first, tg, blocks);
+    return PN_OK;
+}
 
 // ---- operand ranges ---------------------------------------------------------------------------------------------------
 // One workgroup: max |W_ih|, max |W_hh| stored (no atomics, nothing to clear beforehand); it also clears the slots the
@@ -228,12 +314,15 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 2 * PLANE);  // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
-    const int q0 = blockIdx.x * MT;
+    // tile geometry (SeqTiling): the first n_big workgroups take MT paths each, the rest -- the launch's remainder round --
+    // small_rows each, so that the last round runs on every CU instead of a third of them
+    const SeqTile tl = seq_tile_of(p.tiling, (int)blockIdx.x, MT, p.P);
+    const int q0 = tl.q0, rows_here = tl.rows;
     const int col = 32 * wave + li;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);    // the wave's column slice as a scalar (weight stream base)
 
-    for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = q0 + i / p.L < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
-    for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
+    for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = i / p.L < rows_here ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
+    for (int i = tid; i < MT; i += NT) s_slotof[i] = i < rows_here ? p.slotof[q0 + i] : 0;
 
     const FwdScales sc = fwd_scales(p.range, p.xmul);
     f32x16 cst[RB];
@@ -315,11 +404,11 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         for (int i = 0; i < NLD; i++) {
             const int idx = tid_g + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-            const int q = q0 + row;
+            const bool live = row < rows_here;
             float4 v = EARLY_X ? xe[i] : make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
-            if (q >= p.P) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.mask) {
-                if (q < p.P) {
+                if (live) {
                     const float4 m = reinterpret_cast<const float4 *>(
                         p.mask)[((int64_t)t * p.Pmask + s_slotof[row]) * (H / 4) + c4];
                     v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
@@ -330,7 +419,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 v.y = b & 2u ? v.y * keep_scale : 0.0f;
                 v.z = b & 4u ? v.z * keep_scale : 0.0f;
                 v.w = b & 8u ? v.w * keep_scale : 0.0f;
-                if (keep_t && q < p.P) keep_t[((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(H / 4) + c4] = (uint8_t)(b & 15u);
+                if (keep_t && live) keep_t[((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(H / 4) + c4] = (uint8_t)(b & 15u);
             }
             uint32_t a0, a1, b0, b1;
             split2h(v.x * sc.s_x, v.y * sc.s_x, a0, a1);
@@ -338,7 +427,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             unsigned char *d = ldsb + row * PB + 8 * c4;
             *reinterpret_cast<uint2 *>(d) = make_uint2(a0, b0);
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
-            if (xh4_t && q < p.P) {
+            if (xh4_t && live) {
                 float4 *xo = &at_bytes(xh4_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4) * 16u);
                 if (!(PN_ABL & 1)) xo[0] = v;
                 if (t == 0) xo[H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -442,7 +531,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = 32 * rb + acc_row(r, lane_o);
-            const int q = q0 + row;
+            const bool live = row < rows_here;
             float h;
             if (GRU) {
                 // saved: r, z, n, the pre-activation W_hn h + b_hn, h_{t-1}
@@ -453,7 +542,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 const float hp = cst[rb][r];
                 h = (1.0f - zg) * ng + zg * hp;
                 cst[rb][r] = h;
-                if (saved_t && q < p.P) {
+                if (saved_t && live) {
                     float *sv = &at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H) + col) * 4u);
                     sv[0] = rg; sv[H] = zg; sv[2 * H] = ng; sv[3 * H] = nh; sv[4 * H] = hp;
                 }
@@ -465,10 +554,16 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 const float c = fg * cst[rb][r] + ig * gg;
                 cst[rb][r] = c;
                 h = og * tanhf_(c);
-                if (saved_t && q < p.P) {
+                if (saved_t && live) {
                     const uint32_t base = ((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H);
                     if constexpr (PACKED) {
-                        *reinterpret_cast<uint3 *>(&at_bytes(saved_t, (base + 3u * col) * 4u)) = pack_gates(ig, fg, gg, og);
+                        if (PN_SEQH_PLANAR) {
+                            const uint3 pk = pack_gates(ig, fg, gg, og);
+                            uint32_t *sq = reinterpret_cast<uint32_t *>(&at_bytes(saved_t, (base + col) * 4u));
+                            sq[0] = pk.x; sq[H] = pk.y; sq[2 * H] = pk.z;
+                        } else {
+                            *reinterpret_cast<uint3 *>(&at_bytes(saved_t, (base + 3u * col) * 4u)) = pack_gates(ig, fg, gg, og);
+                        }
                         at_bytes(saved_t, (base + 3u * H + col) * 4u) = c;
                     } else {
                         float *sv = &at_bytes(saved_t, (base + col) * 4u);
@@ -477,10 +572,10 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 }
             } else {
                 h = tanhf_(acc[rb][0][r] * sc.inv_S);
-                if (saved_t && q < p.P) at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)H + col) * 4u) = h;
+                if (saved_t && live) at_bytes(saved_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)H + col) * 4u) = h;
             }
             hv[r] = h;
-            if (q < p.P) {
+            if (live) {
                 if (t == p.L - 1)
                     at_bytes(hn_t, ((uint32_t)row * (uint32_t)H + col) * 4u) = h;
                 else if (xh_t)
@@ -706,15 +801,15 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(s_keep + 2 * MT * (H / 4)) +
                                        256u * (uint32_t)(threadIdx.x >> 6));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
-    const int q0 = (PN_BWD_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * MT;
+    // (descending path order: the BPTT starts on the tiles the forward wrote last; its small tiles -- SeqTiling, the
+    //  remainder round -- are therefore the ones at the START of the path range, dispatched last)
+    const SeqTile tl = seq_tile_of(p.tiling, PN_BWD_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, MT, p.P);
+    const int q0 = tl.q0, rows_here = tl.rows;          // rows_here >= 1
     const int col = 32 * wave + li;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-    for (int i = tid; i < MT * p.L; i += NT) {
-        const int q = q0 + i / p.L;
-        s_rowidx[i] = q < p.P ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
-    }
-    for (int i = tid; i < MT; i += NT) s_slotof[i] = q0 + i < p.P ? p.slotof[q0 + i] : 0;
+    for (int i = tid; i < MT * p.L; i += NT) s_rowidx[i] = i / p.L < rows_here ? p.rowidx[(int64_t)q0 * p.L + i] : 0;
+    for (int i = tid; i < MT; i += NT) s_slotof[i] = i < rows_here ? p.slotof[q0 + i] : 0;
 
     const float keep_scale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(1.0f / (1.0f - p.p_drop))));
     const int e_ih = scale_exp(__uint_as_float(p.range->w_ih)), e_hh = scale_exp(__uint_as_float(p.range->w_hh));
@@ -723,7 +818,6 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     float *dG_t = p.dG + tile_row * GH;
     const uint8_t *keep_t = p.keep ? p.keep + tile_row * (H / 4) : nullptr;
     const float *dhn_t = p.dhn + (size_t)q0 * H;
-    const int rows_here = min(MT, p.P - q0);            // >= 1
     f32x16 dh, dc;
     [[maybe_unused]] f32x16 cnext;      // PN_BWDH_CARRY: c_t of the step processed next (= c_{t-1} now)
 #pragma unroll
@@ -752,8 +846,13 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
             const int rc = min(acc_row(r, lane_x), rows_here - 1);
             const uint32_t base = ((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H);
             if constexpr (PACKED) {
-                const uint32_t *gq = reinterpret_cast<const uint32_t *>(&at_bytes(saved_t, (base + 3u * col) * 4u));
-                raw[0][r] = gq[0]; raw[1][r] = gq[1]; raw[2][r] = gq[2];
+                if (PN_SEQH_PLANAR) {
+                    const uint32_t *gq = reinterpret_cast<const uint32_t *>(&at_bytes(saved_t, (base + col) * 4u));
+                    raw[0][r] = gq[0]; raw[1][r] = gq[H]; raw[2][r] = gq[2 * H];
+                } else {
+                    const uint32_t *gq = reinterpret_cast<const uint32_t *>(&at_bytes(saved_t, (base + 3u * col) * 4u));
+                    raw[0][r] = gq[0]; raw[1][r] = gq[1]; raw[2][r] = gq[2];
+                }
                 const float *cp = &at_bytes(saved_t, (base + 3u * H + col) * 4u);
                 raw[3][r] = __float_as_uint(cp[t > 0 ? -(SV * H) : 0]);       // c_{t-1}: the c slot of step t-1 (t = 0: unused)
                 if (!PN_BWDH_CARRY) raw_cn[r] = cp[0];
@@ -983,7 +1082,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
             for (int r = 0; r < 16; r++) {
                 const int rl = acc_row(r, lane_s), row = rl;
                 float dx = acc[0][r] * inv_x;
-                if (q0 + row < p.P) {
+                if (row < rows_here) {
                     if (p.mask)
                         dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col];
                     else if (p.keep)
@@ -1000,20 +1099,20 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
 #pragma unroll 1
             for (int i = 0; i < 16; i++) {
                 const int rl = 16 * hk + i, row = rl;
-                const int rid = q0 + row < p.P ? s_rowidx[row * p.L] : -1;       // (uniform over a half-wave)
+                const int rid = row < rows_here ? s_rowidx[row * p.L] : -1;       // (uniform over a half-wave)
                 if (rid != cur) {
-                    if (cur >= 0) atomicAdd(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
+                    if (cur >= 0) scatter_add(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
                     cur = rid;
                     run = 0.0f;
                 }
                 run += scr[rl * 33 + li_s];
             }
-            if (cur >= 0) atomicAdd(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
+            if (cur >= 0) scatter_add(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = acc_row(r, lane_t);
-                if (q0 + row < p.P) {
+                if (row < rows_here) {
                     float dx = acc[0][r] * inv_x;
                     if (p.mask)
                         dx *= p.mask[((uint64_t)t * p.Pmask + s_slotof[row]) * H + col];
@@ -1022,8 +1121,8 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     float *dst = p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col);
                     if (p.store_dx)
                         *dst = dx;          // deterministic mode: a row of its own per path step (det_scatter_kernel adds them up)
-                    else
-                        atomicAdd(dst, dx);
+                    else if (!PN_BWDH_SKIPZ || dx != 0.0f)
+                        scatter_add(dst, dx);
                 }
                 dh[r] = GRU ? acc[1][r] * inv_h + dc[r] : acc[1][r] * inv_h;
             }
@@ -1210,7 +1309,12 @@ int launch_fwdh_t(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
     const size_t lds_bytes = (size_t)2 * MT * (4 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_fwdh_kernel<H, GC, RB>;
     if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
-    hipLaunchKernelGGL(kern, dim3((sp.P + MT - 1) / MT), dim3(H / 32 * 64), lds_bytes, stream, sp);
+    SeqFwdParams lp = sp;
+    int blocks = 0;
+    if (int rc = plan_tiling(ctx, reinterpret_cast<const void *>(kern), H / 32 * 64, lds_bytes, sp.P, MT, /*small_first=*/false,
+                             &lp.tiling, &blocks))
+        return rc;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64), lds_bytes, stream, lp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -1221,7 +1325,12 @@ int launch_bwdh_t(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
                              (PN_BWDH_TOUCH ? (size_t)(H / 32) * 256 : 0);
     auto kern = seq_bwdh_kernel<H, GC>;
     if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_bytes)) return rc;
-    hipLaunchKernelGGL(kern, dim3((sp.P + MT - 1) / MT), dim3(H / 32 * 64), lds_bytes, stream, sp);
+    SeqBwdParams lp = sp;
+    int blocks = 0;
+    if (int rc = plan_tiling(ctx, reinterpret_cast<const void *>(kern), H / 32 * 64, lds_bytes, sp.P, MT,
+                             /*small_first=*/PN_BWD_REVERSE != 0, &lp.tiling, &blocks))
+        return rc;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64), lds_bytes, stream, lp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -1285,6 +1394,15 @@ extern "C" int pn_debug_set_trace_h(long long *dev_buf) {     // tuning builds o
     return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_h), &dev_buf, sizeof dev_buf) == hipSuccess ? 0 : -4;
 }
 #endif
+
+// the tile split of a launch (host arithmetic only; not part of the ABI): out = {n_big, n_small, small_rows, blocks}
+extern "C" int pn_debug_seq_tiling(int64_t P, int slots, int cus, int mode, int small_first, int32_t out[4]) {
+    pn::SeqTiling tg;
+    int blocks = 0;
+    seq_tiling_for(P, 32, slots, cus, mode, small_first != 0, &tg, &blocks);
+    out[0] = tg.n_big; out[1] = tg.n_small; out[2] = tg.small_rows; out[3] = blocks;
+    return 0;
+}
 
 namespace pn {
 

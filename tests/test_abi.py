@@ -362,3 +362,59 @@ def test_host_code_under_asan_and_ubsan(tmp_path):
     r = subprocess.run([sys.executable, "-c", SAN_SCRIPT, ROOT, os.path.join(csrc, "_obj", "libpn_host_san.so")],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SAN_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def _tile_ranges(P, tg, small_first):
+    """the path ranges seq_tile_of (pn_seqh.hip) gives the workgroups of a launch, restated"""
+    n_big, n_small, rows, blocks = tg
+    out = []
+    for j in range(blocks):
+        if rows == 0:
+            q0, r = 32 * j, min(32, P - 32 * j)
+        elif small_first:
+            q0, r = (j * rows, min(rows, P - j * rows)) if j < n_small else (
+                n_small * rows + (j - n_small) * 32, min(32, P - (n_small * rows + (j - n_small) * 32)))
+        else:
+            q0, r = (32 * j, 32) if j < n_big else (
+                32 * n_big + (j - n_big) * rows, min(rows, P - (32 * n_big + (j - n_big) * rows)))
+        out.append((q0, r))
+    return out
+
+
+def test_remainder_round_tiling_covers_every_path_once():
+    """The fp16 recurrent launches cut their remainder round into tiles of 8 / 16 / 24 paths, one per CU (pn_seqh.hip "tile
+    geometry"): whatever the split, the tiles are disjoint, in order, non-empty and cover [0, P)."""
+    import ctypes
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.pn_debug_seq_tiling.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_int32)]
+    seen_small = set()
+    for P in (1, 7, 31, 32, 33, 679, 3480, 8192, 16384 + 5, 24576, 51960, 52000, 378560, 1234567):
+        for slots, cus in ((512, 256), (768, 256), (256, 256), (12, 4)):
+            for mode in (0, 1, 8, 16, 24):
+                for small_first in (0, 1):
+                    out = (ctypes.c_int32 * 4)()
+                    assert lib.pn_debug_seq_tiling(P, slots, cus, mode, small_first, out) == 0
+                    tg = tuple(out)
+                    tiles = _tile_ranges(P, tg, small_first)
+                    assert len(tiles) == tg[3] and tg[3] == tg[0] + tg[1] if tg[2] else tg[3] == (P + 31) // 32
+                    pos = 0
+                    for q0, r in tiles:
+                        assert q0 == pos and 1 <= r <= 32, (P, slots, mode, small_first, tg)
+                        pos += r
+                    assert pos == P
+                    if mode == 0:
+                        assert tg[2] == 0
+                    if tg[2]:
+                        seen_small.add(tg[2])
+                        assert tg[2] in (8, 16, 24) and tg[1] >= 1
+                        if mode == 1:
+                            assert tg[1] <= cus          # one small tile per CU at most
+    assert seen_small == {8, 16, 24}
+    # the headline shape: 1624 tiles on 512 slots -> three full rounds + 88 tiles; cut into 16-path tiles on 176 CUs
+    out = (ctypes.c_int32 * 4)()
+    lib.pn_debug_seq_tiling(51960, 512, 256, 1, 1, out)
+    assert tuple(out) == (1536, 176, 16, 1712)
+    lib.pn_debug_seq_tiling(51960, 768, 256, 1, 0, out)
+    assert tuple(out) == (1536, 176, 16, 1712)
+

@@ -10,6 +10,7 @@ import socket
 import numpy as np
 import pytest
 import torch
+from gradcheck import ZERO_OK_HETERO, assert_grads_close
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -188,9 +189,7 @@ def test_two_rank_sharding_matches_single_process(variant, mode):
     for rank in range(world):
         out, grads, rows = ret[rank]
         assert np.abs(out - want.detach().numpy()[rows]).max() < 1e-5
-        for k, g in grads.items():
-            ref = params[k].grad.numpy()
-            assert np.abs(g - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), (rank, k)
+        assert_grads_close(grads, {k: params[k].grad for k in grads}, rel=2e-5, zero_ok=ZERO_OK_HETERO, tag="rank %d" % rank)
 
 
 def test_single_process_runner_without_process_group():

@@ -352,11 +352,11 @@ def test_node_list_window_equals_rows_of_the_full_epoch():
             full_i, full_c = smp.sample(13, 77, epoch_begin=3, epoch_count=2)
             nodes = torch.as_tensor(rng.permutation(n)[:123].astype(np.int32)).cuda()       # any order, any subset
             for stage in ("0", "1"):        # first-hop tables from L2 / staged in LDS (the default only stages large launches)
-                os.environ["PN_SAMPLER_STAGE"] = stage
+                old = _lib.set_knob("PN_SAMPLER_STAGE", int(stage))
                 try:
                     got_i, got_c = smp.sample(13, 77, epoch_begin=3, epoch_count=2, nodes=nodes)
                 finally:
-                    os.environ.pop("PN_SAMPLER_STAGE", None)
+                    _lib.set_knob("PN_SAMPLER_STAGE", old)
                 assert got_i.shape == (2, 123, 13, L)
                 assert torch.equal(got_i, full_i[:, nodes.long()]) and torch.equal(got_c, full_c[:, nodes.long()])
             oi, oc = merw.sample_full(n, u, v, p, 13, L, merw.DRAW_PHILOX, 77, epoch_begin=3, epoch_count=2)

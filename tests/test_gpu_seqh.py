@@ -10,6 +10,7 @@ and baseline/GPRGNN/src/copy.py:308,349; the contract is the bf16 kernels': logi
 import numpy as np
 import pytest
 import torch
+from gradcheck import ZERO_OK_HETERO, assert_grads_close
 
 from oracle import pagg_oracle as po
 
@@ -72,10 +73,7 @@ def test_f16_kernels_match_the_bf16_kernels(variant, H, S, W, L, cell, drop):
     out, g = _run(case, "f16x2")
     assert not torch.isnan(out).any()
     assert (out - ref_out).abs().max().item() <= 2e-6
-    for k in ref_g:
-        assert not torch.isnan(g[k]).any(), k
-        tol = 1e-5 * max(1.0, ref_g[k].abs().max().item())
-        assert (g[k] - ref_g[k]).abs().max().item() <= tol, k
+    assert_grads_close(g, ref_g, rel=1e-5, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
 
 
 def _oracle_case(variant, H, S, W, L, N=300, F=40, C=4, keep=0.5, seed=1, cell=None):
@@ -129,8 +127,7 @@ def test_f16_kernels_match_the_oracle(variant, H):
     out, g = _hip(m, X, sel, ids, codes, ms, mc, G, W, L)
     want, wg = _oracle(variant, m, X, sel, ids, codes, ms, mc, G, W, L, torch.float32)
     assert (out - want).abs().max().item() < 1e-5
-    for k in g:
-        assert (g[k] - wg[k]).abs().max().item() <= 3e-5 * max(1.0, wg[k].abs().max().item()), k
+    assert_grads_close(g, wg, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
 
 
 def _against_fp64(variant, m, X, sel, ids, codes, ms, mc, G, W, L, floor):
@@ -246,9 +243,12 @@ def test_inference_forward_with_the_input_gates_applied_before_the_gather(varian
     mask[sel] = True
     args = (X.cuda(), torch.as_tensor(ids.reshape(S, W * L).astype(np.int64)), W, L, mask, torch.as_tensor(codes.astype(np.int64)), None)
     with torch.no_grad():
-        monkeypatch.setenv("PN_EVAL_ZW", "0")
-        plain = m(*args).clone()
-        monkeypatch.setenv("PN_EVAL_ZW", "1")
+        from pathnet_amd import _lib
+        _lib.set_knob("PN_EVAL_ZW", 0)          # (a knob of the context: the library never reads the environment in a call)
+        try:
+            plain = m(*args).clone()
+        finally:
+            _lib.set_knob("PN_EVAL_ZW", 1)
         got = m(*args).clone()
         again = m(*args, reuse_tables=True).clone()         # the test forward of an epoch: tables reused, ZW rebuilt
     params = {k: v.detach().cpu() for k, v in m.state_dict().items()}

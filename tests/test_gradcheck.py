@@ -1,0 +1,69 @@
+"""The gradient checker of the parity tests, tested itself (no GPU): it must reject a zeroed gradient for EVERY parameter
+that carries signal, at the magnitudes the configuration-size tests actually see (the round-4 bound
+3e-5 * max(1, |ref|) accepted a zero gradient for half of the parameters once the upstream gradient was scaled by 1 / S)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gradcheck import GRAD_REL, ZERO_OK_HETERO, assert_grads_close, grad_report
+
+
+def _case(variant):
+    """reference gradients with the per-tensor magnitudes measured at the headline shape (profiles/r04_grad_error_*.json)"""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_grad_error_%s.json" % variant)))["parameters"]
+    rng = np.random.default_rng(3)
+    ref = {}
+    for k, row in d.items():
+        g = rng.standard_normal((8, 16)).astype(np.float32)
+        ref[k] = g / np.abs(g).max() * np.float32(row["grad_inf_norm"])
+    return ref
+
+
+@pytest.mark.parametrize("variant", ["homo", "hetero", "pagg"])
+def test_zeroed_scaled_and_perturbed_gradients_fail(variant):
+    ref = _case(variant)
+    zero_ok = ZERO_OK_HETERO if variant == "hetero" else ()
+    rng = np.random.default_rng(4)
+    # what the product returns: the reference up to fp32-sized relative errors (and noise where the gradient vanishes)
+    good = {k: v * (1 + 2e-6 * rng.standard_normal(v.shape)).astype(np.float32) for k, v in ref.items()}
+    assert_grads_close(good, ref, zero_ok=zero_ok)
+    scale = max(float(np.abs(v).max()) for v in ref.values())
+    old_rule_blind = 0
+    for k in ref:
+        if k in zero_ok:
+            assert np.abs(ref[k]).max() < 1e-11 * scale       # noise, eleven orders below the case's largest gradient
+            continue
+        for what, bad_k in (("zeroed", np.zeros_like(ref[k])), ("doubled", 2 * ref[k]),
+                            ("off by 1e-4 of its own norm", ref[k] + np.float32(1e-4) * np.abs(ref[k]).max())):
+            if what.startswith("off") and np.abs(ref[k]).max() < 1e-6 * scale:
+                continue        # (hetero attw.weight, 1e-8 of the largest gradient: resolved to ~1e-3 of itself, not 1e-4)
+            bad = dict(good)
+            bad[k] = bad_k
+            with pytest.raises(AssertionError):
+                assert_grads_close(bad, ref, zero_ok=zero_ok)
+        # ... and what round 4's bound did with the same zeroed gradient
+        old_rule_blind += bool(np.abs(ref[k]).max() < 3e-5 * max(1.0, float(np.abs(ref[k]).max())))
+    assert old_rule_blind >= {"homo": 4, "hetero": 11, "pagg": 0}[variant]       # parameters that passed with a ZERO gradient
+
+
+def test_a_tensor_that_cannot_be_checked_must_be_named():
+    ref = {"a": np.ones((4, 4), np.float32), "tiny": np.full((4,), 1e-13, np.float32)}
+    with pytest.raises(AssertionError, match="zeroed gradient would pass"):
+        assert_grads_close(ref, ref)
+    assert_grads_close(ref, ref, zero_ok=("tiny",))
+    rows, scale = grad_report(ref, ref)
+    assert scale == 1.0 and rows["a"][1] == pytest.approx(GRAD_REL + 1e-11)
+
+
+def test_non_finite_and_shape_errors():
+    ref = {"a": np.ones((4, 4), np.float32)}
+    got = {"a": np.ones((4, 4), np.float32)}
+    got["a"][1, 1] = np.nan
+    with pytest.raises(AssertionError):
+        assert_grads_close(got, ref)
+    with pytest.raises(AssertionError):
+        assert_grads_close({"a": np.ones((4, 5), np.float32)}, ref)
+    assert_grads_close({"a": np.zeros((3,), np.float32)}, {"a": np.zeros((3,), np.float32)})      # an all-zero case: exact

@@ -1,5 +1,5 @@
 """A/B of the 128-path recurrent kernels (pn_seq4.hip) against the fused ones (pn_pagg.hip) on one GPU, in one process:
-PN_SEQ4 is read at every launch, so the same module / inputs / dropout seed run through either set of kernels.
+PN_SEQ4 is a context knob (pn_context_set_knob), so the same module / inputs / dropout seed run through either set of kernels.
 
   python tools/ab_seq4.py [--masks 0,1,3,7] [--steps 10] [--out gpurun_out/ab_seq4.json] [--skip-parity]
 
@@ -107,7 +107,7 @@ def bench_case(dev):
 
 
 def run_once(case, mask, seed=123):
-    os.environ["PN_SEQ4"] = str(mask)
+    _lib.set_knob("PN_SEQ4", mask)
     m = case["model"]
     torch.manual_seed(seed)
     if case["train"]:
@@ -168,7 +168,7 @@ def timing(case, masks, steps):
     res = {}
     for rnd in range(2):            # two interleaved rounds: box drift shows up as a difference between them
         for mask in masks:
-            os.environ["PN_SEQ4"] = str(mask)
+            _lib.set_knob("PN_SEQ4", mask)
             for _ in range(3):
                 step()
             torch.cuda.synchronize()

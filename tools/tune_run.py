@@ -56,6 +56,7 @@ def main():
     specs = [l.strip().split(" ", 1) for l in open(os.path.join(VAR, "specs.txt")) if l.strip()]
     for n, spec in [(s[0], s[1] if len(s) > 1 else "") for s in specs]:
         env = dict(os.environ, PN_LIB_PATH=os.path.join(VAR, "lib_%s.so" % n))
+        env.update(tok[4:].split("=", 1) for tok in spec.split() if tok.startswith("env:"))     # run-time knobs of the variant
         r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, steps)], env=env, capture_output=True, text=True)
         res = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         if res:
