@@ -44,7 +44,7 @@ GlibcState glibc_seed_state(uint32_t seed);
 // so a concurrent setenv cannot race a launch and a captured step replays the selection it was captured with.
 // A NULL context runs the defaults.
 #ifndef PN_SEQH_TAIL_DEFAULT
-#define PN_SEQH_TAIL_DEFAULT 1
+#define PN_SEQH_TAIL_DEFAULT 0      // measured neutral at the headline shape (profiles/r05_tune_scatter_tiling.txt): off
 #endif
 struct Knobs {
     int node_gemm3 = 7;         // PN_NODE_GEMM3: bit mask -- 1 fc0, 2 distance bank, 4 dense bank dX on the bf16 x 3 GEMM when its
@@ -55,8 +55,8 @@ struct Knobs {
     int sampler_stage = -1;     // PN_SAMPLER_STAGE: first-hop tables in LDS (-1: by launch size)
     int seq4 = 4;               // PN_SEQ4: which 128-path kernels of pn_seq4.hip serve the bf16 mode (bit 2: weight gradient)
     int b4_wide = 0;            // PN_B4_WIDE (experimental builds)
-    int seqh_tail = PN_SEQH_TAIL_DEFAULT;   // PN_SEQH_TAIL: 0 = 32-path tiles only; 1 = the remainder round of the fp16 recurrent
-                                //                launches in smaller tiles, one per CU; 8 / 16 / 24 = that size, always
+    int seqh_tail = PN_SEQH_TAIL_DEFAULT;   // PN_SEQH_TAIL: 0 = 32-path tiles only (default); 1 = the remainder round of the fp16
+                                //                recurrent launches in smaller tiles, one per CU; 8 / 16 / 24 = that size, always
 };
 const Knobs &knobs_of(const pn_context *ctx);
 

@@ -61,11 +61,13 @@ using namespace pn;
 #define PN_BWD_REVERSE 1
 #endif
 #ifndef PN_BWDH_SKIPZ
-#define PN_BWDH_SKIPZ 0     // 1: the scatter issues no atomic for an element dropout zeroed (dx == 0: adding it changes nothing)
-#endif
+#define PN_BWDH_SKIPZ 1     // the scatter issues no atomic for an element dropout zeroed (dx == 0: adding it changes nothing; 70 % of
+#endif                      // the elements at p = 0.7).  BPTT 0.375 -> 0.361, 0.364 -> 0.356 ms; with NO atomics at all (PN_ABL bit 3,
+                            // wrong results) 0.340 / 0.334: the whole scatter is 9 % of the kernel (profiles/r05_tune_scatter_tiling.txt)
 #ifndef PN_SEQH_PLANAR
 #define PN_SEQH_PLANAR 0    // 1: the three dwords of the packed gates as three [H] planes per path step instead of [H][3]: every
-#endif                      // load of the BPTT is then one full line per half-wave (the [H][3] form touches each line three times)
+#endif                      // load of the BPTT is then one full line per half-wave (the [H][3] form touches each line three times).
+                            // Measured neutral (BPTT 0.374 = 0.375 ms, forward 0.236 = 0.236): the repeats hit L1, not counted lines
 
 #ifndef PN_TRACE_H
 #define PN_TRACE_H 0        // 1: tuning builds only -- wave 0 of every workgroup stamps the cycle counter at phase boundaries
@@ -111,6 +113,11 @@ __device__ __forceinline__ void scatter_add(float *dst, float v) {
 // registers r < 4k) and their stores / atomics never issue -- one per CU instead of a 32-path tile on a third of the CUs.
 // Tile j < n_big * (1 - small_first):  paths [32 j, 32 j + 32);  the small ones follow (forward) or come first (BPTT,
 // whose dispatch order is descending: its remainder round is the START of the path range).
+// MEASURED (round 5, profiles/r05_tune_scatter_tiling.txt): no gain -- forward 0.236 = 0.236 ms, BPTT 0.371 / 0.368 against
+// 0.375 / 0.364 with 16-path tiles, slower with 8 (0.252 / 0.387): a lone workgroup's step is its latency chain and the
+// 512 KB weight stream, neither of which shrinks with the rows.  Kept behind the context knob PN_SEQH_TAIL (default 0) with
+// its parity tests (tests/test_gpu_seqh.py runs under forced sizes), as the evidence that a 16-path MFMA instantiation for
+// the remainder round would not pay either.
 __device__ __forceinline__ SeqTile seq_tile_of(const SeqTiling tg, int j, int MT, int P) {
     SeqTile t;
     if (tg.small_rows == 0) {

@@ -29,6 +29,13 @@ What is replicated: the distance bank Z = bank(Xh) over all N rows and its backw
 the bytes over xGMI -- for GEMMs that take 0.06 ms at 8 x 2708 nodes and ~25 ms at 10^7 nodes against
 ~90 ms for moving 30 GB of Z at 7 x 50 GB/s: replication is cheaper at every size.
 
+Two ways to move Xh / d Xh (ShardedAggregator.exchange): "dense" -- the all-gather / reduce-scatter above, every row to
+every rank; "sparse" -- a rank's paths touch a fraction of a large graph (12 500 masked nodes x 40 paths x 6 steps reach
+~26 % of the 10 M nodes of BASELINE.json configs[4]), so each rank asks the owners for exactly the rows its paths name:
+one all-to-all of row ids, one of Xh rows forward, one of d Xh rows back (the owner adds what it receives, in rank
+order).  The aggregator then runs on the compact table of touched rows.  "auto" picks sparse when every rank touches
+less than half of the graph.  Node blocks are ceil(N / world) rows, the last one shorter: any N runs on any world size.
+
 The compute backend is an object with four methods (project / forward / backward /
 linear_backward).  The product backend is HipOps (libpathnet_hip.so); CPU tests plug in a checker
 backend to exercise the sharding and the collectives with gloo.  Collectives go through a Comm object
@@ -52,7 +59,8 @@ class Comm:
         self.group = group
         self.timing = timing
         self.always = always        # run the collectives even in a one-rank group (exercises RCCL on a single GPU)
-        self.seconds = {"all_gather_Xh": 0.0, "reduce_scatter_dXh": 0.0, "all_reduce_grads": 0.0, "all_gather_index": 0.0}
+        self.seconds = {"all_gather_Xh": 0.0, "reduce_scatter_dXh": 0.0, "all_reduce_grads": 0.0, "all_gather_index": 0.0,
+                        "sparse_index": 0.0, "sparse_Xh": 0.0, "sparse_dXh": 0.0}
         # overlap: the two big collectives of a step run on a stream of their own, ordered against the compute stream by
         # events (ShardedAggregator.begin_step / _ShardedFn).  measure_exposed: keep, per kind, the time the compute stream
         # would have to wait for the collective -- from the moment it needs the result to the collective's end (timed events,
@@ -134,6 +142,14 @@ class Comm:
         else:
             dist.all_reduce(t, group=self.group)
 
+    def _all_to_all(self, out, inp, out_splits, in_splits):
+        if self._staged(inp):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(o, inp.cpu(), out_splits, in_splits, group=self.group)
+            out.copy_(o)
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
     # -- what a step uses ----------------------------------------------------------------------------------------------
     def all_gather_rows(self, t, kind="all_gather_Xh"):
         """[rows, ...] per rank (equal rows) -> [world*rows, ...]"""
@@ -150,6 +166,19 @@ class Comm:
 
     def all_reduce(self, t):
         self._timed("all_reduce_grads", lambda: self._all_reduce(t), t)
+
+    def all_to_all_rows(self, t, in_counts, out_counts, kind):
+        """rows of t, in_counts[q] of them for rank q (in rank order) -> the rows the ranks sent here, out_counts[q] from
+        rank q, in rank order"""
+        t = t.contiguous()
+        out = torch.empty((int(sum(out_counts)),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        self._timed(kind, lambda: self._all_to_all(out, t, [int(c) for c in out_counts], [int(c) for c in in_counts]), t)
+        return out
+
+    def count_matrix(self, row, device):
+        """every rank's list of world ints -> [world][world] (row r = rank r's list)"""
+        mine = torch.tensor([[int(v) for v in row]], dtype=torch.int64, device=device)
+        return self.all_gather_rows(mine, kind="all_gather_index").tolist()
 
     def counts(self, n, device):
         """every rank's n -> list of ints"""
@@ -262,20 +291,38 @@ def _new_event(device, timing=False):
     return ev
 
 
+def node_block(n_total, world, rank):
+    """(row_begin, row_count) of `rank`'s node block: ceil(n_total / world) rows each, the last blocks shorter (a block may
+    be empty when world does not divide the graph)"""
+    B = -(-int(n_total) // max(int(world), 1))
+    lo = min(int(rank) * B, int(n_total))
+    return lo, min(B, int(n_total) - lo)
+
+
+class _SparsePlan:
+    """What one step's sparse exchange needs (ShardedAggregator._plan_sparse): the sorted global ids of the rows this rank's
+    paths touch, how many of them each owner holds (need), which of this rank's rows every other rank asked for (serve_local,
+    serve counts), and the node-id -> compact-row map of the step."""
+    __slots__ = ("touched", "need", "serve", "serve_local", "T")
+
+
 class _ShardedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, cfg, X_loc, ids, codes, sel, *params):
         p = M._split_params(params, cfg["L"])
         ops, comm = runner.ops, runner.comm
-        pre = runner._take_prefetched(X_loc, p["fc0_w"], p["fc0_b"])
+        plan = cfg.get("sparse_plan")
+        pre = runner._take_prefetched(X_loc, p["fc0_w"], p["fc0_b"]) if plan is None else None
         if pre is not None:             # begin_step projected and gathered already, on the communication stream
             Xh_loc, Xh, ready = pre
+        elif plan is not None:
+            Xh_loc, Xh, ready = runner._project_and_fetch(cfg["variant"], X_loc, p["fc0_w"], p["fc0_b"], plan)
         else:
             Xh_loc, Xh, ready = runner._project_and_gather(cfg["variant"], X_loc, p["fc0_w"], p["fc0_b"])
         if ready is not None and comm.measure_exposed:
             need = torch.cuda.Event(enable_timing=True)
             need.record()
-            comm.note_exposed("all_gather_Xh", need, runner._ag_done)
+            comm.note_exposed("sparse_Xh" if plan is not None else "all_gather_Xh", need, runner._ag_done)
         if ready is not None and not isinstance(ops, HipOps):      # a checker backend: plain stream order
             torch.cuda.current_stream(X_loc.device).wait_event(ready)
             ready = None
@@ -291,22 +338,33 @@ class _ShardedFn(torch.autograd.Function):
         ops, comm = runner.ops, runner.comm
         X_loc, Xh_loc, fc0_w = ctx.saved_tensors
         dev = X_loc.device
+        plan = cfg.get("sparse_plan")
+        rows = Xh_loc.shape[0]
+
+        def to_owner(g_Xh):
+            """d Xh of the table this rank computed on -> the rows of its own block, summed over the ranks"""
+            if not comm.active():
+                return g_Xh
+            if plan is not None:
+                return runner._return_sparse(g_Xh, plan, rows)
+            return comm.reduce_scatter_rows(g_Xh, runner.block_rows)[:rows]    # the one backward collective
+
         overlap = comm.active() and comm.overlap and X_loc.is_cuda and isinstance(ops, HipOps)
         if not overlap:
             g_Xh, grads = ops.backward(ctx.state, g_out)
-            g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0]) if comm.active() else g_Xh   # the one backward collective
+            g_loc = to_owner(g_Xh)
             grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w,
                                                                  deterministic=cfg.get("deterministic", False))
         else:
             # the library records `ready` as soon as d Xh is complete; its weight-gradient GEMMs then run under the
-            # reduce-scatter and fc0's backward, which follow on the communication stream
+            # reduce-scatter (or the sparse return) and fc0's backward, which follow on the communication stream
             cur, cst = torch.cuda.current_stream(dev), comm.stream(dev)
             ready = _new_event(dev, timing=comm.measure_exposed)
             g_Xh, grads = ops.backward(ctx.state, g_out, ready)
             g_Xh.record_stream(cst)
             with torch.cuda.stream(cst):
                 cst.wait_event(ready)
-                g_loc = comm.reduce_scatter_rows(g_Xh, Xh_loc.shape[0])
+                g_loc = to_owner(g_Xh)
                 grads["fc0_w"], grads["fc0_b"] = ops.linear_backward(cfg["variant"], g_loc, Xh_loc, X_loc, fc0_w,
                                                                      deterministic=cfg.get("deterministic", False))
                 done = torch.cuda.Event(enable_timing=comm.measure_exposed)
@@ -314,7 +372,7 @@ class _ShardedFn(torch.autograd.Function):
             if comm.measure_exposed:        # the compute stream needs fc0's gradients when the library's own work is over
                 need = torch.cuda.Event(enable_timing=True)
                 need.record(cur)
-                comm.note_exposed("reduce_scatter_dXh+fc0_bwd", need, done)
+                comm.note_exposed(("sparse_dXh" if plan is not None else "reduce_scatter_dXh") + "+fc0_bwd", need, done)
             cur.wait_event(done)
             for t in (g_loc, grads["fc0_w"], grads["fc0_b"]):
                 t.record_stream(cur)
@@ -328,18 +386,28 @@ class ShardedAggregator:
     """Runs a PathNet / PathNet_homo / PAGG module on this rank's node block.
 
     module      : the (replicated) aggregator module; its parameters are the trainable state
-    n_total     : nodes in the whole graph;  row_begin/row_count: this rank's block (equal on every rank)
+    n_total     : nodes in the whole graph;  row_begin/row_count: this rank's block = node_block(n_total, world, rank)
+    exchange    : "auto" (default) / "dense" / "sparse" -- how Xh and d Xh travel (module docstring)
     """
 
-    def __init__(self, module, n_total, row_begin, row_count, group=None, ops=None, comm=None, dropout_seed=0):
+    def __init__(self, module, n_total, row_begin, row_count, group=None, ops=None, comm=None, dropout_seed=0,
+                 exchange="auto"):
         self.module, self.n_total, self.row_begin, self.row_count = module, int(n_total), int(row_begin), int(row_count)
         self.comm = comm if comm is not None else Comm(group)
         self.group = self.comm.group
         self.ops = ops if ops is not None else HipOps()
         self.distributed = self.comm.active()
-        if self.row_count * self.comm.world() != self.n_total:
-            raise ValueError("node blocks must be equal: %d rows x %d ranks != %d nodes (pad the graph)"
-                             % (self.row_count, self.comm.world(), self.n_total))
+        world = self.comm.world()
+        want = node_block(self.n_total, world, self.comm.rank())
+        if (self.row_begin, self.row_count) != want:
+            raise ValueError("rank %d of %d owns the node block (begin %d, %d rows) of a %d-node graph -- node_block(); got "
+                             "(%d, %d)" % (self.comm.rank(), world, want[0], want[1], self.n_total, self.row_begin, self.row_count))
+        self.block_rows = -(-self.n_total // world)     # rows of a full block: what the dense collectives move per rank
+        self.n_pad = self.block_rows * world            # rows of the gathered table (rows >= n_total are zero, never indexed)
+        if exchange not in ("auto", "dense", "sparse"):
+            raise ValueError("exchange: auto, dense or sparse")
+        self.exchange = exchange
+        self.last_exchange = None                       # what the last call used ("dense" / "sparse"; None: one rank)
         self._flat = None           # persistent flat gradient buffer (see flat_grads)
         self._flat_ids = None
         self.batch_counts = None    # masked nodes per rank of the last call
@@ -352,15 +420,12 @@ class ShardedAggregator:
         self._ag_done = None
 
     # ---- forward collective, overlapped ------------------------------------------------------------------------------
-    def _project_and_gather(self, variant, X_loc, fc0_w, fc0_b):
-        """Xh_loc = fc0(X_loc) on the current stream, then the all-gather of Xh on the communication stream.
-        -> (Xh_loc, Xh, ready): `ready` is the event the consumer of Xh has to wait for (None: plain stream order)."""
-        ops, comm = self.ops, self.comm
-        Xh_loc = ops.project(variant, X_loc, fc0_w, fc0_b)
-        if not comm.active():
-            return Xh_loc, Xh_loc, None
+    def _on_comm_stream(self, X_loc, Xh_loc, fn):
+        """fn() on the communication stream, after Xh_loc (current stream) is complete.  -> (result, ready event) -- or fn()
+        in plain stream order with ready = None when nothing can overlap."""
+        comm = self.comm
         if not (comm.overlap and X_loc.is_cuda):
-            return Xh_loc, comm.all_gather_rows(Xh_loc), None
+            return fn(), None
         dev = X_loc.device
         cur, cst = torch.cuda.current_stream(dev), comm.stream(dev)
         projected = torch.cuda.Event()
@@ -368,31 +433,118 @@ class ShardedAggregator:
         Xh_loc.record_stream(cst)
         with torch.cuda.stream(cst):
             cst.wait_event(projected)
-            Xh = comm.all_gather_rows(Xh_loc)
+            Xh = fn()
             ready = torch.cuda.Event(enable_timing=comm.measure_exposed)
             ready.record(cst)
         Xh.record_stream(cur)
         self._ag_done = ready
+        return Xh, ready
+
+    def _project_and_gather(self, variant, X_loc, fc0_w, fc0_b):
+        """Xh_loc = fc0(X_loc) on the current stream, then the all-gather of Xh on the communication stream.
+        -> (Xh_loc, Xh, ready): `ready` is the event the consumer of Xh has to wait for (None: plain stream order)."""
+        ops, comm = self.ops, self.comm
+        Xh_loc = ops.project(variant, X_loc, fc0_w, fc0_b)
+        if not comm.active():
+            return Xh_loc, Xh_loc, None
+
+        def gather():
+            send = Xh_loc
+            if Xh_loc.shape[0] < self.block_rows:       # a short last block: zero rows up to the common block size
+                send = torch.nn.functional.pad(Xh_loc, (0, 0, 0, self.block_rows - Xh_loc.shape[0]))
+            return comm.all_gather_rows(send)
+        Xh, ready = self._on_comm_stream(X_loc, Xh_loc, gather)
         return Xh_loc, Xh, ready
+
+    # ---- sparse exchange: the rows the step's paths touch, and nothing else ---------------------------------------------
+    def _plan_sparse(self, ids, sel):
+        """Collective.  Decides the step's exchange mode and, for the sparse one, builds its plan and the compact indices.
+        -> (plan or None, ids', sel').  Three small host round trips (the touched count, the per-owner counts, the ranks'
+        count matrix): the price of moving a quarter of the rows."""
+        comm = self.comm
+        if self.exchange == "dense" or not comm.active():
+            return None, ids, sel
+        dev, N, R, B = ids.device, self.n_total, comm.world(), self.block_rows
+        flags = torch.zeros(self.n_pad, dtype=torch.bool, device=dev)
+        flags[ids.reshape(-1).long().clamp_(0, N - 1)] = True        # (the kernels clamp ids and sel the same way)
+        flags[sel.long().clamp_(0, N - 1)] = True
+        touched = torch.nonzero(flags).flatten()
+        need = torch.bincount(torch.div(touched, B, rounding_mode="floor"), minlength=R).tolist()
+        matrix = comm.count_matrix(need, dev)               # matrix[r][o]: rows rank r needs from owner o
+        if self.exchange == "auto" and max(sum(row) for row in matrix) * 2 >= N:
+            return None, ids, sel                           # some rank touches half of the graph: the dense collectives
+        me = comm.rank()
+        plan = _SparsePlan()
+        plan.touched, plan.need, plan.T = touched, [int(v) for v in need], int(touched.numel())
+        plan.serve = [int(matrix[q][me]) for q in range(R)]
+        asked = comm.all_to_all_rows(touched.to(torch.int32), plan.need, plan.serve, "sparse_index")
+        plan.serve_local = asked.long() - self.row_begin
+        rank_map = torch.cumsum(flags, 0, dtype=torch.int32) - 1
+        ids_c = rank_map[ids.long().clamp_(0, N - 1)]
+        sel_c = rank_map[sel.long().clamp_(0, N - 1)]
+        return plan, ids_c, sel_c
+
+    def _project_and_fetch(self, variant, X_loc, fc0_w, fc0_b, plan):
+        """sparse counterpart of _project_and_gather: -> (Xh_loc, the compact table [T, H] of touched rows in ascending
+        node order, ready)"""
+        ops, comm = self.ops, self.comm
+        Xh_loc = ops.project(variant, X_loc, fc0_w, fc0_b)
+
+        def fetch():
+            send = Xh_loc.index_select(0, plan.serve_local)
+            return comm.all_to_all_rows(send, plan.serve, plan.need, "sparse_Xh")
+        Xh, ready = self._on_comm_stream(X_loc, Xh_loc, fetch)
+        return Xh_loc, Xh, ready
+
+    def _return_sparse(self, g_Xh, plan, rows):
+        """d Xh of the compact table -> the owners; this rank adds what it receives to its block, rank by rank (the rows one
+        rank sends are distinct, so every index_add_ is a plain store-add and the order of the sums is fixed)"""
+        got = self.comm.all_to_all_rows(g_Xh, plan.need, plan.serve, "sparse_dXh")
+        g_loc = torch.zeros((rows, g_Xh.shape[1]), dtype=g_Xh.dtype, device=g_Xh.device)
+        at = 0
+        for q, n in enumerate(plan.serve):
+            if n:
+                g_loc.index_add_(0, plan.serve_local[at:at + n], got[at:at + n])
+            at += n
+        return g_loc
+
+    @staticmethod
+    def _norm_key(X_loc):
+        return (X_loc.data_ptr(), X_loc._version, tuple(X_loc.shape), tuple(X_loc.stride()), X_loc.dtype)
 
     def begin_step(self, X_loc):
         """Start the step's projection and all-gather NOW, before the paths of the step are sampled: the walker (and, inside
         the aggregator call, the touched-row marking, the index plan and the weight packing) then run under the all-gather.
         Optional -- without it the call itself projects and gathers, and only the library's own preamble overlaps.
-        Valid for the next call with the same X_loc and unchanged fc0 parameters; no-grad bookkeeping only: the autograd
-        graph is that of the call (fc0's backward runs on X_loc as always)."""
+        Valid for the next call with the same X_loc and unchanged fc0 parameters (the optimizers -- torch's and
+        pathnet_amd.Adam -- bump the parameters' version counters, which is what the check reads); no-grad bookkeeping only:
+        the autograd graph is that of the call (fc0's backward runs on X_loc as always).  The step then uses the DENSE
+        exchange (the sparse one needs the step's paths before it can ask for rows)."""
         m = self.module
+        if m.hidden_size % 32:
+            return          # (the padded parameters are functions of the real ones, rebuilt per call: nothing to key on)
+        Xn = X_loc.contiguous().float()         # normalised ONCE: the call compares against this very tensor
         with torch.no_grad():
-            pre = self._project_and_gather(m.variant, X_loc.contiguous().float(), m.fc0.weight, m.fc0.bias)
-        self._prefetched = ((X_loc.data_ptr(), X_loc._version, m.fc0.weight.data_ptr(), m.fc0.weight._version,
-                             m.fc0.bias._version), pre)
+            pre = self._project_and_gather(m.variant, Xn, m.fc0.weight, m.fc0.bias)
+        self._prefetched = ((self._norm_key(X_loc), m.fc0.weight.data_ptr(), m.fc0.weight._version, m.fc0.bias._version),
+                            Xn, pre)
 
-    def _take_prefetched(self, X_loc, fc0_w, fc0_b):
-        pre, self._prefetched = self._prefetched, None
+    def _prefetched_input(self, X_loc):
+        """the normalised X of a matching begin_step (so that _take_prefetched sees the tensor begin_step projected), or None"""
+        pre, m = self._prefetched, self.module
         if pre is None:
             return None
-        key = (X_loc.data_ptr(), X_loc._version, fc0_w.data_ptr(), fc0_w._version, fc0_b._version)
-        return pre[1] if pre[0] == key else None
+        key = (self._norm_key(X_loc), m.fc0.weight.data_ptr(), m.fc0.weight._version, m.fc0.bias._version)
+        if pre[0] != key:
+            self._prefetched = None
+            return None
+        return pre[1]
+
+    def _take_prefetched(self, Xn, fc0_w, fc0_b):
+        pre, self._prefetched = self._prefetched, None
+        if pre is None or pre[1] is not Xn:
+            return None
+        return pre[2]
 
     def __call__(self, X_loc, neis, num_w, walk_len, sel_global, layer_type):
         """X_loc [row_count, F]; sel_global: global node ids of this rank's masked nodes (inside its block);
@@ -400,7 +552,9 @@ class ShardedAggregator:
         m = self.module
         dev = X_loc.device
         ids, codes, sel, S = M._as_index_tensors(neis, layer_type, sel_global, num_w, walk_len, dev, n_nodes=self.n_total)
-        fw, fb, params = m._param_inputs()
+        H = m.hidden_size
+        Hk = -(-H // 32) * 32       # the kernels' hidden size; other sizes are zero-padded exactly as the single-GPU module does
+        fw, fb, params = m._param_inputs() if Hk == H else m._padded_param_inputs(Hk)
         p = m.dropout_p() if m.training else 0.0
         comm = self.comm
         multi = comm.active()           # several ranks (or a one-rank group forced through the multi-rank path)
@@ -420,31 +574,42 @@ class ShardedAggregator:
             # the [W, S] re-view reads other ranks' paths: every rank gets the whole batch's index arrays
             ids, codes, sel = (comm.all_gather_ragged(t, counts) for t in (ids, codes, sel))
             local_rows = False
+        Xn = self._prefetched_input(X_loc)
+        plan = None
+        if Xn is None:
+            Xn = X_loc.contiguous().float()
+            plan, ids, sel = self._plan_sparse(ids, sel)
+        self.last_exchange = None if not multi else "sparse" if plan is not None else "dense"
         # one seed per step for all ranks (positions in the batch separate their masks)
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, generator=self._seed_gen).item()) if p > 0 else 0
-        cfg = dict(variant=m.variant, N=self.n_total, F=X_loc.shape[1], H=m.hidden_size, C=m.out_size, S=S,
+        n_table = plan.T if plan is not None else (self.n_pad if multi else self.n_total)
+        cfg = dict(variant=m.variant, N=max(n_table, 1), F=X_loc.shape[1], H=Hk, C=m.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, bank_w=fw, bank_b=fb, seed=seed,
                    S_total=S_total, group_begin=begin, index_rows_local=local_rows and multi, cell=m._cell_kind,
-                   mask_seq=None, mask_cls=None,
+                   mask_seq=None, mask_cls=None, sparse_plan=plan,
                    deterministic=M.deterministic_default() if m.deterministic is None else bool(m.deterministic),
                    compact=M.compact_default(),
                    seq_math=M.seq_math_default() if m.seq_math is None else M._SEQ_MATH[m.seq_math])
-        if m.hidden_size % 32:
-            # (the single-GPU module zero-pads such a hidden size through differentiable pads of its parameters,
-            #  modules._padded_param_inputs; the sharded runner hands the kernels the parameters themselves)
-            raise ValueError("ShardedAggregator: hidden size %d is not a multiple of 32 -- use ReplicatedAggregator (which "
-                             "runs the module itself) or a padded hidden size" % m.hidden_size)
         if not multi:
             cfg["S_total"], cfg["group_begin"] = 0, 0
         if m.training and (self.mask_seq is not None or self.mask_cls is not None):
-            cfg["mask_seq"], cfg["mask_cls"] = self.mask_seq, self.mask_cls
+            ms, mc = self.mask_seq, self.mask_cls
+            if Hk != H:         # explicit masks are given for the module's own hidden size
+                P = torch.nn.functional.pad
+                ms = P(ms, (0, Hk - H)).contiguous() if ms is not None else None
+                mc = P(mc.view(mc.shape[0], 2, H), (0, Hk - H)).reshape(mc.shape[0], 2 * Hk).contiguous() if mc is not None else None
+            if (ms is not None and isinstance(self.ops, HipOps) and cfg["seq_math"] != _lib.SEQ_MATH_BF16X3
+                    and float(ms.abs().max()) > 16.0):
+                raise ValueError("explicit sequence masks must satisfy |m| <= 16 with seq_math f16x2 (include/pathnet_hip.h); "
+                                 "use seq_math='bf16x3' for others")
+            cfg["mask_seq"], cfg["mask_cls"] = ms, mc
             cfg["p_seq"] = cfg["p_cls"] = 0.0
         cfg["batch_groups"] = M.pick_batch_groups(m.variant, cfg["N"], cfg["F"], cfg["H"], cfg["C"], S, cfg["W"],
                                                   cfg["L"], m.workspace_budget, cell=m._cell_kind,
                                                   deterministic=cfg["deterministic"], S_total=cfg["S_total"],
                                                   group_begin=cfg["group_begin"], compact=cfg["compact"],
                                                   seq_math=cfg["seq_math"]) if isinstance(self.ops, HipOps) else 0
-        return _ShardedFn.apply(self, cfg, X_loc.contiguous().float(), ids, codes, sel, *params)
+        return _ShardedFn.apply(self, cfg, Xn, ids, codes, sel, *params)
 
     def set_batch_counts(self, counts):
         """Masked nodes per rank, when they are the same every step (a fixed train mask): spares the per-step
@@ -532,18 +697,26 @@ class ReplicatedAggregator(ShardedAggregator):
         touches a fraction of a large graph (12 500 masked nodes x 40 paths x 6 steps reach ~26 % of the 10 M nodes of
         configs[4]); without this every rank projects, zero-fills and flags ALL N rows each step -- the terms that do not
         shrink with the number of ranks (tools/scale_model.py).  Rows keep their relative order; every row's arithmetic
-        is unchanged (the projection of a row does not depend on the other rows)."""
+        is unchanged (the projection of a row does not depend on the other rows).  Device-resident ids / sel are clamped to
+        the graph first -- the contract of the kernels, which never read them back (modules._as_index_tensors).  One host
+        round trip per step (the number of touched rows sizes X'): a step that is to be captured in a hipGraph
+        (module.step_state set) keeps all rows instead."""
         N = X.shape[0]
         steps = ids.numel() + sel.numel()
-        on = self.compact_nodes if self.compact_nodes is not None else 2 * steps < N
+        on = self.compact_nodes if self.compact_nodes is not None else (2 * steps < N and self.module.step_state is None)
         if not on or steps == 0:
             return X, ids, sel
+        ids_l, sel_l = ids.long().clamp_(0, N - 1), sel.long().clamp_(0, N - 1)
         flags = torch.zeros(N, dtype=torch.bool, device=X.device)
-        flags[ids.reshape(-1).long()] = True
-        flags[sel.long()] = True
+        flags[ids_l.reshape(-1)] = True
+        flags[sel_l] = True
         nodes = torch.nonzero(flags).flatten()                      # (one host round trip for the count)
         rank = torch.cumsum(flags, 0, dtype=torch.int32) - 1
-        return X.index_select(0, nodes), rank[ids.long()], rank[sel.long()]
+        return X.index_select(0, nodes), rank[ids_l], rank[sel_l]
+
+    def begin_step(self, X_loc):
+        """nothing to start early: every rank projects its own copy of X inside the call, there is no forward collective"""
+        return None
 
     @staticmethod
     def cheaper_than_sharding(n_total, in_features, hidden, world, link_GBs=50.0, gemm_TFLOPs=50.0):

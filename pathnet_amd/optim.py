@@ -122,6 +122,11 @@ class Adam(torch.optim.Optimizer):
                                                 group["eps"], group["weight_decay"], step,
                                                 self.step_state.ptr() if self.step_state is not None else None,
                                                 _stream()))
+                # the kernel wrote through raw pointers: tell autograd's version counters, which is what everything that
+                # caches a function of the parameters keys on (the modules' reuse_tables, dist.ShardedAggregator.begin_step) --
+                # torch.optim.Adam's in-place ops bump them as a matter of course.  No launch.
+                for p, _, _ in items:
+                    torch.autograd.graph.increment_version(p)
         return loss
 
 

@@ -87,14 +87,21 @@ class OracleOps:
         return g.t() @ X_loc, g.sum(0)
 
 
-def make_case(variant, seed=0, uneven=False):
+def make_case(variant, seed=0, uneven=False, N=24, H=32, empty_block=None):
     rng = np.random.default_rng(seed)
-    N, F, H, C, W, L = 24, 10, 32, 3, 5, 4
+    F, C, W, L = 10, 3, 5, 4
     X = torch.as_tensor(rng.random((N, F), dtype=np.float32))
     mask = np.zeros(N, bool)
     if uneven:                      # 9 masked nodes in the first row block, 3 in the second
         mask[rng.permutation(N // 2)[:9]] = True
         mask[N // 2 + rng.permutation(N // 2)[:3]] = True
+    elif empty_block is not None:   # ragged counts over `world` blocks, none at all in block `empty_block[1]`
+        from pathnet_amd.dist import node_block
+        world, empty = empty_block
+        for r in range(world):
+            lo, cnt = node_block(N, world, r)
+            take = 0 if r == empty else min(cnt, 2 + 3 * r)
+            mask[lo + rng.permutation(cnt)[:take]] = True
     else:
         mask[rng.permutation(N)[:14]] = True
     sel = np.flatnonzero(mask)
@@ -114,17 +121,16 @@ def build_module(variant, case):
     return m.eval()
 
 
-def worker(rank, world, port, variant, ret, mode="sum"):
+def worker(rank, world, port, variant, ret, mode="sum", case_kw=None, exchange="auto"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pathnet_amd import dist as pdist
-        case = make_case(variant, uneven=(mode == "mean_uneven"))
+        case = make_case(variant, uneven=(mode == "mean_uneven"), **(case_kw or {}))
         m = build_module(variant, case)
-        n_loc = case["N"] // world
-        lo = rank * n_loc
+        lo, n_loc = pdist.node_block(case["N"], world, rank)
         mine = (case["sel"] >= lo) & (case["sel"] < lo + n_loc)
-        runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, ops=OracleOps(variant, case["L"]))
+        runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, ops=OracleOps(variant, case["L"]), exchange=exchange)
         if mode == "masks":             # training mode, explicit masks of the WHOLE batch
             S, W, H = len(case["sel"]), case["W"], case["H"]
             g = torch.Generator().manual_seed(9)
@@ -132,10 +138,11 @@ def worker(rank, world, port, variant, ret, mode="sum"):
             runner.mask_cls = (torch.rand(S, 2 * H, generator=g) >= 0.5).float() / 0.5
             m.train()
         # the sel argument as a NUMPY integer array of node ids (round 1 mistook that for a bool mask)
-        out = runner(case["X"][lo:lo + n_loc], torch.as_tensor(case["ids"][mine].reshape(mine.sum(), -1)), case["W"],
+        out = runner(case["X"][lo:lo + n_loc], torch.as_tensor(case["ids"][mine].reshape(int(mine.sum()), case["W"] * case["L"])), case["W"],
                      case["L"], case["sel"][mine].astype(np.int64), torch.as_tensor(case["codes"][mine]))
-        assert runner.batch_counts == [int(((case["sel"] >= r * n_loc) & (case["sel"] < (r + 1) * n_loc)).sum())
-                                       for r in range(world)]
+        blocks = [pdist.node_block(case["N"], world, r) for r in range(world)]
+        assert runner.batch_counts == [int(((case["sel"] >= b) & (case["sel"] < b + c)).sum()) for b, c in blocks]
+        assert runner.last_exchange == (exchange if exchange != "auto" else runner.last_exchange)
         if mode == "mean_uneven":
             # every rank's loss is the MEAN over its own masked nodes (PathNet_run.py:346); scaled by S_r / S_total the
             # summed gradients are those of the mean over the whole batch
@@ -148,7 +155,7 @@ def worker(rank, world, port, variant, ret, mode="sum"):
         assert all(v.grad.data_ptr() >= flat.data_ptr() and
                    v.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4 for v in m.parameters())   # views of one buffer
         ret[rank] = (out.detach().numpy(), {k: v.grad.numpy().copy() for k, v in m.named_parameters()},
-                     np.flatnonzero(mine))
+                     np.flatnonzero(mine), runner.last_exchange)
     finally:
         dist.destroy_process_group()
 
@@ -187,9 +194,59 @@ def test_two_rank_sharding_matches_single_process(variant, mode):
     else:
         (want * case["G"]).sum().backward()
     for rank in range(world):
-        out, grads, rows = ret[rank]
+        out, grads, rows, _ = ret[rank]
         assert np.abs(out - want.detach().numpy()[rows]).max() < 1e-5
         assert_grads_close(grads, {k: params[k].grad for k in grads}, rel=2e-5, zero_ok=ZERO_OK_HETERO, tag="rank %d" % rank)
+
+
+@pytest.mark.parametrize("variant,world,exchange,N,H", [
+    ("homo", 4, "sparse", 26, 32),      # 26 nodes on 4 ranks: blocks of 7, 7, 7, 5 -- no multiple of the world size
+    ("homo", 4, "dense", 26, 32),
+    ("hetero", 4, "sparse", 26, 32),    # the whole batch's index arrays on every rank, rows fetched for all of them
+    ("pagg", 4, "auto", 26, 32),
+    ("homo", 3, "sparse", 25, 20),      # hidden size 20: zero-padded to the kernels' 32 through differentiable pads
+    ("hetero", 2, "dense", 25, 20),
+    ("homo", 5, "sparse", 13, 32),      # 13 nodes on 5 ranks: blocks 3, 3, 3, 3, 1
+    ("homo", 8, "dense", 13, 32),       # ... on 8: blocks of 2, the last one EMPTY (13 = 6 x 2 + 1 + 0)
+    ("hetero", 8, "sparse", 13, 32),
+])
+def test_ragged_world_sizes_empty_ranks_and_both_exchange_modes(variant, world, exchange, N, H):
+    """World sizes up to 8 with ragged masked-node counts, one rank without any masked node, node counts the world size
+    does not divide (node_block: the last block shorter, or empty), a hidden size that is not a multiple of 32, and both
+    ways of moving Xh / d Xh: all of them the single-process result."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    kw = dict(N=N, H=H, empty_block=(world, 1), seed=5)
+    mp.spawn(worker, args=(world, free_port(), variant, ret, "sum", kw, exchange), nprocs=world, join=True)
+    case = make_case(variant, **kw)
+    m = build_module(variant, case)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    want = po.forward(variant, params, case["X"], case["ids"], case["codes"], case["sel"], case["W"], case["L"])
+    (want * case["G"]).sum().backward()
+    seen = 0
+    for rank in range(world):
+        out, grads, rows, used = ret[rank]
+        seen += len(rows)
+        assert used == (exchange if exchange != "auto" else used) and used in ("dense", "sparse")
+        if len(rows):
+            assert np.abs(out - want.detach().numpy()[rows]).max() < 1e-5
+        assert_grads_close(grads, {k: params[k].grad for k in grads}, rel=2e-5, zero_ok=ZERO_OK_HETERO, tag="rank %d" % rank)
+    assert seen == len(case["sel"]) and len(ret[1][2]) == 0         # rank 1 had no masked node
+    assert all(ret[r][3] == ret[0][3] for r in range(world))        # one mode per step, on every rank
+
+
+def test_node_blocks_cover_the_graph():
+    from pathnet_amd.dist import node_block
+    for n in (1, 7, 13, 24, 2708, 10 ** 7 + 3):
+        for world in (1, 2, 3, 5, 8):
+            at = 0
+            sizes = []
+            for r in range(world):
+                lo, cnt = node_block(n, world, r)
+                assert lo == at and cnt >= 0
+                at += cnt
+                sizes.append(cnt)
+            assert at == n and max(sizes) == -(-n // world) and sorted(sizes, reverse=True) == sizes
 
 
 def test_single_process_runner_without_process_group():
@@ -204,7 +261,7 @@ def test_single_process_runner_without_process_group():
                       case["L"])
     assert (out - want).abs().max().item() < 1e-5
     with pytest.raises(ValueError):
-        pdist.ShardedAggregator(m, case["N"] + 1, 0, case["N"], ops=OracleOps("homo", case["L"]))
+        pdist.ShardedAggregator(m, case["N"] + 1, 0, case["N"], ops=OracleOps("homo", case["L"]))     # not this rank's block
 
 
 def test_index_argument_conventions():

@@ -16,9 +16,9 @@ from gradcheck import ZERO_OK_HETERO, assert_grads_close
 pytestmark = pytest.mark.gpu
 
 
-def make_case(seed=0, empty_rank1=False):
+def make_case(seed=0, empty_rank1=False, N=160, H=128):
     rng = np.random.default_rng(seed)
-    N, F, H, C, W, L = 160, 48, 128, 5, 40, 4
+    F, C, W, L = 48, 5, 40, 4
     X = torch.as_tensor(rng.random((N, F), dtype=np.float32))
     mask = np.zeros(N, bool)
     mask[rng.permutation(N // 2)[:37]] = True                   # uneven: 37 masked nodes in block 0, 21 in block 1
@@ -46,28 +46,30 @@ def masks(case, p=0.5):
             (torch.rand(S, 2 * H, generator=g) >= p).float() / (1 - p))
 
 
-def worker(rank, world, port, variant, ret, empty_rank1=False, mode="sharded"):
+def worker(rank, world, port, variant, ret, empty_rank1=False, mode="sharded", case_kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pathnet_amd import dist as pdist
 
-        case = make_case(empty_rank1=empty_rank1)
+        case = make_case(empty_rank1=empty_rank1, **(case_kw or {}))
         m = build(variant, case).train()
-        n_loc = case["N"] // world
-        lo = rank * n_loc
+        lo, n_loc = pdist.node_block(case["N"], world, rank)
         mine = (case["sel"] >= lo) & (case["sel"] < lo + n_loc)
         if mode.startswith("replicated"):   # every rank holds all of X: plain data parallelism over the masked nodes
             runner = pdist.ReplicatedAggregator(m, case["N"], comm=pdist.Comm())
             runner.compact_nodes = mode == "replicated_touched"     # ... restricted to the rows of X its paths touch
             X_in = case["X"].cuda()
         else:
-            runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, comm=pdist.Comm())      # ops = HipOps (default); gloo: staged
+            runner = pdist.ShardedAggregator(m, case["N"], lo, n_loc, comm=pdist.Comm(),      # ops = HipOps (default); gloo: staged
+                                             exchange="sparse" if "sparse" in mode else "dense")
             assert isinstance(runner.ops, pdist.HipOps)
             X_in = case["X"][lo:lo + n_loc].cuda()
         assert runner.distributed
-        if mode == "sharded_serial":        # collectives on the compute stream, as before round 4
+        if mode.endswith("_serial"):        # collectives on the compute stream, as before round 4
             runner.comm.overlap = False
+        if mode == "sharded_sparse":
+            runner.comm.measure_exposed = True
         if mode == "sharded_begin":         # projection + all-gather started ahead of the call (under the sampler, in a step)
             runner.comm.measure_exposed = True
             runner.begin_step(X_in)
@@ -83,6 +85,11 @@ def worker(rank, world, port, variant, ret, empty_rank1=False, mode="sharded"):
         if mode == "sharded_begin":
             ex = runner.comm.exposed_ms()
             assert set(ex) == {"all_gather_Xh", "reduce_scatter_dXh+fc0_bwd"} and all(v >= 0.0 for v in ex.values()), ex
+        if mode == "sharded_sparse":
+            ex = runner.comm.exposed_ms()
+            assert set(ex) == {"sparse_Xh", "sparse_dXh+fc0_bwd"} and all(v >= 0.0 for v in ex.values()), ex
+        if mode.startswith("sharded"):
+            assert runner.last_exchange == ("sparse" if "sparse" in mode else "dense")
         ret[rank] = (out.detach().cpu().numpy(), {k: v.grad.cpu().numpy().copy() for k, v in m.named_parameters()},
                      np.flatnonzero(mine))
     finally:
@@ -100,15 +107,23 @@ def free_port():
 @pytest.mark.parametrize("variant,empty_rank1,mode", [("homo", False, "sharded"), ("hetero", False, "sharded"), ("pagg", False, "sharded"),
                                                       ("homo", True, "sharded"), ("hetero", True, "sharded"),
                                                       ("homo", False, "sharded_begin"), ("hetero", True, "sharded_begin"),
-                                                      ("homo", False, "sharded_serial")])
+                                                      ("homo", False, "sharded_serial"),
+                                                      # the sparse exchange: rows asked for by id, all-to-all both ways (dist.py)
+                                                      ("homo", False, "sharded_sparse"), ("hetero", False, "sharded_sparse"),
+                                                      ("pagg", False, "sharded_sparse"), ("homo", True, "sharded_sparse"),
+                                                      ("hetero", True, "sharded_sparse_serial"),
+                                                      # 163 nodes on two ranks (blocks of 82 and 81), hidden size 100 (padded to 128)
+                                                      ("homo", False, "sharded_odd"), ("hetero", False, "sharded_sparse_odd"),
+                                                      ("pagg", True, "sharded_sparse_odd")])
 def test_two_ranks_hip_ops_match_the_single_process_module(variant, empty_rank1, mode):
     """empty_rank1: rank 1 has no masked node -- its aggregator calls run with S = 0 (empty index arrays, NULL pointers) and must
     still take part in the collectives with zero gradients"""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1, mode), nprocs=world, join=True)
-    case = make_case(empty_rank1=empty_rank1)
+    kw = dict(N=163, H=100) if mode.endswith("_odd") else {}
+    mp.spawn(worker, args=(world, free_port(), variant, ret, empty_rank1, mode, kw), nprocs=world, join=True)
+    case = make_case(empty_rank1=empty_rank1, **kw)
     m = build(variant, case).train()
     ms, mc = masks(case)
     m._mask_seq, m._mask_cls = ms.cuda(), mc.cuda()

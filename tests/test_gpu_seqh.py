@@ -256,3 +256,25 @@ def test_inference_forward_with_the_input_gates_applied_before_the_gather(varian
     assert (got - plain).abs().max().item() <= 2e-6
     assert torch.equal(got, again)
     assert (got.cpu() - want).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("variant,H,S,W,L,cell,rows", [
+    ("homo", 128, 97, 7, 4, None, 16), ("homo", 128, 97, 7, 4, None, 8), ("homo", 128, 97, 7, 4, None, 24),
+    ("hetero", 128, 61, 9, 4, None, 16), ("pagg", 96, 50, 5, 4, None, 8), ("homo", 64, 40, 9, 6, "gru", 24),
+    ("homo", 128, 700, 40, 4, None, 1),         # 28 000 paths = 875 tiles on 768 / 512 slots: a real remainder round, sized by the library
+])
+def test_remainder_round_tiles_match_the_default_tiling(variant, H, S, W, L, cell, rows):
+    """pn_seqh.hip "tile geometry": the last round of the forward / BPTT launches cut into tiles of 8 / 16 / 24 paths (context
+    knob PN_SEQH_TAIL; off by default -- measured neutral, profiles/r05_tune_scatter_tiling.txt).  A path's arithmetic does not
+    depend on the tile it sits in: bit-equal logits, gradients equal up to the order of the scatter's atomics."""
+    from pathnet_amd import _lib
+    case = _case(variant, H, S, W, L, cell, 0.5, N=max(400, S + 50))
+    old = _lib.set_knob("PN_SEQH_TAIL", 0)
+    try:
+        ref_out, ref_g = _run(case, "f16x2")
+        _lib.set_knob("PN_SEQH_TAIL", rows)
+        out, g = _run(case, "f16x2")
+    finally:
+        _lib.set_knob("PN_SEQH_TAIL", old)
+    assert torch.equal(out, ref_out)
+    assert_grads_close(g, ref_g, rel=1e-5, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
