@@ -126,16 +126,49 @@ def seq_flops(P, L, H, G=4):
     return survey * (2 * L - 1) / (2 * L), survey
 
 
-def roofline_block(dominant, dom_ms, launches, P, L, H, traffic, math=None):
+L2_PEAK_GBS = 34500.0        # aggregate L2 -> CU, same guide ("L2 (per XCD)": ~34.5 TB/s)
+
+
+def algorithmic_bytes(kernel, P, L, H, G=4):
+    """HBM bytes one launch of a recurrent kernel has to move by SURVEY.md 8(d)'s per-path figures: the gather forward
+    L*H*4 + L*5 (2068 B at L = 4, H = 128), the gather backward 2*L*H*4 (upstream gradient read + accumulated row written);
+    8(d) has no figure for the weight-gradient GEMM -- a GEMM in a launch of its own reads its two operands once,
+    L*(G*H + 2*H)*4 per path.  Everything else these kernels move (saved gates, cell states, [x|h] rows, gate gradients)
+    is the DESIGN's traffic, which is what `traffic` (PMC) shows beside it."""
+    per_path = {"seq_fwd": L * H * 4 + L * 5, "seq_bwd": 2 * L * H * 4, "wgrad": L * (G * H + 2 * H) * 4}[kernel]
+    return float(P) * per_path
+
+
+def roofline_block(dominant, dom_ms, launches, P, L, H, traffic, math=None, l2_requests=None):
     alg, survey = seq_flops(P, L, H)
     math = math or seq_math_name()
     if dominant in ("seq_fwd", "seq_bwd", "wgrad"):
         per = MFMAS_PER_PRODUCT[math]
         peak = BF16_MFMA_PEAK_TFLOPS / per
         achieved = alg / (dom_ms * 1e-3) / 1e12
-        blk = {"kernel": dominant, "bound": "mfma", "achieved": round(achieved, 3),
-               "peak": round(peak, 1), "unit": "TFLOP/s",
-               "frac": round(achieved / peak, 4), "traffic": traffic,
+        # ---- which resource the launch leans on hardest: matrix pipe by its algorithmic flops, HBM by the bytes the PMC
+        #      passes counted for this very build, L2 -> CU by the counted requests (128 B each).  `bound` is the larger of
+        #      the first two (the contract knows "mfma" and "hbm"); all three are printed.  Without a PMC stamp of this build
+        #      only the matrix side is known and `bound` says so.
+        alg_b = algorithmic_bytes(dominant, P, L, H)
+        ev = {"mfma_frac": round(achieved / peak, 4),
+              "hbm_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+              "l2_frac": round(l2_requests * 128.0 / (dom_ms * 1e-3) / 1e9 / L2_PEAK_GBS, 4) if l2_requests else None,
+              "note": "mfma_frac: algorithmic fp32 flops / (2.5 PFLOP/s / MFMAs per product); hbm_frac: PMC HBM bytes of the launch / "
+                      "its duration / 8 TB/s; l2_frac: TCC_REQ x 128 B / duration / 34.5 TB/s.  None = no PMC pass of this build "
+                      "(profiles/pmc_traffic.json carries another source hash)"}
+        ev["largest"] = max((k for k in ("mfma_frac", "hbm_frac", "l2_frac") if ev[k] is not None), key=lambda k: ev[k])[:-5]
+        hbm_bound = ev["hbm_frac"] is not None and ev["hbm_frac"] > ev["mfma_frac"]
+        as_mfma = {"achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4)}
+        hbm_ach = alg_b / (dom_ms * 1e-3) / 1e9
+        as_hbm = {"achieved": round(hbm_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 4),
+                  "algorithmic_bytes_per_launch": alg_b,
+                  "traffic_over_algorithmic": round(traffic / alg_b, 2) if traffic else None}
+        top = as_hbm if hbm_bound else as_mfma
+        blk = {"kernel": dominant, "bound": "hbm" if hbm_bound else "mfma", "achieved": top["achieved"],
+               "peak": top["peak"], "unit": top["unit"],
+               "frac": top["frac"], "traffic": traffic,
+               "bound_evidence": ev, "as_mfma": as_mfma, "as_hbm": as_hbm,
                "avg_launch_ms": round(dom_ms, 4), "launches_timed": int(launches),
                "seq_math": math,
                "algorithmic_flops_per_launch": alg,
@@ -174,6 +207,17 @@ def pmc_traffic(kernel, key):
     except (OSError, ValueError, KeyError):
         pass
     return None, None
+
+
+def pmc_l2_requests(kernel, key):
+    """TCC_REQ per launch from the same stamped passes (key: "l2_requests_per_launch" / "pubmed_l2_requests_per_launch")"""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if tr.get("source_hash") == source_hash():
+            return tr.get(key, {}).get(kernel)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def cpu_baseline(wl, seconds_budget=20.0):
@@ -359,23 +403,24 @@ def pubmed_workload(seed=3):
 def bgp_workload(world=1, seed=5):
     """BASELINE.json configs[3] (BGP, other_data: bgp.in and other_data.zip are absent from the reference mount): a
     synthetic stand-in of the published size of that dataset -- 63 977 nodes, 287 features, 8 classes -- with the class
-    the reference uses for it, PathNet (hetero, PathNet_run.py:286-291).  With world > 1 the node count is padded to a
-    multiple of the world size (equal row blocks)."""
+    the reference uses for it, PathNet (hetero, PathNet_run.py:286-291).  The node count is what it is: the sharded runner's
+    node blocks are ceil(n / world) rows, the last one shorter (dist.node_block)."""
     n0, F, C, H, W, L = 63977, 287, 8, 128, 40, 4
-    n = (n0 + world - 1) // world * world
+    n = n0
     g = synthetic_graph(n, seed, avg_und_deg=3.2)
     rng = np.random.default_rng(seed + 1)
     X = rng.random((n, F)).astype(np.float32)
     Y = rng.integers(0, C, n)
     mask = np.zeros(n, bool)
     mask[rng.permutation(n0)[: int(0.48 * n0)]] = True
-    return dict(n=n, n_loc=n // world, F=F, C=C, H=H, W=W, L=L, graph=g, X=X, Y=Y, mask=mask, cls="PathNet")
+    return dict(n=n, n_loc=-(-n // world), F=F, C=C, H=H, W=W, L=L, graph=g, X=X, Y=Y, mask=mask, cls="PathNet")
 
 
 class StepRunner:
     """One training step of the reference loop on a workload, everything resident on the GPU."""
 
-    def __init__(self, wl, dev, rank, world, sharded, timing_comm=False, hops="auto", device_state=False):
+    def __init__(self, wl, dev, rank, world, sharded, timing_comm=False, hops="auto", device_state=False, replicated=False,
+                 exchange="auto"):
         """device_state: epoch, dropout seed and Adam's step count live in device memory (pathnet_amd.StepState), so that
         a step captured into a hipGraph replays as the next step (measure_graph)."""
         import pathnet_amd
@@ -397,30 +442,36 @@ class StepRunner:
         self.runner = None
         self.overlap = os.environ.get("PN_BENCH_OVERLAP", "1") not in ("", "0")    # collectives on their own stream (dist.py)
         self.seed_backward = os.environ.get("PN_BENCH_PLAIN_BACKWARD", "0") in ("", "0")
+        to_dev = lambda a: a.to(dev) if torch.is_tensor(a) else torch.from_numpy(a).to(dev)     # noqa: E731
         if not sharded:
-            self.X = torch.from_numpy(wl["X"]).to(dev)
+            self.X = to_dev(wl["X"])
             self.sel = torch.from_numpy(np.flatnonzero(wl["mask"]).astype(np.int64)).to(dev)
             self.sel32 = self.sel.to(torch.int32)
             self.node_begin, self.node_count = 0, n
             self.loss_scale = 1.0
         else:
             from pathnet_amd import dist as pdist
-            n_loc = wl["n_loc"]
-            self.node_begin, self.node_count = rank * n_loc, n_loc
-            self.X = torch.from_numpy(wl["X"][self.node_begin:self.node_begin + n_loc]).to(dev)   # this rank's rows only
+            self.node_begin, n_loc = pdist.node_block(n, world, rank)       # ceil(n / world) rows, the last block shorter
+            self.node_count = n_loc
             loc_mask = wl["mask"][self.node_begin:self.node_begin + n_loc]
             self.sel = torch.from_numpy(np.flatnonzero(loc_mask).astype(np.int64)).to(dev)        # local row ids
             self.sel32 = (self.sel + self.node_begin).to(torch.int32)                             # global node ids
             self.comm = pdist.Comm(timing=timing_comm)
             self.comm.overlap = self.overlap
-            self.runner = pdist.ShardedAggregator(self.model, n_total=n, row_begin=self.node_begin, row_count=n_loc,
-                                                  comm=self.comm)
+            if replicated:      # all of X on every rank, each rank aggregates the masked nodes of its block (dist.py)
+                self.X = to_dev(wl["X"])
+                self.runner = pdist.ReplicatedAggregator(self.model, n_total=n, comm=self.comm)
+            else:
+                self.X = to_dev(wl["X"][self.node_begin:self.node_begin + n_loc]).contiguous()        # this rank's rows only
+                self.runner = pdist.ShardedAggregator(self.model, n_total=n, row_begin=self.node_begin, row_count=n_loc,
+                                                      comm=self.comm, exchange=exchange)
             # the mask is fixed: every rank knows every rank's count (no per-step exchange of counts)
-            counts = [int(wl["mask"][r * n_loc:(r + 1) * n_loc].sum()) for r in range(world)]
+            counts = [int(wl["mask"][b:b + c].sum()) for b, c in (pdist.node_block(n, world, r) for r in range(world))]
             self.runner.set_batch_counts(counts)
             self.loss_scale = world * counts[rank] / max(sum(counts), 1)      # mean over the WHOLE batch (dist.py)
         self.S = int(self.sel.numel())
         self.Ysel = Y[self.sel + (self.node_begin if sharded else 0)]
+        self.sharded = sharded
         # the step samples the paths of its masked nodes only (PathNet_run.py:345 picks them out of the epoch's file)
         self.ids_buf = torch.empty((1, self.S, W, L), dtype=torch.int32, device=dev)
         self.codes_buf = torch.empty((1, self.S, W, L), dtype=torch.uint8, device=dev)
@@ -429,7 +480,7 @@ class StepRunner:
         import pathnet_amd
         wl = self.wl
         W, L = wl["W"], wl["L"]
-        if self.runner is not None and hasattr(self.runner, "begin_step") and self.overlap:
+        if self.runner is not None and self.overlap and getattr(self.runner, "exchange", None) != "sparse":
             self.runner.begin_step(self.X)      # fc0 of the rank's rows + the all-gather of Xh start now, under the sampler
         if self.state is not None:
             self.state.advance()        # (one tiny launch: epoch + 1, Adam step + 1, the step's dropout seed)
@@ -462,7 +513,7 @@ class StepRunner:
         return loss
 
 
-def measure(sr, lib, ctx, names, steps, warmup, barrier):
+def measure(sr, lib, ctx, names, steps, warmup, barrier, repeats=0):
     """warm-up with every stage bracketed (finds the dominant kernel) -> exactly `steps` timed steps with only the
     dominant kernel carrying an event pair -> per-stage breakdown.  Returns a dict."""
     from pathnet_amd import _lib
@@ -481,12 +532,35 @@ def measure(sr, lib, ctx, names, steps, warmup, barrier):
         sr.step(500 + e)
     barrier()
     read_profile(lib, names, ctx)    # (drop their event pairs)
+    # how stable the number is: an event at every step boundary of the timed region (a host-side record, nothing on the
+    # GPU's critical path) gives the steps' own durations; after the region, `repeats` more regions of `steps` steps (each
+    # between two device synchronisations, outside the timed one) say how much a K-step mean moves from block to block
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for e in range(steps):
         sr.step(1000 + e)
+        marks[e + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     dom = read_profile(lib, names, ctx)[dominant]
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    blocks = [elapsed / steps * 1e3]
+    for r in range(max(0, repeats)):
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for e in range(steps):
+            sr.step(2000 + r * steps + e)
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - tb) / steps * 1e3)
+    sb = sorted(blocks)
+    dispersion = {"step_ms": {"min": round(per_step[0], 4), "median": round(per_step[len(per_step) // 2], 4),
+                              "max": round(per_step[-1], 4)},
+                  "block_ms_per_step": {"min": round(sb[0], 4), "median": round(sb[len(sb) // 2], 4), "max": round(sb[-1], 4),
+                                        "blocks": [round(b, 4) for b in blocks], "steps_per_block": steps},
+                  "note": "step_ms: GPU time between consecutive step boundaries inside the timed region (events); "
+                          "block_ms_per_step: wall time per step of the timed region (first entry) and of %d more regions of the "
+                          "same length run right after it -- a change smaller than max - min of these is not a result" % max(0, repeats)}
     _lib.check(lib.pn_profile_configure(ctx, 1, -1))
     for e in range(min(10, steps)):
         sr.step(5000 + e)
@@ -494,7 +568,7 @@ def measure(sr, lib, ctx, names, steps, warmup, barrier):
     prof = read_profile(lib, names, ctx)
     _lib.check(lib.pn_profile_configure(ctx, 0, -1))
     return {"elapsed": elapsed, "dominant": dominant, "dom_ms": dom[0] / dom[1], "dom_launches": dom[1],
-            "stages_ms": {k: round(v[0] / v[1], 4) for k, v in prof.items()}}
+            "stages_ms": {k: round(v[0] / v[1], 4) for k, v in prof.items()}, "dispersion": dispersion}
 
 
 def measure_graph(wl, dev, steps, warmup, barrier):
@@ -575,6 +649,17 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
     paths = big_e * wl["n"] * W
     out["sampler"] = {"value": paths / dt, "unit": "sampled paths/s", "draws": "philox", "paths_per_launch": paths,
                       "ms_per_launch": dt * 1e3, "hop_table": "dense %d^2 B (cache resident)" % wl["n"]}
+
+    # the bit-exact mode: glibc's rand() stream regenerated on the device (srand(seed), two draws per step, the reference's
+    # draw order -- gen_merw.cpp:81-91, :182-209); same graph, same launch size
+    def smp_glibc():
+        cnt[0] += 1
+        sr.smp.sample(W, 99, epoch_begin=cnt[0] * big_e, epoch_count=big_e, check=False, out=(ids_big, codes_big),
+                      draw_source=pathnet_amd.DRAW_GLIBC_REPLAY)
+    dt_g = time_launches(smp_glibc, 20)
+    out["sampler_glibc_replay"] = {"value": paths / dt_g, "unit": "sampled paths/s", "draws": "glibc rand() replay (bit-exact to "
+                                   "the reference binary for the same seed)", "paths_per_launch": paths, "ms_per_launch": dt_g * 1e3,
+                                   "vs_philox": round(dt / dt_g, 3)}
     del ids_big, codes_big
 
     # ---- forward only (metric (i): "report forward-only too"): the inference forward of the headline
@@ -622,7 +707,8 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
     steps_p = max(5, args.steps // 2)
     Pp = psr.S * W
     tr, tr_src = pmc_traffic(m["dominant"], "pubmed_hbm_bytes_per_launch")
-    rb = roofline_block(m["dominant"], m["dom_ms"], m["dom_launches"], Pp, L, H, tr)
+    rb = roofline_block(m["dominant"], m["dom_ms"], m["dom_launches"], Pp, L, H, tr,
+                        l2_requests=pmc_l2_requests(m["dominant"], "pubmed_l2_requests_per_launch"))
     if tr_src:
         rb["traffic_source"] = tr_src
     out["pubmed_scale_step"] = {
@@ -740,6 +826,126 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
     return out
 
 
+def configs4_workload(dev, n=10_000_000, masked=100_000, seed=0):
+    """BASELINE.json configs[4]: Erdos-Renyi graph, n nodes, degree ~16, feat = 128, path_num = 40, path_len = 6; `masked`
+    masked nodes drawn uniformly.  X is generated on the device (5.1 GB at 10 M nodes: the same values on every rank)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_sampler_large import er_graph
+    F, C, H, W, L = 128, 8, 128, 40, 6
+    g = er_graph(n, 16, seed)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 1)
+    X = torch.rand((n, F), device=dev, generator=gen)
+    rng = np.random.default_rng(seed + 2)
+    mask = np.zeros(n, bool)
+    mask[rng.choice(n, masked, replace=False)] = True
+    return dict(n=n, n_loc=-(-n // 1), F=F, C=C, H=H, W=W, L=L, graph=g, X=X, Y=rng.integers(0, C, n), mask=mask)
+
+
+def _model_prediction(block, world):
+    """tools/scale_model.py's row for `block` at `world` ranks, from the newest single-GPU bench line under profiles/ --
+    printed NEXT TO the measurement so that a SCALE record reads against the model without further arithmetic."""
+    try:
+        import importlib.util
+        import contextlib
+        import io
+        spec = importlib.util.spec_from_file_location("scale_model", os.path.join(ROOT, "tools", "scale_model.py"))
+        sm = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(sm)
+        src = sm.newest_bench_json()
+        rows = sm.rows_for(json.load(open(src)), block)
+        for R, t, sp, parts in rows:
+            if R == world:
+                return {"source": os.path.basename(src), "ms_per_step": round(t, 3), "speed_up_or_efficiency": round(sp, 3),
+                        "collectives_ms": round(parts["collectives"], 3), "link_GBs": sm.DEFAULT_LINK_GBS,
+                        "latency_us": sm.DEFAULT_LATENCY_US}
+    except Exception as e:      # noqa: BLE001  (a prediction is an annotation: never fatal)
+        return {"error": repr(e)[:200]}
+    return None
+
+
+def multi_gpu_blocks(lib, ctx, names, dev, rank, world, red_dev, barrier, args):
+    """N > 1 only, after the timed headline: the two configurations north_star names for the 8-GPU box, each a handful of
+    steps with every collective's EXPOSED time (what the compute stream actually waits for) per rank:
+      bgp_strong           configs[3] stand-in, hetero class, ONE 63 977-node graph node-sharded over the ranks
+                           (dist.ShardedAggregator; strong scaling)
+      configs4_replicated  configs[4]: 10 M-node Erdos-Renyi graph, path_len 6, 100 000 masked nodes split over the ranks,
+                           all of X on every rank, the call restricted to the rows its paths touch (dist.ReplicatedAggregator)
+      configs4_sharded     the same step node-sharded with the SPARSE exchange of touched rows
+    Sizes shrink with PN_BENCH_MULTI_SMALL=1 (the one-GPU test of this code path)."""
+    import torch.distributed as dist
+    small = os.environ.get("PN_BENCH_MULTI_SMALL", "0") not in ("", "0")
+    out = {}
+
+    def run_block(name, wl, steps, model_key, **kw):
+        t0 = time.time()
+        sr = StepRunner(wl, dev, rank, world, sharded=True, **kw)
+        setup = time.time() - t0
+        m = measure(sr, lib, ctx, names, steps, 2, barrier)
+        t = torch.tensor([m["elapsed"]], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s_tot = torch.tensor([sr.S], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(s_tot)
+        sr.comm.measure_exposed = True
+        k = min(3, steps)
+        for e in range(k):
+            sr.step(8000 + e)
+        torch.cuda.synchronize()
+        exposed = {kk: round(v / k, 4) for kk, v in sr.comm.exposed_ms().items()}
+        sr.comm.measure_exposed = False
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"exposed_ms": exposed, "masked_nodes": sr.S, "stages_ms": m["stages_ms"],
+                                          "exchange": getattr(sr.runner, "last_exchange", None)})
+        ms = float(t.item()) / steps * 1e3
+        out[name] = {"config": "%s: N=%d F=%d hid=%d path_num=%d path_len=%d, %d masked nodes = %d paths/step over %d ranks, %s"
+                               % (name, wl["n"], wl["F"], wl["H"], wl["W"], wl["L"], int(s_tot.item()), int(s_tot.item()) * wl["W"],
+                                  world, wl.get("cls", "PathNet_homo")),
+                     "ms_per_step": ms, "value": int(s_tot.item()) * wl["W"] / (ms * 1e-3), "unit": "paths/s", "steps": steps,
+                     "scaling": "strong", "by_rank": gathered, "setup_s": round(setup, 1),
+                     "model_prediction": _model_prediction(model_key, world)}
+        del sr
+        torch.cuda.empty_cache()
+
+    run_block("bgp_strong", bgp_workload(world) if not small else dict(F=287, C=8, H=128, W=40, L=4, cls="PathNet", **_shrunk_bgp()),
+              max(3, args.steps // 5), "bgp_overlap")
+    n4, m4 = (10_000_000, 100_000) if not small else (200_000, 4_000)
+    wl4 = configs4_workload(dev, n4, m4)
+    run_block("configs4_replicated", wl4, 2, "configs4_replicated_touched", hops="otf", replicated=True)
+    run_block("configs4_sharded", wl4, 2, "configs4_sharded_sparse", hops="otf", exchange="sparse")
+    return out
+
+
+def _shrunk_bgp():
+    """a 4 001-node stand-in of the stand-in for the one-GPU test of the N > 1 code path (odd size: blocks are unequal)"""
+    n = 4001
+    g = synthetic_graph(n, 5, avg_und_deg=3.2)
+    rng = np.random.default_rng(6)
+    mask = np.zeros(n, bool)
+    mask[rng.permutation(n)[: int(0.48 * n)]] = True
+    return dict(n=n, n_loc=n, graph=g, X=rng.random((n, 287)).astype(np.float32), Y=rng.integers(0, 8, n), mask=mask)
+
+
+def spawn_ranks(args, dry_run=False):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the form the
+    driver uses for N > 1; a bare invocation must not fail for launch reasons).  Fewer visible GPUs than ranks (the
+    one-GPU test box): the ranks share devices, which RCCL refuses -- the collectives then go through gloo, staged
+    through the host, and the line says so (collectives.backend)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if torch.cuda.device_count() < args.gpus and "PN_DIST_BACKEND" not in env:
+        env["PN_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if dry_run:
+        return cmd, env
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -757,8 +963,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)           # (does not return)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or without a "
+                         "launcher at all (bench.py then starts its own ranks)" % (args.gpus, world, args.gpus))
     local_rank %= max(1, torch.cuda.device_count())     # (ranks share GPUs only in the one-GPU tests of the N > 1 path)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -798,7 +1007,7 @@ def main():
         torch.cuda.synchronize()
 
     clk0 = clock_mhz(lib, dev)
-    m = measure(sr, lib, ctx, names, args.steps, args.warmup, barrier)
+    m = measure(sr, lib, ctx, names, args.steps, args.warmup, barrier, repeats=4 if world == 1 else 0)
     clk1 = clock_mhz(lib, dev)
     elapsed, dominant, dom_ms = m["elapsed"], m["dominant"], m["dom_ms"]
     collectives = None
@@ -856,9 +1065,14 @@ def main():
     P = S * W
     tr, tr_src = pmc_traffic(dominant, "hbm_bytes_per_launch" if args.workload == "cora" else
                              "pubmed_hbm_bytes_per_launch") if world == 1 else (None, None)
-    roofline = roofline_block(dominant, dom_ms, m["dom_launches"], P, L, H, tr)
+    l2r = pmc_l2_requests(dominant, "l2_requests_per_launch" if args.workload == "cora" else
+                          "pubmed_l2_requests_per_launch") if world == 1 else None
+    roofline = roofline_block(dominant, dom_ms, m["dom_launches"], P, L, H, tr, l2_requests=l2r)
     if tr_src:
         roofline["traffic_source"] = tr_src
+    multi = {}
+    if world > 1 and not args.no_extras and args.workload == "cora":
+        multi = multi_gpu_blocks(lib, ctx, names, dev, rank, world, red_dev, barrier, args)
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
@@ -881,6 +1095,7 @@ def main():
                    "nodes": n, "paths_per_step": S_total * W, "parallelism": "node-shard x%d" % world},
         "roofline": roofline,
         "stages_ms": m["stages_ms"],
+        "dispersion": m["dispersion"],
         "device": {"name": info.name.decode(errors="replace"), "arch": info.arch.decode(errors="replace"),
                    "compute_units": info.compute_units, "max_clock_mhz": info.clock_khz / 1e3,
                    "shader_clock_mhz_probe": {"before": clk0, "after": clk1},
@@ -890,6 +1105,8 @@ def main():
     }
     if collectives:
         result["collectives"] = collectives
+        result["collectives"]["model_prediction"] = _model_prediction("cora_weak_overlap", world)
+    result.update(multi)
     if world == 1 and not sharded and not args.no_graph and args.workload == "cora":
         # the same K steps as one captured hipGraph replayed K times (`value` / `ms_per_step` above stay the eager run)
         try:

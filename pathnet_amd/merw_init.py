@@ -113,30 +113,45 @@ def merw_probabilities(n, edge_index, device="cuda", tol=1e-13, max_iter=200000,
     ph = np.zeros(len(col), np.float64)
     psi = np.zeros(n, np.float64)
     sizes = np.bincount(lab, minlength=n)
-    best, total_iters, lam_of, single_entries = (-1.0, -1), 0, {}, []
-    for r in roots.tolist():
-        nodes = np.flatnonzero(lab == r)
-        ent = np.flatnonzero(lab[rows_of] == r)                     # its stored entries (rows and columns stay inside it)
-        if len(nodes) == 1:                                         # a single node: lambda = A[u,u], P[u,u] = 1 on its own
-            lam_c = float(val[ent].sum()) if len(ent) else 0.0
-            ph[ent] = 1.0
-            single_entries.append(ent)
-            psi_c = np.ones(1)
-        else:
-            pos = np.full(n, -1, np.int64)
-            pos[nodes] = np.arange(len(nodes))
-            ro = np.concatenate([[0], np.cumsum(np.diff(row_off)[nodes])]).astype(np.int64)
-            p_c, psi_c, lam_c, it = _power_iteration(lib, dev, ro, pos[col[ent]].astype(np.int32), val[ent], tol, max_iter)
-            ph[ent] = p_c
-            total_iters += it
+    # nodes and stored entries grouped by component ONCE (argsort + segment offsets): the work per component is then its own
+    # size -- citeseer has ~440 components, a large graph with many isolated nodes has as many as it has such nodes, and a
+    # flatnonzero over all nodes / entries per component would be quadratic
+    node_order = np.argsort(lab, kind="stable")
+    node_seg = np.concatenate([[0], np.cumsum(sizes[roots])])
+    ent_lab = lab[rows_of]
+    ent_order = np.argsort(ent_lab, kind="stable")
+    ent_seg = np.concatenate([[0], np.cumsum(np.bincount(ent_lab, minlength=n)[roots])])
+    # single nodes, all at once: lambda = A[u,u] (0 without a self loop), P[u,u] = 1 on its own
+    single = sizes[roots] == 1
+    diag = np.zeros(n, np.float64)
+    np.add.at(diag, rows_of, np.where(sizes[ent_lab] == 1, val, 0.0))
+    single_ent = np.flatnonzero(sizes[ent_lab] == 1)
+    ph[single_ent] = 1.0
+    best, total_iters, dom, psi_dom, nodes_dom = (-1.0, -1), 0, None, None, None
+    if single.any():
+        r_s = roots[single]
+        k = int(np.argmax(diag[r_s]))       # (a component's label is its smallest node: the node itself here)
+        best, dom, psi_dom, nodes_dom = (float(diag[r_s[k]]), 1), int(r_s[k]), np.ones(1), np.array([int(r_s[k])])
+        # (ties between single nodes: the first one, as the sequential loop did -- np.argmax returns the first maximum)
+    lam_of = {}
+    pos = np.full(n, -1, np.int64)
+    for i in np.flatnonzero(~single).tolist():                      # power iteration only where there is something to iterate
+        r = int(roots[i])
+        nodes = np.sort(node_order[node_seg[i]:node_seg[i + 1]])
+        ent = np.sort(ent_order[ent_seg[i]:ent_seg[i + 1]])         # its stored entries (rows and columns stay inside it)
+        pos[nodes] = np.arange(len(nodes))
+        ro = np.concatenate([[0], np.cumsum(np.diff(row_off)[nodes])]).astype(np.int64)
+        p_c, psi_c, lam_c, it = _power_iteration(lib, dev, ro, pos[col[ent]].astype(np.int32), val[ent], tol, max_iter)
+        ph[ent] = p_c
+        total_iters += it
         lam_of[r] = lam_c
-        if (lam_c, len(nodes)) > best:
+        if (lam_c, len(nodes)) > best or ((lam_c, len(nodes)) == best and r < dom):
             best, dom, psi_dom, nodes_dom = (lam_c, len(nodes)), r, psi_c, nodes
-    lam = lam_of[dom]
+    lam = best[0]
     psi[nodes_dom] = psi_dom
-    for ent in single_entries:                                      # the reference's value on a single node outside the
-        if len(ent) and lab[rows_of[ent[0]]] != dom:                # dominant component: A[u,u] psi_u / (lambda psi_u)
-            ph[ent] = val[ent] / lam
+    # the reference's value on a single node outside the dominant component: A[u,u] psi_u / (lambda psi_u)
+    off_dom = single_ent[ent_lab[single_ent] != dom]
+    ph[off_dom] = val[off_dom] / lam
     defined = (lab[u] == dom) | (sizes[lab[u]] == 1)
     return dict(p_uv=ph[k_uv], p_vu=ph[k_vu], psi=psi, lam=lam, iters=total_iters, components=len(roots),
                 reference_defined=defined)

@@ -30,3 +30,39 @@ def test_workload_is_the_cora_configuration_and_shards_evenly():
     wa, wb = bench.workload(0, 2), bench.workload(1, 2)
     assert wa["n"] == wb["n"] == 2 * 2708 and wa["n_loc"] == 2708
     assert (wa["graph"][1] == wb["graph"][1]).all() and (wa["X"] == wb["X"]).all() and (wa["mask"] == wb["mask"]).all()
+
+
+def test_roofline_bound_follows_the_evidence():
+    """roofline.bound is the larger of the matrix-pipe fraction (algorithmic flops) and the HBM fraction (PMC bytes of the
+    same build); without a PMC stamp only the matrix side is known.  Both sides are always printed."""
+    P, L, H = 51960, 4, 128
+    no_pmc = bench.roofline_block("seq_bwd", 0.3563, 20, P, L, H, None)
+    assert no_pmc["bound"] == "mfma" and no_pmc["unit"] == "TFLOP/s" and no_pmc["bound_evidence"]["hbm_frac"] is None
+    assert abs(no_pmc["frac"] - 47.67e9 / 0.3563e-3 / 1e12 / (2500.0 / 3)) < 2e-3            # round 4's 0.16
+    r4 = bench.roofline_block("seq_bwd", 0.3563, 20, P, L, H, 1.139e9, l2_requests=3.0e7)
+    ev = r4["bound_evidence"]
+    assert r4["bound"] == "hbm" and ev["largest"] == "hbm" and 0.39 < ev["hbm_frac"] < 0.41 and 0.15 < ev["mfma_frac"] < 0.17
+    assert r4["unit"] == "GB/s" and r4["peak"] == 8000.0 and r4["traffic"] == 1.139e9
+    # achieved = ALGORITHMIC bytes (SURVEY.md 8d: gather backward, 2 * L * H * 4 per path) / duration
+    assert abs(r4["achieved"] - P * 4096 / 0.3563e-3 / 1e9) < 1.0 and abs(r4["frac"] - r4["achieved"] / 8000.0) < 1e-3
+    assert 5.2 < r4["as_hbm"]["traffic_over_algorithmic"] < 5.5 and r4["as_mfma"]["frac"] == ev["mfma_frac"]
+    assert bench.algorithmic_bytes("seq_fwd", 1, 4, 128) == 2068 and bench.algorithmic_bytes("seq_bwd", 1, 4, 128) == 4096
+    fast = bench.roofline_block("seq_fwd", 0.05, 20, P, L, H, 1.0e8)          # a launch that is far from its bytes
+    assert fast["bound"] == "mfma"
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` without WORLD_SIZE re-executes itself under torch.distributed.run"""
+    import argparse
+    import sys
+    old = sys.argv
+    sys.argv = ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"]
+    try:
+        cmd, env = bench.spawn_ranks(argparse.Namespace(gpus=4), dry_run=True)
+    finally:
+        sys.argv = old
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert env.get("PN_DIST_BACKEND") == "gloo"          # (no GPU here: fewer devices than ranks -> host-staged collectives)

@@ -222,23 +222,30 @@ def test_rccl_collectives_in_a_one_rank_group():
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("workload", ["cora", "bgp"])
-def test_bench_with_two_ranks_on_one_gpu(workload):
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), with both
-    ranks on the one GPU of a test box: PN_DIST_BACKEND=gloo replaces RCCL (which needs a GPU per rank), everything
-    else -- sharded workload, ShardedAggregator with the HIP kernels, max-over-ranks timing, per-rank collective times,
-    the JSON line -- is the N > 1 path of the bench."""
+@pytest.mark.parametrize("workload,launcher", [("cora", "self"), ("bgp", "torchrun")])
+def test_bench_with_two_ranks_on_one_gpu(workload, launcher):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) AND as a bare command
+    (`python bench.py --gpus 2`: it then starts its own ranks), with both ranks on the one GPU of a test
+    box: gloo replaces RCCL (which needs a GPU per rank; chosen automatically when there are fewer devices than ranks),
+    everything else -- sharded workload, ShardedAggregator with the HIP kernels, max-over-ranks timing, per-rank collective
+    times, the JSON line -- is the N > 1 path of the bench.  The cora line also carries the configurations north_star names
+    for the 8-GPU box (bgp_strong, configs4_replicated, configs4_sharded: shrunk here, PN_BENCH_MULTI_SMALL) with the
+    exposed time of every collective per rank and the scale model's prediction for the same world size."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PN_BENCH_MULTI_SMALL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PN_DIST_BACKEND"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        env["PN_DIST_BACKEND"] = "gloo"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + tail
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads(lines[0])
@@ -250,7 +257,18 @@ def test_bench_with_two_ranks_on_one_gpu(workload):
     assert d["collectives"]["rccl_ranks_seen"] == 2 and d["collectives"]["backend"] == "gloo"
     assert d["collectives"]["distinct_devices"] == 1
     assert len(per_rank) == 2 and all(c["all_gather_Xh"] > 0 and c["all_reduce_grads"] > 0 for c in per_rank)
+    assert d["dispersion"]["step_ms"]["min"] <= d["dispersion"]["step_ms"]["median"] <= d["dispersion"]["step_ms"]["max"]
     if workload == "cora":
         assert d["config"]["nodes"] == 2 * 2708 and abs(d["config"]["paths_per_step"] - 2 * 1299 * 40) <= 2 * 40
+        pred = d["collectives"]["model_prediction"]
+        assert pred and "error" not in pred and 0.5 < pred["speed_up_or_efficiency"] <= 1.0
+        for name, exch in (("bgp_strong", "dense"), ("configs4_replicated", None), ("configs4_sharded", "sparse")):
+            blk = d[name]
+            assert blk["value"] > 0 and blk["scaling"] == "strong" and len(blk["by_rank"]) == 2, name
+            assert sum(rk["masked_nodes"] for rk in blk["by_rank"]) * 40 == round(blk["value"] * blk["ms_per_step"] * 1e-3), name
+            assert all(rk["exchange"] == exch for rk in blk["by_rank"]), (name, blk["by_rank"])
+            assert blk["model_prediction"] and "error" not in blk["model_prediction"], name
+        assert set(d["configs4_sharded"]["by_rank"][0]["exposed_ms"]) == {"sparse_Xh", "sparse_dXh+fc0_bwd"}
+        assert set(d["bgp_strong"]["by_rank"][0]["exposed_ms"]) == {"all_gather_Xh", "reduce_scatter_dXh+fc0_bwd"}
     # (which stage comes out as the dominant one is not asserted: two processes time-share the GPU here)
     assert "cpu_baseline" not in d and d["roofline"]["kernel"] in d["stages_ms"]

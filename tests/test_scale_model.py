@@ -52,3 +52,28 @@ def test_model_rows_are_consistent_with_the_measured_step():
     for (R, t0, _, p0), (_, t1, _, p1) in zip(full, part):
         assert abs(p1["own_rows"] - p0["own_rows"] / R) < 1e-9
         assert abs((t0 - t1) - (p0["own_rows"] - p1["own_rows"]) - zx * (1.0 - 1.0 / R)) < 1e-9
+
+
+def test_sparse_exchange_row_of_the_sharded_configs4_step():
+    """Round 5: the node-sharded step at configs[4] with the sparse exchange of touched rows (dist.ShardedAggregator(exchange=
+    "sparse")).  The dense exchange moves N x H x 4 bytes each way whatever the ranks' paths touch and models at 3.2 x on 8
+    ranks; the sparse one moves the touched quarter.  What the arithmetic must respect: never more traffic than the dense
+    form, never faster than the step without collectives, and the speed-up the DESIGN quotes (5.8 x at the model's
+    conservative 50 GB/s per link and direction, >= 6 x from 64 GB/s up -- SURVEY.md section 8(e) expects ~77)."""
+    sm = _load()
+    b = sm.load_bench(sm.newest_bench_json())
+    keys = [k for k, _, _, _ in sm.all_rows(b)]
+    assert {"cora_weak_overlap", "bgp_overlap", "configs4_sharded_dense_overlap", "configs4_sharded_sparse",
+            "configs4_replicated_touched"} <= set(keys)
+    dense = sm.rows_for(b, "configs4_sharded_dense_overlap")
+    sparse = sm.rows_for(b, "configs4_sharded_sparse")
+    for (R, t0, s0, p0), (_, t1, s1, p1) in zip(dense, sparse):
+        if R == 1:
+            assert abs(t0 - t1) < 1e-9
+            continue
+        assert p1["collectives"] < p0["collectives"] and t1 < t0
+        assert t1 >= t0 - p0["collectives"] - 1e-9              # not faster than the dense step with its collectives for free
+        assert s1 <= R + 1e-9
+    assert dense[-1][2] < 3.5 and 5.5 < sparse[-1][2] < 6.0      # 8 ranks, 50 GB/s per link and direction
+    assert sm.rows_for(b, "configs4_sharded_sparse", link_GBs=64.0)[-1][2] >= 6.0
+    assert sm.rows_for(b, "configs4_sharded_sparse", link_GBs=77.0)[-1][2] >= 6.2

@@ -25,13 +25,15 @@ def per_kernel(root):
                 name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
                 name = name.split("(")[0].split("<")[0].strip()
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    out = {}
+    out, l2 = {}, {}
     for k, cs in acc.items():
         if k in STAGE and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
             w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
             out[STAGE[k]] = (2.0 * f + w) * 1024.0
-    return out
+        if k in STAGE and "TCC_REQ_sum" in cs:          # L2 <- CU requests of 128 B (bench.py: roofline.bound_evidence.l2_frac)
+            l2[STAGE[k]] = sum(cs["TCC_REQ_sum"]) / len(cs["TCC_REQ_sum"])
+    return out, l2
 
 
 def main():
@@ -40,9 +42,10 @@ def main():
     res = {"source_hash": bench.source_hash(),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_passes.sh) on this build; bytes = "
                      "(2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch, FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section",
-           "hbm_bytes_per_launch": per_kernel(os.path.join(root, "cora"))}
+           }
+    res["hbm_bytes_per_launch"], res["l2_requests_per_launch"] = per_kernel(os.path.join(root, "cora"))
     if os.path.isdir(os.path.join(root, "pubmed")):
-        res["pubmed_hbm_bytes_per_launch"] = per_kernel(os.path.join(root, "pubmed"))
+        res["pubmed_hbm_bytes_per_launch"], res["pubmed_l2_requests_per_launch"] = per_kernel(os.path.join(root, "pubmed"))
     json.dump(res, open(dst, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
