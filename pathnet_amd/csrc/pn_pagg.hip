@@ -2668,6 +2668,7 @@ struct WsLayout {
     size_t xh, keep, dG, dhn, dl1, gx, gout, bankT;                      // per micro-batch, saved / backward
     size_t flags, rank, list, seg, bsum;                                 // touched-row compaction (Dims.compact)
     size_t dx, keys, iota, skey, ssrc, stmp, cpart, dsel, dds, datt, dgemm;  // deterministic backward (Dims.det)
+    size_t okey[3], osrc[3];            // its three destination orders, sorted once per micro-batch (prepare_det_orders)
     size_t stmp_bytes;
     int wgrad_split, wgrad_tiles;
     size_t total;
@@ -2699,7 +2700,7 @@ WsLayout ws_layout(const Dims &d) {
         // (Pubmed, BGP size: +10 % on the kernel for nothing hidden) it keeps every CU.  profiles/r04_wgrad_cus_ab.txt
         const size_t rows = Pb * L, tiles = std::max<size_t>(1, ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN));
         const double wg_flops = 2.0 * (double)rows * (double)(G * H) * (double)(2 * H);
-        size_t cus = (!d.det && wg_flops <= 1.2e11) ? WGRAD_CUS_SHARED : 256;        // (deterministic mode runs its stages serially)
+        size_t cus = wg_flops <= 1.2e11 ? WGRAD_CUS_SHARED : 256;
         // (tuning / A-B runs, tools/ab_wgrad_cus.sh; read ONCE per process: the split sizes the workspace, and the size query,
         //  the forward and the backward of a call must agree on it)
         static const int env_cus = [] { const char *e = getenv("PN_WGRAD_CUS"); return e ? std::max(8, atoi(e)) : 0; }();
@@ -2751,6 +2752,8 @@ WsLayout ws_layout(const Dims &d) {
         w.iota = take(K * 4);
         w.skey = take(K * 4);
         w.ssrc = take(K * 4);
+        const size_t ord[3] = {Sb, Pb, Pb * L};        // DET_SEL, DET_EGO, DET_ROW
+        for (int i = 0; i < 3; i++) w.okey[i] = take(ord[i] * 4), w.osrc[i] = take(ord[i] * 4);
         w.stmp_bytes = sort_temp_reserve((int64_t)K);
         w.stmp = take(w.stmp_bytes);
         w.cpart = take(((K + DET_CHUNK - 1) / DET_CHUNK) * 2 * H * 4);
@@ -3208,19 +3211,63 @@ int run_tables(const Call &c, JoinGuard &joiner) {
     return PN_OK;
 }
 
-// dst[clamp(keys[i])] += contribution i (rows[i] or scal[i] * vec) for i < K, in the order of i (deterministic mode)
-int run_det_scatter(const Call &c, const int32_t *keys, int64_t K, int64_t max_key, const float *rows, const float *scal,
-                    const float *vec, float *dst) {
+// ---- deterministic mode: the three scatters of a backward and their destination orders ------------------------------------
+// dst[key[i]] += contribution i, added in the order of i, for  DET_SEL  the ego half of d layer1 onto the masked nodes' rows
+// of d Xh (keys: sel),  DET_EGO  the attention-ego term onto the ego rows (keys: egoidx),  DET_ROW  the gather backward
+// (keys: rowidx).  All three key arrays come out of the index plan -- nothing of the backward enters them -- so their
+// stable sort by key runs ONCE per micro-batch, right behind the plan and on the context's second stream under the
+// forward's recurrence (round 5; until then: a radix sort in front of each scatter, on the backward's critical path --
+// 0.10 of the 0.27 ms the mode cost at the headline shape were the pooling backward's two sorts alone).
+enum { DET_SEL = 0, DET_EGO = 1, DET_ROW = 2 };
+struct DetOrder {
+    const int32_t *keys;
+    int64_t K, max_key;
+};
+inline DetOrder det_order(const Call &c, int which, int b) {
+    const Dims &d = c.d;
+    const int64_t Sb = c.groups(b), Pb = Sb * d.W;
+    const bool homo = d.variant == PN_VARIANT_HOMO;
+    switch (which) {
+        case DET_SEL: return DetOrder{c.sel(b), Sb, (int64_t)d.N - 1};
+        case DET_EGO: return DetOrder{c.at<const int32_t>(c.w.egoidx), Pb, homo ? d.ZR - 1 : (int64_t)d.N - 1};
+        default: return DetOrder{c.at<const int32_t>(c.w.rowidx), Pb * d.L, d.ZR - 1};
+    }
+}
+
+int prepare_det_orders(const Call &c, hipStream_t s, int b) {
+    int32_t *ck = c.at<int32_t>(c.w.keys), *io = c.at<int32_t>(c.w.iota);
+    const bool has_att = c.d.variant != PN_VARIANT_PAGG;
+    for (int which = 0; which < 3; which++) {
+        if (which == DET_EGO && !has_att) continue;
+        const DetOrder o = det_order(c, which, b);
+        if (o.K <= 0) continue;
+        hipLaunchKernelGGL(det_keys_kernel, dim3((unsigned)((o.K + 255) / 256)), dim3(256), 0, s, o.keys, o.K, (int)o.max_key, ck, io);
+        PN_CHECK_HIP(hipGetLastError());
+        int bits = 1;
+        while (bits < 31 && (o.max_key >> bits) != 0) bits++;
+        if (int rc = sort_pairs_i32(c.at<void>(c.w.stmp), c.w.stmp_bytes, ck, c.at<int32_t>(c.w.okey[which]), io,
+                                    c.at<int32_t>(c.w.osrc[which]), o.K, bits, s))
+            return rc;
+    }
+    return PN_OK;       // (iota is left holding the identity over Pb * L entries: what the BPTT indexes its rows with)
+}
+
+// the orders of micro-batch b on the second stream when there is one (joined by the guard on the way out), else in line
+int fork_det_orders(const Call &c, JoinGuard &joiner, int b) {
+    hipStream_t s = c.stream;
+    if (PN_SIDE_SMALL && !profiling_every_stage(c.ctx))
+        if (void *side = context_fork(c.ctx, c.stream)) s = (hipStream_t)side;
+    if (int rc = prepare_det_orders(c, s, b)) return rc;
+    if (s != c.stream) return joiner.mark();
+    return PN_OK;
+}
+
+int run_det_scatter(const Call &c, int which, int b, const float *rows, const float *scal, const float *vec, float *dst) {
+    const int64_t K = det_order(c, which, b).K;
     if (K <= 0) return PN_OK;
     hipStream_t s = c.stream;
-    int32_t *ck = c.at<int32_t>(c.w.keys), *io = c.at<int32_t>(c.w.iota);
-    int32_t *skey = c.at<int32_t>(c.w.skey), *ssrc = c.at<int32_t>(c.w.ssrc);
-    hipLaunchKernelGGL(det_keys_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, keys, K, (int)max_key, ck, io);
-    PN_CHECK_HIP(hipGetLastError());
-    int bits = 1;
-    while (bits < 31 && (max_key >> bits) != 0) bits++;
-    if (int rc = sort_pairs_i32(c.at<void>(c.w.stmp), c.w.stmp_bytes, ck, skey, io, ssrc, K, bits, s)) return rc;
-    DetScatterParams p{skey, ssrc, K, rows, scal, vec, dst, c.at<float>(c.w.cpart), c.d.H};
+    DetScatterParams p{c.at<int32_t>(c.w.okey[which]), c.at<int32_t>(c.w.osrc[which]), K, rows, scal, vec, dst,
+                       c.at<float>(c.w.cpart), c.d.H};
     const int gpb = 256 / (c.d.H / 4);
     const int64_t chunks = (K + DET_CHUNK - 1) / DET_CHUNK;
     const unsigned blocks = (unsigned)((chunks + gpb - 1) / gpb);
@@ -3376,6 +3423,8 @@ int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *a, void *stream_) {
     JoinGuard joiner{ctx, stream};
     if (int rc = run_tables(c, joiner)) return rc;
     const bool save = d.nb == 1 && !a->no_save;  // several micro-batches: the backward re-runs each one's recurrence
+    if (save && d.det)                           // the backward's scatter orders: second stream, under the recurrence
+        if (int rc = fork_det_orders(c, joiner, 0)) return rc;
     for (int b = 0; b < d.nb; b++) {
         if (b > 0) {
             StageTimer tm(ctx, ST_PLAN_PACK, stream);
@@ -3473,8 +3522,11 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     JoinGuard joiner{ctx, stream};
     if (fused)
         if (int rc = run_tables(c, joiner)) return rc;
-    // (per-stage timings are taken serially; so is the deterministic mode, whose stages share scratch buffers)
-    const bool side_ok = !profiling_every_stage(ctx) && !d.det;
+    // (per-stage timings are taken serially.  Deterministic mode: the classifier's weight gradient shares the chunk-sum
+    //  buffer `dgemm` with the bank / fc0 backward and stays in line; the recurrent weight gradient -- its own partials,
+    //  reduced in a fixed order -- goes to the second stream as in the default mode: streams do not reorder a kernel's sums)
+    const bool overlap_ok = !profiling_every_stage(ctx);
+    const bool side_ok = overlap_ok && !d.det;
     const bool f16 = d.math == PN_SEQ_MATH_F16X2;
     const int seq4 = f16 ? 0 : seq4_select(ctx, H, G, L);
     SeqRange *range = c.at<SeqRange>(c.w.range);
@@ -3509,6 +3561,8 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 StageTimer tm(ctx, ST_PLAN_PACK, stream);
                 if (int rc = run_plan(c, stream, b)) return rc;
             }
+            if (d.det)                      // the scatters' destination orders: second stream, under this forward
+                if (int rc = fork_det_orders(c, joiner, b)) return rc;
             if (int rc = run_seq_fwd(c, b, true)) return rc;
             float *out_b = fused ? a->out + (size_t)b * d.Sb * d.C : c.at<float>(c.w.outb);
             if (int rc = run_pool_fwd(c, b, out_b)) return rc;
@@ -3602,12 +3656,13 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 PN_CHECK_HIP(hipGetLastError());
             }
             if (d.det) {
+                // (this micro-batch's orders were sorted on the second stream under its forward, when the backward re-ran it)
+                if (fused || d.nb > 1)
+                    if (int rc = joiner.join()) return rc;
                 // the ego half of d layer1 onto the masked nodes' rows of dXh; the attention-ego term onto the ego rows
-                if (int rc = run_det_scatter(c, pp.sel, Sb, d.N - 1, pp.det_sel, nullptr, nullptr, dXh)) return rc;
+                if (int rc = run_det_scatter(c, DET_SEL, b, pp.det_sel, nullptr, nullptr, dXh)) return rc;
                 if (has_att)
-                    if (int rc = run_det_scatter(c, pp.egoidx, Pb, homo ? d.ZR - 1 : (int64_t)d.N - 1, nullptr, pp.det_ds,
-                                                 a->att_w + H, pp.dego))
-                        return rc;
+                    if (int rc = run_det_scatter(c, DET_EGO, b, nullptr, pp.det_ds, a->att_w + H, pp.dego)) return rc;
             }
         }
 
@@ -3651,14 +3706,13 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         }
         if (d.det) {        // the stored mask * dx rows onto their table rows, in the order of the path steps
             StageTimer tm(ctx, ST_SEQ_BWD, stream);
-            if (int rc = run_det_scatter(c, c.at<int32_t>(c.w.rowidx), Pb * L, d.ZR - 1, c.at<float>(c.w.dx), nullptr, nullptr, dZ))
-                return rc;
+            if (int rc = run_det_scatter(c, DET_ROW, b, c.at<float>(c.w.dx), nullptr, nullptr, dZ)) return rc;
         }
 
         // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG)
         if (G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) {
             hipStream_t wstream = stream;
-            if (PN_BWD_OVERLAP && side_ok)
+            if (PN_BWD_OVERLAP && overlap_ok)
                 if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;
             WgradParams wp{};
             wp.dG = dG;
