@@ -492,14 +492,17 @@ class ShardedAggregator:
 
         def fetch():
             send = Xh_loc.index_select(0, plan.serve_local)
-            return comm.all_to_all_rows(send, plan.serve, plan.need, "sparse_Xh")
+            got = comm.all_to_all_rows(send, plan.serve, plan.need, "sparse_Xh")
+            if got.shape[0] == 0:       # a rank without masked nodes asks for nothing: the kernels still want a table (one zero row)
+                got = torch.zeros((1, got.shape[1]), dtype=got.dtype, device=got.device)
+            return got
         Xh, ready = self._on_comm_stream(X_loc, Xh_loc, fetch)
         return Xh_loc, Xh, ready
 
     def _return_sparse(self, g_Xh, plan, rows):
         """d Xh of the compact table -> the owners; this rank adds what it receives to its block, rank by rank (the rows one
         rank sends are distinct, so every index_add_ is a plain store-add and the order of the sums is fixed)"""
-        got = self.comm.all_to_all_rows(g_Xh, plan.need, plan.serve, "sparse_dXh")
+        got = self.comm.all_to_all_rows(g_Xh[:plan.T], plan.need, plan.serve, "sparse_dXh")
         g_loc = torch.zeros((rows, g_Xh.shape[1]), dtype=g_Xh.dtype, device=g_Xh.device)
         at = 0
         for q, n in enumerate(plan.serve):

@@ -5,9 +5,13 @@ Every tensor is held to a bound RELATIVE TO ITS OWN largest gradient element,
     max |got - ref|  <=  rel * max |ref|  +  NOISE * scale,        scale = the largest |ref| over all tensors of the case,
 
 so that a test whose upstream gradient is scaled by 1 / S (gradients of 1e-3 ... 1e-7) is exactly as strict as one whose
-gradients are of order one.  The additive term is there for the gradients that vanish ANALYTICALLY -- the hetero class's
-attention bias under its softmax (shift invariance): reference and product both return rounding noise there -- and is
-eleven orders below the case's largest gradient: no tensor that carries signal is excused by it.
+gradients are of order one.  The additive term is there for gradients that are cancelling sums of much larger terms -- the
+hetero class's attention bias (its softmax makes it vanish whenever the scores share a sign: reference and product both
+return rounding noise there), attention weights of a freshly initialised module -- and is nine orders below the case's
+largest gradient, sixty times below one fp32 ulp of it: no tensor that carries signal is excused by it.  Calibrated on
+the 238 comparisons of the GPU suite (PN_GRADCHECK_LOG, round 5): with 1e-9 one of them fails -- a 5-node x 100-path
+degenerate case whose attention-bias gradient is a sum of 500 terms each a thousand times larger than the result; that
+test passes its own `noise`.
 
 `assert_grads_close` also refuses to be vacuous: a tensor whose reference gradient lies inside its own tolerance would pass
 with a zeroed gradient, so every such tensor must be named in `zero_ok` (tests/test_gradcheck.py exercises the checker
@@ -21,8 +25,8 @@ import os
 import numpy as np
 
 GRAD_REL = 3e-5
-NOISE = 1e-11
-ZERO_OK_HETERO = ("attw.bias",)        # softmax over the W paths of a node: adding a constant to the scores changes nothing
+NOISE = 1e-9
+ZERO_OK_HETERO = ("attw.bias",)        # softmax over the W paths of a node: a constant added to same-signed scores changes nothing
 
 
 def _np(a):
@@ -53,7 +57,9 @@ def assert_grads_close(got, ref, rel=GRAD_REL, noise=NOISE, zero_ok=(), tag=None
     _log(tag, rows, scale, rel)
     bad = {k: (e, t, m) for k, (e, t, m) in rows.items() if not e <= t}
     assert not bad, "gradients off (name: error, tolerance, |ref|_inf): %r" % (bad,)
-    vacuous = sorted(k for k, (e, t, m) in rows.items() if m <= t and scale > 0.0)
+    # (a reference gradient that is EXACTLY zero -- a distance layer no path of the case uses, W_hh at path length 1 -- is
+    #  checked by the bound itself: the product must return zero up to the noise term)
+    vacuous = sorted(k for k, (e, t, m) in rows.items() if 0.0 < m <= t)
     assert set(vacuous) <= set(zero_ok), "a zeroed gradient would pass for %r (scale %.3g)" % (vacuous, scale)
     return rows
 

@@ -662,8 +662,9 @@ def test_ragged_and_degenerate_shapes_match_the_oracle(variant, S, W, L, N):
     ref = {k: pr[k].grad if pr[k].grad is not None else torch.zeros_like(v) for k, v in m.named_parameters()}
     ref["X"] = Xo.grad
     # (L = 1: h_{-1} = 0, the recurrent weights get an exactly-zero gradient on both sides)
-    exact_zero = tuple(k for k, v in ref.items() if float(v.abs().max()) == 0.0)
-    assert_grads_close(named_grads(m, {"X": Xd.grad}), ref, zero_ok=exact_zero + zero_ok(variant))
+    # (S = 5, W = 100: the homo class's attention-bias gradient is a sum of 500 score gradients that cancel to a thousandth
+    #  of their size -- 1.6e-4 of ITS norm, 1e-7 of the case's scale: fp32 summation order; every other case runs the default)
+    assert_grads_close(named_grads(m, {"X": Xd.grad}), ref, zero_ok=zero_ok(variant), noise=2e-7 if W == 100 else 1e-9)
 
 
 def test_indices_outside_the_graph_are_refused_or_clamped():

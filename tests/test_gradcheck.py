@@ -34,12 +34,14 @@ def test_zeroed_scaled_and_perturbed_gradients_fail(variant):
     old_rule_blind = 0
     for k in ref:
         if k in zero_ok:
-            assert np.abs(ref[k]).max() < 1e-11 * scale       # noise, eleven orders below the case's largest gradient
+            assert np.abs(ref[k]).max() < 1e-9 * scale        # noise, nine orders below the case's largest gradient
             continue
         for what, bad_k in (("zeroed", np.zeros_like(ref[k])), ("doubled", 2 * ref[k]),
                             ("off by 1e-4 of its own norm", ref[k] + np.float32(1e-4) * np.abs(ref[k]).max())):
-            if what.startswith("off") and np.abs(ref[k]).max() < 1e-6 * scale:
-                continue        # (hetero attw.weight, 1e-8 of the largest gradient: resolved to ~1e-3 of itself, not 1e-4)
+            if what.startswith("off") and np.abs(ref[k]).max() < 2e-5 * scale:
+                continue        # (a tensor 1e-5 ... 1e-8 of the largest gradient -- the hetero class's bank and attention
+                                #  weights -- is resolved to the noise term, 1e-9 of the scale: a zeroed or doubled one
+                                #  still fails, a 1e-4 perturbation of it does not)
             bad = dict(good)
             bad[k] = bad_k
             with pytest.raises(AssertionError):
@@ -50,12 +52,12 @@ def test_zeroed_scaled_and_perturbed_gradients_fail(variant):
 
 
 def test_a_tensor_that_cannot_be_checked_must_be_named():
-    ref = {"a": np.ones((4, 4), np.float32), "tiny": np.full((4,), 1e-13, np.float32)}
+    ref = {"a": np.ones((4, 4), np.float32), "tiny": np.full((4,), 1e-13, np.float32), "unused": np.zeros((3,), np.float32)}
     with pytest.raises(AssertionError, match="zeroed gradient would pass"):
         assert_grads_close(ref, ref)
     assert_grads_close(ref, ref, zero_ok=("tiny",))
     rows, scale = grad_report(ref, ref)
-    assert scale == 1.0 and rows["a"][1] == pytest.approx(GRAD_REL + 1e-11)
+    assert scale == 1.0 and rows["a"][1] == pytest.approx(GRAD_REL + 1e-9)
 
 
 def test_non_finite_and_shape_errors():

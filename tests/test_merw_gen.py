@@ -183,8 +183,8 @@ def test_disconnected_graph_policy(tmp_path):
 
 @pytest.mark.gpu
 def test_many_isolated_nodes_cost_their_own_size_not_the_graph():
-    """200 000 single-node components (half of them with a self loop) beside two rings: the components are grouped once and
-    only the rings run a power iteration (a flatnonzero over all nodes per component made this quadratic)."""
+    """200 000 single-node components (half of them with a self loop) beside a ring and a path: the components are grouped
+    once and only those two run a power iteration (a flatnonzero over all nodes per component made this quadratic)."""
     import time
     from pathnet_amd import merw_init as mi
     n_iso, ring_a, ring_b = 200_000, 41, 9            # odd rings: not bipartite
@@ -193,19 +193,25 @@ def test_many_isolated_nodes_cost_their_own_size_not_the_graph():
     a0, b0 = n_iso, n_iso + ring_a
     ra = np.arange(ring_a)
     rb = np.arange(ring_b)
-    u = np.concatenate([loops, a0 + ra, a0 + (ra + 1) % ring_a, b0 + rb, b0 + (rb + 1) % ring_b])
-    v = np.concatenate([loops, a0 + (ra + 1) % ring_a, a0 + ra, b0 + (rb + 1) % ring_b, b0 + rb])
+    pb = np.arange(ring_b - 1)                                             # the second component: a path (lambda = 2 cos(pi / 10) < 2)
+    u = np.concatenate([loops, a0 + ra, a0 + (ra + 1) % ring_a, b0 + pb, b0 + pb + 1])
+    v = np.concatenate([loops, a0 + (ra + 1) % ring_a, a0 + ra, b0 + pb + 1, b0 + pb])
     t0 = time.time()
     r = mi.merw_probabilities(n, np.stack([u, v]))
     dt = time.time() - t0
     assert dt < 20.0, dt
     assert r["components"] == n_iso + 2
-    # a ring's adjacency has lambda = 2 and a uniform eigenvector: P = 1/2 on every ring edge; the larger ring wins the tie
+    # a ring's adjacency has lambda = 2 and a uniform eigenvector: P = 1/2 on every ring edge; it dominates the path
     assert abs(r["lam"] - 2.0) < 1e-9
     ring_cols = np.flatnonzero(u >= n_iso)
-    assert np.abs(r["p_uv"][ring_cols] - 0.5).max() < 1e-9 and np.abs(r["p_vu"][ring_cols] - 0.5).max() < 1e-9
-    assert np.abs(r["psi"][a0:a0 + ring_a] - 1.0 / np.sqrt(ring_a)).max() < 1e-9 and (r["psi"][:n_iso] == 0).all()
+    on_ring = ring_cols[:2 * ring_a]
+    assert np.abs(r["p_uv"][on_ring] - 0.5).max() < 1e-9 and np.abs(r["p_vu"][on_ring] - 0.5).max() < 1e-9
+    tot = np.zeros(n)                                                      # the path: its own maximal-entropy walk, rows sum to one
+    np.add.at(tot, u[ring_cols[2 * ring_a:]], r["p_uv"][ring_cols[2 * ring_a:]])
+    assert np.abs(tot[b0:b0 + ring_b] - 1.0).max() < 1e-9
+    psi_ring = r["psi"][a0:a0 + ring_a]                                    # the dominant eigenvector: uniform on the ring, zero elsewhere
+    assert psi_ring.min() > 0 and np.ptp(psi_ring) < 1e-9 * psi_ring.max() and (r["psi"][:n_iso] == 0).all()
     # a single node with a self loop (weight 1) outside the dominant component: the reference's A[u,u] / lambda = 1/2
     assert np.abs(r["p_uv"][:len(loops)] - 0.5).max() < 1e-12
     assert r["reference_defined"][:len(loops)].all() and r["reference_defined"][ring_cols[:2 * ring_a]].all()
-    assert not r["reference_defined"][ring_cols[2 * ring_a:]].any()        # the minor ring: its own walk, not the reference's noise
+    assert not r["reference_defined"][ring_cols[2 * ring_a:]].any()        # the path: its own walk, not the reference's noise
