@@ -4,6 +4,7 @@
     rocprofv3 --kernel-trace -d <dir>/graph -o t -- python tools/graph_vs_eager.py run graph
     python tools/graph_vs_eager.py analyse <dir>/eager <dir>/graph  > profiles/r05_graph_vs_eager.txt
 
+(`run det`: the eager step with the deterministic backward -- where its extra time goes, kernel by kernel.)
 `run` drives the headline training step (bench.StepRunner with its per-step values in device memory, so that both modes
 launch the very same kernels) 40 times, eagerly or as one captured hipGraph replayed; the first launch of every step is
 step_state_advance_kernel, which is how `analyse` cuts the kernel trace into steps.  Per step it reports: kernels, the span
@@ -29,6 +30,8 @@ def run(mode):
     torch.cuda.set_device(dev)
     wl = bench.workload(0, 1)
     sr = bench.StepRunner(wl, dev, 0, 1, sharded=False, device_state=True)
+    if mode == "det":           # the eager step with the fixed-order backward (pn_pagg_shape.deterministic)
+        sr.model.deterministic = True
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -110,6 +113,14 @@ def analyse_one(rows):
                idle_in_span_us=(agg["span"] - agg["union"]) / n, overlapped_us=(agg["total"] - agg["union"]) / n,
                period_us=agg["period"] / max(n - 1, 1), queues=len(streams))
     out["gaps"] = sorted(((sum(v) / n, len(v) / n, k) for k, v in gaps.items()), reverse=True)[:14]
+    per = {}
+    for st in steps:
+        for r in st:
+            k = short(r["name"])
+            a = per.setdefault(k, [0.0, 0])
+            a[0] += (r["end"] - r["start"]) / 1e3
+            a[1] += 1
+    out["kernels"] = sorted(((v[0] / n, v[1] / n, k) for k, v in per.items()), reverse=True)
     return out
 
 
@@ -126,6 +137,9 @@ def analyse(dirs):
         print("   largest idle gaps (us per step, occurrences per step, predecessor -> successor):")
         for us, cnt, k in a["gaps"]:
             print("     %7.2f  x%.1f  %s" % (us, cnt, k))
+        print("   kernel time per step (us, launches per step):")
+        for us, cnt, k in a["kernels"]:
+            print("     %8.2f  x%.1f  %s" % (us, cnt, k))
 
 
 if __name__ == "__main__":
