@@ -2362,24 +2362,38 @@ __global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
         int key = p.skey[b];
         bool lead = b > 0 && p.skey[b - 1] == key;      // the chunk opens inside a run
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t i = b; i < e; i++) {
-            const int k = p.skey[i];
-            if (k != key) {                              // the run of `key` ends inside the chunk
-                if (lead)
-                    cpart[(c * 2 + 0) * hv + ln] = acc;
-                else
-                    add_to(dst + (int64_t)key * hv + ln, acc);
-                lead = false;
-                key = k;
-                acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // four positions per trip: their contributions are requested together (the walk was one dependent 512-byte row load
+        // per position -- latency, 85 us for the 208 k rows of the headline shape) and added in the order of the positions
+        constexpr int DU = 4;
+        for (int64_t i0 = b; i0 < e; i0 += DU) {
+            int kk[DU];
+            float4 vv[DU];
+#pragma unroll
+            for (int j = 0; j < DU; j++) {
+                const int64_t i = min(i0 + j, e - 1);   // (past the end: a harmless re-load of the last position)
+                kk[j] = p.skey[i];
+                const int64_t src = p.ssrc[i];
+                if (p.rows) {
+                    vv[j] = reinterpret_cast<const float4 *>(p.rows)[src * hv + ln];
+                } else {
+                    const float sc = p.scal[src];
+                    vv[j] = make_float4(sc * vec.x, sc * vec.y, sc * vec.z, sc * vec.w);
+                }
             }
-            const int64_t src = p.ssrc[i];
-            if (p.rows) {
-                const float4 v = reinterpret_cast<const float4 *>(p.rows)[src * hv + ln];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            } else {
-                const float sc = p.scal[src];
-                acc.x += sc * vec.x; acc.y += sc * vec.y; acc.z += sc * vec.z; acc.w += sc * vec.w;
+#pragma unroll
+            for (int j = 0; j < DU; j++) {
+                if (i0 + j >= e) break;
+                const int k = kk[j];
+                if (k != key) {                          // the run of `key` ends inside the chunk
+                    if (lead)
+                        cpart[(c * 2 + 0) * hv + ln] = acc;
+                    else
+                        add_to(dst + (int64_t)key * hv + ln, acc);
+                    lead = false;
+                    key = k;
+                    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                acc.x += vv[j].x; acc.y += vv[j].y; acc.z += vv[j].z; acc.w += vv[j].w;
             }
         }
         const bool cont = e < p.K && p.skey[e] == key;   // the last run goes on in the next chunk
