@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/final}
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --maxfail=10 > $OUT/tests.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --maxfail=10 > $OUT/tests.log 2>&1
 tail -3 $OUT/tests.log
 timeout 420 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -2 $OUT/bench.err
@@ -20,4 +20,7 @@ cp $OUT/pmc/pmc_traffic.json profiles/pmc_traffic.json
 timeout 200 python bench.py --no-extras --no-cpu-baseline > $OUT/bench_traffic.json 2> $OUT/bench_traffic.err
 PN_BENCH_FORCE_SHARDED=1 timeout 200 python bench.py --workload bgp --steps 3 --warmup 1 --no-extras --no-cpu-baseline > $OUT/bgp_sharded_path.json 2> $OUT/bgp_sharded_path.err
 tail -1 $OUT/bgp_sharded_path.err
+# the N > 1 line as a bare command (bench.py starts its own ranks; two ranks share this one GPU: gloo, shrunk configs[3] / [4] blocks)
+PN_BENCH_MULTI_SMALL=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 > $OUT/bench_two_ranks_one_gpu.json 2> $OUT/bench_two_ranks_one_gpu.err
+tail -1 $OUT/bench_two_ranks_one_gpu.err
 ls $OUT $OUT/pmc
