@@ -428,7 +428,10 @@ class StepRunner:
         self.state = pathnet_amd.StepState(dev, seed=1234, first_epoch=0) if device_state else None
         n, F, C, H, W, L = wl["n"], wl["F"], wl["C"], wl["H"], wl["W"], wl["L"]
         gn, u, v, p = wl["graph"]
-        self.smp = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev, hops=hops)
+        key = ("_sampler", hops, str(dev))
+        self.smp = wl.get(key)
+        if self.smp is None:        # (the tables of a 10 M-node graph take ~10 s of host time: built once per workload and device)
+            self.smp = wl[key] = pathnet_amd.MerwSampler(gn, u, v, p, L, device=dev, hops=hops)
         torch.manual_seed(0)
         self.model = getattr(pathnet_amd, wl.get("cls", "PathNet_homo"))(F, H, C, L, dropout=0.7).to(dev)
         self.model.step_state = self.state
@@ -877,10 +880,39 @@ def multi_gpu_blocks(lib, ctx, names, dev, rank, world, red_dev, barrier, args):
     small = os.environ.get("PN_BENCH_MULTI_SMALL", "0") not in ("", "0")
     out = {}
 
-    def run_block(name, wl, steps, model_key, **kw):
+    def all_ok(ok):
+        """every rank's flag: a block runs only where ALL ranks got through its set-up, and counts only where all finished it"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def run_block(name, make_wl, steps, model_key, **kw):
+        # set-up (host graph, sampler tables, device tensors: no collective in it) may fail on one rank alone -- out of host
+        # or device memory on a box smaller than planned for: the ranks vote, and a block that cannot run everywhere is
+        # reported as skipped instead of hanging the others.  Nothing here may take the headline line down with it.
         t0 = time.time()
-        sr = StepRunner(wl, dev, rank, world, sharded=True, **kw)
+        sr, err = None, None
+        try:
+            wl = make_wl()
+            sr = StepRunner(wl, dev, rank, world, sharded=True, **kw)
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)[:300]
+        if not all_ok(sr is not None):
+            out[name] = {"skipped": "set-up failed on at least one rank", "this_rank_error": err}
+            return
         setup = time.time() - t0
+        try:
+            measure_block(name, wl, sr, steps, model_key, setup)
+            done = True
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": repr(e)[:300]}
+            done = False
+        if not all_ok(done) and "error" not in out.get(name, {}):
+            out[name] = {"error": "another rank failed inside this block"}
+        del sr
+        torch.cuda.empty_cache()
+
+    def measure_block(name, wl, sr, steps, model_key, setup):
         m = measure(sr, lib, ctx, names, steps, 2, barrier)
         t = torch.tensor([m["elapsed"]], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -903,15 +935,18 @@ def multi_gpu_blocks(lib, ctx, names, dev, rank, world, red_dev, barrier, args):
                      "ms_per_step": ms, "value": int(s_tot.item()) * wl["W"] / (ms * 1e-3), "unit": "paths/s", "steps": steps,
                      "scaling": "strong", "by_rank": gathered, "setup_s": round(setup, 1),
                      "model_prediction": _model_prediction(model_key, world)}
-        del sr
-        torch.cuda.empty_cache()
 
-    run_block("bgp_strong", bgp_workload(world) if not small else dict(F=287, C=8, H=128, W=40, L=4, cls="PathNet", **_shrunk_bgp()),
+    run_block("bgp_strong", lambda: bgp_workload(world) if not small else dict(F=287, C=8, H=128, W=40, L=4, cls="PathNet", **_shrunk_bgp()),
               max(3, args.steps // 5), "bgp_overlap")
     n4, m4 = (10_000_000, 100_000) if not small else (200_000, 4_000)
-    wl4 = configs4_workload(dev, n4, m4)
-    run_block("configs4_replicated", wl4, 2, "configs4_replicated_touched", hops="otf", replicated=True)
-    run_block("configs4_sharded", wl4, 2, "configs4_sharded_sparse", hops="otf", exchange="sparse")
+    wl4 = {}
+
+    def c4():       # built once (the host graph and the sampler's tables take a minute at 10 M nodes), used by both blocks
+        if not wl4:
+            wl4.update(configs4_workload(dev, n4, m4))
+        return wl4
+    run_block("configs4_replicated", c4, 2, "configs4_replicated_touched", hops="otf", replicated=True)
+    run_block("configs4_sharded", c4, 2, "configs4_sharded_sparse", hops="otf", exchange="sparse")
     return out
 
 
@@ -977,10 +1012,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        # (a rank that dies inside a collective must not hang the others for the default ten minutes to half an hour)
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("PN_BENCH_PG_TIMEOUT_S", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import pathnet_amd      # noqa: F401
@@ -1071,8 +1109,11 @@ def main():
     if tr_src:
         roofline["traffic_source"] = tr_src
     multi = {}
-    if world > 1 and not args.no_extras and args.workload == "cora":
-        multi = multi_gpu_blocks(lib, ctx, names, dev, rank, world, red_dev, barrier, args)
+    if world > 1 and not args.no_extras and args.workload == "cora" and os.environ.get("PN_BENCH_MULTI_EXTRAS", "1") != "0":
+        try:
+            multi = multi_gpu_blocks(lib, ctx, names, dev, rank, world, red_dev, barrier, args)
+        except Exception as e:      # noqa: BLE001  (annotations of the N > 1 line: never fatal to it)
+            multi = {"multi_gpu_blocks_error": repr(e)[:300]}
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
