@@ -516,6 +516,9 @@ class StepRunner:
         return loss
 
 
+SETTLE_STEPS = 10
+
+
 def measure(sr, lib, ctx, names, steps, warmup, barrier, repeats=0):
     """warm-up with every stage bracketed (finds the dominant kernel) -> exactly `steps` timed steps with only the
     dominant kernel carrying an event pair -> per-stage breakdown.  Returns a dict."""
@@ -531,7 +534,10 @@ def measure(sr, lib, ctx, names, steps, warmup, barrier, repeats=0):
     kernel_stages = {k: v[0] / v[1] for k, v in prof.items()}
     dominant = max(kernel_stages, key=kernel_stages.get)
     _lib.check(lib.pn_profile_configure(ctx, 2, names.index(dominant)))
-    for e in range(2):          # two more untimed steps in exactly the timed configuration
+    # untimed steps in exactly the timed configuration: the warm-up above ran with every stage bracketed (serial, no second
+    # stream) and is followed by synchronisations and a profile read-back -- the first steps after that run ~2 % slower than
+    # the steady state every later block of the same length shows (dispersion.block_ms_per_step, profiles/r05_bench_final.json)
+    for e in range(SETTLE_STEPS):
         sr.step(500 + e)
     barrier()
     read_profile(lib, names, ctx)    # (drop their event pairs)
@@ -1101,10 +1107,9 @@ def main():
     value = S_total * W / (elapsed / args.steps)
 
     P = S * W
-    tr, tr_src = pmc_traffic(dominant, "hbm_bytes_per_launch" if args.workload == "cora" else
-                             "pubmed_hbm_bytes_per_launch") if world == 1 else (None, None)
-    l2r = pmc_l2_requests(dominant, "l2_requests_per_launch" if args.workload == "cora" else
-                          "pubmed_l2_requests_per_launch") if world == 1 else None
+    pmc_key = {"cora": "", "pubmed": "pubmed_"}.get(args.workload) if world == 1 and not sharded else None
+    tr, tr_src = pmc_traffic(dominant, pmc_key + "hbm_bytes_per_launch") if pmc_key is not None else (None, None)
+    l2r = pmc_l2_requests(dominant, pmc_key + "l2_requests_per_launch") if pmc_key is not None else None
     roofline = roofline_block(dominant, dom_ms, m["dom_launches"], P, L, H, tr, l2_requests=l2r)
     if tr_src:
         roofline["traffic_source"] = tr_src
@@ -1123,6 +1128,7 @@ def main():
         "metric": "paths aggregated/sec (PAGG fwd+bwd, one training step incl. on-GPU MERW sampling + Adam)",
         "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
+        "untimed_steps_before_timed_region": max(1, args.warmup) + SETTLE_STEPS,
         "scaling": "strong" if args.workload == "bgp" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "dtype_note": "fp32 in, fp32 out, fp32 accumulation; the recurrent GEMM products run as %s, everything else in fp32"

@@ -54,6 +54,10 @@ using namespace pn;
 #ifndef PN_BWDH_CARRY
 #define PN_BWDH_CARRY 1     // 1: c_{t-1}, loaded for step t, stays in registers as step t-1's c_t
 #endif
+#ifndef PN_SEQH_QUAD
+#define PN_SEQH_QUAD 0      // 1: what the BPTT needs of a path step and unit as ONE 16-byte quad {packed gates (3 dwords), c_{t-1}}: the
+#endif                      // forward writes it with one store, the BPTT reads it with one dwordx4 load per accumulator register -- 16 saved-value
+                            // loads per step instead of 64 (with the 16 scatter atomics: below the 63 a wave can have outstanding)
 #ifndef PN_ABL
 #define PN_ABL 0            // tuning builds only (wrong results, times are the point): bit 0 the forward does not store x_t, bit 1
 #endif                      // forward and BPTT skip the o gate's saved value, bit 2 the BPTT does not store dG
@@ -558,12 +562,17 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 const float fg = sigmoidf_(acc[rb][G > 1 ? 1 : 0][r] * sc.inv_S);
                 const float gg = tanhf_(acc[rb][G > 2 ? 2 : 0][r] * sc.inv_S);
                 const float og = sigmoidf_(acc[rb][G > 3 ? 3 : 0][r] * sc.inv_S);
-                const float c = fg * cst[rb][r] + ig * gg;
+                const float cprev = cst[rb][r];
+                const float c = fg * cprev + ig * gg;
                 cst[rb][r] = c;
                 h = og * tanhf_(c);
                 if (saved_t && live) {
                     const uint32_t base = ((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H);
-                    if constexpr (PACKED) {
+                    if constexpr (PACKED && PN_SEQH_QUAD) {
+                        const uint3 pk = pack_gates(ig, fg, gg, og);
+                        *reinterpret_cast<uint4 *>(&at_bytes(saved_t, (base + 4u * col) * 4u)) =
+                            make_uint4(pk.x, pk.y, pk.z, __float_as_uint(cprev));
+                    } else if constexpr (PACKED) {
                         if (PN_SEQH_PLANAR) {
                             const uint3 pk = pack_gates(ig, fg, gg, og);
                             uint32_t *sq = reinterpret_cast<uint32_t *>(&at_bytes(saved_t, (base + col) * 4u));
@@ -834,7 +843,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         const float dh0 = at_bytes(dhn_t, ((uint32_t)rc * (uint32_t)H + col) * 4u);     // unconditional load, select afterwards
         dh[r] = row < rows_here ? dh0 : 0.0f;
         dc[r] = 0.0f;
-        if (PN_BWDH_CARRY && G == 4 && !GRU)
+        if (PN_BWDH_CARRY && G == 4 && !GRU && !(PACKED && PN_SEQH_QUAD))      // (the quad layout: c_{L-1} = f c_{L-2} + i g, below)
             cnext[r] = at_bytes(saved_t, ((((uint32_t)rc * (uint32_t)p.L + (p.L - 1)) * SV + (PACKED ? 3 : 4)) * (uint32_t)H + col) * 4u);
     }
     float launch_max = 0.0f;        // largest |dG| this workgroup has seen (wave-uniform after each step)
@@ -852,7 +861,10 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         for (int r = 0; r < 16; r++) {
             const int rc = min(acc_row(r, lane_x), rows_here - 1);
             const uint32_t base = ((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H);
-            if constexpr (PACKED) {
+            if constexpr (PACKED && PN_SEQH_QUAD) {
+                const uint4 qd = *reinterpret_cast<const uint4 *>(&at_bytes(saved_t, (base + 4u * col) * 4u));
+                raw[0][r] = qd.x; raw[1][r] = qd.y; raw[2][r] = qd.z; raw[NRAW > 3 ? 3 : 0][r] = qd.w;
+            } else if constexpr (PACKED) {
                 if (PN_SEQH_PLANAR) {
                     const uint32_t *gq = reinterpret_cast<const uint32_t *>(&at_bytes(saved_t, (base + col) * 4u));
                     raw[0][r] = gq[0]; raw[1][r] = gq[H]; raw[2][r] = gq[2 * H];
@@ -909,6 +921,9 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     unpack_gates(make_uint3(raw[0][r], raw[NRAW > 1 ? 1 : 0][r], raw[NRAW > 2 ? 2 : 0][r]), vi_, vf_, vg_, vo_);
                     vc_ = t > 0 ? __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]) : 0.0f;
                     vn_ = PN_BWDH_CARRY ? cnext[r] : raw_cn[r];
+                    // (quad layout: the last step's c is not stored -- it is f c_{t-1} + i g of the values just unpacked, which
+                    //  differs from the forward's by the gates' 24-bit rounding, 2^-24 of a value that enters through tanh)
+                    if (PN_SEQH_QUAD && t == p.L - 1) vn_ = vf_ * vc_ + vi_ * vg_;
                 } else if (GRU) {
                     vi_ = __uint_as_float(raw[0][r]); vf_ = __uint_as_float(raw[NRAW > 1 ? 1 : 0][r]); vg_ = __uint_as_float(raw[NRAW > 2 ? 2 : 0][r]);
                     vo_ = __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]);
