@@ -2254,7 +2254,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void wgrad3_kernel(WgradParams p) {
 // walking all splits alone took 46 us for the 67 MB of partials of the bench workload.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part_w,
                                                            const float *__restrict__ part_b, int nsplit, int GH, int H,
-                                                           int accumulate, int gru, float *__restrict__ g_w_ih,
+                                                           int accumulate, int gru, int quad, float *__restrict__ g_w_ih,
                                                            float *__restrict__ g_w_hh, float *__restrict__ g_b_ih,
                                                            float *__restrict__ g_b_hh) {
     __shared__ float4 red[3][64];
@@ -2290,7 +2290,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         const int64_t i = i0 + e;
         const float v = sv[e];
         if (i < nw) {
-            const int m = (int)(i / (2 * H)), n = (int)(i - (int64_t)m * 2 * H);
+            int m = (int)(i / (2 * H));
+            const int n = (int)(i - (int64_t)m * 2 * H);
+            if (quad) m = (m & 3) * H + (m >> 2);        // dG came as [R][H][4]: row 4 j + slot -> slot H + j
             const bool xhalf = n < H;
             int row = m;
             if (gru) {
@@ -2303,7 +2305,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
             dst += (int64_t)row * H + (xhalf ? n : n - H);
             *dst = accumulate ? *dst + v : v;
         } else {
-            const int m = (int)(i - nw);
+            int m = (int)(i - nw);
+            if (quad) m = (m & 3) * H + (m >> 2);
             if (gru) {
                 const int slot = m / H, j = m - slot * H, wr = gru_weight_row(slot, j, H);
                 if (g_b_ih && slot != 3) g_b_ih[wr] = accumulate ? g_b_ih[wr] + v : v;
@@ -3771,7 +3774,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 const int64_t nred = (int64_t)GH * 2 * H + GH;
                 hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
                                    wp.part_w, wp.part_b, nz_red, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
-                                   a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
+                                   (f16 && !d.generic && G == 4 && seqh_dg_quad()) ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
                 PN_CHECK_HIP(hipGetLastError());
             }
             if (wstream != stream)

@@ -130,5 +130,6 @@ int launch_seq_fwdh(pn_context *ctx, void *stream, int H, int gc, const SeqFwdPa
 int launch_seq_fwdzw(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
 int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp);
 int launch_wgradh(pn_context *ctx, void *stream, const WgradParams &wp, int H, int nsplit);
+int seqh_dg_quad();     // 1: seq_bwdh_kernel writes dG as [R][H][4 gate slots] (G = 4): wgrad_reduce_kernel un-permutes the rows
 
 }  // namespace pn

@@ -54,10 +54,17 @@ using namespace pn;
 #ifndef PN_BWDH_CARRY
 #define PN_BWDH_CARRY 1     // 1: c_{t-1}, loaded for step t, stays in registers as step t-1's c_t
 #endif
+#ifndef PN_SEQH_DGQUAD
+#define PN_SEQH_DGQUAD 0    // 1: the gate gradients of a (path step, unit) as one 16-byte quad, dG [R][H][4] instead of [R][4][H]: 16 stores per
+#endif                      // BPTT step instead of 64; the weight-gradient GEMM sees a column permutation that wgrad_reduce_kernel undoes
+                            // Measured neutral (wall 0.927 vs 0.931 ms over three passes, one spilled register at 256): off
 #ifndef PN_SEQH_QUAD
-#define PN_SEQH_QUAD 0      // 1: what the BPTT needs of a path step and unit as ONE 16-byte quad {packed gates (3 dwords), c_{t-1}}: the
+#define PN_SEQH_QUAD 1      // what the BPTT needs of a path step and unit as ONE 16-byte quad {packed gates (3 dwords), c_{t-1}}: the
 #endif                      // forward writes it with one store, the BPTT reads it with one dwordx4 load per accumulator register -- 16 saved-value
-                            // loads per step instead of 64 (with the 16 scatter atomics: below the 63 a wave can have outstanding)
+                            // loads per step instead of 64 (with the 16 scatter atomics: below the 63 a wave can have outstanding).
+                            // Two sessions of three passes each (profiles/r05_tune_quad.txt): wall fwd+bwd 0.932 -> 0.919 ms in the first,
+                            // 0.931 = 0.931 in the second -- a quarter of the memory instructions for at best 1.4 %; kept because it is
+                            // also less code on both sides.  0 keeps round 4's [H][3] + [H] layout
 #ifndef PN_ABL
 #define PN_ABL 0            // tuning builds only (wrong results, times are the point): bit 0 the forward does not store x_t, bit 1
 #endif                      // forward and BPTT skip the o gate's saved value, bit 2 the BPTT does not store dG
@@ -940,6 +947,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                 const int row = acc_row(r, lane_t);
                 const bool ok = row < rows_here;
                 float *d = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col) * 4u);
+                [[maybe_unused]] float *dq = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)p.L + t) * (uint32_t)GH + 4u * col) * 4u);
                 if (GRU) {
                     // h = (1 - z) n + z h_prev,  n = tanh(nx + r nh):  gradients of the four slots r, z, nx, nh; the direct
                     // path d h_t / d h_{t-1} = z is carried in dc[] across the GEMM and added to its dh output
@@ -954,7 +962,10 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     dc[r] = ok ? dhv * zg : 0.0f;
                     dgv[0][r] = a_r; dgv[G > 1 ? 1 : 0][r] = a_z; dgv[G > 2 ? 2 : 0][r] = a_nx; dgv[G > 3 ? 3 : 0][r] = a_nh;
                     if (ok) {
-                        d[0] = a_r; d[H] = a_z; d[2 * (G > 1 ? H : 0)] = a_nx; d[3 * (G > 1 ? H : 0)] = a_nh;
+                        if (PN_SEQH_DGQUAD && G == 4)
+                            *reinterpret_cast<float4 *>(dq) = make_float4(a_r, a_z, a_nx, a_nh);
+                        else
+                            d[0] = a_r, d[H] = a_z, d[2 * (G > 1 ? H : 0)] = a_nx, d[3 * (G > 1 ? H : 0)] = a_nh;
                     }
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a_r), fabsf(a_z))), fmaxf(fabsf(a_nx), fabsf(a_nh)));
                 } else if (G == 4) {
@@ -972,7 +983,10 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     if (PN_BWDH_CARRY) cnext[r] = cprev;
                     dgv[0][r] = a_i; dgv[G > 1 ? 1 : 0][r] = a_f; dgv[G > 2 ? 2 : 0][r] = a_g; dgv[G > 3 ? 3 : 0][r] = a_o;
                     if (ok && !(PN_ABL & 4)) {
-                        d[0] = a_i; d[H] = a_f; d[2 * (G > 1 ? H : 0)] = a_g; d[3 * (G > 1 ? H : 0)] = a_o;
+                        if (PN_SEQH_DGQUAD && G == 4)
+                            *reinterpret_cast<float4 *>(dq) = make_float4(a_i, a_f, a_g, a_o);
+                        else
+                            d[0] = a_i, d[H] = a_f, d[2 * (G > 1 ? H : 0)] = a_g, d[3 * (G > 1 ? H : 0)] = a_o;
                     }
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a_i), fabsf(a_f))), fmaxf(fabsf(a_g), fabsf(a_o)));
                 } else {
@@ -1427,6 +1441,10 @@ extern "C" int pn_debug_seq_tiling(int64_t P, int slots, int cus, int mode, int 
 }
 
 namespace pn {
+
+// dG of the fp16 BPTT with four gate slots is [R][H][4] (PN_SEQH_DGQUAD): the weight-gradient GEMM's rows come out in that
+// order and wgrad_reduce_kernel maps them back (asked at run time: tuning builds recompile this file alone)
+int seqh_dg_quad() { return PN_SEQH_DGQUAD; }
 
 int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, int clear_x, SeqRange *range) {
     hipLaunchKernelGGL(range_w_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_ih, w_hh, n_each / 4, clear_x, range);
