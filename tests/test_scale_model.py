@@ -59,7 +59,7 @@ def test_sparse_exchange_row_of_the_sharded_configs4_step():
     "sparse")).  The dense exchange moves N x H x 4 bytes each way whatever the ranks' paths touch and models at 3.2 x on 8
     ranks; the sparse one moves the touched quarter.  What the arithmetic must respect: never more traffic than the dense
     form, never faster than the step without collectives, and the speed-up the DESIGN quotes (5.8 x at the model's
-    conservative 50 GB/s per link and direction, >= 6 x from 64 GB/s up -- SURVEY.md section 8(e) expects ~77)."""
+    conservative 50 GB/s per link and direction, 6.2 x at 64 GB/s, 6.5 x at the ~77 SURVEY.md section 8(e) expects)."""
     sm = _load()
     b = sm.load_bench(sm.newest_bench_json())
     keys = [k for k, _, _, _ in sm.all_rows(b)]
