@@ -478,17 +478,6 @@ class StepRunner:
         # the step samples the paths of its masked nodes only (PathNet_run.py:345 picks them out of the epoch's file)
         self.ids_buf = torch.empty((1, self.S, W, L), dtype=torch.int32, device=dev)
         self.codes_buf = torch.empty((1, self.S, W, L), dtype=torch.uint8, device=dev)
-        # The walker does not depend on the weights: the paths of step k + 1 are sampled on a stream of their own WHILE step k
-        # runs (two buffers), the way a data loader prefetches -- the reference samples offline altogether (gen_merw.cpp writes
-        # the file PathNet_run.py:325-334 reads).  Every step still samples one epoch's paths inside the timed region; what
-        # leaves the critical path is the walker's 8 us and the dependency gap behind it.  PN_BENCH_PREFETCH=0: sample, then
-        # aggregate, on one stream (rounds 1-4).  Not with the sharded runners (begin_step overlaps there) nor with the
-        # device-resident step state of the captured step (the sampler reads the epoch when it runs).
-        self.prefetch = (os.environ.get("PN_BENCH_PREFETCH", "1") not in ("", "0")) and not sharded and not device_state
-        if self.prefetch:
-            self.pstream = torch.cuda.Stream(device=dev)
-            self.bufs = [(self.ids_buf, self.codes_buf), (torch.empty_like(self.ids_buf), torch.empty_like(self.codes_buf))]
-            self.pref = None            # (epoch, buffer, event): what the sampling stream is producing
 
     def step(self, epoch):
         import pathnet_amd
@@ -500,31 +489,10 @@ class StepRunner:
             self.state.advance()        # (one tiny launch: epoch + 1, Adam step + 1, the step's dropout seed)
             self.smp.sample(W, 0, nodes=self.sel32, draw_source=pathnet_amd.DRAW_PHILOX, check=False,
                             out=(self.ids_buf, self.codes_buf), step_state=self.state)
-            ids, codes = self.ids_buf[0], self.codes_buf[0]
-        elif self.prefetch:
-            cur = torch.cuda.current_stream(self.dev)
-            if self.pref is not None and self.pref[0] == epoch:         # sampled while the previous step ran
-                slot = self.pref[1]
-                cur.wait_event(self.pref[2])
-            else:                                                       # first step / a jump in the epoch sequence: sample now
-                slot = 0 if self.pref is None else 1 - self.pref[1]     # (not the buffer the sampling stream may be writing)
-                self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, nodes=self.sel32,
-                                draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=self.bufs[slot])
-            ids, codes = self.bufs[slot][0][0], self.bufs[slot][1][0]
-            # the next epoch's paths into the other buffer: its last readers (the previous step) precede this point on `cur`
-            here = torch.cuda.Event()
-            here.record(cur)
-            with torch.cuda.stream(self.pstream):
-                self.pstream.wait_event(here)
-                self.smp.sample(W, 1234, epoch_begin=epoch + 1, epoch_count=1, nodes=self.sel32,
-                                draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=self.bufs[1 - slot])
-                done = torch.cuda.Event()
-                done.record(self.pstream)
-            self.pref = (epoch + 1, 1 - slot, done)
         else:
             self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, nodes=self.sel32,
                             draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(self.ids_buf, self.codes_buf))
-            ids, codes = self.ids_buf[0], self.codes_buf[0]
+        ids, codes = self.ids_buf[0], self.codes_buf[0]
         self.model.train()
         if self.runner is None and self.fused:
             # forward, CrossEntropyLoss and backward in one library call (pn_pagg_train_step): same kernels, same values
