@@ -2336,8 +2336,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 // ================================================================================================
 constexpr int DET_CHUNK = 32;
 struct DetScatterParams {
-    const int32_t *skey, *ssrc;     // sorted keys; the unsorted position of every sorted one
-    int64_t K;
+    const int32_t *skey, *ssrc;     // sorted keys (with the scatter's segment number above `kmask`); the unsorted position of every one
+    int32_t kmask;
+    int64_t K, chunk0;              // positions; first chunk of this scatter's region of cpart
     const float *rows;              // [K, H] or null
     const float *scal, *vec;        // [K], [H]
     float *dst;                     // [., H]
@@ -2345,8 +2346,13 @@ struct DetScatterParams {
     int H;
 };
 
+struct DetScatterPair {          // blockIdx.y picks the scatter: the pooling backward's two run in one launch
+    DetScatterParams s[2];
+};
+
 template <int PASS>
-__global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
+__global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterPair pp) {
+    const DetScatterParams &p = pp.s[blockIdx.y];
     const int hv = p.H / 4, gpb = 256 / hv;
     const int grp = threadIdx.x / hv, ln = threadIdx.x - grp * hv;
     if (grp >= gpb) return;
@@ -2354,7 +2360,8 @@ __global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
     if (b >= p.K) return;
     const int64_t e = min(p.K, b + (int64_t)DET_CHUNK);
     float4 *dst = reinterpret_cast<float4 *>(p.dst);
-    float4 *cpart = reinterpret_cast<float4 *>(p.cpart);
+    float4 *cpart = reinterpret_cast<float4 *>(p.cpart) + p.chunk0 * 2 * hv;
+    const int32_t km = p.kmask;
     auto add_to = [&](float4 *d, const float4 &a) {
         float4 v = *d;
         v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
@@ -2362,8 +2369,8 @@ __global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
     };
     if (PASS == 1) {
         const float4 vec = p.rows ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<const float4 *>(p.vec)[ln];
-        int key = p.skey[b];
-        bool lead = b > 0 && p.skey[b - 1] == key;      // the chunk opens inside a run
+        int key = p.skey[b] & km;
+        bool lead = b > 0 && (p.skey[b - 1] & km) == key;      // the chunk opens inside a run
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         // four positions per trip: their contributions are requested together (the walk was one dependent 512-byte row load
         // per position -- latency, 85 us for the 208 k rows of the headline shape) and added in the order of the positions
@@ -2374,7 +2381,7 @@ __global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
 #pragma unroll
             for (int j = 0; j < DU; j++) {
                 const int64_t i = min(i0 + j, e - 1);   // (past the end: a harmless re-load of the last position)
-                kk[j] = p.skey[i];
+                kk[j] = p.skey[i] & km;
                 const int64_t src = p.ssrc[i];
                 if (p.rows) {
                     vv[j] = reinterpret_cast<const float4 *>(p.rows)[src * hv + ln];
@@ -2399,7 +2406,7 @@ __global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
                 acc.x += vv[j].x; acc.y += vv[j].y; acc.z += vv[j].z; acc.w += vv[j].w;
             }
         }
-        const bool cont = e < p.K && p.skey[e] == key;   // the last run goes on in the next chunk
+        const bool cont = e < p.K && (p.skey[e] & km) == key;   // the last run goes on in the next chunk
         if (lead)
             cpart[(c * 2 + 0) * hv + ln] = acc;
         else if (cont)
@@ -2407,15 +2414,15 @@ __global__ __launch_bounds__(256) void det_scatter_kernel(DetScatterParams p) {
         else
             add_to(dst + (int64_t)key * hv + ln, acc);
     } else {
-        const int key = p.skey[e - 1];
-        if (!(e < p.K && p.skey[e] == key)) return;                      // nothing crosses this chunk's end
-        if (p.skey[b] == key && b > 0 && p.skey[b - 1] == key) return;   // a middle chunk of the run: its head's chunk adds
+        const int key = p.skey[e - 1] & km;
+        if (!(e < p.K && (p.skey[e] & km) == key)) return;                      // nothing crosses this chunk's end
+        if ((p.skey[b] & km) == key && b > 0 && (p.skey[b - 1] & km) == key) return;   // a middle chunk of the run: its head's chunk adds
         float4 acc = cpart[(c * 2 + 1) * hv + ln];
         for (int64_t c2 = c + 1;; c2++) {
             const int64_t e2 = min(p.K, (c2 + 1) * (int64_t)DET_CHUNK);
             const float4 v = cpart[(c2 * 2 + 0) * hv + ln];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            if (p.skey[e2 - 1] != key || !(e2 < p.K && p.skey[e2] == key)) break;
+            if ((p.skey[e2 - 1] & km) != key || !(e2 < p.K && (p.skey[e2] & km) == key)) break;
         }
         add_to(dst + (int64_t)key * hv + ln, acc);
     }
@@ -2428,6 +2435,24 @@ __global__ __launch_bounds__(256) void det_keys_kernel(const int32_t *__restrict
     if (i >= n) return;
     keys[i] = min(max(in[i], 0), hi);
     iota[i] = (int32_t)i;
+}
+
+// the three scatters' keys, each clamped to its table and tagged with its segment number above `shift`, beside the position
+// inside its own segment: ONE stable sort then leaves segment s at [off_s, off_s + n_s) of the output, sorted by key
+struct DetKeys3 {
+    const int32_t *keys[3];
+    int64_t n[3];
+    int32_t hi[3];
+    int shift;
+};
+__global__ __launch_bounds__(256) void det_keys3_kernel(DetKeys3 q, int32_t *__restrict__ keys, int32_t *__restrict__ pos) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t at = i;
+    int seg = 0;
+    while (seg < 3 && i >= q.n[seg]) i -= q.n[seg], seg++;
+    if (seg >= 3) return;
+    keys[at] = min(max(q.keys[seg][i], 0), q.hi[seg]) | (seg << q.shift);
+    pos[at] = (int32_t)i;
 }
 
 __global__ __launch_bounds__(256) void det_iota_kernel(int32_t *__restrict__ iota, int64_t n) {
@@ -2765,15 +2790,20 @@ WsLayout ws_layout(const Dims &d) {
         // pooling backward's per-group / per-path / per-workgroup terms; the chunk sums of the weight-gradient GEMMs
         const size_t K = std::max(Pb * L, Sb), C = d.C, F = d.F;
         w.dx = take(Pb * L * H * 4);
-        w.keys = take(K * 4);
-        w.iota = take(K * 4);
-        w.skey = take(K * 4);
-        w.ssrc = take(K * 4);
+        // the three scatters' (destination, position) pairs are sorted TOGETHER (prepare_det_orders): keys / positions before the
+        // sort (keys, skey), after it (okey / osrc: one block, a segment per scatter), the identity the BPTT indexes with (iota)
         const size_t ord[3] = {Sb, Pb, Pb * L};        // DET_SEL, DET_EGO, DET_ROW
-        for (int i = 0; i < 3; i++) w.okey[i] = take(ord[i] * 4), w.osrc[i] = take(ord[i] * 4);
-        w.stmp_bytes = sort_temp_reserve((int64_t)K);
+        const size_t Kt = ord[0] + ord[1] + ord[2];
+        w.keys = take(Kt * 4);
+        w.iota = take(K * 4);
+        w.skey = take(Kt * 4);
+        w.ssrc = take(0);
+        const size_t ok0 = take(Kt * 4), os0 = take(Kt * 4);
+        size_t pre = 0;
+        for (int i = 0; i < 3; i++) w.okey[i] = ok0 + pre * 4, w.osrc[i] = os0 + pre * 4, pre += ord[i];
+        w.stmp_bytes = sort_temp_reserve((int64_t)Kt);
         w.stmp = take(w.stmp_bytes);
-        w.cpart = take(((K + DET_CHUNK - 1) / DET_CHUNK) * 2 * H * 4);
+        w.cpart = take((Kt / DET_CHUNK + 4) * 2 * H * 4);      // (a region per scatter: SEL and EGO run in one launch)
         w.dsel = take(Sb * H * 4);
         w.dds = take(Pb * 4);
         w.dgemm = take(std::max({det_gemm_floats(C, 2 * H), det_gemm_floats(d.compact ? H : L * H, H), det_gemm_floats(H, F)}) * 4);
@@ -3252,21 +3282,30 @@ inline DetOrder det_order(const Call &c, int which, int b) {
 }
 
 int prepare_det_orders(const Call &c, hipStream_t s, int b) {
-    int32_t *ck = c.at<int32_t>(c.w.keys), *io = c.at<int32_t>(c.w.iota);
     const bool has_att = c.d.variant != PN_VARIANT_PAGG;
+    DetKeys3 q{};
+    int64_t total = 0, max_key = 0;
     for (int which = 0; which < 3; which++) {
-        if (which == DET_EGO && !has_att) continue;
         const DetOrder o = det_order(c, which, b);
-        if (o.K <= 0) continue;
-        hipLaunchKernelGGL(det_keys_kernel, dim3((unsigned)((o.K + 255) / 256)), dim3(256), 0, s, o.keys, o.K, (int)o.max_key, ck, io);
-        PN_CHECK_HIP(hipGetLastError());
-        int bits = 1;
-        while (bits < 31 && (o.max_key >> bits) != 0) bits++;
-        if (int rc = sort_pairs_i32(c.at<void>(c.w.stmp), c.w.stmp_bytes, ck, c.at<int32_t>(c.w.okey[which]), io,
-                                    c.at<int32_t>(c.w.osrc[which]), o.K, bits, s))
-            return rc;
+        q.keys[which] = o.keys;
+        q.n[which] = (which == DET_EGO && !has_att) ? 0 : std::max<int64_t>(o.K, 0);
+        q.hi[which] = (int32_t)o.max_key;
+        total += q.n[which];
+        if (q.n[which]) max_key = std::max(max_key, o.max_key);
     }
-    return PN_OK;       // (iota is left holding the identity over Pb * L entries: what the BPTT indexes its rows with)
+    if (total <= 0) return PN_OK;
+    int bits = 1;
+    while (bits < 31 && (max_key >> bits) != 0) bits++;
+    if (bits + 2 > 31) PN_FAIL(PN_ERR_ARG, "deterministic mode: %lld table rows leave no room for the scatters' segment bits", (long long)max_key + 1);
+    q.shift = bits;
+    int32_t *ck = c.at<int32_t>(c.w.keys), *pos = c.at<int32_t>(c.w.skey);
+    hipLaunchKernelGGL(det_keys3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, ck, pos);
+    PN_CHECK_HIP(hipGetLastError());
+    // (okey[0] / osrc[0] are the heads of the two contiguous output blocks; an empty EGO segment leaves its slot unused: the
+    //  segments that follow start where the sort puts them only if the layout matches -- so the outputs are addressed by the
+    //  running sum of the ACTUAL counts, which equals the layout's whenever a segment is present)
+    return sort_pairs_i32(c.at<void>(c.w.stmp), c.w.stmp_bytes, ck, c.at<int32_t>(c.w.okey[0]), pos, c.at<int32_t>(c.w.osrc[0]), total,
+                          bits + 2, s);
 }
 
 // the orders of micro-batch b on the second stream when there is one (joined by the guard on the way out), else in line
@@ -3279,19 +3318,41 @@ int fork_det_orders(const Call &c, JoinGuard &joiner, int b) {
     return PN_OK;
 }
 
-int run_det_scatter(const Call &c, int which, int b, const float *rows, const float *scal, const float *vec, float *dst) {
-    const int64_t K = det_order(c, which, b).K;
-    if (K <= 0) return PN_OK;
-    hipStream_t s = c.stream;
-    DetScatterParams p{c.at<int32_t>(c.w.okey[which]), c.at<int32_t>(c.w.osrc[which]), K, rows, scal, vec, dst,
-                       c.at<float>(c.w.cpart), c.d.H};
+// where the one sort left scatter `which` of micro-batch b: its offset is the sum of the segments before it that exist
+DetScatterParams det_params(const Call &c, int which, int b, const float *rows, const float *scal, const float *vec, float *dst) {
+    const bool has_att = c.d.variant != PN_VARIANT_PAGG;
+    int64_t off = 0, max_key = 0;
+    for (int w = 0; w < 3; w++) {
+        const DetOrder o = det_order(c, w, b);
+        const int64_t n = (w == DET_EGO && !has_att) ? 0 : std::max<int64_t>(o.K, 0);
+        if (w < which) off += n;
+        if (n) max_key = std::max(max_key, o.max_key);
+    }
+    int bits = 1;
+    while (bits < 31 && (max_key >> bits) != 0) bits++;
+    const int64_t K = (which == DET_EGO && !has_att) ? 0 : std::max<int64_t>(det_order(c, which, b).K, 0);
+    return DetScatterParams{c.at<int32_t>(c.w.okey[0]) + off, c.at<int32_t>(c.w.osrc[0]) + off, (int32_t)((1u << bits) - 1u), K,
+                            off / DET_CHUNK + which, rows, scal, vec, dst, c.at<float>(c.w.cpart), c.d.H};
+}
+
+// one or two scatters (the pooling backward's pair) per launch: pass 1, then pass 2
+int run_det_scatters(const Call &c, const DetScatterParams *list, int count) {
+    DetScatterPair pp{};
+    int64_t kmax = 0;
+    for (int i = 0; i < count; i++) pp.s[i] = list[i], kmax = std::max(kmax, list[i].K);
+    if (kmax <= 0) return PN_OK;
     const int gpb = 256 / (c.d.H / 4);
-    const int64_t chunks = (K + DET_CHUNK - 1) / DET_CHUNK;
-    const unsigned blocks = (unsigned)((chunks + gpb - 1) / gpb);
-    hipLaunchKernelGGL(det_scatter_kernel<1>, dim3(blocks), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(det_scatter_kernel<2>, dim3(blocks), dim3(256), 0, s, p);
+    const int64_t chunks = (kmax + DET_CHUNK - 1) / DET_CHUNK;
+    const dim3 grid((unsigned)((chunks + gpb - 1) / gpb), (unsigned)count);
+    hipLaunchKernelGGL(det_scatter_kernel<1>, grid, dim3(256), 0, c.stream, pp);
+    hipLaunchKernelGGL(det_scatter_kernel<2>, grid, dim3(256), 0, c.stream, pp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
+}
+
+int run_det_scatter(const Call &c, int which, int b, const float *rows, const float *scal, const float *vec, float *dst) {
+    const DetScatterParams p = det_params(c, which, b, rows, scal, vec, dst);
+    return run_det_scatters(c, &p, 1);
 }
 
 }  // namespace
@@ -3677,9 +3738,17 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 if (fused || d.nb > 1)
                     if (int rc = joiner.join()) return rc;
                 // the ego half of d layer1 onto the masked nodes' rows of dXh; the attention-ego term onto the ego rows
-                if (int rc = run_det_scatter(c, DET_SEL, b, pp.det_sel, nullptr, nullptr, dXh)) return rc;
-                if (has_att)
-                    if (int rc = run_det_scatter(c, DET_EGO, b, nullptr, pp.det_ds, a->att_w + H, pp.dego)) return rc;
+                // (one launch per pass for the two: they write different rows -- or, for the hetero / PAGG classes whose ego rows
+                //  live in dXh as well, the same rows in a fixed order: SEL first would need a launch boundary, see below)
+                const DetScatterParams two[2] = {det_params(c, DET_SEL, b, pp.det_sel, nullptr, nullptr, dXh),
+                                                 det_params(c, DET_EGO, b, nullptr, pp.det_ds, a->att_w + H, pp.dego)};
+                if (has_att && pp.dego != dXh) {
+                    if (int rc = run_det_scatters(c, two, 2)) return rc;
+                } else {        // both add into dXh: one after the other
+                    if (int rc = run_det_scatters(c, two, 1)) return rc;
+                    if (has_att)
+                        if (int rc = run_det_scatters(c, two + 1, 1)) return rc;
+                }
             }
         }
 

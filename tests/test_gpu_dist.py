@@ -114,11 +114,14 @@ def free_port():
                                                       ("hetero", True, "sharded_sparse_serial"),
                                                       # 163 nodes on two ranks (blocks of 82 and 81), hidden size 100 (padded to 128)
                                                       ("homo", False, "sharded_odd"), ("hetero", False, "sharded_sparse_odd"),
-                                                      ("pagg", True, "sharded_sparse_odd")])
+                                                      ("pagg", True, "sharded_sparse_odd"),
+                                                      # three ranks on the one GPU: blocks of 55 / 55 / 53 nodes, ragged counts
+                                                      ("homo", False, "sharded_sparse_odd_w3"), ("hetero", False, "sharded_odd_w3")])
 def test_two_ranks_hip_ops_match_the_single_process_module(variant, empty_rank1, mode):
     """empty_rank1: rank 1 has no masked node -- its aggregator calls run with S = 0 (empty index arrays, NULL pointers) and must
     still take part in the collectives with zero gradients"""
-    world = 2
+    world = 3 if mode.endswith("_w3") else 2
+    mode = mode[:-3] if mode.endswith("_w3") else mode
     mgr = mp.Manager()
     ret = mgr.dict()
     kw = dict(N=163, H=100) if mode.endswith("_odd") else {}
