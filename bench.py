@@ -516,7 +516,7 @@ class StepRunner:
         return loss
 
 
-SETTLE_STEPS = 10
+SETTLE_STEPS = 20
 
 
 def measure(sr, lib, ctx, names, steps, warmup, barrier, repeats=0):
@@ -537,14 +537,21 @@ def measure(sr, lib, ctx, names, steps, warmup, barrier, repeats=0):
     # untimed steps in exactly the timed configuration: the warm-up above ran with every stage bracketed (serial, no second
     # stream) and is followed by synchronisations and a profile read-back -- the first steps after that run ~2 % slower than
     # the steady state every later block of the same length shows (dispersion.block_ms_per_step, profiles/r05_bench_final.json)
-    for e in range(SETTLE_STEPS):
-        sr.step(500 + e)
+    for e in range(2):
+        sr.step(480 + e)
     barrier()
-    read_profile(lib, names, ctx)    # (drop their event pairs)
+    read_profile(lib, names, ctx)    # (drop the event pairs of the switch-over)
     # how stable the number is: an event at every step boundary of the timed region (a host-side record, nothing on the
     # GPU's critical path) gives the steps' own durations; after the region, `repeats` more regions of `steps` steps (each
     # between two device synchronisations, outside the timed one) say how much a K-step mean moves from block to block
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # ... and only now the settling steps: between them and the timed region lies nothing but the barrier (a read-back or a
+    # burst of event creations here lets the device idle for a millisecond, and the first steps after that run ~3 % slower)
+    _lib.check(lib.pn_profile_configure(ctx, 0, -1))     # (no event pairs to read back in front of the region)
+    for e in range(SETTLE_STEPS):
+        sr.step(500 + e)
+    barrier()
+    _lib.check(lib.pn_profile_configure(ctx, 2, names.index(dominant)))      # host-side switch: the dominant kernel's pair per step
     t0 = time.perf_counter()
     marks[0].record()
     for e in range(steps):
@@ -1128,7 +1135,7 @@ def main():
         "metric": "paths aggregated/sec (PAGG fwd+bwd, one training step incl. on-GPU MERW sampling + Adam)",
         "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True,
-        "untimed_steps_before_timed_region": max(1, args.warmup) + SETTLE_STEPS,
+        "untimed_steps_before_timed_region": max(1, args.warmup) + 2 + SETTLE_STEPS,
         "scaling": "strong" if args.workload == "bgp" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "dtype_note": "fp32 in, fp32 out, fp32 accumulation; the recurrent GEMM products run as %s, everything else in fp32"
