@@ -600,3 +600,24 @@ def test_hidden_size_that_is_not_a_multiple_of_32(variant, H, cell):
         e2 = m(X.cuda(), neis, W, L, mask, torch.as_tensor(codes.astype(np.int64)), None, reuse_tables=True)
     we = po.forward(variant, {k: v.detach() for k, v in params.items()}, X, ids, codes, sel, W, L, cell=cell)
     assert (e1.cpu() - we).abs().max().item() < TOL_OUT and torch.equal(e1, e2)
+
+
+# ---- training mode against the reference classes themselves: their forward / backward in .train() with the dropout masks
+# they drew recorded (tests/golden/make_golden_pagg_train.py); the module is handed the same masks -------------------------
+@pytest.mark.parametrize("name", golden_files("paggtrain_*.npz"))
+def test_training_mode_matches_reference_golden(name):
+    g = golden(name)
+    variant = str(g["variant"])
+    N, F, H, C, W, L = (int(g[k]) for k in "NFHCWL")
+    params = {k[len("param/"):]: v for k, v in g.items() if k.startswith("param/")}
+    m = build_module(variant, F, H, C, L, N, params).train()
+    m.set_dropout(float(g["p"]))
+    m._mask_seq, m._mask_cls = torch.as_tensor(g["mask_seq"]).cuda(), torch.as_tensor(g["mask_cls"]).cuda()
+    X = torch.as_tensor(g["X"]).cuda().requires_grad_(True)
+    out = run_module(m, X, g["ids"], g["codes"], g["mask"], W, L)
+    err = np.abs(out.detach().cpu().numpy() - g["out"]).max()
+    assert err < TOL_OUT * max(1.0, np.abs(g["out"]).max()), err
+    (out * torch.as_tensor(g["G"]).cuda()).sum().backward()
+    ref = {k: g["grad/" + k] for k, _ in m.named_parameters()}
+    ref["X"] = g["grad_X"]
+    assert_grads_close(named_grads(m, {"X": X.grad}), ref, zero_ok=zero_ok(variant))

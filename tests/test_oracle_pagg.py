@@ -130,3 +130,48 @@ def test_oracle_gru_cell_is_torch_nn_gru():
         assert torch.allclose(isum["h"], inter["y"].sum(dim=1), atol=1e-6)
     with pytest.raises(ValueError):
         po.forward("homo", params, X, ids, codes, sel, W, L, cell="lstm2")
+
+
+# ---- training mode: the reference classes' own forward/backward with the dropout masks they drew recorded
+# (tests/golden/make_golden_pagg_train.py) ---------------------------------------------------------------------------------
+TRAIN_GOLDENS = golden_files("paggtrain_*.npz")
+
+
+def test_training_mode_goldens_are_committed():
+    assert len(TRAIN_GOLDENS) >= 8
+    for name in TRAIN_GOLDENS:
+        g = golden(name)
+        L, S, W, H = (int(g[k]) for k in "LSWH")
+        assert g["mask_seq"].shape == (L, S * W, H) and g["mask_cls"].shape == (S, 2 * H)
+        p = float(g["p"])
+        scale = np.float32(1.0 / (1.0 - p))
+        for m in (g["mask_seq"], g["mask_cls"]):        # keep bits scaled by 1 / (1 - p), nothing else
+            assert np.isin(m, (np.float32(0.0), m.max())).all() and abs(m.max() - scale) < 1e-5 * scale
+            assert abs(float((m > 0).mean()) - (1.0 - p)) < 0.05
+
+
+@pytest.mark.parametrize("name", TRAIN_GOLDENS)
+def test_oracle_training_mode_matches_reference_golden(name):
+    from gradcheck import ZERO_OK_HETERO, assert_grads_close
+    g, params, grads = load_case(name)
+    variant = str(g["variant"])
+    sel = np.nonzero(g["mask"])[0]
+    params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    X = torch.tensor(g["X"]).requires_grad_(True)
+    out = po.forward(variant, params, X, g["ids"], g["codes"], sel, int(g["W"]), int(g["L"]),
+                     drop_seq=torch.tensor(g["mask_seq"]), drop_cls=torch.tensor(g["mask_cls"]))
+    assert np.abs(out.detach().numpy() - g["out"]).max() < 2e-6 * max(1.0, np.abs(g["out"]).max())
+    (out * torch.tensor(g["G"])).sum().backward()
+    got = {k: v.grad for k, v in params.items() if k in grads}
+    got["X"] = X.grad
+    ref = dict(grads, X=torch.tensor(g["grad_X"]))
+    assert_grads_close(got, ref, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
+
+
+@pytest.mark.parametrize("name", TRAIN_GOLDENS[:3])
+def test_training_mode_golden_needs_its_masks(name):
+    """the fixtures are not eval-mode outputs in disguise: without the masks the oracle lands far away"""
+    g, params, _ = load_case(name)
+    sel = np.nonzero(g["mask"])[0]
+    out = po.forward(str(g["variant"]), params, torch.tensor(g["X"]), g["ids"], g["codes"], sel, int(g["W"]), int(g["L"]))
+    assert np.abs(out.numpy() - g["out"]).max() > 1e-2
