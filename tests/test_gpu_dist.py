@@ -193,17 +193,30 @@ for variant in ("homo", "hetero"):
     (want * case["G"].cuda()).sum().backward()
     ref = {k: v.grad.clone() for k, v in m.named_parameters()}
     m.zero_grad()
-    runner = pdist.ShardedAggregator(m, case["N"], 0, case["N"], comm=pdist.Comm(always=True, timing=True))
-    assert runner.distributed
-    out = runner(X, torch.as_tensor(case["ids"].reshape(S, -1)), case["W"], case["L"],
-                 torch.as_tensor(case["sel"].astype(np.int32)), torch.as_tensor(case["codes"]))
-    (out * case["G"].cuda()).sum().backward()
-    runner.allreduce_grads(average=True)
-    torch.cuda.synchronize()
-    assert (out - want).abs().max().item() < 2e-6, variant
     from gradcheck import ZERO_OK_HETERO, assert_grads_close
-    assert_grads_close({k: v.grad for k, v in m.named_parameters()}, ref, zero_ok=ZERO_OK_HETERO)
-    assert all(t >= 0 for t in runner.comm.seconds.values()) and runner.comm.seconds["all_gather_Xh"] > 0
+    # dense: all-gather / reduce-scatter; sparse: the three all-to-alls of the touched-row exchange (row ids, Xh rows, dXh
+    # rows -- all_to_all_single with split sizes through RCCL); replicated: the index all-gather + the gradient all-reduce
+    for mode in ("dense", "sparse", "replicated"):
+        m.zero_grad(set_to_none=True)
+        comm = pdist.Comm(always=True, timing=True)
+        if mode == "replicated":
+            runner = pdist.ReplicatedAggregator(m, case["N"], comm=comm)
+        else:
+            runner = pdist.ShardedAggregator(m, case["N"], 0, case["N"], comm=comm, exchange=mode)
+        assert runner.distributed
+        out = runner(X, torch.as_tensor(case["ids"].reshape(S, -1)), case["W"], case["L"],
+                     torch.as_tensor(case["sel"].astype(np.int32)), torch.as_tensor(case["codes"]))
+        (out * case["G"].cuda()).sum().backward()
+        runner.allreduce_grads(average=True)
+        torch.cuda.synchronize()
+        assert (out - want).abs().max().item() < 2e-6, (variant, mode)
+        assert_grads_close({k: v.grad for k, v in m.named_parameters()}, ref, zero_ok=ZERO_OK_HETERO, tag=variant + "/" + mode)
+        sec = runner.comm.seconds
+        assert all(t >= 0 for t in sec.values()) and sec["all_reduce_grads"] > 0, sec
+        if mode == "dense":
+            assert sec["all_gather_Xh"] > 0 and sec["reduce_scatter_dXh"] > 0, sec
+        if mode == "sparse":
+            assert sec["sparse_index"] > 0 and sec["sparse_Xh"] > 0 and sec["sparse_dXh"] > 0 and sec["all_gather_Xh"] == 0, sec
 dist.barrier()
 dist.destroy_process_group()
 print("RCCL_OK")
@@ -213,7 +226,8 @@ print("RCCL_OK")
 def test_rccl_collectives_in_a_one_rank_group():
     """The collectives of the sharded step through RCCL itself (backend "nccl"), in a one-rank group forced through
     the multi-rank path (Comm(always=True)): all-gather of Xh, of the counts and of the hetero class's index arrays,
-    reduce-scatter of dXh, all-reduce of the flat gradient buffer -- identities at world size 1, but the very calls
+    reduce-scatter of dXh, the sparse exchange's three all-to-alls, the replicated mode, all-reduce of the flat gradient
+    buffer -- identities at world size 1, but the very calls
     `bench.py --gpus N` makes on an 8-GPU node, here on the one GPU a test box has."""
     import subprocess
     import sys
