@@ -254,7 +254,8 @@ class _PaggLossFunction(torch.autograd.Function):
         ws = cfg.get("workspace")
         with torch.cuda.device(dev):
             out = torch.empty((cfg["S"], cfg["C"]), dtype=torch.float32, device=dev)
-            loss = torch.zeros((), dtype=torch.float32, device=dev)
+            # (pn_pagg_train_step stores the loss -- or clears it itself before accumulating over micro-batches: no fill here)
+            loss = (torch.empty if cfg["S"] > 0 else torch.zeros)((), dtype=torch.float32, device=dev)
             if ws is None or ws.numel() < nbytes or ws.device != dev:
                 ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
             a = _PaggFunction._args(cfg, X, ids, codes, sel, p)
