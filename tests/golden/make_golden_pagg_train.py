@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from ref_extract import reference_classes  # noqa: E402
 
 warnings.filterwarnings("ignore")
+torch.set_num_threads(1)        # index_select's backward sums in thread order: one thread = the same bits on every run
 OUT = os.path.dirname(os.path.abspath(__file__))
 CLASS = {"hetero": "PathNet", "homo": "PathNet_homo", "pagg": "PAGG"}
 
