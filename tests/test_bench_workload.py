@@ -72,3 +72,55 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
         assert env.get("PN_DIST_BACKEND") == "gloo"
     else:
         assert "PN_DIST_BACKEND" not in env or env["PN_DIST_BACKEND"] == os.environ.get("PN_DIST_BACKEND")
+
+
+def _fail_constant(name):
+    raise ValueError("non-strict JSON constant %s" % name)
+
+
+REQUIRED_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_line_is_small_and_strict_json():
+    """the driver could not parse round 5's 20 KB stdout line.  The stdout line is a slim, numbers-only
+    projection (< 6 KB, strict JSON, every contract key); the full record goes to bench_extras.json / stderr.  Checked on
+    round 5's real full record (profiles/r05_bench_fresh_box.json) and on the two-rank one."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("r05_bench_fresh_box.json", "r05_bench_two_ranks_one_gpu.json", "r05_bench_four_ranks_one_gpu.json"):
+        full = json.load(open(os.path.join(root, "profiles", name)))
+        assert len(json.dumps(full)) > 8000                   # (the record that broke the parse)
+        line = bench.slim_line(full)
+        assert "\n" not in line and len(line.encode()) < 6144, len(line)
+        got = json.loads(line, parse_constant=_fail_constant)
+        need = [k for k in REQUIRED_LINE_KEYS if k != "cpu_baseline" or full["n_gpus"] == 1]
+        assert not [k for k in need if k not in got], [k for k in need if k not in got]
+        assert got["value"] == float("%.6g" % full["value"]) and got["config"]["workload"] == full["config"]["workload"]
+        r = got["roofline"]
+        assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r)
+        assert r["frac"] == full["roofline"]["frac"]
+        if r["kernel"] in ("seq_fwd", "seq_bwd", "wgrad"):
+            assert "frac" in r["as_mfma"] and "frac" in r["as_hbm"]
+        if full["n_gpus"] == 1:
+            cb = got["cpu_baseline"]
+            assert {"value", "unit", "cores", "kind", "sample"} <= set(cb) and len(cb["sample"]) <= 160
+            assert {"min", "median", "max"} <= set(got["dispersion"]["block_ms_per_step"])
+            assert got["gather"]["standalone_frac"] and got["gather"]["fused_frac"]
+        assert not any(k in got for k in ("graph_replay", "dtype_note", "device", "hid512_step"))   # extras stay out
+    # a pathological record still yields a line under the cap (stages dropped before anything the contract names)
+    fat = dict(full, stages_ms={"s%d" % i: 1.0 / 3 for i in range(600)})
+    assert len(bench.slim_line(fat)) < 6144 and "roofline" in json.loads(bench.slim_line(fat))
+
+
+def test_emit_prints_the_slim_line_last_on_stdout(tmp_path, capsys, monkeypatch):
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    full = json.load(open(os.path.join(root, "profiles", "r05_bench_fresh_box.json")))
+    monkeypatch.setenv("PN_BENCH_EXTRAS", str(tmp_path / "extras.json"))
+    bench.emit(full)
+    cap = capsys.readouterr()
+    lines = cap.out.strip().split("\n")
+    assert len(lines) == 1 and json.loads(lines[0])["metric"] == full["metric"]
+    assert json.loads(cap.err.strip().split("\n")[-1]) == full                       # everything else: stderr ...
+    assert json.load(open(tmp_path / "extras.json")) == full                          # ... and the extras file

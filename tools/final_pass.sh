@@ -7,8 +7,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --maxfail=10 > $OUT/tests.log 2>&1
 tail -3 $OUT/tests.log
-timeout 420 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-tail -2 $OUT/bench.err
+# exactly the driver's command; the stdout line must stay under 6 KB (round 5's 20 KB line came back unparsed)
+timeout 420 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+echo "stdout line bytes: $(tail -1 $OUT/bench.json | wc -c) (limit 6144), lines: $(wc -l < $OUT/bench.json)"
+cp bench_extras.json $OUT/bench_extras.json
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/kt.log 2>&1
 DB=$(find $OUT/kt -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/kernel_stats.md > /dev/null
