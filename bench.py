@@ -272,9 +272,9 @@ def slim_line(full):
         ex = c.get("exposed_ms_per_step_by_rank") or []
         out["collectives"] = dict(_pick(c, "rccl_ranks_seen", "backend", "distinct_devices", "overlap", "bytes_per_step"),
                                   exposed_ms_per_step_max={k: max(e.get(k, 0.0) for e in ex) for k in (ex[0] if ex else {})})
-    for k, v in full.items():           # the N > 1 blocks (configs[3] / configs[4] sharded): their numbers only
-        if k.endswith("_sharded_step") and isinstance(v, dict):
-            out[k] = _pick(v, "value", "unit", "ms_per_step", "scaling")
+    for k in ("bgp_strong", "configs4_replicated", "configs4_sharded"):     # the N > 1 blocks (configs[3] / [4]): numbers only
+        if isinstance(full.get(k), dict):
+            out[k] = _pick(full[k], "value", "unit", "ms_per_step", "scaling")
     out["library_source_hash"] = full.get("library_source_hash")
     out["extras"] = "bench_extras.json"
 

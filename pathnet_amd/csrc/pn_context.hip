@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <new>
+#include <tuple>
 #include <vector>
 
 #include "pn_internal.h"
@@ -23,7 +24,7 @@ struct pn_context {
     std::vector<Rec> recs;
     std::vector<hipEvent_t> free_events;
     std::map<const void *, int> lds_attr;      // kernel -> dynamic LDS bytes already granted on this device
-    std::map<const void *, int> slots;         // kernel -> resident workgroups per CU (at the LDS size it is launched with)
+    std::map<std::tuple<const void *, size_t, int>, int> slots;    // (kernel, dynamic LDS bytes, threads) -> resident workgroups per CU
     int cus = 0;
     pn::Knobs knobs;
 };
@@ -78,7 +79,8 @@ struct KnobName {
 const KnobName kKnobs[] = {{"PN_NODE_GEMM3", &pn::Knobs::node_gemm3}, {"PN_EVAL_ZW", &pn::Knobs::eval_zw},
                            {"PN_POOL_BWD_WG", &pn::Knobs::pool_bwd_wg}, {"PN_NODE_RGRAD", &pn::Knobs::node_rgrad},
                            {"PN_SAMPLER_STAGE", &pn::Knobs::sampler_stage}, {"PN_SEQ4", &pn::Knobs::seq4},
-                           {"PN_B4_WIDE", &pn::Knobs::b4_wide}, {"PN_SEQH_TAIL", &pn::Knobs::seqh_tail}};
+                           {"PN_B4_WIDE", &pn::Knobs::b4_wide}, {"PN_SEQH_TAIL", &pn::Knobs::seqh_tail},
+                           {"PN_BWD_TAIL_OVERLAP", &pn::Knobs::bwd_tail_overlap}};
 
 }  // namespace
 
@@ -93,7 +95,7 @@ bool profiling_every_stage(const pn_context *ctx) { return ctx && ctx->prof_mode
 
 int resident_slots(pn_context *ctx, const void *kernel, int threads, size_t lds_bytes, int *slots, int *cus) {
     if (ctx) {
-        auto it = ctx->slots.find(kernel);
+        auto it = ctx->slots.find(std::make_tuple(kernel, lds_bytes, threads));
         if (it != ctx->slots.end() && ctx->cus > 0) {
             *slots = it->second * ctx->cus;
             *cus = ctx->cus;
@@ -105,7 +107,7 @@ int resident_slots(pn_context *ctx, const void *kernel, int threads, size_t lds_
     PN_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     PN_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds_bytes));
     if (ctx) {
-        ctx->slots[kernel] = per_cu;
+        ctx->slots[std::make_tuple(kernel, lds_bytes, threads)] = per_cu;
         ctx->cus = n_cu;
     }
     *slots = per_cu * n_cu;

@@ -57,6 +57,8 @@ struct Knobs {
     int b4_wide = 0;            // PN_B4_WIDE (experimental builds)
     int seqh_tail = PN_SEQH_TAIL_DEFAULT;   // PN_SEQH_TAIL: 0 = 32-path tiles only (default); 1 = the remainder round of the fp16
                                 //                recurrent launches in smaller tiles, one per CU; 8 / 16 / 24 = that size, always
+    int bwd_tail_overlap = 1;   // PN_BWD_TAIL_OVERLAP: the BPTT's remainder round (the tiles beyond whole rounds of resident workgroups)
+                                //                as a launch of its own, with the weight-gradient GEMM of the whole rounds' rows beside it
 };
 const Knobs &knobs_of(const pn_context *ctx);
 

@@ -2702,6 +2702,7 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     return PN_OK;
 }
 
+constexpr int WGRAD_TAIL_SPLITS = 32;   // K splits of the weight-gradient launch over the BPTT's remainder round (bwd_tail_overlap)
 constexpr int WGRAD_CUS_SHARED = 224;   // CUs of the weight-gradient launch when something is meant to run beside it (of 256)
 struct WsLayout {
     size_t Xh, Z, range;                                                 // node tables (first: reuse_tables relies on it)
@@ -2753,7 +2754,7 @@ WsLayout ws_layout(const Dims &d) {
         if (nz < 1) nz = 1;
         w.wgrad_split = (int)nz;
         w.wgrad_tiles = (int)tiles;
-        w.wpart = take(nz * (G * H * 2 * H + G * H) * 4);
+        w.wpart = take((nz + WGRAD_TAIL_SPLITS) * (G * H * 2 * H + G * H) * 4);     // (+ the remainder round's own partials)
     }
     {
         const int nz = std::max(gemm_split_count(d.N, d.H, d.F), gemm_split_count(d.N, d.H, d.L * d.H));
@@ -2810,6 +2811,17 @@ WsLayout ws_layout(const Dims &d) {
     }
     w.total = at;
     return w;
+}
+
+// the paths the fp16 BPTT leaves to a second launch (its remainder round; 0 = one launch): the tiles beyond whole rounds of
+// resident workgroups, when there is at least one whole round and the remainder fills at most half the slots
+int bwd_tail_paths(pn_context *ctx, int H, int gc, int L, int64_t Pb, int *slots, int64_t *tail) {
+    int mt = 32;
+    *tail = 0;
+    if (int rc = seq_bwdh_slots(ctx, H, gc, L, slots, &mt)) return rc;
+    const int64_t T = (Pb + mt - 1) / mt, rem = *slots > 0 ? T % *slots : 0;
+    if (*slots > 0 && T > *slots && rem > 0 && 2 * rem <= *slots) *tail = rem * mt;
+    return PN_OK;
 }
 
 #ifndef PN_BWD_OVERLAP
@@ -3452,6 +3464,15 @@ int pn_debug_set_trace(long long *dev_buf) {
 }
 #endif
 
+// the BPTT's launch split for P paths (tests; not part of the ABI): out = {resident workgroup slots, paths of the second launch}
+int pn_debug_bwd_tail(pn_context *ctx, int32_t H, int32_t gc, int32_t L, int64_t P, int32_t out[4]) {
+    int slots = 0;
+    int64_t tail = 0;
+    if (int rc = bwd_tail_paths(ctx, H, gc, L, P, &slots, &tail)) return rc;
+    out[0] = slots; out[1] = (int32_t)tail; out[2] = out[3] = 0;
+    return PN_OK;
+}
+
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
     if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_debug_offsets: null");
     Dims d;
@@ -3752,6 +3773,72 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             }
         }
 
+        // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG) over the rows
+        // [row0, row0 + rows) of this micro-batch, K-split partials into slots [slot0, ...) of `wpart`; the launch with
+        // last = true is followed by the reduction over every slot written.  Second stream, forked off `stream` here.
+        const bool wgrad_wanted = G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh);
+        int64_t tail_paths = 0;     // > 0: the BPTT ran paths [tail_paths, Pb) first (their weight gradient is under way)
+        int wgrad_slots_used = 0;
+        auto run_wgrad = [&](int64_t row0, int64_t rows, int slot0, bool last) -> int {
+            hipStream_t wstream = stream;
+            if (PN_BWD_OVERLAP && overlap_ok)
+                if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;
+            WgradParams wp{};
+            wp.dG = dG + (size_t)row0 * GH;
+            wp.xh = c.at<const float>(c.w.xh) + (size_t)row0 * 2 * H;
+            wp.R = rows;
+            wp.GH = GH;
+            wp.H2 = 2 * H;
+            const int cap = c.w.wgrad_split + WGRAD_TAIL_SPLITS;        // partial slots in the workspace
+            int nz = last && slot0 > 0 ? WGRAD_TAIL_SPLITS : c.w.wgrad_split;
+            // a node-sharded caller runs its reduce-scatter of d Xh (RCCL's kernels) and fc0's backward under this launch
+            // (g_Xh_ready): they need CUs whose registers are not all taken, whatever the launch's length
+            if (a->Xh_in && a->g_Xh_ready) nz = std::min(nz, std::max(1, (WGRAD_CUS_SHARED + c.w.wgrad_tiles - 1) / c.w.wgrad_tiles));
+            int64_t rps = (wp.R + nz - 1) / nz;
+            rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
+            wp.rows_per_split = rps;
+#if PN_WGRAD_STRIDED
+            const int64_t ntiles = (wp.R + WG_KT - 1) / WG_KT;
+            const int nz_used = (int)(ntiles < nz ? ntiles : nz);
+#else
+            const int nz_used = (int)((wp.R + rps - 1) / rps);
+#endif
+            float *part_w0 = c.at<float>(c.w.wpart), *part_b0 = part_w0 + (size_t)cap * GH * 2 * H;
+            wp.part_w = part_w0 + (size_t)slot0 * GH * 2 * H;
+            wp.part_b = part_b0 + (size_t)slot0 * GH;
+            {
+                StageTimer tm(ctx, ST_WGRAD, wstream);
+                int nz_red = nz_used;
+                wp.range = range;
+                wp.xmul = seq_xmul(a);
+                if (f16 && !d.generic) {        // the two-stage pipeline on fp16 planes (pn_seqh.hip)
+                    const int64_t nt16 = (wp.R + 15) / 16;
+                    nz_red = (int)(nt16 < nz ? nt16 : nz);
+                    if (int rc = launch_wgradh(ctx, wstream, wp, H, nz_red)) return rc;
+                } else if (seq4 & SEQ4_WGRAD) {        // two-stage pipeline over K tiles of 16 rows (pn_seq4.hip)
+                    const int64_t nt16 = (wp.R + 15) / 16;
+                    nz_red = (int)(nt16 < nz ? nt16 : nz);
+                    if (int rc = launch_wgrad4(ctx, wstream, wp, nz_red)) return rc;
+                } else {
+                    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(wgrad3_kernel), W3_LDS_BYTES)) return rc;
+                    hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
+                                       dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
+                    PN_CHECK_HIP(hipGetLastError());
+                }
+                wgrad_slots_used = slot0 + nz_red;
+                if (last) {
+                    const int64_t nred = (int64_t)GH * 2 * H + GH;
+                    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
+                                       part_w0, part_b0, wgrad_slots_used, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
+                                       (f16 && !d.generic && G == 4 && seqh_dg_quad()) ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
+                    PN_CHECK_HIP(hipGetLastError());
+                }
+            }
+            if (wstream != stream)
+                if (int rc = joiner.mark()) return rc;   // `stream` waits for the weight gradients on the way out
+            return PN_OK;
+        };
+
         // BPTT + gather-backward scatter (mean / sum encoders: the scatter alone)
         // (the fp16 BPTT stores its rows outright; the other kernels add into a zero-filled buffer)
         if (d.det && !(f16 && G > 0 && !d.generic))
@@ -3782,7 +3869,25 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             sp.range = range;
             sp.store_dx = d.det && f16;
             if (f16) {
-                if (int rc = launch_seq_bwdh(ctx, stream, H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp)) return rc;
+                const int gc = d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1;
+                // The launch runs as rounds of `slots` resident workgroups (two per CU at H = 128) and its last, partial round
+                // leaves most CUs idle (1624 tiles on 512 slots at the headline shape: 14 % of the launch at a fifth of the
+                // chip).  With a weight gradient to follow, that round becomes a launch of its own -- the kernel dispatches
+                // tiles in descending path order, so it is the START of the path range -- and the weight-gradient GEMM over
+                // the whole rounds' rows starts beside it on the second stream instead of behind it.
+                if (wgrad_wanted && PN_BWD_OVERLAP && overlap_ok && !d.det && knobs_of(ctx).bwd_tail_overlap) {
+                    int slots = 0;
+                    if (int rc = bwd_tail_paths(ctx, H, gc, L, Pb, &slots, &tail_paths)) return rc;
+                }
+                if (tail_paths > 0) {
+                    SeqBwdParams spa = sp;
+                    spa.q_base = (int)tail_paths;
+                    spa.P = (int)(Pb - tail_paths);
+                    if (int rc = launch_seq_bwdh(ctx, stream, H, gc, spa)) return rc;
+                    if (int rc = run_wgrad(tail_paths * L, (Pb - tail_paths) * L, 0, /*last=*/false)) return rc;
+                    sp.P = (int)tail_paths;
+                }
+                if (int rc = launch_seq_bwdh(ctx, stream, H, gc, sp)) return rc;
             } else if (seq4 & SEQ4_BWD) {
                 if (int rc = launch_seq_bwd4(ctx, stream, d.cell == CELL_GRU ? 3 : 4, sp)) return rc;
             } else if (int rc = (d.cell == CELL_GRU    ? dispatch_seq_bwd<3>(ctx, stream, H, sp)
@@ -3795,60 +3900,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             if (int rc = run_det_scatter(c, DET_ROW, b, c.at<float>(c.w.dx), nullptr, nullptr, dZ)) return rc;
         }
 
-        // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG)
-        if (G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh)) {
-            hipStream_t wstream = stream;
-            if (PN_BWD_OVERLAP && overlap_ok)
-                if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;
-            WgradParams wp{};
-            wp.dG = dG;
-            wp.xh = c.at<const float>(c.w.xh);
-            wp.R = Pb * L;
-            wp.GH = GH;
-            wp.H2 = 2 * H;
-            int nz = c.w.wgrad_split;
-            // a node-sharded caller runs its reduce-scatter of d Xh (RCCL's kernels) and fc0's backward under this launch
-            // (g_Xh_ready): they need CUs whose registers are not all taken, whatever the launch's length
-            if (a->Xh_in && a->g_Xh_ready) nz = std::min(nz, std::max(1, (WGRAD_CUS_SHARED + c.w.wgrad_tiles - 1) / c.w.wgrad_tiles));
-            int64_t rps = (wp.R + nz - 1) / nz;
-            rps = (rps + WG_KT - 1) / WG_KT * WG_KT;
-            wp.rows_per_split = rps;
-#if PN_WGRAD_STRIDED
-            const int64_t ntiles = (wp.R + WG_KT - 1) / WG_KT;
-            const int nz_used = (int)(ntiles < nz ? ntiles : nz);
-#else
-            const int nz_used = (int)((wp.R + rps - 1) / rps);
-#endif
-            wp.part_w = c.at<float>(c.w.wpart);
-            wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
-            {
-                StageTimer tm(ctx, ST_WGRAD, wstream);
-                int nz_red = nz_used;
-                wp.range = range;
-                wp.xmul = seq_xmul(a);
-                if (f16 && !d.generic) {        // the two-stage pipeline on fp16 planes (pn_seqh.hip)
-                    const int64_t nt16 = (wp.R + 15) / 16;
-                    nz_red = (int)(nt16 < nz ? nt16 : nz);
-                    if (int rc = launch_wgradh(ctx, wstream, wp, H, nz_red)) return rc;
-                } else if (seq4 & SEQ4_WGRAD) {        // two-stage pipeline over K tiles of 16 rows (pn_seq4.hip)
-                    const int64_t nt16 = (wp.R + 15) / 16;
-                    nz_red = (int)(nt16 < nz ? nt16 : nz);
-                    if (int rc = launch_wgrad4(ctx, wstream, wp, nz_red)) return rc;
-                } else {
-                    if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(wgrad3_kernel), W3_LDS_BYTES)) return rc;
-                    hipLaunchKernelGGL(wgrad3_kernel, dim3((2 * H + WG_BN - 1) / WG_BN, (GH + WG_BM - 1) / WG_BM, nz_used),
-                                       dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
-                    PN_CHECK_HIP(hipGetLastError());
-                }
-                const int64_t nred = (int64_t)GH * 2 * H + GH;
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
-                                   wp.part_w, wp.part_b, nz_red, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
-                                   (f16 && !d.generic && G == 4 && seqh_dg_quad()) ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
-                PN_CHECK_HIP(hipGetLastError());
-            }
-            if (wstream != stream)
-                if (int rc = joiner.mark()) return rc;   // `stream` waits for the weight gradients on the way out
-        }
+        // recurrent weight / bias gradients of the rows not yet done (all of them unless the BPTT split off its remainder round)
+        if (wgrad_wanted)
+            if (int rc = run_wgrad(0, tail_paths > 0 ? tail_paths * L : Pb * L, wgrad_slots_used, /*last=*/true)) return rc;
         // the next micro-batch rewrites the [x|h] rows and dG the weight-gradient GEMM is reading
         if (b + 1 < d.nb)
             if (int rc = joiner.join()) return rc;

@@ -262,10 +262,20 @@ def test_bench_with_two_ranks_on_one_gpu(workload, launcher):
         env["PN_DIST_BACKEND"] = "gloo"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + tail
+    import tempfile
+    extras = os.path.join(tempfile.mkdtemp(), "bench_extras.json")
+    env["PN_BENCH_EXTRAS"] = extras
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
-    d = json.loads(lines[0])
+    # stdout: the slim line the driver parses (< 6 KB, the contract's keys); the full record: bench_extras.json
+    assert len(lines[0]) < 6144
+    slim = json.loads(lines[0])
+    d = json.load(open(extras))
+    assert slim["n_gpus"] == 2 and slim["value"] == float("%.6g" % d["value"]) and slim["roofline"]["kernel"] == d["roofline"]["kernel"]
+    assert slim["collectives"]["rccl_ranks_seen"] == 2 and slim["config"] == {k: d["config"][k] for k in slim["config"]}
+    if workload == "cora":
+        assert all(slim[k]["value"] == float("%.6g" % d[k]["value"]) for k in ("bgp_strong", "configs4_replicated", "configs4_sharded"))
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["ms_per_step"] > 0
     assert d["config"]["parallelism"] == "node-shard x2"
     assert d["scaling"] == ("weak" if workload == "cora" else "strong")
