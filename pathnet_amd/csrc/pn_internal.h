@@ -51,14 +51,13 @@ struct Knobs {
                                 //                tiles fill the GPU; 8: the compact bank dX as well (measured slower)
     int eval_zw = 1;            // PN_EVAL_ZW: inference forwards apply W_ih to the bank rows before the gather
     int pool_bwd_wg = 1;        // PN_POOL_BWD_WG: pooling backward as a workgroup per node
+    int pool_step = 1;          // PN_POOL_STEP: pn_pagg_train_step runs pooling forward, loss and pooling backward of a node in one launch
     int node_rgrad = 1;         // PN_NODE_RGRAD: row-reduction kernel for the node-level weight gradients of large graphs
     int sampler_stage = -1;     // PN_SAMPLER_STAGE: first-hop tables in LDS (-1: by launch size)
     int seq4 = 4;               // PN_SEQ4: which 128-path kernels of pn_seq4.hip serve the bf16 mode (bit 2: weight gradient)
     int b4_wide = 0;            // PN_B4_WIDE (experimental builds)
     int seqh_tail = PN_SEQH_TAIL_DEFAULT;   // PN_SEQH_TAIL: 0 = 32-path tiles only (default); 1 = the remainder round of the fp16
                                 //                recurrent launches in smaller tiles, one per CU; 8 / 16 / 24 = that size, always
-    int bwd_tail_overlap = 1;   // PN_BWD_TAIL_OVERLAP: the BPTT's remainder round (the tiles beyond whole rounds of resident workgroups)
-                                //                as a launch of its own, with the weight-gradient GEMM of the whole rounds' rows beside it
 };
 const Knobs &knobs_of(const pn_context *ctx);
 

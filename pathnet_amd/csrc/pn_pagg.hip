@@ -1294,8 +1294,7 @@ struct PoolParams {
     float *out;             // [S, C]
 };
 
-__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
-    extern __shared__ float lds[];
+__device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = blockIdx.x, H = p.H, W = p.W;
     float *sc = lds;                                            // [W] scores, then coefficients
@@ -1407,6 +1406,10 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
         part = wave_sum(part);
         if (lane == 0) p.out[(int64_t)g * p.C + c] = part + p.fc2_b[c];
     }
+}
+__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolParams p) {
+    extern __shared__ float lds[];
+    pool_fwd_body(p, lds);
 }
 
 
@@ -1585,8 +1588,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 //      times the waves hide them.  (Round 2 had rejected this layout for quadrupling the atomics on the 2H + 1
 //      attention-weight addresses; those now go through per-workgroup partials, det_att: [groups][2H + 4].)
 template <int HI>
-__global__ __launch_bounds__(256) void pool_bwd_wg_kernel(PoolBwdParams p) {
-    extern __shared__ float lds[];
+__device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *lds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = p.H, W = p.W;
     float *dco = lds;                        // [W] d coef
@@ -1721,6 +1723,69 @@ __global__ __launch_bounds__(256) void pool_bwd_wg_kernel(PoolBwdParams p) {
     float *out = p.det_att + (int64_t)blockIdx.x * (2 * H + 4);
     for (int j = tid; j < 2 * H; j += 256) out[j] = red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j];
     if (lane == 0) out[2 * H + wave] = gab;
+}
+template <int HI>
+__global__ __launch_bounds__(256) void pool_bwd_wg_kernel(PoolBwdParams p) {
+    extern __shared__ float lds[];
+    pool_bwd_wg_body<HI>(p, lds);
+}
+
+// ---- pooling forward, loss and pooling backward of a group in ONE launch (pn_pagg_train_step, default mode) -----------------
+// Between the recurrence and the BPTT a training step has, per masked node and independent of every other node: attention +
+// pooling + classifier (pool_fwd_kernel), softmax cross entropy of its C logits (cross_entropy_kernel) and the pooling /
+// attention backward (pool_bwd_wg_kernel) -- three dependent launches of ~20 us each for work that touches 40 KB per node.
+// One workgroup per node runs the three bodies back to back: the node's h_n and ego rows are re-read from the CU's own
+// caches, the logits and their gradient never leave the workgroup's sight.  The same code as the three kernels (the
+// bodies ARE those kernels'), so logits, g_out, d h_n and every gradient term are bit-identical to the three launches;
+// the loss is the fixed-order sum of the per-node terms (loss_sum_kernel, off the critical path).
+// Replaces /root/reference/PathNet_run.py:196-210 / :266-277 (forward), :346 (loss) and autograd's backward of both.
+struct PoolStepParams {
+    PoolParams f;
+    PoolBwdParams b;
+    const int64_t *target;  // [S] class of each group
+    float scale;            // d loss / d (row loss): grad_scale / rows of the whole batch
+    float *gout;            // [S, C] d loss / d logits (read by the classifier's weight-gradient GEMM)
+    float *lossg;           // [S] logsumexp - logit[target] per group
+};
+template <int HI>
+__global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
+    extern __shared__ float lds[];
+    pool_fwd_body(p.f, lds);
+    __syncthreads();            // (workgroup-scope fence: out[g, :] written above is visible below; LDS is free again)
+    if (threadIdx.x == 0) {     // the row's cross entropy exactly as cross_entropy_kernel computes it
+        const int g = blockIdx.x, classes = p.f.C;
+        const float *x = p.f.out + (int64_t)g * classes;
+        float m = x[0];
+        for (int c = 1; c < classes; c++) m = fmaxf(m, x[c]);
+        float sum = 0.0f;
+        for (int c = 0; c < classes; c++) sum += expf(x[c] - m);
+        const float lse = m + logf(sum);
+        const int t = (int)p.target[g];
+        p.lossg[g] = lse - x[t];
+        float *go = p.gout + (int64_t)g * classes;
+        for (int c = 0; c < classes; c++) go[c] = (expf(x[c] - lse) - (c == t ? 1.0f : 0.0f)) * p.scale;
+    }
+    __syncthreads();
+    pool_bwd_wg_body<HI>(p.b, lds);
+}
+// loss[0] (+)= scale * sum of the rows' terms, in cross_entropy_kernel's order (one workgroup of 1024 threads)
+__global__ __launch_bounds__(1024) void loss_sum_kernel(const float *__restrict__ lossg, int rows, float scale,
+                                                        float *__restrict__ loss, int store) {
+    __shared__ float part[16];
+    float mine = 0.0f;
+    for (int r = threadIdx.x; r < rows; r += 1024) mine += lossg[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; w++) t += part[w];
+        if (store)
+            *loss = t * scale;
+        else
+            atomicAdd(loss, t * scale);
+    }
 }
 
 // ---- BPTT through the recurrent cell, fused with the gather-backward scatter ---------------------
@@ -2702,7 +2767,6 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     return PN_OK;
 }
 
-constexpr int WGRAD_TAIL_SPLITS = 32;   // K splits of the weight-gradient launch over the BPTT's remainder round (bwd_tail_overlap)
 constexpr int WGRAD_CUS_SHARED = 224;   // CUs of the weight-gradient launch when something is meant to run beside it (of 256)
 struct WsLayout {
     size_t Xh, Z, range;                                                 // node tables (first: reuse_tables relies on it)
@@ -2754,7 +2818,7 @@ WsLayout ws_layout(const Dims &d) {
         if (nz < 1) nz = 1;
         w.wgrad_split = (int)nz;
         w.wgrad_tiles = (int)tiles;
-        w.wpart = take((nz + WGRAD_TAIL_SPLITS) * (G * H * 2 * H + G * H) * 4);     // (+ the remainder round's own partials)
+        w.wpart = take(nz * (G * H * 2 * H + G * H) * 4);
     }
     {
         const int nz = std::max(gemm_split_count(d.N, d.H, d.F), gemm_split_count(d.N, d.H, d.L * d.H));
@@ -2811,17 +2875,6 @@ WsLayout ws_layout(const Dims &d) {
     }
     w.total = at;
     return w;
-}
-
-// the paths the fp16 BPTT leaves to a second launch (its remainder round; 0 = one launch): the tiles beyond whole rounds of
-// resident workgroups, when there is at least one whole round and the remainder fills at most half the slots
-int bwd_tail_paths(pn_context *ctx, int H, int gc, int L, int64_t Pb, int *slots, int64_t *tail) {
-    int mt = 32;
-    *tail = 0;
-    if (int rc = seq_bwdh_slots(ctx, H, gc, L, slots, &mt)) return rc;
-    const int64_t T = (Pb + mt - 1) / mt, rem = *slots > 0 ? T % *slots : 0;
-    if (*slots > 0 && T > *slots && rem > 0 && 2 * rem <= *slots) *tail = rem * mt;
-    return PN_OK;
 }
 
 #ifndef PN_BWD_OVERLAP
@@ -3128,7 +3181,7 @@ int run_seq_fwd(const Call &c, int b, bool save) {
                                  : dispatch_seq_fwd<1>(c.ctx, c.stream, d.H, sp);
 }
 
-int run_pool_fwd(const Call &c, int b, float *out) {
+PoolParams pool_fwd_params(const Call &c, int b, float *out) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
     const int homo = d.variant == PN_VARIANT_HOMO;
@@ -3157,8 +3210,13 @@ int run_pool_fwd(const Call &c, int b, float *out) {
     pp.rawsc = c.at<float>(c.w.rawsc);
     pp.layer1 = c.at<float>(c.w.layer1);
     pp.out = out;
+    return pp;
+}
+inline size_t pool_fwd_lds_bytes(const Dims &d) { return (size_t)(2 * d.W + 6 * d.H) * sizeof(float); }
+int run_pool_fwd(const Call &c, int b, float *out) {
+    const PoolParams pp = pool_fwd_params(c, b, out);
     StageTimer tm(c.ctx, ST_POOL_FWD, c.stream);
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(pp.S), dim3(256), (size_t)(2 * d.W + 6 * d.H) * sizeof(float), c.stream, pp);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(pp.S), dim3(256), pool_fwd_lds_bytes(c.d), c.stream, pp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
@@ -3464,15 +3522,6 @@ int pn_debug_set_trace(long long *dev_buf) {
 }
 #endif
 
-// the BPTT's launch split for P paths (tests; not part of the ABI): out = {resident workgroup slots, paths of the second launch}
-int pn_debug_bwd_tail(pn_context *ctx, int32_t H, int32_t gc, int32_t L, int64_t P, int32_t out[4]) {
-    int slots = 0;
-    int64_t tail = 0;
-    if (int rc = bwd_tail_paths(ctx, H, gc, L, P, &slots, &tail)) return rc;
-    out[0] = slots; out[1] = (int32_t)tail; out[2] = out[3] = 0;
-    return PN_OK;
-}
-
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
     if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_debug_offsets: null");
     Dims d;
@@ -3626,6 +3675,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
     //  reduced in a fixed order -- goes to the second stream as in the default mode: streams do not reorder a kernel's sums)
     const bool overlap_ok = !profiling_every_stage(ctx);
     const bool side_ok = overlap_ok && !d.det;
+    // pn_pagg_train_step, default mode: pooling forward + loss + pooling backward of a node as one launch (pool_step_kernel)
+    const bool pool_step = fused && !d.det && knobs_of(ctx).pool_step != 0 && knobs_of(ctx).pool_bwd_wg != 0 &&
+                           (!has_att || !PN_POOL_ATT_ATOMIC);
     const bool f16 = d.math == PN_SEQ_MATH_F16X2;
     const int seq4 = f16 ? 0 : seq4_select(ctx, H, G, L);
     SeqRange *range = c.at<SeqRange>(c.w.range);
@@ -3664,18 +3716,27 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 if (int rc = fork_det_orders(c, joiner, b)) return rc;
             if (int rc = run_seq_fwd(c, b, true)) return rc;
             float *out_b = fused ? a->out + (size_t)b * d.Sb * d.C : c.at<float>(c.w.outb);
-            if (int rc = run_pool_fwd(c, b, out_b)) return rc;
-            if (fused)
-                if (int rc = launch_cross_entropy(out_b, target + (size_t)b * d.Sb, Sb, d.C, grad_scale, loss,
-                                                  c.at<float>(c.w.gout), stream, d.nb == 1))
-                    return rc;
+            if (!pool_step) {
+                if (int rc = run_pool_fwd(c, b, out_b)) return rc;
+                if (fused)
+                    if (int rc = launch_cross_entropy(out_b, target + (size_t)b * d.Sb, Sb, d.C, grad_scale, loss,
+                                                      c.at<float>(c.w.gout), stream, d.nb == 1))
+                        return rc;
+            }
             if (fused && b == 0)
                 if (int rc = flush_zero()) return rc;
         }
         // classifier: g_fc2_w += g_out^T . layer1, g_fc2_b += colsum(g_out) -- nothing below reads them: second stream
+        // (after the fused pooling step also the loss: the fixed-order sum of the per-node terms)
+        auto run_fc2_grad = [&]() -> int {
         hipStream_t cstream = stream;
         if (PN_SIDE_SMALL && side_ok)
             if (void *side = context_fork(ctx, stream)) cstream = (hipStream_t)side;
+        if (pool_step) {
+            hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, cstream, c.at<const float>(c.w.outb), Sb, grad_scale, loss,
+                               d.nb == 1 ? 1 : 0);
+            PN_CHECK_HIP(hipGetLastError());
+        }
         {
             StageTimer tm(ctx, ST_FC2_GRAD, cstream);
             if (a->g_fc2_w && d.det) {
@@ -3692,6 +3753,10 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         }
         if (cstream != stream)
             if (int rc = joiner.mark()) return rc;
+        return PN_OK;
+        };
+        if (!pool_step)
+            if (int rc = run_fc2_grad()) return rc;
 
         // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
         {
@@ -3730,11 +3795,36 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 pp.det_ds = c.at<float>(c.w.dds);
             }
             const size_t lds_bytes = (size_t)(4 * (2 * d.W + H) + 8 * H + 8 * d.W) * sizeof(float);
-            StageTimer tm(ctx, ST_POOL_BWD, stream);
             // a workgroup per group (four waves share its members) unless PN_POOL_BWD_WG=0; it needs the partials buffer
             const bool wg = (!has_att || pp.det_att) && knobs_of(ctx).pool_bwd_wg != 0;
             int att_blocks = (Sb + 3) / 4;
-            if (wg) {
+            if (pool_step) {        // pooling forward, loss and this backward in one launch (pool_step_kernel)
+                if (!wg) PN_FAIL(PN_ERR_ARG, "internal: the fused pooling step needs the workgroup-per-node backward");
+                att_blocks = Sb;
+                PoolStepParams ps{};
+                ps.f = pool_fwd_params(c, b, a->out + (size_t)b * d.Sb * d.C);
+                ps.b = pp;
+                ps.b.g_out = c.at<float>(c.w.gout);
+                ps.target = target + (size_t)b * d.Sb;
+                ps.scale = grad_scale;
+                ps.gout = c.at<float>(c.w.gout);
+                ps.lossg = c.at<float>(c.w.outb);       // (the fused step's logits go to the caller: the slot is free)
+                const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d));
+                {
+                    StageTimer tm(ctx, ST_POOL_FWD, stream);
+                    if (H <= 256) {
+                        hipLaunchKernelGGL(pool_step_kernel<4>, dim3(Sb), dim3(256), lds_step, stream, ps);
+                    } else {
+                        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16>), (int)lds_step)) return rc;
+                        hipLaunchKernelGGL(pool_step_kernel<16>, dim3(Sb), dim3(256), lds_step, stream, ps);
+                    }
+                    PN_CHECK_HIP(hipGetLastError());
+                }
+                if (int rc = run_fc2_grad()) return rc;
+            }
+            StageTimer tm(ctx, ST_POOL_BWD, stream);
+            if (pool_step) {
+            } else if (wg) {
                 att_blocks = Sb;
                 if (H <= 256) {
                     hipLaunchKernelGGL(pool_bwd_wg_kernel<4>, dim3(Sb), dim3(256), lds_bytes, stream, pp);
@@ -3773,24 +3863,20 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             }
         }
 
-        // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG) over the rows
-        // [row0, row0 + rows) of this micro-batch, K-split partials into slots [slot0, ...) of `wpart`; the launch with
-        // last = true is followed by the reduction over every slot written.  Second stream, forked off `stream` here.
+        // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG) over the Pb * L rows of this
+        // micro-batch: K-split partials into `wpart`, then their reduction.  Second stream, forked off `stream` where it is called.
         const bool wgrad_wanted = G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh);
-        int64_t tail_paths = 0;     // > 0: the BPTT ran paths [tail_paths, Pb) first (their weight gradient is under way)
-        int wgrad_slots_used = 0;
-        auto run_wgrad = [&](int64_t row0, int64_t rows, int slot0, bool last) -> int {
+        auto run_wgrad = [&]() -> int {
             hipStream_t wstream = stream;
             if (PN_BWD_OVERLAP && overlap_ok)
                 if (void *side = context_fork(ctx, stream)) wstream = (hipStream_t)side;
             WgradParams wp{};
-            wp.dG = dG + (size_t)row0 * GH;
-            wp.xh = c.at<const float>(c.w.xh) + (size_t)row0 * 2 * H;
-            wp.R = rows;
+            wp.dG = dG;
+            wp.xh = c.at<const float>(c.w.xh);
+            wp.R = Pb * L;
             wp.GH = GH;
             wp.H2 = 2 * H;
-            const int cap = c.w.wgrad_split + WGRAD_TAIL_SPLITS;        // partial slots in the workspace
-            int nz = last && slot0 > 0 ? WGRAD_TAIL_SPLITS : c.w.wgrad_split;
+            int nz = c.w.wgrad_split;
             // a node-sharded caller runs its reduce-scatter of d Xh (RCCL's kernels) and fc0's backward under this launch
             // (g_Xh_ready): they need CUs whose registers are not all taken, whatever the launch's length
             if (a->Xh_in && a->g_Xh_ready) nz = std::min(nz, std::max(1, (WGRAD_CUS_SHARED + c.w.wgrad_tiles - 1) / c.w.wgrad_tiles));
@@ -3803,9 +3889,8 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
 #else
             const int nz_used = (int)((wp.R + rps - 1) / rps);
 #endif
-            float *part_w0 = c.at<float>(c.w.wpart), *part_b0 = part_w0 + (size_t)cap * GH * 2 * H;
-            wp.part_w = part_w0 + (size_t)slot0 * GH * 2 * H;
-            wp.part_b = part_b0 + (size_t)slot0 * GH;
+            wp.part_w = c.at<float>(c.w.wpart);
+            wp.part_b = wp.part_w + (size_t)nz * GH * 2 * H;
             {
                 StageTimer tm(ctx, ST_WGRAD, wstream);
                 int nz_red = nz_used;
@@ -3825,14 +3910,11 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                                        dim3(WG_THREADS), W3_LDS_BYTES, wstream, wp);
                     PN_CHECK_HIP(hipGetLastError());
                 }
-                wgrad_slots_used = slot0 + nz_red;
-                if (last) {
-                    const int64_t nred = (int64_t)GH * 2 * H + GH;
-                    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
-                                       part_w0, part_b0, wgrad_slots_used, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
-                                       (f16 && !d.generic && G == 4 && seqh_dg_quad()) ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
-                    PN_CHECK_HIP(hipGetLastError());
-                }
+                const int64_t nred = (int64_t)GH * 2 * H + GH;
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, wstream,
+                                   wp.part_w, wp.part_b, nz_red, GH, H, b > 0 ? 1 : 0, d.cell == CELL_GRU ? 1 : 0,
+                                   (f16 && !d.generic && G == 4 && seqh_dg_quad()) ? 1 : 0, a->g_w_ih, a->g_w_hh, a->g_b_ih, a->g_b_hh);
+                PN_CHECK_HIP(hipGetLastError());
             }
             if (wstream != stream)
                 if (int rc = joiner.mark()) return rc;   // `stream` waits for the weight gradients on the way out
@@ -3870,23 +3952,6 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             sp.store_dx = d.det && f16;
             if (f16) {
                 const int gc = d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1;
-                // The launch runs as rounds of `slots` resident workgroups (two per CU at H = 128) and its last, partial round
-                // leaves most CUs idle (1624 tiles on 512 slots at the headline shape: 14 % of the launch at a fifth of the
-                // chip).  With a weight gradient to follow, that round becomes a launch of its own -- the kernel dispatches
-                // tiles in descending path order, so it is the START of the path range -- and the weight-gradient GEMM over
-                // the whole rounds' rows starts beside it on the second stream instead of behind it.
-                if (wgrad_wanted && PN_BWD_OVERLAP && overlap_ok && !d.det && knobs_of(ctx).bwd_tail_overlap) {
-                    int slots = 0;
-                    if (int rc = bwd_tail_paths(ctx, H, gc, L, Pb, &slots, &tail_paths)) return rc;
-                }
-                if (tail_paths > 0) {
-                    SeqBwdParams spa = sp;
-                    spa.q_base = (int)tail_paths;
-                    spa.P = (int)(Pb - tail_paths);
-                    if (int rc = launch_seq_bwdh(ctx, stream, H, gc, spa)) return rc;
-                    if (int rc = run_wgrad(tail_paths * L, (Pb - tail_paths) * L, 0, /*last=*/false)) return rc;
-                    sp.P = (int)tail_paths;
-                }
                 if (int rc = launch_seq_bwdh(ctx, stream, H, gc, sp)) return rc;
             } else if (seq4 & SEQ4_BWD) {
                 if (int rc = launch_seq_bwd4(ctx, stream, d.cell == CELL_GRU ? 3 : 4, sp)) return rc;
@@ -3900,9 +3965,8 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             if (int rc = run_det_scatter(c, DET_ROW, b, c.at<float>(c.w.dx), nullptr, nullptr, dZ)) return rc;
         }
 
-        // recurrent weight / bias gradients of the rows not yet done (all of them unless the BPTT split off its remainder round)
         if (wgrad_wanted)
-            if (int rc = run_wgrad(0, tail_paths > 0 ? tail_paths * L : Pb * L, wgrad_slots_used, /*last=*/true)) return rc;
+            if (int rc = run_wgrad()) return rc;
         // the next micro-batch rewrites the [x|h] rows and dG the weight-gradient GEMM is reading
         if (b + 1 < d.nb)
             if (int rc = joiner.join()) return rc;

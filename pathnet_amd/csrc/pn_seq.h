@@ -61,8 +61,7 @@ struct SeqBwdParams {
     const float *WpT;
     float *dG;              // [P, L, G*H] pre-activation gate gradients (input of the weight-gradient GEMM)
     float *dZ;              // [N*L, H]    += d x_t   (atomic scatter: the backward of the row gather)
-    int P, L;               // paths of this launch, path length
-    int q_base;             // fp16 kernel: first path of this launch (every tensor is indexed from path 0 of the micro-batch)
+    int P, L;
     int merge0;             // step 0 scatters the W paths of a node into one table row (homo / PAGG index plans): add up runs first
     int64_t Pmask;          // slots of the whole batch (explicit mask [L, Pmask, H])
     float p_drop;
@@ -131,8 +130,6 @@ int launch_seq_fwdh(pn_context *ctx, void *stream, int H, int gc, const SeqFwdPa
 int launch_seq_fwdzw(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
 int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp);
 int launch_wgradh(pn_context *ctx, void *stream, const WgradParams &wp, int H, int nsplit);
-// resident workgroups of the BPTT kernel for this shape on the whole device (occupancy x CUs), and its paths per tile
-int seq_bwdh_slots(pn_context *ctx, int H, int gc, int L, int *slots, int *tile_paths);
 int seqh_dg_quad();     // 1: seq_bwdh_kernel writes dG as [R][H][4 gate slots] (G = 4): wgrad_reduce_kernel un-permutes the rows
 
 }  // namespace pn

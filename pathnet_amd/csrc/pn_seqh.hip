@@ -827,7 +827,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     // (descending path order: the BPTT starts on the tiles the forward wrote last; its small tiles -- SeqTiling, the
     //  remainder round -- are therefore the ones at the START of the path range, dispatched last)
     const SeqTile tl = seq_tile_of(p.tiling, PN_BWD_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, MT, p.P);
-    const int q0 = tl.q0 + p.q_base, rows_here = tl.rows;          // rows_here >= 1
+    const int q0 = tl.q0, rows_here = tl.rows;          // rows_here >= 1
     const int col = 32 * wave + li;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
@@ -1361,25 +1361,6 @@ constexpr size_t bwdh_lds_bytes(int L) {
            (PN_BWDH_TOUCH ? (size_t)(H / 32) * 256 : 0);
 }
 template <int H, int GC>
-int slots_bwdh_t(pn_context *ctx, int L, int *slots) {
-    int cus = 0;
-    return resident_slots(ctx, reinterpret_cast<const void *>(seq_bwdh_kernel<H, GC>), H / 32 * 64, bwdh_lds_bytes<H, GC>(L), slots, &cus);
-}
-template <int GC>
-int dispatch_slots_bwdh(pn_context *ctx, int H, int L, int *slots) {
-    switch (H) {
-        case 32: return slots_bwdh_t<32, GC>(ctx, L, slots);
-        case 64: return slots_bwdh_t<64, GC>(ctx, L, slots);
-        case 96: return slots_bwdh_t<96, GC>(ctx, L, slots);
-        case 128: return slots_bwdh_t<128, GC>(ctx, L, slots);
-        case 160: return slots_bwdh_t<160, GC>(ctx, L, slots);
-        case 192: return slots_bwdh_t<192, GC>(ctx, L, slots);
-        case 224: return slots_bwdh_t<224, GC>(ctx, L, slots);
-        case 256: return slots_bwdh_t<256, GC>(ctx, L, slots);
-    }
-    PN_FAIL(PN_ERR_ARG, "hidden size %d not supported", H);
-}
-template <int H, int GC>
 int launch_bwdh_t(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
     constexpr int MT = 32;
     const size_t lds_bytes = bwdh_lds_bytes<H, GC>(sp.L);
@@ -1518,12 +1499,6 @@ int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdPa
     if (!sp.range) PN_FAIL(PN_ERR_ARG, "seq_bwdh: operand ranges missing");
     hipStream_t s = (hipStream_t)stream;        // (range->dg was cleared by the forward's launch_range_w)
     return gc == 3 ? dispatch_bwdh<3>(ctx, s, H, sp) : gc == 4 ? dispatch_bwdh<4>(ctx, s, H, sp) : dispatch_bwdh<1>(ctx, s, H, sp);
-}
-
-int seq_bwdh_slots(pn_context *ctx, int H, int gc, int L, int *slots, int *tile_paths) {
-    *tile_paths = 32;
-    return gc == 3 ? dispatch_slots_bwdh<3>(ctx, H, L, slots) : gc == 4 ? dispatch_slots_bwdh<4>(ctx, H, L, slots)
-                                                                     : dispatch_slots_bwdh<1>(ctx, H, L, slots);
 }
 
 int launch_wgradh(pn_context *ctx, void *stream, const WgradParams &wp, int H, int nsplit) {

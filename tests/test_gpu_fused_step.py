@@ -5,7 +5,7 @@ in micro-batches, where the fused call saves each micro-batch's second forward; 
 import numpy as np
 import pytest
 import torch
-from gradcheck import assert_grads_close
+from gradcheck import ZERO_OK_HETERO, assert_grads_close
 
 from oracle import pagg_oracle as po
 
@@ -132,3 +132,44 @@ def test_fused_step_needs_grad_mode_and_matching_targets():
         m.forward_loss(X, ids, 4, 4, sel, codes, y, fused=True)
     with pytest.raises(ValueError):
         m.forward_loss(X, ids, 4, 4, sel, codes, y[:-1])
+
+
+@pytest.mark.parametrize("variant,S,W,L,H,cell,micro", [
+    ("homo", 300, 40, 4, 128, None, 0),         # the headline cell and path count per node
+    ("homo", 300, 12, 4, 128, None, 70),        # micro-batches: the loss accumulates over five launches
+    ("hetero", 200, 9, 4, 128, None, 0),        # softmax attention, a row per member in the ego scatter
+    ("pagg", 150, 8, 4, 64, None, 0),           # no attention: the backward body returns early
+    ("homo", 100, 6, 3, 288, "gru", 0),         # H > 256: the 16-chunk instantiation
+    ("homo", 100, 6, 5, 100, "mean", 0),        # zero-padded hidden size
+])
+def test_pooling_step_in_one_launch_is_the_three_launches(variant, S, W, L, H, cell, micro):
+    """Round 6: in the default (atomic) mode pn_pagg_train_step runs pooling forward, cross entropy and pooling backward of
+    a node as ONE launch (pool_step_kernel: the three kernels' bodies back to back in one workgroup; context knob
+    PN_POOL_STEP, default 1).  Same code, same order inside a node: logits and loss bit-equal to the three launches and to
+    the three library calls; gradients equal up to the order of the float atomics (which differs from run to run anyway)."""
+    from pathnet_amd import _lib
+    from pathnet_amd import modules as M
+    case = _case(variant, S, W, L, H=H, cell=cell)
+    m = case[0]
+    m.deterministic = False
+    if micro:
+        Hk = -(-H // 32) * 32
+        kw = dict(cell=m._cell_kind, deterministic=False)
+        m.workspace_budget = M.workspace_bytes(variant, 900, 40, Hk, 5, S, W, L, batch_groups=micro, **kw)
+        assert M.pick_batch_groups(variant, 900, 40, Hk, 5, S, W, L, m.workspace_budget, **kw) == micro
+    l0, o0, g0 = _separate(case)
+    old = _lib.set_knob("PN_POOL_STEP", 0)
+    try:
+        l1, o1, g1 = _fused(case)
+        _lib.set_knob("PN_POOL_STEP", 1)
+        l2, o2, g2 = _fused(case)
+    finally:
+        _lib.set_knob("PN_POOL_STEP", old)
+    assert torch.equal(o0, o1) and torch.equal(o1, o2)
+    if micro:
+        assert abs(l1.item() - l2.item()) <= 1e-6 * max(1.0, abs(l1.item()))
+    else:
+        assert l0.item() == l1.item() == l2.item()
+    zero_ok = ZERO_OK_HETERO if variant == "hetero" else ()
+    assert_grads_close(g2, g1, rel=1e-5, zero_ok=zero_ok)
+    assert_grads_close(g2, g0, rel=1e-5, zero_ok=zero_ok)

@@ -7,8 +7,6 @@ magnitudes weight decay leaves in saved_models/cornell.pth), gathered rows up to
 and 1e+4.  They replace nn.LSTM / nn.RNN forward and autograd backward of /root/reference/PathNet_run.py:164,195,265,351
 and baseline/GPRGNN/src/copy.py:308,349; the contract is the bf16 kernels': logits within 1e-5, gradients within
 3e-5 * max(1, |g|_inf)."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch
@@ -280,36 +278,3 @@ def test_remainder_round_tiles_match_the_default_tiling(variant, H, S, W, L, cel
         _lib.set_knob("PN_SEQH_TAIL", old)
     assert torch.equal(out, ref_out)
     assert_grads_close(g, ref_g, rel=1e-5, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
-
-
-@pytest.mark.parametrize("variant,cell,S,W", [("homo", None, 450, 40),      # 18 000 paths = 563 tiles: one whole round of 512 + 51
-                                                ("hetero", None, 420, 41),    # ragged last tile, the hetero index plan
-                                                ("pagg", None, 700, 40),      # tanh RNN (its own occupancy -> its own round size)
-                                                ("homo", "gru", 450, 40)])
-def test_bptt_remainder_round_as_its_own_launch_gives_the_same_gradients(variant, cell, S, W):
-    """Round 6: when the BPTT's tile count is not a multiple of the resident workgroups, the whole rounds run first and the
-    weight-gradient GEMM over their rows starts on the second stream beside the remainder round (context knob
-    PN_BWD_TAIL_OVERLAP, default 1; pn_pagg.hip `tail_paths`).  Same logits bit for bit; gradients equal up to the
-    summation order of the K-split partials and of the scatter atomics (which differs from run to run anyway)."""
-    from pathnet_amd import _lib
-    L, H = 4, 128
-    case = _case(variant, H, S, W, L, cell, 0.5, N=2000)
-    old = _lib.set_knob("PN_BWD_TAIL_OVERLAP", 0)
-    try:
-        ref_out, ref_g = _run(case, "f16x2")
-        _lib.set_knob("PN_BWD_TAIL_OVERLAP", 1)
-        out, g = _run(case, "f16x2")
-        out2, g2 = _run(case, "f16x2")
-    finally:
-        _lib.set_knob("PN_BWD_TAIL_OVERLAP", old)
-    assert torch.equal(out, ref_out) and torch.equal(out2, ref_out)
-    assert_grads_close(g, ref_g, rel=2e-6, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
-    assert_grads_close(g2, g, rel=2e-6, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
-    # and the split really happened at this size: the library reports the paths it left to the second launch
-    info = (ctypes.c_int32 * 4)()
-    _lib.load().pn_debug_bwd_tail.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
-                                              ctypes.POINTER(ctypes.c_int32)]
-    _lib.check(_lib.load().pn_debug_bwd_tail(_lib.context("cuda"), H, {"gru": 3, None: 1 if variant == "pagg" else 4}[cell], L,
-                                             S * W, info))
-    slots, tail = int(info[0]), int(info[1])
-    assert slots >= 256 and 0 < tail < S * W and tail % 32 == 0 and (S * W - tail) % (slots * 32) < 32 * slots

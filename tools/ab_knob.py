@@ -2,7 +2,8 @@
 loss + backward + Adam) on a workload, blocks of steps alternating between the knob's values so that box-to-box and
 minute-to-minute drift cancel.  Prints the blocks' wall ms/step per value and their medians.
 
-    python tools/ab_knob.py PN_BWD_TAIL_OVERLAP 0 1 [workload=cora|pubmed|bgp] [blocks=6] [steps=30] [fused=0|1]
+    python tools/ab_knob.py PN_POOL_STEP 0 1 [workload=cora|pubmed|bgp] [blocks=6] [steps=30] [fused=0|1]
+    python tools/ab_knob.py FUSED 0 1            (pseudo-knob: three library calls vs pn_pagg_train_step)
 """
 import json
 import os
@@ -41,7 +42,10 @@ def main():
     e = 100
     for b in range(blocks):
         for v in values:
-            _lib.set_knob(name, v, dev)
+            if name == "FUSED":         # pseudo-knob: the step as three library calls (0) or through pn_pagg_train_step (1)
+                sr.fused = bool(v)
+            else:
+                _lib.set_knob(name, v, dev)
             for _ in range(5):
                 sr.step(e)
                 e += 1
