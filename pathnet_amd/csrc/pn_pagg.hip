@@ -30,6 +30,8 @@
 // is 1e-5 on fp32 logits against the reference CPU path, tests measure 3e-7 against float64.
 #include <hip/hip_runtime.h>
 
+#include <functional>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -1294,7 +1296,14 @@ struct PoolParams {
     float *out;             // [S, C]
 };
 
-__device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds) {
+// LDS copies of a group's h_n rows and of its members' ego rows (pool_step_kernel stages them once for the three bodies);
+// hn == nullptr: the bodies read global memory, as the stand-alone kernels do
+struct PoolTiles {
+    const float *hn;        // [W][pitch]
+    const float *ego;       // [W][ego_pitch] or a single row (ego_pitch = 0: every member has the same ego row)
+    int pitch, ego_pitch;
+};
+__device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, const PoolTiles tl = PoolTiles{nullptr, nullptr, 0, 0}) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = blockIdx.x, H = p.H, W = p.W;
     float *sc = lds;                                            // [W] scores, then coefficients
@@ -1315,8 +1324,9 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds) {
             const int mem = m0 + m8;
             const int memc = min(mem, W - 1);
             const int64_t s = (int64_t)g * W + memc;
-            const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + s * H + part * jw);
-            const float4 *e4 = reinterpret_cast<const float4 *>(p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
+            const float4 *h4 = reinterpret_cast<const float4 *>(tl.hn ? tl.hn + memc * tl.pitch + part * jw : p.hn + s * H + part * jw);
+            const float4 *e4 = reinterpret_cast<const float4 *>(tl.hn ? tl.ego + memc * tl.ego_pitch + part * jw
+                                                                      : p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
             const float4 *a4 = reinterpret_cast<const float4 *>(p.att_w + part * jw);
             const float4 *b4 = reinterpret_cast<const float4 *>(p.att_w + H + part * jw);
             float acc = 0.0f;
@@ -1372,7 +1382,8 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds) {
         for (int j = lane; j < H; j += 64) {
             float acc = 0.0f;
 #pragma unroll 8
-            for (int mem = wave * per; mem < mem_end; mem++) acc += sc[mem] * p.hn[((int64_t)g * W + mem) * H + j];
+            for (int mem = wave * per; mem < mem_end; mem++)
+                acc += sc[mem] * (tl.hn ? tl.hn[mem * tl.pitch + j] : p.hn[((int64_t)g * W + mem) * H + j]);
             part4[wave * H + j] = acc;
         }
     }
@@ -1588,7 +1599,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 //      times the waves hide them.  (Round 2 had rejected this layout for quadrupling the atomics on the 2H + 1
 //      attention-weight addresses; those now go through per-workgroup partials, det_att: [groups][2H + 4].)
 template <int HI>
-__device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *lds) {
+__device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *lds, const PoolTiles tl = PoolTiles{nullptr, nullptr, 0, 0}) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = p.H, W = p.W;
     float *dco = lds;                        // [W] d coef
@@ -1632,7 +1643,8 @@ __device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *
         const int m32 = tid >> 3, part = tid & 7, jw = H / 8;
         for (int m0 = 0; m0 < W; m0 += 32) {
             const int mem = m0 + m32;
-            const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + ((int64_t)g * W + min(mem, W - 1)) * H + part * jw);
+            const float4 *h4 = reinterpret_cast<const float4 *>(tl.hn ? tl.hn + min(mem, W - 1) * tl.pitch + part * jw
+                                                                      : p.hn + ((int64_t)g * W + min(mem, W - 1)) * H + part * jw);
             float acc = 0.0f;
             for (int j = 0; j < jw / 4; j++) {
                 const float4 hv = h4[j];
@@ -1684,8 +1696,8 @@ __device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *
                 float dh = cf * dp[j];
                 if (has_att) {
                     dh += ds * p.att_w[j];
-                    gaw_h[i] += ds * p.hn[s * H + j];
-                    gaw_e[i] += ds * p.ego_tab[erow + j];
+                    gaw_h[i] += ds * (tl.hn ? tl.hn[mem * tl.pitch + j] : p.hn[s * H + j]);
+                    gaw_e[i] += ds * (tl.hn ? tl.ego[mem * tl.ego_pitch + j] : p.ego_tab[erow + j]);
                     const float eg = ds * p.att_w[H + j];
                     if (one_row)
                         ego_acc[i] += eg;
@@ -1747,11 +1759,60 @@ struct PoolStepParams {
     float *gout;            // [S, C] d loss / d logits (read by the classifier's weight-gradient GEMM)
     float *lossg;           // [S] logsumexp - logit[target] per group
 };
-template <int HI>
+// STAGED: the group's W h_n rows and its members' ego rows go to LDS first -- all their loads in flight at once -- and the
+// bodies read the tiles: the kernel is a chain of dependent phases (ego rows, scores, pooled sum, classifier, backward dot
+// products, per-member terms), and with a global load in every phase the chain, not the 40 KB a node reads, set its time
+// (~46 us for the two bodies back to back at the headline shape).  The launcher picks it when the tiles fit 64 KB of LDS.
+constexpr int POOL_STAGE_MAX = 10;      // float4 loads per thread and tile
+inline size_t pool_step_scratch_floats(int W, int H) { return (size_t)std::max(2 * W + 6 * H, 4 * (2 * W + H) + 8 * H + 8 * W); }
+inline size_t pool_step_staged_lds_bytes(int W, int H) {
+    return (pool_step_scratch_floats(W, H) + (size_t)W + 2 * (size_t)W * (H + 4)) * sizeof(float);
+}
+template <int HI, bool STAGED>
 __global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
     extern __shared__ float lds[];
-    pool_fwd_body(p.f, lds);
-    __syncthreads();            // (workgroup-scope fence: out[g, :] written above is visible below; LDS is free again)
+    PoolTiles tl{nullptr, nullptr, 0, 0};
+    if constexpr (STAGED) {
+        const int tid = threadIdx.x, W = p.f.W, H = p.f.H, H4 = H / 4, pitch = H + 4, g = blockIdx.x;
+        const int scratch = max(2 * W + 6 * H, 4 * (2 * W + H) + 8 * H + 8 * W);
+        int *st_erow = reinterpret_cast<int *>(lds + scratch);
+        float *th = lds + scratch + W, *te = th + W * pitch;
+        const bool has_ego = p.f.variant != PN_VARIANT_PAGG;
+        const int n4 = W * H4;
+        float4 rh[POOL_STAGE_MAX];
+        const float4 *src = reinterpret_cast<const float4 *>(p.f.hn + (int64_t)g * W * H);       // the group's rows are contiguous
+#pragma unroll
+        for (int k = 0; k < POOL_STAGE_MAX; k++)
+            if (tid + 256 * k < n4) rh[k] = src[tid + 256 * k];
+        int same = 1;
+        if (has_ego) {
+            for (int mem = tid; mem < W; mem += 256) st_erow[mem] = p.f.egoidx[(int64_t)g * W + mem];
+            __syncthreads();
+            for (int mem = tid; mem < W; mem += 256) same &= st_erow[mem] == st_erow[0];
+        }
+        const bool one_row = __syncthreads_and(same) != 0;
+        float4 re[POOL_STAGE_MAX];
+        const int ne4 = !has_ego ? 0 : one_row ? H4 : n4;
+#pragma unroll
+        for (int k = 0; k < POOL_STAGE_MAX; k++) {
+            const int i = tid + 256 * k;
+            if (i < ne4) re[k] = reinterpret_cast<const float4 *>(p.f.ego_tab + (int64_t)st_erow[i / H4] * H)[i % H4];
+        }
+#pragma unroll
+        for (int k = 0; k < POOL_STAGE_MAX; k++) {
+            const int i = tid + 256 * k;
+            if (i < n4) *reinterpret_cast<float4 *>(th + (i / H4) * pitch + 4 * (i % H4)) = rh[k];
+        }
+#pragma unroll
+        for (int k = 0; k < POOL_STAGE_MAX; k++) {
+            const int i = tid + 256 * k;
+            if (i < ne4) *reinterpret_cast<float4 *>(te + (i / H4) * pitch + 4 * (i % H4)) = re[k];
+        }
+        tl = PoolTiles{th, te, pitch, one_row ? 0 : pitch};
+        __syncthreads();
+    }
+    pool_fwd_body(p.f, lds, tl);
+    __syncthreads();            // (workgroup-scope fence: out[g, :] written above is visible below; the scratch is free again)
     if (threadIdx.x == 0) {     // the row's cross entropy exactly as cross_entropy_kernel computes it
         const int g = blockIdx.x, classes = p.f.C;
         const float *x = p.f.out + (int64_t)g * classes;
@@ -1766,7 +1827,7 @@ __global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
         for (int c = 0; c < classes; c++) go[c] = (expf(x[c] - lse) - (c == t ? 1.0f : 0.0f)) * p.scale;
     }
     __syncthreads();
-    pool_bwd_wg_body<HI>(p.b, lds);
+    pool_bwd_wg_body<HI>(p.b, lds, tl);
 }
 // loss[0] (+)= scale * sum of the rows' terms, in cross_entropy_kernel's order (one workgroup of 1024 threads)
 __global__ __launch_bounds__(1024) void loss_sum_kernel(const float *__restrict__ lossg, int rows, float scale,
@@ -3234,7 +3295,8 @@ int check_forward_args(const Call &c, const char *who) {
 
 // What a forward does before its first micro-batch: the touched rows, the index plan of micro-batch 0 and the packed
 // weights (second stream), Xh = fc0(X), Z = bank(Xh); joined, so that the recurrence can follow.
-int run_tables(const Call &c, JoinGuard &joiner) {
+// side_extra: one more launch for the second stream (pn_pagg_train_step: the zero fill of the backward's accumulators)
+int run_tables(const Call &c, JoinGuard &joiner, const std::function<int(hipStream_t)> *side_extra = nullptr) {
     pn_context *ctx = c.ctx;
     hipStream_t stream = c.stream;
     const pn_pagg_args *a = c.a;
@@ -3255,6 +3317,8 @@ int run_tables(const Call &c, JoinGuard &joiner) {
         if (int rc = run_plan(c, pstream, 0)) return rc;
         if (int rc = run_pack_fwd(c, pstream)) return rc;
     }
+    if (side_extra)
+        if (int rc = (*side_extra)(pstream)) return rc;
     if (pstream != stream)
         if (int rc = joiner.mark()) return rc;
     if (!a->reuse_tables) {
@@ -3627,10 +3691,11 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         }
         return PN_OK;
     };
-    auto flush_zero = [&]() -> int {
+    auto flush_zero = [&](hipStream_t zs = nullptr) -> int {
+        if (!zs) zs = stream;
         if (zl.n) {
-            StageTimer tm(ctx, ST_ZERO_FILL, stream);       // (d Z and d Xh are the bulk: rows of the graph, not paths)
-            hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, stream, zl);
+            StageTimer tm(ctx, ST_ZERO_FILL, zs);       // (d Z and d Xh are the bulk: rows of the graph, not paths)
+            hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, zs, zl);
             PN_CHECK_HIP(hipGetLastError());
             zl.n = 0;
         }
@@ -3668,8 +3733,13 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         if (int rc = flush_zero()) return rc;
 
     JoinGuard joiner{ctx, stream};
-    if (fused)
-        if (int rc = run_tables(c, joiner)) return rc;
+    if (fused) {
+        // the zero fill rides on the second stream with the index plan (joined before the recurrence): off the chain
+        // recurrence -> pooling -> BPTT, where it used to sit because the forward's gigabyte of saved tensors evicts the
+        // freshly zeroed d Z -- 7 MB to fetch again, ~1 us of HBM time, against 5 us of launch in the chain
+        const std::function<int(hipStream_t)> zero_side = [&](hipStream_t zs) { return flush_zero(zs); };
+        if (int rc = run_tables(c, joiner, knobs_of(ctx).zero_early ? &zero_side : nullptr)) return rc;
+    }
     // (per-stage timings are taken serially.  Deterministic mode: the classifier's weight gradient shares the chunk-sum
     //  buffer `dgemm` with the bank / fc0 backward and stays in line; the recurrent weight gradient -- its own partials,
     //  reduced in a fixed order -- goes to the second stream as in the default mode: streams do not reorder a kernel's sums)
@@ -3728,9 +3798,15 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         }
         // classifier: g_fc2_w += g_out^T . layer1, g_fc2_b += colsum(g_out) -- nothing below reads them: second stream
         // (after the fused pooling step also the loss: the fixed-order sum of the per-node terms)
+        // Where it runs: on the second stream, forked here -- or, when the recurrent weight gradient forks off behind the BPTT
+        // anyway (defer_small), on `stream` right behind that fork together with the attention-weight reduction: every
+        // fork / join is an event between two kernels of the queue and costs ~6 us of idle time there, and the BPTT waits
+        // for none of the three (profiles/r06_glue.txt).
+        const bool wgrad_wanted = G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh);
+        const bool defer_small = side_ok && PN_SIDE_SMALL && PN_BWD_OVERLAP && wgrad_wanted && ctx != nullptr;
         auto run_fc2_grad = [&]() -> int {
         hipStream_t cstream = stream;
-        if (PN_SIDE_SMALL && side_ok)
+        if (PN_SIDE_SMALL && side_ok && !defer_small)
             if (void *side = context_fork(ctx, stream)) cstream = (hipStream_t)side;
         if (pool_step) {
             hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, cstream, c.at<const float>(c.w.outb), Sb, grad_scale, loss,
@@ -3755,10 +3831,11 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             if (int rc = joiner.mark()) return rc;
         return PN_OK;
         };
-        if (!pool_step)
+        if (!pool_step && !defer_small)
             if (int rc = run_fc2_grad()) return rc;
 
         // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
+        std::function<int()> att_reduce = [] { return PN_OK; };
         {
             PoolBwdParams pp{};
             pp.variant = d.variant;
@@ -3809,18 +3886,23 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 ps.scale = grad_scale;
                 ps.gout = c.at<float>(c.w.gout);
                 ps.lossg = c.at<float>(c.w.outb);       // (the fused step's logits go to the caller: the slot is free)
-                const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d));
+                const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d)), lds_staged = pool_step_staged_lds_bytes(d.W, H);
+                const bool staged = H <= 256 && lds_staged <= 65536 && (size_t)d.W * (H / 4) <= 256 * (size_t)POOL_STAGE_MAX &&
+                                    knobs_of(ctx).pool_step != 2;
                 {
                     StageTimer tm(ctx, ST_POOL_FWD, stream);
-                    if (H <= 256) {
-                        hipLaunchKernelGGL(pool_step_kernel<4>, dim3(Sb), dim3(256), lds_step, stream, ps);
+                    if (staged) {
+                        hipLaunchKernelGGL((pool_step_kernel<4, true>), dim3(Sb), dim3(256), lds_staged, stream, ps);
+                    } else if (H <= 256) {
+                        hipLaunchKernelGGL((pool_step_kernel<4, false>), dim3(Sb), dim3(256), lds_step, stream, ps);
                     } else {
-                        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16>), (int)lds_step)) return rc;
-                        hipLaunchKernelGGL(pool_step_kernel<16>, dim3(Sb), dim3(256), lds_step, stream, ps);
+                        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16, false>), (int)lds_step)) return rc;
+                        hipLaunchKernelGGL((pool_step_kernel<16, false>), dim3(Sb), dim3(256), lds_step, stream, ps);
                     }
                     PN_CHECK_HIP(hipGetLastError());
                 }
-                if (int rc = run_fc2_grad()) return rc;
+                if (!defer_small)
+                    if (int rc = run_fc2_grad()) return rc;
             }
             StageTimer tm(ctx, ST_POOL_BWD, stream);
             if (pool_step) {
@@ -3839,11 +3921,16 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 hipLaunchKernelGGL(pool_bwd_kernel<16>, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
             }
             PN_CHECK_HIP(hipGetLastError());
-            if (has_att && pp.det_att) {        // the attention weights' terms in workgroup order
-                hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, att_blocks, H,
-                                   pp.g_att_w, pp.g_att_b);
-                PN_CHECK_HIP(hipGetLastError());
-            }
+            att_reduce = [=]() -> int {        // the attention weights' terms in workgroup order
+                if (has_att && pp.det_att) {
+                    hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, att_blocks, H,
+                                       pp.g_att_w, pp.g_att_b);
+                    PN_CHECK_HIP(hipGetLastError());
+                }
+                return PN_OK;
+            };
+            if (!defer_small)
+                if (int rc = att_reduce()) return rc;
             if (d.det) {
                 // (this micro-batch's orders were sorted on the second stream under its forward, when the backward re-ran it)
                 if (fused || d.nb > 1)
@@ -3865,7 +3952,6 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
 
         // recurrent weight / bias gradients: [g_W_ih | g_W_hh] (+)= dG^T . XH, g_b (+)= colsum(dG) over the Pb * L rows of this
         // micro-batch: K-split partials into `wpart`, then their reduction.  Second stream, forked off `stream` where it is called.
-        const bool wgrad_wanted = G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh);
         auto run_wgrad = [&]() -> int {
             hipStream_t wstream = stream;
             if (PN_BWD_OVERLAP && overlap_ok)
@@ -3967,6 +4053,10 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
 
         if (wgrad_wanted)
             if (int rc = run_wgrad()) return rc;
+        if (defer_small) {      // behind the fork: beside the weight-gradient GEMM, ahead of the node-level GEMMs
+            if (int rc = run_fc2_grad()) return rc;
+            if (int rc = att_reduce()) return rc;
+        }
         // the next micro-batch rewrites the [x|h] rows and dG the weight-gradient GEMM is reading
         if (b + 1 < d.nb)
             if (int rc = joiner.join()) return rc;

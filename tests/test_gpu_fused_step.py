@@ -144,9 +144,10 @@ def test_fused_step_needs_grad_mode_and_matching_targets():
 ])
 def test_pooling_step_in_one_launch_is_the_three_launches(variant, S, W, L, H, cell, micro):
     """Round 6: in the default (atomic) mode pn_pagg_train_step runs pooling forward, cross entropy and pooling backward of
-    a node as ONE launch (pool_step_kernel: the three kernels' bodies back to back in one workgroup; context knob
-    PN_POOL_STEP, default 1).  Same code, same order inside a node: logits and loss bit-equal to the three launches and to
-    the three library calls; gradients equal up to the order of the float atomics (which differs from run to run anyway)."""
+    a node as ONE launch (pool_step_kernel: the three kernels' bodies back to back in one workgroup, the node's h_n and
+    ego rows staged in LDS when they fit; context knob PN_POOL_STEP: 0 three launches, 2 one launch reading global memory,
+    1 = default).  Same code, same order inside a node: logits and loss equal to the three launches and to the three library
+    calls; gradients equal up to the order of the float atomics (which differs from run to run anyway)."""
     from pathnet_amd import _lib
     from pathnet_amd import modules as M
     case = _case(variant, S, W, L, H=H, cell=cell)
@@ -160,16 +161,21 @@ def test_pooling_step_in_one_launch_is_the_three_launches(variant, S, W, L, H, c
     l0, o0, g0 = _separate(case)
     old = _lib.set_knob("PN_POOL_STEP", 0)
     try:
-        l1, o1, g1 = _fused(case)
+        l1, o1, g1 = _fused(case)                   # three launches inside the fused call
+        _lib.set_knob("PN_POOL_STEP", 2)
+        l2, o2, g2 = _fused(case)                   # one launch, the bodies read global memory
         _lib.set_knob("PN_POOL_STEP", 1)
-        l2, o2, g2 = _fused(case)
+        l3, o3, g3 = _fused(case)                   # one launch, h_n / ego tiles staged in LDS (the default when they fit)
     finally:
         _lib.set_knob("PN_POOL_STEP", old)
     assert torch.equal(o0, o1) and torch.equal(o1, o2)
+    assert (o3 - o1).abs().max().item() <= 1e-6     # (same arithmetic order; the compiler may contract differently)
     if micro:
         assert abs(l1.item() - l2.item()) <= 1e-6 * max(1.0, abs(l1.item()))
     else:
         assert l0.item() == l1.item() == l2.item()
+    assert abs(l3.item() - l1.item()) <= 1e-6 * max(1.0, abs(l1.item()))
     zero_ok = ZERO_OK_HETERO if variant == "hetero" else ()
-    assert_grads_close(g2, g1, rel=1e-5, zero_ok=zero_ok)
-    assert_grads_close(g2, g0, rel=1e-5, zero_ok=zero_ok)
+    for g in (g2, g3):
+        assert_grads_close(g, g1, rel=1e-5, zero_ok=zero_ok)
+        assert_grads_close(g, g0, rel=1e-5, zero_ok=zero_ok)
