@@ -1300,12 +1300,17 @@ struct PoolParams {
 // hn == nullptr: the bodies read global memory, as the stand-alone kernels do
 struct PoolTiles {
     const float *hn;        // [W][pitch]
-    const float *ego;       // [W][ego_pitch] or a single row (ego_pitch = 0: every member has the same ego row)
+    const float *ego;       // [W][ego_pitch] or a single row (ego_pitch = 0: every member has the same ego row); null: global
     int pitch, ego_pitch;
+    const float *att_w;     // [2H] attention weights
+    const float *fc2_w;     // [C][2H] classifier weights
+    const float *xrow;      // [H] Xh[sel[g]]
 };
-__device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, const PoolTiles tl = PoolTiles{nullptr, nullptr, 0, 0}) {
+constexpr PoolTiles NO_TILES{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+__device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, const PoolTiles tl = NO_TILES) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = blockIdx.x, H = p.H, W = p.W;
+    const float *att_w = tl.hn ? tl.att_w : p.att_w, *fc2_w = tl.hn ? tl.fc2_w : p.fc2_w;
     float *sc = lds;                                            // [W] scores, then coefficients
     int *s_erow = reinterpret_cast<int *>(sc + W);              // [W] ego rows of the group's members
     float *part4 = reinterpret_cast<float *>(s_erow + W);       // [4][H] the waves' partial pooled sums
@@ -1325,10 +1330,10 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, c
             const int memc = min(mem, W - 1);
             const int64_t s = (int64_t)g * W + memc;
             const float4 *h4 = reinterpret_cast<const float4 *>(tl.hn ? tl.hn + memc * tl.pitch + part * jw : p.hn + s * H + part * jw);
-            const float4 *e4 = reinterpret_cast<const float4 *>(tl.hn ? tl.ego + memc * tl.ego_pitch + part * jw
-                                                                      : p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
-            const float4 *a4 = reinterpret_cast<const float4 *>(p.att_w + part * jw);
-            const float4 *b4 = reinterpret_cast<const float4 *>(p.att_w + H + part * jw);
+            const float4 *e4 = reinterpret_cast<const float4 *>(tl.ego ? tl.ego + memc * tl.ego_pitch + part * jw
+                                                                       : p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
+            const float4 *a4 = reinterpret_cast<const float4 *>(att_w + part * jw);
+            const float4 *b4 = reinterpret_cast<const float4 *>(att_w + H + part * jw);
             float acc = 0.0f;
             for (int j = 0; j < jw / 4; j++) {
                 const float4 hv = h4[j], ev = e4[j], av = a4[j], bv = b4[j];
@@ -1390,7 +1395,7 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, c
     __syncthreads();
     // layer1 = dropout([Xh[sel[g]] ; pooled])
     float *l1 = p.layer1 + (int64_t)g * 2 * H;
-    const float *ego = p.Xh + (int64_t)min(max(p.sel[g], 0), p.N - 1) * H;
+    const float *ego = tl.hn ? tl.xrow : p.Xh + (int64_t)min(max(p.sel[g], 0), p.N - 1) * H;
     for (int j = tid; j < H; j += 256) {
         float a = ego[j], b = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
         const uint64_t gg = (uint64_t)(p.goff + g);
@@ -1413,7 +1418,7 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, c
     __syncthreads();
     for (int c = wave; c < p.C; c += 4) {
         float part = 0.0f;
-        for (int j = lane; j < 2 * H; j += 64) part += l1s[j] * p.fc2_w[(int64_t)c * 2 * H + j];
+        for (int j = lane; j < 2 * H; j += 64) part += l1s[j] * fc2_w[(int64_t)c * 2 * H + j];
         part = wave_sum(part);
         if (lane == 0) p.out[(int64_t)g * p.C + c] = part + p.fc2_b[c];
     }
@@ -1599,9 +1604,10 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 //      times the waves hide them.  (Round 2 had rejected this layout for quadrupling the atomics on the 2H + 1
 //      attention-weight addresses; those now go through per-workgroup partials, det_att: [groups][2H + 4].)
 template <int HI>
-__device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *lds, const PoolTiles tl = PoolTiles{nullptr, nullptr, 0, 0}) {
+__device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *lds, const PoolTiles tl = NO_TILES) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = p.H, W = p.W;
+    const float *att_w = tl.hn ? tl.att_w : p.att_w, *fc2_w = tl.hn ? tl.fc2_w : p.fc2_w;
     float *dco = lds;                        // [W] d coef
     float *dsc = dco + W;                    // [W] d score
     float *dp = dsc + W;                     // [H] d pooled / W
@@ -1620,8 +1626,8 @@ __device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *
         float a = 0.0f, b = 0.0f;
         for (int c = 0; c < p.C; c++) {
             const float go = p.g_out[(int64_t)g * p.C + c];
-            a += go * p.fc2_w[(int64_t)c * 2 * H + j];
-            b += go * p.fc2_w[(int64_t)c * 2 * H + H + j];
+            a += go * fc2_w[(int64_t)c * 2 * H + j];
+            b += go * fc2_w[(int64_t)c * 2 * H + H + j];
         }
         const uint64_t gg = (uint64_t)(p.goff + g);
         if (p.mask) {
@@ -1695,10 +1701,10 @@ __device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *
             if (j < H) {
                 float dh = cf * dp[j];
                 if (has_att) {
-                    dh += ds * p.att_w[j];
+                    dh += ds * att_w[j];
                     gaw_h[i] += ds * (tl.hn ? tl.hn[mem * tl.pitch + j] : p.hn[s * H + j]);
-                    gaw_e[i] += ds * (tl.hn ? tl.ego[mem * tl.ego_pitch + j] : p.ego_tab[erow + j]);
-                    const float eg = ds * p.att_w[H + j];
+                    gaw_e[i] += ds * (tl.ego ? tl.ego[mem * tl.ego_pitch + j] : p.ego_tab[erow + j]);
+                    const float eg = ds * att_w[H + j];
                     if (one_row)
                         ego_acc[i] += eg;
                     else if (!p.det_ds)
@@ -1759,45 +1765,66 @@ struct PoolStepParams {
     float *gout;            // [S, C] d loss / d logits (read by the classifier's weight-gradient GEMM)
     float *lossg;           // [S] logsumexp - logit[target] per group
 };
-// STAGED: the group's W h_n rows and its members' ego rows go to LDS first -- all their loads in flight at once -- and the
-// bodies read the tiles: the kernel is a chain of dependent phases (ego rows, scores, pooled sum, classifier, backward dot
-// products, per-member terms), and with a global load in every phase the chain, not the 40 KB a node reads, set its time
-// (~46 us for the two bodies back to back at the headline shape).  The launcher picks it when the tiles fit 64 KB of LDS.
+// STAGED: everything the three bodies read more than once goes to LDS first, all loads in flight at once -- the group's W
+// h_n rows, its members' ego rows (one row when they all share it -- the homo index plan -- else W rows if the launcher
+// left room, else they stay in global memory), the node's own projected row, the attention and classifier weights.  The
+// kernel is a chain of ~30 dependent phases (ego rows, scores, pooled sum, classifier, loss, backward dot products,
+// per-member terms); with a global load in every phase the chain, not the 40 KB a node reads, sets its time: 47 us for the
+// bodies back to back on global memory at the headline shape (profiles/r06_glue.txt).
 constexpr int POOL_STAGE_MAX = 10;      // float4 loads per thread and tile
-inline size_t pool_step_scratch_floats(int W, int H) { return (size_t)std::max(2 * W + 6 * H, 4 * (2 * W + H) + 8 * H + 8 * W); }
-inline size_t pool_step_staged_lds_bytes(int W, int H) {
-    return (pool_step_scratch_floats(W, H) + (size_t)W + 2 * (size_t)W * (H + 4)) * sizeof(float);
+struct PoolStageLayout {
+    int hn, ego, att, fc2, xrow, total;     // offsets in floats (the bodies' scratch sits at 0, the members' ego row numbers below hn)
+};
+__host__ __device__ inline PoolStageLayout pool_stage_layout(int W, int H, int C, int ego_rows) {
+    PoolStageLayout l;
+    const int a = 2 * W + 6 * H, b = 4 * (2 * W + H) + 8 * H + 8 * W;
+    l.hn = ((a > b ? a : b) + W + 3) / 4 * 4;
+    l.ego = l.hn + W * (H + 4);
+    l.att = l.ego + ego_rows * (H + 4);
+    l.fc2 = l.att + 2 * H;
+    l.xrow = l.fc2 + C * 2 * H;
+    l.total = l.xrow + H;
+    return l;
 }
 template <int HI, bool STAGED>
-__global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
-    extern __shared__ float lds[];
-    PoolTiles tl{nullptr, nullptr, 0, 0};
+__global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p, int ego_rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    PoolTiles tl = NO_TILES;
     if constexpr (STAGED) {
-        const int tid = threadIdx.x, W = p.f.W, H = p.f.H, H4 = H / 4, pitch = H + 4, g = blockIdx.x;
-        const int scratch = max(2 * W + 6 * H, 4 * (2 * W + H) + 8 * H + 8 * W);
-        int *st_erow = reinterpret_cast<int *>(lds + scratch);
-        float *th = lds + scratch + W, *te = th + W * pitch;
+        const int tid = threadIdx.x, W = p.f.W, H = p.f.H, H4 = H / 4, pitch = H + 4, g = blockIdx.x, C = p.f.C;
+        const PoolStageLayout L = pool_stage_layout(W, H, C, ego_rows);
+        int *st_erow = reinterpret_cast<int *>(lds + L.hn) - W;        // (just below the tiles, above the bodies' scratch)
+        float *th = lds + L.hn, *te = lds + L.ego, *ta = lds + L.att, *tf = lds + L.fc2, *tx = lds + L.xrow;
         const bool has_ego = p.f.variant != PN_VARIANT_PAGG;
         const int n4 = W * H4;
+        // (1) the loads that depend on nothing: h_n tile, weights, the members' ego row numbers, the node's own row number
         float4 rh[POOL_STAGE_MAX];
         const float4 *src = reinterpret_cast<const float4 *>(p.f.hn + (int64_t)g * W * H);       // the group's rows are contiguous
 #pragma unroll
         for (int k = 0; k < POOL_STAGE_MAX; k++)
             if (tid + 256 * k < n4) rh[k] = src[tid + 256 * k];
-        int same = 1;
+        const int selrow = min(max(p.f.sel[g], 0), p.f.N - 1);
         if (has_ego) {
             for (int mem = tid; mem < W; mem += 256) st_erow[mem] = p.f.egoidx[(int64_t)g * W + mem];
-            __syncthreads();
-            for (int mem = tid; mem < W; mem += 256) same &= st_erow[mem] == st_erow[0];
+            for (int i = tid; i < 2 * H / 4; i += 256) reinterpret_cast<float4 *>(ta)[i] = reinterpret_cast<const float4 *>(p.f.att_w)[i];
         }
+        for (int i = tid; i < C * 2 * H / 4; i += 256) reinterpret_cast<float4 *>(tf)[i] = reinterpret_cast<const float4 *>(p.f.fc2_w)[i];
+        __syncthreads();
+        // (2) the rows named by what just arrived: the members' ego rows, the node's own row
+        int same = 1;
+        if (has_ego)
+            for (int mem = tid; mem < W; mem += 256) same &= st_erow[mem] == st_erow[0];
         const bool one_row = __syncthreads_and(same) != 0;
+        const bool ego_staged = has_ego && (one_row || ego_rows >= W);
+        const int ne4 = !ego_staged ? 0 : one_row ? H4 : n4;
         float4 re[POOL_STAGE_MAX];
-        const int ne4 = !has_ego ? 0 : one_row ? H4 : n4;
 #pragma unroll
         for (int k = 0; k < POOL_STAGE_MAX; k++) {
             const int i = tid + 256 * k;
             if (i < ne4) re[k] = reinterpret_cast<const float4 *>(p.f.ego_tab + (int64_t)st_erow[i / H4] * H)[i % H4];
         }
+        for (int i = tid; i < H4; i += 256)
+            reinterpret_cast<float4 *>(tx)[i] = reinterpret_cast<const float4 *>(p.f.Xh + (int64_t)selrow * H)[i];
 #pragma unroll
         for (int k = 0; k < POOL_STAGE_MAX; k++) {
             const int i = tid + 256 * k;
@@ -1808,7 +1835,7 @@ __global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
             const int i = tid + 256 * k;
             if (i < ne4) *reinterpret_cast<float4 *>(te + (i / H4) * pitch + 4 * (i % H4)) = re[k];
         }
-        tl = PoolTiles{th, te, pitch, one_row ? 0 : pitch};
+        tl = PoolTiles{th, ego_staged ? te : nullptr, pitch, one_row ? 0 : pitch, ta, tf, tx};
         __syncthreads();
     }
     pool_fwd_body(p.f, lds, tl);
@@ -3886,18 +3913,23 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 ps.scale = grad_scale;
                 ps.gout = c.at<float>(c.w.gout);
                 ps.lossg = c.at<float>(c.w.outb);       // (the fused step's logits go to the caller: the slot is free)
-                const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d)), lds_staged = pool_step_staged_lds_bytes(d.W, H);
+                const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d));
+                // the staged kernel: tiles + weights within 64 KB of LDS; the hetero class's members have ego rows of their own
+                // (W rows staged if they fit as well), the homo / PAGG plans one row per node
+                int ego_rows = d.variant == PN_VARIANT_HETERO ? d.W : 1;
+                if (ego_rows > 1 && (size_t)pool_stage_layout(d.W, H, d.C, ego_rows).total * 4 > 65536) ego_rows = 1;
+                const size_t lds_staged = (size_t)pool_stage_layout(d.W, H, d.C, ego_rows).total * sizeof(float);
                 const bool staged = H <= 256 && lds_staged <= 65536 && (size_t)d.W * (H / 4) <= 256 * (size_t)POOL_STAGE_MAX &&
                                     knobs_of(ctx).pool_step != 2;
                 {
                     StageTimer tm(ctx, ST_POOL_FWD, stream);
                     if (staged) {
-                        hipLaunchKernelGGL((pool_step_kernel<4, true>), dim3(Sb), dim3(256), lds_staged, stream, ps);
+                        hipLaunchKernelGGL((pool_step_kernel<4, true>), dim3(Sb), dim3(256), lds_staged, stream, ps, ego_rows);
                     } else if (H <= 256) {
-                        hipLaunchKernelGGL((pool_step_kernel<4, false>), dim3(Sb), dim3(256), lds_step, stream, ps);
+                        hipLaunchKernelGGL((pool_step_kernel<4, false>), dim3(Sb), dim3(256), lds_step, stream, ps, 0);
                     } else {
                         if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16, false>), (int)lds_step)) return rc;
-                        hipLaunchKernelGGL((pool_step_kernel<16, false>), dim3(Sb), dim3(256), lds_step, stream, ps);
+                        hipLaunchKernelGGL((pool_step_kernel<16, false>), dim3(Sb), dim3(256), lds_step, stream, ps, 0);
                     }
                     PN_CHECK_HIP(hipGetLastError());
                 }

@@ -288,6 +288,9 @@ class _PaggLossFunction(torch.autograd.Function):
         ctx.grads = (gX,) + head + tuple(g_bank_w[d] for d in range(L)) + tuple(g_bank_b[d] for d in range(L))
         ctx.flat = flat
         ctx.mark_non_differentiable(out)
+        # (without this autograd materialises a zero gradient for `out` -- an [S, C] fill launch in front of the optimizer,
+        #  on the step's critical path: profiles/r06_glue.txt)
+        ctx.set_materialize_grads(False)
         return loss, out
 
     @staticmethod
@@ -302,6 +305,8 @@ class _PaggLossFunction(torch.autograd.Function):
         # (d loss' / d loss: 1 for loss.backward().  The gradients were computed once, in forward(): a single backward, no
         #  double backward -- once_differentiable says so to autograd; a second backward raises above)
         from . import optim
+        if g_loss is None:      # (set_materialize_grads(False): the loss took no part in what is being differentiated)
+            return (None,) * (6 + len(grads) - 1)
         one = optim._UNIT.get(g_loss.device)
         if one is None or g_loss.data_ptr() != one.data_ptr():       # (optim.backward(loss) seeds with the cached 1.0: nothing to scale)
             flat.mul_(g_loss)

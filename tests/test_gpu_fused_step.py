@@ -176,6 +176,8 @@ def test_pooling_step_in_one_launch_is_the_three_launches(variant, S, W, L, H, c
         assert l0.item() == l1.item() == l2.item()
     assert abs(l3.item() - l1.item()) <= 1e-6 * max(1.0, abs(l1.item()))
     zero_ok = ZERO_OK_HETERO if variant == "hetero" else ()
+    # (noise: the attention bias' gradient is a cancelling sum of S * W terms a thousand times its size, added by atomics in
+    #  a different order every run -- two runs of the SAME configuration differ by as much)
     for g in (g2, g3):
-        assert_grads_close(g, g1, rel=1e-5, zero_ok=zero_ok)
-        assert_grads_close(g, g0, rel=1e-5, zero_ok=zero_ok)
+        assert_grads_close(g, g1, rel=1e-5, noise=1e-8, zero_ok=zero_ok)
+        assert_grads_close(g, g0, rel=1e-5, noise=1e-8, zero_ok=zero_ok)
