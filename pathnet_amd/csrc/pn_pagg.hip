@@ -1296,21 +1296,9 @@ struct PoolParams {
     float *out;             // [S, C]
 };
 
-// LDS copies of a group's h_n rows and of its members' ego rows (pool_step_kernel stages them once for the three bodies);
-// hn == nullptr: the bodies read global memory, as the stand-alone kernels do
-struct PoolTiles {
-    const float *hn;        // [W][pitch]
-    const float *ego;       // [W][ego_pitch] or a single row (ego_pitch = 0: every member has the same ego row); null: global
-    int pitch, ego_pitch;
-    const float *att_w;     // [2H] attention weights
-    const float *fc2_w;     // [C][2H] classifier weights
-    const float *xrow;      // [H] Xh[sel[g]]
-};
-constexpr PoolTiles NO_TILES{nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
-__device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, const PoolTiles tl = NO_TILES) {
+__device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int g = blockIdx.x, H = p.H, W = p.W;
-    const float *att_w = tl.hn ? tl.att_w : p.att_w, *fc2_w = tl.hn ? tl.fc2_w : p.fc2_w;
     float *sc = lds;                                            // [W] scores, then coefficients
     int *s_erow = reinterpret_cast<int *>(sc + W);              // [W] ego rows of the group's members
     float *part4 = reinterpret_cast<float *>(s_erow + W);       // [4][H] the waves' partial pooled sums
@@ -1329,11 +1317,10 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, c
             const int mem = m0 + m8;
             const int memc = min(mem, W - 1);
             const int64_t s = (int64_t)g * W + memc;
-            const float4 *h4 = reinterpret_cast<const float4 *>(tl.hn ? tl.hn + memc * tl.pitch + part * jw : p.hn + s * H + part * jw);
-            const float4 *e4 = reinterpret_cast<const float4 *>(tl.ego ? tl.ego + memc * tl.ego_pitch + part * jw
-                                                                       : p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
-            const float4 *a4 = reinterpret_cast<const float4 *>(att_w + part * jw);
-            const float4 *b4 = reinterpret_cast<const float4 *>(att_w + H + part * jw);
+            const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + s * H + part * jw);
+            const float4 *e4 = reinterpret_cast<const float4 *>(p.ego_tab + (int64_t)s_erow[memc] * H + part * jw);
+            const float4 *a4 = reinterpret_cast<const float4 *>(p.att_w + part * jw);
+            const float4 *b4 = reinterpret_cast<const float4 *>(p.att_w + H + part * jw);
             float acc = 0.0f;
             for (int j = 0; j < jw / 4; j++) {
                 const float4 hv = h4[j], ev = e4[j], av = a4[j], bv = b4[j];
@@ -1387,15 +1374,14 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, c
         for (int j = lane; j < H; j += 64) {
             float acc = 0.0f;
 #pragma unroll 8
-            for (int mem = wave * per; mem < mem_end; mem++)
-                acc += sc[mem] * (tl.hn ? tl.hn[mem * tl.pitch + j] : p.hn[((int64_t)g * W + mem) * H + j]);
+            for (int mem = wave * per; mem < mem_end; mem++) acc += sc[mem] * p.hn[((int64_t)g * W + mem) * H + j];
             part4[wave * H + j] = acc;
         }
     }
     __syncthreads();
     // layer1 = dropout([Xh[sel[g]] ; pooled])
     float *l1 = p.layer1 + (int64_t)g * 2 * H;
-    const float *ego = tl.hn ? tl.xrow : p.Xh + (int64_t)min(max(p.sel[g], 0), p.N - 1) * H;
+    const float *ego = p.Xh + (int64_t)min(max(p.sel[g], 0), p.N - 1) * H;
     for (int j = tid; j < H; j += 256) {
         float a = ego[j], b = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
         const uint64_t gg = (uint64_t)(p.goff + g);
@@ -1418,7 +1404,7 @@ __device__ __forceinline__ void pool_fwd_body(const PoolParams &p, float *lds, c
     __syncthreads();
     for (int c = wave; c < p.C; c += 4) {
         float part = 0.0f;
-        for (int j = lane; j < 2 * H; j += 64) part += l1s[j] * fc2_w[(int64_t)c * 2 * H + j];
+        for (int j = lane; j < 2 * H; j += 64) part += l1s[j] * p.fc2_w[(int64_t)c * 2 * H + j];
         part = wave_sum(part);
         if (lane == 0) p.out[(int64_t)g * p.C + c] = part + p.fc2_b[c];
     }
@@ -1604,10 +1590,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolBwdParams p) {
 //      times the waves hide them.  (Round 2 had rejected this layout for quadrupling the atomics on the 2H + 1
 //      attention-weight addresses; those now go through per-workgroup partials, det_att: [groups][2H + 4].)
 template <int HI>
-__device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *lds, const PoolTiles tl = NO_TILES) {
+__device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *lds) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int H = p.H, W = p.W;
-    const float *att_w = tl.hn ? tl.att_w : p.att_w, *fc2_w = tl.hn ? tl.fc2_w : p.fc2_w;
     float *dco = lds;                        // [W] d coef
     float *dsc = dco + W;                    // [W] d score
     float *dp = dsc + W;                     // [H] d pooled / W
@@ -1626,8 +1611,8 @@ __device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *
         float a = 0.0f, b = 0.0f;
         for (int c = 0; c < p.C; c++) {
             const float go = p.g_out[(int64_t)g * p.C + c];
-            a += go * fc2_w[(int64_t)c * 2 * H + j];
-            b += go * fc2_w[(int64_t)c * 2 * H + H + j];
+            a += go * p.fc2_w[(int64_t)c * 2 * H + j];
+            b += go * p.fc2_w[(int64_t)c * 2 * H + H + j];
         }
         const uint64_t gg = (uint64_t)(p.goff + g);
         if (p.mask) {
@@ -1649,8 +1634,7 @@ __device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *
         const int m32 = tid >> 3, part = tid & 7, jw = H / 8;
         for (int m0 = 0; m0 < W; m0 += 32) {
             const int mem = m0 + m32;
-            const float4 *h4 = reinterpret_cast<const float4 *>(tl.hn ? tl.hn + min(mem, W - 1) * tl.pitch + part * jw
-                                                                      : p.hn + ((int64_t)g * W + min(mem, W - 1)) * H + part * jw);
+            const float4 *h4 = reinterpret_cast<const float4 *>(p.hn + ((int64_t)g * W + min(mem, W - 1)) * H + part * jw);
             float acc = 0.0f;
             for (int j = 0; j < jw / 4; j++) {
                 const float4 hv = h4[j];
@@ -1701,10 +1685,10 @@ __device__ __forceinline__ void pool_bwd_wg_body(const PoolBwdParams &p, float *
             if (j < H) {
                 float dh = cf * dp[j];
                 if (has_att) {
-                    dh += ds * att_w[j];
-                    gaw_h[i] += ds * (tl.hn ? tl.hn[mem * tl.pitch + j] : p.hn[s * H + j]);
-                    gaw_e[i] += ds * (tl.ego ? tl.ego[mem * tl.ego_pitch + j] : p.ego_tab[erow + j]);
-                    const float eg = ds * att_w[H + j];
+                    dh += ds * p.att_w[j];
+                    gaw_h[i] += ds * p.hn[s * H + j];
+                    gaw_e[i] += ds * p.ego_tab[erow + j];
+                    const float eg = ds * p.att_w[H + j];
                     if (one_row)
                         ego_acc[i] += eg;
                     else if (!p.det_ds)
@@ -1765,81 +1749,11 @@ struct PoolStepParams {
     float *gout;            // [S, C] d loss / d logits (read by the classifier's weight-gradient GEMM)
     float *lossg;           // [S] logsumexp - logit[target] per group
 };
-// STAGED: everything the three bodies read more than once goes to LDS first, all loads in flight at once -- the group's W
-// h_n rows, its members' ego rows (one row when they all share it -- the homo index plan -- else W rows if the launcher
-// left room, else they stay in global memory), the node's own projected row, the attention and classifier weights.  The
-// kernel is a chain of ~30 dependent phases (ego rows, scores, pooled sum, classifier, loss, backward dot products,
-// per-member terms); with a global load in every phase the chain, not the 40 KB a node reads, sets its time: 47 us for the
-// bodies back to back on global memory at the headline shape (profiles/r06_glue.txt).
-constexpr int POOL_STAGE_MAX = 10;      // float4 loads per thread and tile
-struct PoolStageLayout {
-    int hn, ego, att, fc2, xrow, total;     // offsets in floats (the bodies' scratch sits at 0, the members' ego row numbers below hn)
-};
-__host__ __device__ inline PoolStageLayout pool_stage_layout(int W, int H, int C, int ego_rows) {
-    PoolStageLayout l;
-    const int a = 2 * W + 6 * H, b = 4 * (2 * W + H) + 8 * H + 8 * W;
-    l.hn = ((a > b ? a : b) + W + 3) / 4 * 4;
-    l.ego = l.hn + W * (H + 4);
-    l.att = l.ego + ego_rows * (H + 4);
-    l.fc2 = l.att + 2 * H;
-    l.xrow = l.fc2 + C * 2 * H;
-    l.total = l.xrow + H;
-    return l;
-}
-template <int HI, bool STAGED>
-__global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p, int ego_rows) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    PoolTiles tl = NO_TILES;
-    if constexpr (STAGED) {
-        const int tid = threadIdx.x, W = p.f.W, H = p.f.H, H4 = H / 4, pitch = H + 4, g = blockIdx.x, C = p.f.C;
-        const PoolStageLayout L = pool_stage_layout(W, H, C, ego_rows);
-        int *st_erow = reinterpret_cast<int *>(lds + L.hn) - W;        // (just below the tiles, above the bodies' scratch)
-        float *th = lds + L.hn, *te = lds + L.ego, *ta = lds + L.att, *tf = lds + L.fc2, *tx = lds + L.xrow;
-        const bool has_ego = p.f.variant != PN_VARIANT_PAGG;
-        const int n4 = W * H4;
-        // (1) the loads that depend on nothing: h_n tile, weights, the members' ego row numbers, the node's own row number
-        float4 rh[POOL_STAGE_MAX];
-        const float4 *src = reinterpret_cast<const float4 *>(p.f.hn + (int64_t)g * W * H);       // the group's rows are contiguous
-#pragma unroll
-        for (int k = 0; k < POOL_STAGE_MAX; k++)
-            if (tid + 256 * k < n4) rh[k] = src[tid + 256 * k];
-        const int selrow = min(max(p.f.sel[g], 0), p.f.N - 1);
-        if (has_ego) {
-            for (int mem = tid; mem < W; mem += 256) st_erow[mem] = p.f.egoidx[(int64_t)g * W + mem];
-            for (int i = tid; i < 2 * H / 4; i += 256) reinterpret_cast<float4 *>(ta)[i] = reinterpret_cast<const float4 *>(p.f.att_w)[i];
-        }
-        for (int i = tid; i < C * 2 * H / 4; i += 256) reinterpret_cast<float4 *>(tf)[i] = reinterpret_cast<const float4 *>(p.f.fc2_w)[i];
-        __syncthreads();
-        // (2) the rows named by what just arrived: the members' ego rows, the node's own row
-        int same = 1;
-        if (has_ego)
-            for (int mem = tid; mem < W; mem += 256) same &= st_erow[mem] == st_erow[0];
-        const bool one_row = __syncthreads_and(same) != 0;
-        const bool ego_staged = has_ego && (one_row || ego_rows >= W);
-        const int ne4 = !ego_staged ? 0 : one_row ? H4 : n4;
-        float4 re[POOL_STAGE_MAX];
-#pragma unroll
-        for (int k = 0; k < POOL_STAGE_MAX; k++) {
-            const int i = tid + 256 * k;
-            if (i < ne4) re[k] = reinterpret_cast<const float4 *>(p.f.ego_tab + (int64_t)st_erow[i / H4] * H)[i % H4];
-        }
-        for (int i = tid; i < H4; i += 256)
-            reinterpret_cast<float4 *>(tx)[i] = reinterpret_cast<const float4 *>(p.f.Xh + (int64_t)selrow * H)[i];
-#pragma unroll
-        for (int k = 0; k < POOL_STAGE_MAX; k++) {
-            const int i = tid + 256 * k;
-            if (i < n4) *reinterpret_cast<float4 *>(th + (i / H4) * pitch + 4 * (i % H4)) = rh[k];
-        }
-#pragma unroll
-        for (int k = 0; k < POOL_STAGE_MAX; k++) {
-            const int i = tid + 256 * k;
-            if (i < ne4) *reinterpret_cast<float4 *>(te + (i / H4) * pitch + 4 * (i % H4)) = re[k];
-        }
-        tl = PoolTiles{th, ego_staged ? te : nullptr, pitch, one_row ? 0 : pitch, ta, tf, tx};
-        __syncthreads();
-    }
-    pool_fwd_body(p.f, lds, tl);
-    __syncthreads();            // (workgroup-scope fence: out[g, :] written above is visible below; the scratch is free again)
+template <int HI>
+__global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
+    extern __shared__ float lds[];
+    pool_fwd_body(p.f, lds);
+    __syncthreads();            // (workgroup-scope fence: out[g, :] written above is visible below; LDS is free again)
     if (threadIdx.x == 0) {     // the row's cross entropy exactly as cross_entropy_kernel computes it
         const int g = blockIdx.x, classes = p.f.C;
         const float *x = p.f.out + (int64_t)g * classes;
@@ -1854,7 +1768,304 @@ __global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p, int eg
         for (int c = 0; c < classes; c++) go[c] = (expf(x[c] - lse) - (c == t ? 1.0f : 0.0f)) * p.scale;
     }
     __syncthreads();
-    pool_bwd_wg_body<HI>(p.b, lds, tl);
+    pool_bwd_wg_body<HI>(p.b, lds);
+}
+// ---- the pooling kernels with everything in LDS ---------------------------------------------------------------------------
+// pool_fwd_kernel / pool_bwd_wg_kernel are chains of ~15 dependent phases each, and every phase waits for a global load
+// (the members' rows, the weights, the coefficients written a phase earlier): 22 us per kernel for 40 KB and 20 k multiply-
+// adds per node (profiles/r06_glue.txt).  Here a workgroup first pulls everything its node needs into LDS -- h_n rows, ego
+// row(s), the node's own projected row, attention / classifier weights; two dependent waits in all -- and the phases run on
+// LDS alone.  One template, three launches:
+//   <FWD>            pooling forward + classifier                       (pn_pagg_forward; replaces pool_fwd_kernel)
+//   <BWD>            pooling / attention backward                       (pn_pagg_backward; replaces pool_bwd_wg_kernel)
+//   <FWD, LOSS, BWD> both and the node's cross entropy in between        (pn_pagg_train_step; replaces three launches)
+// Default (atomic) mode, H <= 256; the launcher falls back to the kernels above when the tiles do not fit.
+// Reference: /root/reference/PathNet_run.py:196-210 / :266-277, :346 and autograd's backward of both.
+struct PoolLds {        // offsets in floats
+    int hn, ego, xrow, aw, fw, fb, l1, mk, dp, red, sc, coef, raw, dco, dsc, erow, lg, go, misc, total;
+};
+__host__ __device__ inline PoolLds pool_lds(int W, int H, int C, int ego_rows) {
+    PoolLds l;
+    int at = 0;
+    auto take = [&](int n) { const int o = at; at += (n + 3) / 4 * 4; return o; };
+    l.hn = take(W * H);
+    l.ego = take(ego_rows * H);
+    l.xrow = take(H);
+    l.aw = take(2 * H);
+    l.fw = take(C * 2 * H);
+    l.fb = take(C);
+    l.l1 = take(2 * H);
+    l.mk = take(2 * H);
+    l.dp = take(H);
+    l.red = take(8 * H);
+    l.sc = take(W);
+    l.coef = take(W);
+    l.raw = take(W);
+    l.dco = take(W);
+    l.dsc = take(W);
+    l.erow = take(W);
+    l.lg = take(C);
+    l.go = take(C);
+    l.misc = take(16);
+    l.total = at;
+    return l;
+}
+template <bool FWD, bool LOSS, bool BWD>
+__global__ __launch_bounds__(256) void pool_fast_kernel(PoolStepParams p, int ego_rows) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const PoolParams &f = p.f;          // (the launcher fills the fields the two structs share in both)
+    const PoolBwdParams &b = p.b;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.x;
+    const int W = f.W, H = f.H, C = f.C, H4 = H >> 2;
+    const PoolLds L = pool_lds(W, H, C, ego_rows);
+    float *hn = lds + L.hn, *ego = lds + L.ego, *xrow = lds + L.xrow, *aw = lds + L.aw, *fw = lds + L.fw, *fb = lds + L.fb;
+    float *l1 = lds + L.l1, *mk = lds + L.mk, *dp = lds + L.dp, *red = lds + L.red, *sc = lds + L.sc, *coef = lds + L.coef;
+    float *raw = lds + L.raw, *dco = lds + L.dco, *dsc = lds + L.dsc, *lg = lds + L.lg, *go = lds + L.go, *misc = lds + L.misc;
+    int *erow = reinterpret_cast<int *>(lds + L.erow);
+    const bool has_att = f.variant != PN_VARIANT_PAGG;
+    const float inv_w = 1.0f / (float)W;
+    const uint64_t gg = (uint64_t)(f.goff + g);
+
+    // ---- (A) loads that depend on nothing: four 16-byte loads per thread in flight at a time
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(f.hn + (int64_t)g * W * H);        // the group's rows are contiguous
+        float4 *dst = reinterpret_cast<float4 *>(hn);
+        const int n4 = W * H4;
+        for (int i0 = tid; i0 < n4; i0 += 1024) {
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+            if (i0 < n4) r0 = src[i0];
+            if (i0 + 256 < n4) r1 = src[i0 + 256];
+            if (i0 + 512 < n4) r2 = src[i0 + 512];
+            if (i0 + 768 < n4) r3 = src[i0 + 768];
+            if (i0 < n4) dst[i0] = r0;
+            if (i0 + 256 < n4) dst[i0 + 256] = r1;
+            if (i0 + 512 < n4) dst[i0 + 512] = r2;
+            if (i0 + 768 < n4) dst[i0 + 768] = r3;
+        }
+    }
+    int selrow = 0;
+    if (FWD) selrow = min(max(f.sel[g], 0), f.N - 1);
+    if (has_att) {
+        for (int m = tid; m < W; m += 256) erow[m] = f.egoidx[(int64_t)g * W + m];
+        for (int i = tid; i < 2 * H4; i += 256) reinterpret_cast<float4 *>(aw)[i] = reinterpret_cast<const float4 *>(f.att_w)[i];
+    }
+    for (int i = tid; i < C * 2 * H4; i += 256) reinterpret_cast<float4 *>(fw)[i] = reinterpret_cast<const float4 *>(f.fc2_w)[i];
+    if (FWD)
+        for (int c = tid; c < C; c += 256) fb[c] = f.fc2_b[c];
+    if (FWD && has_att && tid == 0) misc[0] = f.att_b[0];
+    if (BWD && !FWD) {
+        for (int m = tid; m < W; m += 256) {
+            coef[m] = b.coef[(int64_t)g * W + m];
+            if (f.variant == PN_VARIANT_HETERO) raw[m] = b.rawsc[(int64_t)g * W + m];
+        }
+        for (int c = tid; c < C; c += 256) go[c] = b.g_out[(int64_t)g * C + c];
+    }
+    __syncthreads();
+    // ---- (B) the rows named by what just arrived
+    int same = 1;
+    if (has_att)
+        for (int m = tid; m < W; m += 256) same &= erow[m] == erow[0];
+    const bool one_row = __syncthreads_and(same) != 0;
+    const bool ego_lds = has_att && (one_row || ego_rows >= W);
+    if (ego_lds) {
+        const int n4 = one_row ? H4 : W * H4;
+        for (int i = tid; i < n4; i += 256)
+            reinterpret_cast<float4 *>(ego)[i] = reinterpret_cast<const float4 *>(f.ego_tab + (int64_t)erow[i / H4] * H)[i % H4];
+    }
+    if (FWD)
+        for (int i = tid; i < H4; i += 256)
+            reinterpret_cast<float4 *>(xrow)[i] = reinterpret_cast<const float4 *>(f.Xh + (int64_t)selrow * H)[i];
+    __syncthreads();
+    const int ego_pitch = one_row ? 0 : H;
+    auto ego_at = [&](int m, int j) -> float {
+        return ego_lds ? ego[m * ego_pitch + j] : f.ego_tab[(int64_t)erow[m] * H + j];
+    };
+
+    if (FWD) {
+        // ---- scores: a wave per member, lanes over the columns
+        if (has_att) {
+            const float ab = misc[0];
+            for (int m = wave; m < W; m += 4) {
+                float acc = 0.0f;
+                for (int j = lane; j < H; j += 64) acc += hn[m * H + j] * aw[j] + ego_at(m, j) * aw[H + j];
+                acc = wave_sum(acc);
+                if (lane == 0) {
+                    sc[m] = acc + ab;
+                    f.rawsc[(int64_t)g * W + m] = acc + ab;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- pooling coefficients
+        if (f.variant == PN_VARIANT_HETERO) {       // softmax over the members of LeakyReLU(score); every wave the same sums
+            float mx = -3.4e38f;
+            for (int m = lane; m < W; m += 64) {
+                float v = sc[m];
+                v = v > 0.0f ? v : 0.01f * v;
+                mx = fmaxf(mx, v);
+            }
+            mx = wave_max(mx);
+            float sum = 0.0f;
+            for (int m = lane; m < W; m += 64) {
+                float v = sc[m];
+                v = v > 0.0f ? v : 0.01f * v;
+                sum += expf(v - mx);
+            }
+            sum = wave_sum(sum);
+            for (int m = tid; m < W; m += 256) {
+                float v = sc[m];
+                raw[m] = v;
+                v = v > 0.0f ? v : 0.01f * v;
+                coef[m] = expf(v - mx) / sum;
+            }
+        } else {
+            for (int m = tid; m < W; m += 256) coef[m] = f.variant == PN_VARIANT_HOMO ? 1.0f + sc[m] : 1.0f;
+        }
+        __syncthreads();
+        for (int m = tid; m < W; m += 256) f.coef[(int64_t)g * W + m] = coef[m];
+        // ---- layer1 = dropout([Xh[sel[g]] ; mean_w coef_w h_w])
+        for (int j = tid; j < 2 * H; j += 256) {
+            float v;
+            if (j < H) {
+                v = xrow[j];
+            } else {
+                float acc = 0.0f;
+                for (int m = 0; m < W; m++) acc += coef[m] * hn[m * H + (j - H)];
+                v = acc * inv_w;
+            }
+            float mf = 1.0f;
+            if (f.mask)
+                mf = f.mask[gg * 2 * H + j];
+            else if (f.p_drop > 0.0f)
+                mf = dropout1(f.dyn ? f.dyn->seed : f.seed, gg * 2 * H + j, 2u, f.p_drop);
+            v *= mf;
+            mk[j] = mf;
+            l1[j] = v;
+            f.layer1[(int64_t)g * 2 * H + j] = v;
+        }
+        __syncthreads();
+        // ---- classifier
+        for (int c = wave; c < C; c += 4) {
+            float part = 0.0f;
+            for (int j = lane; j < 2 * H; j += 64) part += l1[j] * fw[c * 2 * H + j];
+            part = wave_sum(part);
+            if (lane == 0) {
+                lg[c] = part + fb[c];
+                f.out[(int64_t)g * C + c] = part + fb[c];
+            }
+        }
+        __syncthreads();
+    } else if (BWD) {
+        // the classifier input's dropout factors again (the forward launch drew the same ones)
+        for (int j = tid; j < 2 * H; j += 256) {
+            float mf = 1.0f;
+            if (f.mask)
+                mf = f.mask[gg * 2 * H + j];
+            else if (f.p_drop > 0.0f)
+                mf = dropout1(f.dyn ? f.dyn->seed : f.seed, gg * 2 * H + j, 2u, f.p_drop);
+            mk[j] = mf;
+        }
+    }
+    if (LOSS) {
+        // ---- softmax cross entropy of the node's C logits (wave 0, a lane per class; C > 64: strided)
+        if (wave == 0) {
+            float m = -3.4e38f;
+            for (int c = lane; c < C; c += 64) m = fmaxf(m, lg[c]);
+            m = wave_max(m);
+            float sum = 0.0f;
+            for (int c = lane; c < C; c += 64) sum += expf(lg[c] - m);
+            sum = wave_sum(sum);
+            const float lse = m + logf(sum);
+            const int t = (int)p.target[g];
+            if (lane == 0) p.lossg[g] = lse - lg[t];
+            for (int c = lane; c < C; c += 64) {
+                const float gv = (expf(lg[c] - lse) - (c == t ? 1.0f : 0.0f)) * p.scale;
+                go[c] = gv;
+                p.gout[(int64_t)g * C + c] = gv;
+            }
+        }
+    }
+    if (!BWD) return;
+    __syncthreads();
+    // ---- d layer1 = g_out . fc2_w, masked: the ego half goes to the node's row of d Xh, the pooled half to the members
+    for (int j = tid; j < 2 * H; j += 256) {
+        float acc = 0.0f;
+        for (int c = 0; c < C; c++) acc += go[c] * fw[c * 2 * H + j];
+        acc *= mk[j];
+        if (j < H)
+            atomicAdd(&b.dXh[(int64_t)min(max(b.sel[g], 0), b.N - 1) * H + j], acc);
+        else
+            dp[j - H] = acc * inv_w;
+    }
+    __syncthreads();
+    // ---- d coef[m] = h_m . d pooled / W
+    for (int m = wave; m < W; m += 4) {
+        float acc = 0.0f;
+        for (int j = lane; j < H; j += 64) acc += hn[m * H + j] * dp[j];
+        acc = wave_sum(acc);
+        if (lane == 0) dco[m] = acc;
+    }
+    __syncthreads();
+    if (f.variant == PN_VARIANT_HETERO) {
+        float tot = 0.0f;
+        for (int m = lane; m < W; m += 64) tot += coef[m] * dco[m];
+        tot = wave_sum(tot);
+        for (int m = tid; m < W; m += 256) dsc[m] = coef[m] * (dco[m] - tot) * (raw[m] > 0.0f ? 1.0f : 0.01f);
+    } else {
+        for (int m = tid; m < W; m += 256) dsc[m] = f.variant == PN_VARIANT_HOMO ? dco[m] : 0.0f;
+    }
+    __syncthreads();
+    // ---- per member: d h_n, the attention-weight terms, the attention-ego term; wave w takes members w, w + 4, ...
+    float gaw_h[4], gaw_e[4], ego_acc[4], gab = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) gaw_h[i] = gaw_e[i] = ego_acc[i] = 0.0f;
+    for (int m = wave; m < W; m += 4) {
+        const float ds = dsc[m], cf = coef[m];
+        const int64_t s = (int64_t)g * W + m;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = lane + 64 * i;
+            if (j < H) {
+                float dh = cf * dp[j];
+                if (has_att) {
+                    dh += ds * aw[j];
+                    gaw_h[i] += ds * hn[m * H + j];
+                    gaw_e[i] += ds * ego_at(m, j);
+                    const float eg = ds * aw[H + j];
+                    if (one_row)
+                        ego_acc[i] += eg;
+                    else
+                        atomicAdd(&b.dego[(int64_t)erow[m] * H + j], eg);
+                }
+                b.dhn[s * H + j] = dh;
+            }
+        }
+        gab += ds;
+    }
+    if (!has_att) return;       // block-uniform
+    if (one_row) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = lane + 64 * i;
+            if (j < H) red[wave * H + j] = ego_acc[i];
+        }
+        __syncthreads();
+        const int64_t e0 = (int64_t)erow[0] * H;
+        for (int j = tid; j < H; j += 256) atomicAdd(&b.dego[e0 + j], (red[j] + red[H + j]) + (red[2 * H + j] + red[3 * H + j]));
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int j = lane + 64 * i;
+        if (j < H) {
+            red[wave * 2 * H + j] = gaw_h[i];
+            red[wave * 2 * H + H + j] = gaw_e[i];
+        }
+    }
+    __syncthreads();
+    float *out = b.det_att + (int64_t)blockIdx.x * (2 * H + 4);
+    for (int j = tid; j < 2 * H; j += 256) out[j] = red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j];
+    if (lane == 0) out[2 * H + wave] = gab;
 }
 // loss[0] (+)= scale * sum of the rows' terms, in cross_entropy_kernel's order (one workgroup of 1024 threads)
 __global__ __launch_bounds__(1024) void loss_sum_kernel(const float *__restrict__ lossg, int rows, float scale,
@@ -3269,6 +3480,22 @@ int run_seq_fwd(const Call &c, int b, bool save) {
                                  : dispatch_seq_fwd<1>(c.ctx, c.stream, d.H, sp);
 }
 
+// picks the ego rows a launch stages (the hetero class's members have rows of their own) and the launch's LDS; false when
+// the tiles do not fit -- the caller then runs the kernels that read global memory
+inline bool pool_fast_plan(const Dims &d, int *ego_rows, size_t *lds_bytes) {
+    if (d.H > 256 || d.H % 4) return false;
+    int er = d.variant == PN_VARIANT_HETERO ? d.W : 1;
+    size_t bytes = (size_t)pool_lds(d.W, d.H, d.C, er).total * sizeof(float);
+    if (bytes > 96 * 1024 && er > 1) {
+        er = 1;
+        bytes = (size_t)pool_lds(d.W, d.H, d.C, er).total * sizeof(float);
+    }
+    if (bytes > 96 * 1024) return false;
+    *ego_rows = er;
+    *lds_bytes = bytes;
+    return true;
+}
+
 PoolParams pool_fwd_params(const Call &c, int b, float *out) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
@@ -3304,6 +3531,17 @@ inline size_t pool_fwd_lds_bytes(const Dims &d) { return (size_t)(2 * d.W + 6 * 
 int run_pool_fwd(const Call &c, int b, float *out) {
     const PoolParams pp = pool_fwd_params(c, b, out);
     StageTimer tm(c.ctx, ST_POOL_FWD, c.stream);
+    int ego_rows = 0;
+    size_t lds_fast = 0;
+    if (!c.d.det && knobs_of(c.ctx).pool_fast != 0 && pool_fast_plan(c.d, &ego_rows, &lds_fast)) {
+        PoolStepParams ps{};        // the forward with its node's rows and weights staged in LDS (pool_fast_kernel)
+        ps.f = pp;
+        auto kern = pool_fast_kernel<true, false, false>;
+        if (int rc = ensure_dynamic_lds(c.ctx, reinterpret_cast<const void *>(kern), (int)lds_fast)) return rc;
+        hipLaunchKernelGGL(kern, dim3(pp.S), dim3(256), lds_fast, c.stream, ps, ego_rows);
+        PN_CHECK_HIP(hipGetLastError());
+        return PN_OK;
+    }
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(pp.S), dim3(256), pool_fwd_lds_bytes(c.d), c.stream, pp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
@@ -3914,22 +4152,20 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 ps.gout = c.at<float>(c.w.gout);
                 ps.lossg = c.at<float>(c.w.outb);       // (the fused step's logits go to the caller: the slot is free)
                 const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d));
-                // the staged kernel: tiles + weights within 64 KB of LDS; the hetero class's members have ego rows of their own
-                // (W rows staged if they fit as well), the homo / PAGG plans one row per node
-                int ego_rows = d.variant == PN_VARIANT_HETERO ? d.W : 1;
-                if (ego_rows > 1 && (size_t)pool_stage_layout(d.W, H, d.C, ego_rows).total * 4 > 65536) ego_rows = 1;
-                const size_t lds_staged = (size_t)pool_stage_layout(d.W, H, d.C, ego_rows).total * sizeof(float);
-                const bool staged = H <= 256 && lds_staged <= 65536 && (size_t)d.W * (H / 4) <= 256 * (size_t)POOL_STAGE_MAX &&
-                                    knobs_of(ctx).pool_step != 2;
+                int ego_rows = 0;
+                size_t lds_fast = 0;
+                const bool fast = knobs_of(ctx).pool_fast != 0 && pool_fast_plan(d, &ego_rows, &lds_fast);
                 {
                     StageTimer tm(ctx, ST_POOL_FWD, stream);
-                    if (staged) {
-                        hipLaunchKernelGGL((pool_step_kernel<4, true>), dim3(Sb), dim3(256), lds_staged, stream, ps, ego_rows);
+                    if (fast) {         // everything a node needs staged in LDS (pool_fast_kernel)
+                        auto kern = pool_fast_kernel<true, true, true>;
+                        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_fast)) return rc;
+                        hipLaunchKernelGGL(kern, dim3(Sb), dim3(256), lds_fast, stream, ps, ego_rows);
                     } else if (H <= 256) {
-                        hipLaunchKernelGGL((pool_step_kernel<4, false>), dim3(Sb), dim3(256), lds_step, stream, ps, 0);
+                        hipLaunchKernelGGL(pool_step_kernel<4>, dim3(Sb), dim3(256), lds_step, stream, ps);
                     } else {
-                        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16, false>), (int)lds_step)) return rc;
-                        hipLaunchKernelGGL((pool_step_kernel<16, false>), dim3(Sb), dim3(256), lds_step, stream, ps, 0);
+                        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16>), (int)lds_step)) return rc;
+                        hipLaunchKernelGGL(pool_step_kernel<16>, dim3(Sb), dim3(256), lds_step, stream, ps);
                     }
                     PN_CHECK_HIP(hipGetLastError());
                 }
@@ -3937,7 +4173,17 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                     if (int rc = run_fc2_grad()) return rc;
             }
             StageTimer tm(ctx, ST_POOL_BWD, stream);
+            int ego_rows_b = 0;
+            size_t lds_fast_b = 0;
             if (pool_step) {
+            } else if (wg && !d.det && knobs_of(ctx).pool_fast != 0 && pool_fast_plan(d, &ego_rows_b, &lds_fast_b)) {
+                att_blocks = Sb;        // the backward with its node's rows and weights staged in LDS (pool_fast_kernel)
+                PoolStepParams ps{};
+                ps.f = pool_fwd_params(c, b, nullptr);      // (the fields the two structs share; nothing of the forward is written)
+                ps.b = pp;
+                auto kern = pool_fast_kernel<false, false, true>;
+                if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_fast_b)) return rc;
+                hipLaunchKernelGGL(kern, dim3(Sb), dim3(256), lds_fast_b, stream, ps, ego_rows_b);
             } else if (wg) {
                 att_blocks = Sb;
                 if (H <= 256) {
