@@ -52,7 +52,6 @@ struct Knobs {
     int eval_zw = 1;            // PN_EVAL_ZW: inference forwards apply W_ih to the bank rows before the gather
     int pool_bwd_wg = 1;        // PN_POOL_BWD_WG: pooling backward as a workgroup per node
     int zero_early = 1;         // PN_ZERO_EARLY: pn_pagg_train_step zero-fills the backward's accumulators on the second stream, under fc0 / bank
-    int pool_fast = 1;          // PN_POOL_FAST: the pooling kernels that stage a node's rows and weights in LDS (0: the ones that read global memory)
     int pool_step = 1;          // PN_POOL_STEP: pn_pagg_train_step runs pooling forward, loss and pooling backward of a node in one launch
     int node_rgrad = 1;         // PN_NODE_RGRAD: row-reduction kernel for the node-level weight gradients of large graphs
     int sampler_stage = -1;     // PN_SAMPLER_STAGE: first-hop tables in LDS (-1: by launch size)

@@ -1770,303 +1770,6 @@ __global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
     __syncthreads();
     pool_bwd_wg_body<HI>(p.b, lds);
 }
-// ---- the pooling kernels with everything in LDS ---------------------------------------------------------------------------
-// pool_fwd_kernel / pool_bwd_wg_kernel are chains of ~15 dependent phases each, and every phase waits for a global load
-// (the members' rows, the weights, the coefficients written a phase earlier): 22 us per kernel for 40 KB and 20 k multiply-
-// adds per node (profiles/r06_glue.txt).  Here a workgroup first pulls everything its node needs into LDS -- h_n rows, ego
-// row(s), the node's own projected row, attention / classifier weights; two dependent waits in all -- and the phases run on
-// LDS alone.  One template, three launches:
-//   <FWD>            pooling forward + classifier                       (pn_pagg_forward; replaces pool_fwd_kernel)
-//   <BWD>            pooling / attention backward                       (pn_pagg_backward; replaces pool_bwd_wg_kernel)
-//   <FWD, LOSS, BWD> both and the node's cross entropy in between        (pn_pagg_train_step; replaces three launches)
-// Default (atomic) mode, H <= 256; the launcher falls back to the kernels above when the tiles do not fit.
-// Reference: /root/reference/PathNet_run.py:196-210 / :266-277, :346 and autograd's backward of both.
-struct PoolLds {        // offsets in floats
-    int hn, ego, xrow, aw, fw, fb, l1, mk, dp, red, sc, coef, raw, dco, dsc, erow, lg, go, misc, total;
-};
-__host__ __device__ inline PoolLds pool_lds(int W, int H, int C, int ego_rows) {
-    PoolLds l;
-    int at = 0;
-    auto take = [&](int n) { const int o = at; at += (n + 3) / 4 * 4; return o; };
-    l.hn = take(W * H);
-    l.ego = take(ego_rows * H);
-    l.xrow = take(H);
-    l.aw = take(2 * H);
-    l.fw = take(C * 2 * H);
-    l.fb = take(C);
-    l.l1 = take(2 * H);
-    l.mk = take(2 * H);
-    l.dp = take(H);
-    l.red = take(8 * H);
-    l.sc = take(W);
-    l.coef = take(W);
-    l.raw = take(W);
-    l.dco = take(W);
-    l.dsc = take(W);
-    l.erow = take(W);
-    l.lg = take(C);
-    l.go = take(C);
-    l.misc = take(16);
-    l.total = at;
-    return l;
-}
-template <bool FWD, bool LOSS, bool BWD>
-__global__ __launch_bounds__(256) void pool_fast_kernel(PoolStepParams p, int ego_rows) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const PoolParams &f = p.f;          // (the launcher fills the fields the two structs share in both)
-    const PoolBwdParams &b = p.b;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.x;
-    const int W = f.W, H = f.H, C = f.C, H4 = H >> 2;
-    const PoolLds L = pool_lds(W, H, C, ego_rows);
-    float *hn = lds + L.hn, *ego = lds + L.ego, *xrow = lds + L.xrow, *aw = lds + L.aw, *fw = lds + L.fw, *fb = lds + L.fb;
-    float *l1 = lds + L.l1, *mk = lds + L.mk, *dp = lds + L.dp, *red = lds + L.red, *sc = lds + L.sc, *coef = lds + L.coef;
-    float *raw = lds + L.raw, *dco = lds + L.dco, *dsc = lds + L.dsc, *lg = lds + L.lg, *go = lds + L.go, *misc = lds + L.misc;
-    int *erow = reinterpret_cast<int *>(lds + L.erow);
-    const bool has_att = f.variant != PN_VARIANT_PAGG;
-    const float inv_w = 1.0f / (float)W;
-    const uint64_t gg = (uint64_t)(f.goff + g);
-
-    // ---- (A) loads that depend on nothing: four 16-byte loads per thread in flight at a time
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(f.hn + (int64_t)g * W * H);        // the group's rows are contiguous
-        float4 *dst = reinterpret_cast<float4 *>(hn);
-        const int n4 = W * H4;
-        for (int i0 = tid; i0 < n4; i0 += 1024) {
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-            if (i0 < n4) r0 = src[i0];
-            if (i0 + 256 < n4) r1 = src[i0 + 256];
-            if (i0 + 512 < n4) r2 = src[i0 + 512];
-            if (i0 + 768 < n4) r3 = src[i0 + 768];
-            if (i0 < n4) dst[i0] = r0;
-            if (i0 + 256 < n4) dst[i0 + 256] = r1;
-            if (i0 + 512 < n4) dst[i0 + 512] = r2;
-            if (i0 + 768 < n4) dst[i0 + 768] = r3;
-        }
-    }
-    int selrow = 0;
-    if (FWD) selrow = min(max(f.sel[g], 0), f.N - 1);
-    if (has_att) {
-        for (int m = tid; m < W; m += 256) erow[m] = f.egoidx[(int64_t)g * W + m];
-        for (int i = tid; i < 2 * H4; i += 256) reinterpret_cast<float4 *>(aw)[i] = reinterpret_cast<const float4 *>(f.att_w)[i];
-    }
-    for (int i = tid; i < C * 2 * H4; i += 256) reinterpret_cast<float4 *>(fw)[i] = reinterpret_cast<const float4 *>(f.fc2_w)[i];
-    if (FWD)
-        for (int c = tid; c < C; c += 256) fb[c] = f.fc2_b[c];
-    if (FWD && has_att && tid == 0) misc[0] = f.att_b[0];
-    if (BWD && !FWD) {
-        for (int m = tid; m < W; m += 256) {
-            coef[m] = b.coef[(int64_t)g * W + m];
-            if (f.variant == PN_VARIANT_HETERO) raw[m] = b.rawsc[(int64_t)g * W + m];
-        }
-        for (int c = tid; c < C; c += 256) go[c] = b.g_out[(int64_t)g * C + c];
-    }
-    __syncthreads();
-    // ---- (B) the rows named by what just arrived
-    int same = 1;
-    if (has_att)
-        for (int m = tid; m < W; m += 256) same &= erow[m] == erow[0];
-    const bool one_row = __syncthreads_and(same) != 0;
-    const bool ego_lds = has_att && (one_row || ego_rows >= W);
-    if (ego_lds) {
-        const int n4 = one_row ? H4 : W * H4;
-        for (int i = tid; i < n4; i += 256)
-            reinterpret_cast<float4 *>(ego)[i] = reinterpret_cast<const float4 *>(f.ego_tab + (int64_t)erow[i / H4] * H)[i % H4];
-    }
-    if (FWD)
-        for (int i = tid; i < H4; i += 256)
-            reinterpret_cast<float4 *>(xrow)[i] = reinterpret_cast<const float4 *>(f.Xh + (int64_t)selrow * H)[i];
-    __syncthreads();
-    const int ego_pitch = one_row ? 0 : H;
-    auto ego_at = [&](int m, int j) -> float {
-        return ego_lds ? ego[m * ego_pitch + j] : f.ego_tab[(int64_t)erow[m] * H + j];
-    };
-
-    if (FWD) {
-        // ---- scores: a wave per member, lanes over the columns
-        if (has_att) {
-            const float ab = misc[0];
-            for (int m = wave; m < W; m += 4) {
-                float acc = 0.0f;
-                for (int j = lane; j < H; j += 64) acc += hn[m * H + j] * aw[j] + ego_at(m, j) * aw[H + j];
-                acc = wave_sum(acc);
-                if (lane == 0) {
-                    sc[m] = acc + ab;
-                    f.rawsc[(int64_t)g * W + m] = acc + ab;
-                }
-            }
-            __syncthreads();
-        }
-        // ---- pooling coefficients
-        if (f.variant == PN_VARIANT_HETERO) {       // softmax over the members of LeakyReLU(score); every wave the same sums
-            float mx = -3.4e38f;
-            for (int m = lane; m < W; m += 64) {
-                float v = sc[m];
-                v = v > 0.0f ? v : 0.01f * v;
-                mx = fmaxf(mx, v);
-            }
-            mx = wave_max(mx);
-            float sum = 0.0f;
-            for (int m = lane; m < W; m += 64) {
-                float v = sc[m];
-                v = v > 0.0f ? v : 0.01f * v;
-                sum += expf(v - mx);
-            }
-            sum = wave_sum(sum);
-            for (int m = tid; m < W; m += 256) {
-                float v = sc[m];
-                raw[m] = v;
-                v = v > 0.0f ? v : 0.01f * v;
-                coef[m] = expf(v - mx) / sum;
-            }
-        } else {
-            for (int m = tid; m < W; m += 256) coef[m] = f.variant == PN_VARIANT_HOMO ? 1.0f + sc[m] : 1.0f;
-        }
-        __syncthreads();
-        for (int m = tid; m < W; m += 256) f.coef[(int64_t)g * W + m] = coef[m];
-        // ---- layer1 = dropout([Xh[sel[g]] ; mean_w coef_w h_w])
-        for (int j = tid; j < 2 * H; j += 256) {
-            float v;
-            if (j < H) {
-                v = xrow[j];
-            } else {
-                float acc = 0.0f;
-                for (int m = 0; m < W; m++) acc += coef[m] * hn[m * H + (j - H)];
-                v = acc * inv_w;
-            }
-            float mf = 1.0f;
-            if (f.mask)
-                mf = f.mask[gg * 2 * H + j];
-            else if (f.p_drop > 0.0f)
-                mf = dropout1(f.dyn ? f.dyn->seed : f.seed, gg * 2 * H + j, 2u, f.p_drop);
-            v *= mf;
-            mk[j] = mf;
-            l1[j] = v;
-            f.layer1[(int64_t)g * 2 * H + j] = v;
-        }
-        __syncthreads();
-        // ---- classifier
-        for (int c = wave; c < C; c += 4) {
-            float part = 0.0f;
-            for (int j = lane; j < 2 * H; j += 64) part += l1[j] * fw[c * 2 * H + j];
-            part = wave_sum(part);
-            if (lane == 0) {
-                lg[c] = part + fb[c];
-                f.out[(int64_t)g * C + c] = part + fb[c];
-            }
-        }
-        __syncthreads();
-    } else if (BWD) {
-        // the classifier input's dropout factors again (the forward launch drew the same ones)
-        for (int j = tid; j < 2 * H; j += 256) {
-            float mf = 1.0f;
-            if (f.mask)
-                mf = f.mask[gg * 2 * H + j];
-            else if (f.p_drop > 0.0f)
-                mf = dropout1(f.dyn ? f.dyn->seed : f.seed, gg * 2 * H + j, 2u, f.p_drop);
-            mk[j] = mf;
-        }
-    }
-    if (LOSS) {
-        // ---- softmax cross entropy of the node's C logits (wave 0, a lane per class; C > 64: strided)
-        if (wave == 0) {
-            float m = -3.4e38f;
-            for (int c = lane; c < C; c += 64) m = fmaxf(m, lg[c]);
-            m = wave_max(m);
-            float sum = 0.0f;
-            for (int c = lane; c < C; c += 64) sum += expf(lg[c] - m);
-            sum = wave_sum(sum);
-            const float lse = m + logf(sum);
-            const int t = (int)p.target[g];
-            if (lane == 0) p.lossg[g] = lse - lg[t];
-            for (int c = lane; c < C; c += 64) {
-                const float gv = (expf(lg[c] - lse) - (c == t ? 1.0f : 0.0f)) * p.scale;
-                go[c] = gv;
-                p.gout[(int64_t)g * C + c] = gv;
-            }
-        }
-    }
-    if (!BWD) return;
-    __syncthreads();
-    // ---- d layer1 = g_out . fc2_w, masked: the ego half goes to the node's row of d Xh, the pooled half to the members
-    for (int j = tid; j < 2 * H; j += 256) {
-        float acc = 0.0f;
-        for (int c = 0; c < C; c++) acc += go[c] * fw[c * 2 * H + j];
-        acc *= mk[j];
-        if (j < H)
-            atomicAdd(&b.dXh[(int64_t)min(max(b.sel[g], 0), b.N - 1) * H + j], acc);
-        else
-            dp[j - H] = acc * inv_w;
-    }
-    __syncthreads();
-    // ---- d coef[m] = h_m . d pooled / W
-    for (int m = wave; m < W; m += 4) {
-        float acc = 0.0f;
-        for (int j = lane; j < H; j += 64) acc += hn[m * H + j] * dp[j];
-        acc = wave_sum(acc);
-        if (lane == 0) dco[m] = acc;
-    }
-    __syncthreads();
-    if (f.variant == PN_VARIANT_HETERO) {
-        float tot = 0.0f;
-        for (int m = lane; m < W; m += 64) tot += coef[m] * dco[m];
-        tot = wave_sum(tot);
-        for (int m = tid; m < W; m += 256) dsc[m] = coef[m] * (dco[m] - tot) * (raw[m] > 0.0f ? 1.0f : 0.01f);
-    } else {
-        for (int m = tid; m < W; m += 256) dsc[m] = f.variant == PN_VARIANT_HOMO ? dco[m] : 0.0f;
-    }
-    __syncthreads();
-    // ---- per member: d h_n, the attention-weight terms, the attention-ego term; wave w takes members w, w + 4, ...
-    float gaw_h[4], gaw_e[4], ego_acc[4], gab = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; i++) gaw_h[i] = gaw_e[i] = ego_acc[i] = 0.0f;
-    for (int m = wave; m < W; m += 4) {
-        const float ds = dsc[m], cf = coef[m];
-        const int64_t s = (int64_t)g * W + m;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int j = lane + 64 * i;
-            if (j < H) {
-                float dh = cf * dp[j];
-                if (has_att) {
-                    dh += ds * aw[j];
-                    gaw_h[i] += ds * hn[m * H + j];
-                    gaw_e[i] += ds * ego_at(m, j);
-                    const float eg = ds * aw[H + j];
-                    if (one_row)
-                        ego_acc[i] += eg;
-                    else
-                        atomicAdd(&b.dego[(int64_t)erow[m] * H + j], eg);
-                }
-                b.dhn[s * H + j] = dh;
-            }
-        }
-        gab += ds;
-    }
-    if (!has_att) return;       // block-uniform
-    if (one_row) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int j = lane + 64 * i;
-            if (j < H) red[wave * H + j] = ego_acc[i];
-        }
-        __syncthreads();
-        const int64_t e0 = (int64_t)erow[0] * H;
-        for (int j = tid; j < H; j += 256) atomicAdd(&b.dego[e0 + j], (red[j] + red[H + j]) + (red[2 * H + j] + red[3 * H + j]));
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int j = lane + 64 * i;
-        if (j < H) {
-            red[wave * 2 * H + j] = gaw_h[i];
-            red[wave * 2 * H + H + j] = gaw_e[i];
-        }
-    }
-    __syncthreads();
-    float *out = b.det_att + (int64_t)blockIdx.x * (2 * H + 4);
-    for (int j = tid; j < 2 * H; j += 256) out[j] = red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j];
-    if (lane == 0) out[2 * H + wave] = gab;
-}
 // loss[0] (+)= scale * sum of the rows' terms, in cross_entropy_kernel's order (one workgroup of 1024 threads)
 __global__ __launch_bounds__(1024) void loss_sum_kernel(const float *__restrict__ lossg, int rows, float scale,
                                                         float *__restrict__ loss, int store) {
@@ -3480,22 +3183,6 @@ int run_seq_fwd(const Call &c, int b, bool save) {
                                  : dispatch_seq_fwd<1>(c.ctx, c.stream, d.H, sp);
 }
 
-// picks the ego rows a launch stages (the hetero class's members have rows of their own) and the launch's LDS; false when
-// the tiles do not fit -- the caller then runs the kernels that read global memory
-inline bool pool_fast_plan(const Dims &d, int *ego_rows, size_t *lds_bytes) {
-    if (d.H > 256 || d.H % 4) return false;
-    int er = d.variant == PN_VARIANT_HETERO ? d.W : 1;
-    size_t bytes = (size_t)pool_lds(d.W, d.H, d.C, er).total * sizeof(float);
-    if (bytes > 96 * 1024 && er > 1) {
-        er = 1;
-        bytes = (size_t)pool_lds(d.W, d.H, d.C, er).total * sizeof(float);
-    }
-    if (bytes > 96 * 1024) return false;
-    *ego_rows = er;
-    *lds_bytes = bytes;
-    return true;
-}
-
 PoolParams pool_fwd_params(const Call &c, int b, float *out) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
@@ -3531,17 +3218,6 @@ inline size_t pool_fwd_lds_bytes(const Dims &d) { return (size_t)(2 * d.W + 6 * 
 int run_pool_fwd(const Call &c, int b, float *out) {
     const PoolParams pp = pool_fwd_params(c, b, out);
     StageTimer tm(c.ctx, ST_POOL_FWD, c.stream);
-    int ego_rows = 0;
-    size_t lds_fast = 0;
-    if (!c.d.det && knobs_of(c.ctx).pool_fast != 0 && pool_fast_plan(c.d, &ego_rows, &lds_fast)) {
-        PoolStepParams ps{};        // the forward with its node's rows and weights staged in LDS (pool_fast_kernel)
-        ps.f = pp;
-        auto kern = pool_fast_kernel<true, false, false>;
-        if (int rc = ensure_dynamic_lds(c.ctx, reinterpret_cast<const void *>(kern), (int)lds_fast)) return rc;
-        hipLaunchKernelGGL(kern, dim3(pp.S), dim3(256), lds_fast, c.stream, ps, ego_rows);
-        PN_CHECK_HIP(hipGetLastError());
-        return PN_OK;
-    }
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(pp.S), dim3(256), pool_fwd_lds_bytes(c.d), c.stream, pp);
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
@@ -4152,16 +3828,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 ps.gout = c.at<float>(c.w.gout);
                 ps.lossg = c.at<float>(c.w.outb);       // (the fused step's logits go to the caller: the slot is free)
                 const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d));
-                int ego_rows = 0;
-                size_t lds_fast = 0;
-                const bool fast = knobs_of(ctx).pool_fast != 0 && pool_fast_plan(d, &ego_rows, &lds_fast);
                 {
                     StageTimer tm(ctx, ST_POOL_FWD, stream);
-                    if (fast) {         // everything a node needs staged in LDS (pool_fast_kernel)
-                        auto kern = pool_fast_kernel<true, true, true>;
-                        if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_fast)) return rc;
-                        hipLaunchKernelGGL(kern, dim3(Sb), dim3(256), lds_fast, stream, ps, ego_rows);
-                    } else if (H <= 256) {
+                    if (H <= 256) {
                         hipLaunchKernelGGL(pool_step_kernel<4>, dim3(Sb), dim3(256), lds_step, stream, ps);
                     } else {
                         if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16>), (int)lds_step)) return rc;
@@ -4173,17 +3842,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                     if (int rc = run_fc2_grad()) return rc;
             }
             StageTimer tm(ctx, ST_POOL_BWD, stream);
-            int ego_rows_b = 0;
-            size_t lds_fast_b = 0;
             if (pool_step) {
-            } else if (wg && !d.det && knobs_of(ctx).pool_fast != 0 && pool_fast_plan(d, &ego_rows_b, &lds_fast_b)) {
-                att_blocks = Sb;        // the backward with its node's rows and weights staged in LDS (pool_fast_kernel)
-                PoolStepParams ps{};
-                ps.f = pool_fwd_params(c, b, nullptr);      // (the fields the two structs share; nothing of the forward is written)
-                ps.b = pp;
-                auto kern = pool_fast_kernel<false, false, true>;
-                if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(kern), (int)lds_fast_b)) return rc;
-                hipLaunchKernelGGL(kern, dim3(Sb), dim3(256), lds_fast_b, stream, ps, ego_rows_b);
             } else if (wg) {
                 att_blocks = Sb;
                 if (H <= 256) {

@@ -144,11 +144,10 @@ def test_fused_step_needs_grad_mode_and_matching_targets():
 ])
 def test_pooling_step_in_one_launch_is_the_three_launches(variant, S, W, L, H, cell, micro):
     """Round 6: in the default (atomic) mode pn_pagg_train_step runs pooling forward, cross entropy and pooling backward of
-    a node as ONE launch (context knob PN_POOL_STEP, default 1), and the pooling kernels -- alone or fused -- stage the node's
-    h_n / ego rows and the attention / classifier weights in LDS when they fit (pool_fast_kernel; PN_POOL_FAST, default 1;
-    H > 256 keeps the kernels that read global memory).  Logits and loss equal the old kernels' (bitwise for the un-staged
-    bodies, to rounding for the staged ones); gradients equal up to the order of the float atomics (which differs from run
-    to run anyway)."""
+    a node as ONE launch (pool_step_kernel: the two kernels' bodies back to back in one workgroup, the node's cross entropy
+    in between; context knob PN_POOL_STEP, default 1).  Same code, same order inside a node: logits and loss bit-equal to the
+    three launches and to the three library calls; gradients equal up to the order of the float atomics (which differs
+    from run to run anyway)."""
     from pathnet_amd import _lib
     from pathnet_amd import modules as M
     case = _case(variant, S, W, L, H=H, cell=cell)
@@ -159,29 +158,21 @@ def test_pooling_step_in_one_launch_is_the_three_launches(variant, S, W, L, H, c
         kw = dict(cell=m._cell_kind, deterministic=False)
         m.workspace_budget = M.workspace_bytes(variant, 900, 40, Hk, 5, S, W, L, batch_groups=micro, **kw)
         assert M.pick_batch_groups(variant, 900, 40, Hk, 5, S, W, L, m.workspace_budget, **kw) == micro
-    old_step, old_fast = _lib.set_knob("PN_POOL_STEP", 0), _lib.set_knob("PN_POOL_FAST", 0)
+    old_step = _lib.set_knob("PN_POOL_STEP", 0)
     try:
-        l0, o0, g0 = _separate(case)                # three library calls, the pooling kernels that read global memory
+        l0, o0, g0 = _separate(case)                # three library calls
         l1, o1, g1 = _fused(case)                   # the same three launches inside the fused call
         _lib.set_knob("PN_POOL_STEP", 1)
-        l2, o2, g2 = _fused(case)                   # one launch: the two kernels' bodies back to back
-        _lib.set_knob("PN_POOL_FAST", 1)
-        l3, o3, g3 = _fused(case)                   # one launch with the node's rows and weights staged in LDS (default)
-        l4, o4, g4 = _separate(case)                # three calls with the staged forward / backward kernels (default)
+        l2, o2, g2 = _fused(case)                   # one launch: the two kernels' bodies back to back, the loss in between
     finally:
         _lib.set_knob("PN_POOL_STEP", old_step)
-        _lib.set_knob("PN_POOL_FAST", old_fast)
     assert torch.equal(o0, o1) and torch.equal(o1, o2)
     if micro:
         assert abs(l1.item() - l2.item()) <= 1e-6 * max(1.0, abs(l1.item()))
     else:
         assert l0.item() == l1.item() == l2.item()
     zero_ok = ZERO_OK_HETERO if variant == "hetero" else ()
-    # the staged kernels sum a member's columns across a wave (the others: eight lanes per member): same values to rounding
-    for o, l in ((o3, l3), (o4, l4)):
-        assert (o - o0).abs().max().item() <= 2e-6 * max(1.0, o0.abs().max().item())
-        assert abs(l.item() - l0.item()) <= 2e-6 * max(1.0, abs(l0.item()))
     # (noise: the attention bias' gradient is a cancelling sum of S * W terms a thousand times its size, added by atomics in
     #  a different order every run -- two runs of the SAME configuration differ by as much)
-    for g in (g1, g2, g3, g4):
-        assert_grads_close(g, g0, rel=1e-5, noise=1e-8, zero_ok=zero_ok)
+    for g in (g1, g2):
+        assert_grads_close(g, g0, rel=1e-5, noise=3e-8, zero_ok=zero_ok)
