@@ -132,6 +132,10 @@ struct GemmParams {
     // on the host is their upper bound (it sizes the grid), workgroups past the real count leave at once.
     const int32_t *seg, *list;
     int ind;
+    // operand range of the fp16 recurrence taken where the values are produced (run_tables): `absmax` = atomicMax of the bit
+    // patterns of |C| over what this launch stores (after bias / ReLU); `clear_word` is set to 0 by one thread of the launch --
+    // the GEMM in front of the one that takes the maximum, on the same stream
+    uint32_t *absmax, *clear_word;
 };
 enum { GEMM_IND_NONE = 0,
        GEMM_IND_A_ROWS = 1,     // A row m = list[b + m] (rows of Xh by node), C row m = b + m (compact rows)
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         //  it stores zeros)
         if (m0 >= pM || ((int)blockIdx.z * p.kchunk >= pK && p.mode != GEMM_PARTIAL)) return;
     }
+    if (p.clear_word && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) *p.clear_word = 0u;
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = max(kbeg, min(pK, kbeg + p.kchunk));
     f32x16 acc;
@@ -222,6 +227,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
             atomicAdd(&p.rowsum[m0 + tid], rsum);
     }
     const int col = n0 + wn * 32 + li;
+    float vmax = 0.0f;
+    if (p.absmax) {             // (only GEMM_STORE launches ask for it: what is stored is the final value)
+        const float bias_m = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + acc_row(r, lane);
+            float v = acc[r] + bias_m;
+            if (p.relu) v = fmaxf(v, 0.0f);
+            if (row < pM && col < p.N) vmax = fmaxf(vmax, fabsf(v));
+        }
+        vmax = wave_max(vmax);
+        // one atomic per wave at most, and none once a larger value is in (a plain read first: stale is fine, it only grows)
+        if (lane == 0 && vmax > 0.0f && __float_as_uint(vmax) > *reinterpret_cast<volatile uint32_t *>(p.absmax))
+            atomicMax(p.absmax, __float_as_uint(vmax));
+    }
     if (col >= p.N) return;
     const float bias = (p.bias && blockIdx.z == 0 && p.mode != GEMM_PARTIAL) ? p.bias[col] : 0.0f;
 #pragma unroll
@@ -269,9 +289,10 @@ void launch_gemm_variant(hipStream_t stream, dim3 grid, bool ak, bool bk, const 
 int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
                 int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
                 int mode, int ksplit, float *rowsum = nullptr, int ind = GEMM_IND_NONE, const int32_t *seg = nullptr,
-                const int32_t *list = nullptr) {
+                const int32_t *list = nullptr, uint32_t *absmax = nullptr, uint32_t *clear_word = nullptr) {
     if (M <= 0 || N <= 0) return PN_OK;
-    GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0, rowsum, seg, list, ind};
+    GemmParams p{A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 0, rowsum, seg, list, ind, absmax, clear_word};
+    if (absmax && (mode != GEMM_STORE || ksplit > 1)) PN_FAIL(PN_ERR_ARG, "internal: gemm absmax needs a storing launch");
     if (ksplit < 1) ksplit = 1;
     if (mode != GEMM_ATOMIC && mode != GEMM_PARTIAL) ksplit = 1;
     int kchunk = (K + ksplit - 1) / ksplit;
@@ -2679,14 +2700,16 @@ int gemm_split_count(int M, int N, int K) {
 
 int launch_gemm_split(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, const float *gateA, const float *B,
                       int64_t sBn, int64_t sBk, float *C, int64_t ldc, const float *bias, int M, int N, int K, int relu,
-                      int mode, float *partial) {
+                      int mode, float *partial, uint32_t *clear_word = nullptr) {
     int nz = gemm_split_count(M, N, K);
     if (nz <= 1 || !partial || M <= 0 || N <= 0)
-        return launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 1);
+        return launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, C, ldc, bias, M, N, K, relu, mode, 1, nullptr, GEMM_IND_NONE,
+                           nullptr, nullptr, nullptr, clear_word);
     int kchunk = (K + nz - 1) / nz;
     kchunk = (kchunk + GEMM_KT - 1) / GEMM_KT * GEMM_KT;
     nz = (K + kchunk - 1) / kchunk;
-    if (int rc = launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, partial, N, nullptr, M, N, K, 0, GEMM_PARTIAL, nz))
+    if (int rc = launch_gemm(stream, A, sAm, sAk, gateA, B, sBn, sBk, partial, N, nullptr, M, N, K, 0, GEMM_PARTIAL, nz, nullptr,
+                             GEMM_IND_NONE, nullptr, nullptr, nullptr, clear_word))
         return rc;
     const int64_t n = (int64_t)M * N;
     hipLaunchKernelGGL(gemm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, partial, nz, M, N,
@@ -3056,6 +3079,17 @@ int run_seq_bwd_generic(const Call &c, int b) {
     return PN_OK;
 }
 
+// true when max |Z| (SeqRange.x, the fp16 recurrence's operand range) is taken in the bank GEMM's epilogue: dense bank and
+// fc0 both on gemm_kernel in this call -- fc0's launch clears the slot, the bank's adds to it, both on the caller's stream
+// (range_rows_kernel and its place on the critical path between the bank and the recurrence are then not needed, and
+// range_w_kernel on the packing stream must NOT clear the slot: it would race the bank)
+inline bool bank_epilogue_range(const Call &c) {
+    const Dims &d = c.d;
+    const pn_pagg_args *a = c.a;
+    return d.math == PN_SEQ_MATH_F16X2 && d.G > 0 && !d.generic && !d.compact && a->reuse_tables == 0 && !a->Xh_in &&
+           !gemm3_pays(c.ctx, d.N, d.H, d.F, G3_FC0) && !gemm3_pays(c.ctx, d.N, d.L * d.H, d.H, G3_BANK);
+}
+
 int run_pack_fwd(const Call &c, hipStream_t s) {
     const Dims &d = c.d;
     if (d.G == 0) return PN_OK;         // mean / sum: nothing to pack
@@ -3070,7 +3104,8 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
     if (d.math == PN_SEQ_MATH_F16X2) {      // two fp16 planes, scaled by the weights' own maxima (pn_seqh.hip)
         SeqRange *rg = c.at<SeqRange>(c.w.range);
         // (it also clears the slots this call's atomicMax launches add to; a reused dense bank keeps its range.x)
-        if (int rc = launch_range_w(s, c.a->w_ih, c.a->w_hh, (int64_t)d.Gw * d.H * d.H, d.compact || c.a->reuse_tables != 1, rg))
+        if (int rc = launch_range_w(s, c.a->w_ih, c.a->w_hh, (int64_t)d.Gw * d.H * d.H,
+                                    (d.compact || c.a->reuse_tables != 1) && !bank_epilogue_range(c), rg))
             return rc;
         if (int rc = launch_pack_fwdh(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg,
                                       c.at<void>(c.w.Wp), c.at<float>(c.w.biasc)))
@@ -3244,6 +3279,7 @@ int run_tables(const Call &c, JoinGuard &joiner, const std::function<int(hipStre
     const Dims &d = c.d;
     const int H = d.H, L = d.L;
     const int homo = d.variant == PN_VARIANT_HOMO;
+    const bool epi_range = bank_epilogue_range(c);
     // the index plan (of the first micro-batch) and the weight packing do not depend on fc0 / bank: second stream,
     // joined before the recurrence
     if (d.compact) {        // the compact rows first: the index plan and the bank both read them
@@ -3270,7 +3306,8 @@ int run_tables(const Call &c, JoinGuard &joiner, const std::function<int(hipStre
                 if (int rc = launch_gemm3(stream, a->X, d.F, a->fc0_w, d.F, c.at<float>(c.w.Xh), H, a->fc0_b, d.N, H, d.F, homo))
                     return rc;
             } else if (int rc = launch_gemm_split(stream, a->X, d.F, 1, nullptr, a->fc0_w, d.F, 1, c.at<float>(c.w.Xh), H,
-                                                  a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart)))
+                                                  a->fc0_b, d.N, H, d.F, homo, GEMM_STORE, c.at<float>(c.w.gpart),
+                                                  epi_range ? &c.at<SeqRange>(c.w.range)->x : nullptr))
                 return rc;
         }
     }
@@ -3299,14 +3336,15 @@ int run_tables(const Call &c, JoinGuard &joiner, const std::function<int(hipStre
         if (gemm3_pays(c.ctx, d.N, L * H, H, G3_BANK)) {
             if (int rc = launch_gemm3(stream, c.Xh, H, a->bank_w, H, c.Z, (int64_t)L * H, a->bank_b, d.N, L * H, H, homo)) return rc;
         } else if (int rc = launch_gemm(stream, c.Xh, H, 1, nullptr, a->bank_w, H, 1, c.Z, (int64_t)L * H, a->bank_b, d.N,
-                                        L * H, H, homo, GEMM_STORE, 1))
+                                        L * H, H, homo, GEMM_STORE, 1, nullptr, GEMM_IND_NONE, nullptr, nullptr,
+                                        epi_range ? &c.at<SeqRange>(c.w.range)->x : nullptr))
             return rc;
     }
     // the fp16 recurrence scales the gathered rows by a power of two taken from the largest |Z| of the rows just computed
     // (a reused dense Z keeps its record: it sits next to Z in the workspace)
     if (int rc = joiner.join()) return rc;      // the recurrence needs the plan and the packed weights
     // (after the join: the packing stream's range_w_kernel cleared the slot this launch adds to)
-    if (d.math == PN_SEQ_MATH_F16X2 && (d.compact || a->reuse_tables != 1)) {
+    if (d.math == PN_SEQ_MATH_F16X2 && (d.compact || a->reuse_tables != 1) && !epi_range) {
         StageTimer tm(ctx, ST_BANK, stream);
         if (int rc = launch_range_rows(stream, c.Z, d.ZR, H, d.compact ? c.at<const int32_t>(c.w.seg) + L : nullptr,
                                        c.at<SeqRange>(c.w.range)))
