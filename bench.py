@@ -610,6 +610,7 @@ class StepRunner:
 
 
 SETTLE_STEPS = 20
+DOM_EVERY = 4       # the dominant kernel is bracketed by HIP events on every 4th step of the timed region
 
 
 def measure(sr, lib, ctx, names, steps, warmup, barrier, repeats=0):
@@ -644,30 +645,42 @@ def measure(sr, lib, ctx, names, steps, warmup, barrier, repeats=0):
     for e in range(SETTLE_STEPS):
         sr.step(500 + e)
     barrier()
-    _lib.check(lib.pn_profile_configure(ctx, 2, names.index(dominant)))      # host-side switch: the dominant kernel's pair per step
+    # the dominant kernel's event pair on every DOM_EVERY-th step of the timed region (a host-side switch per step, nothing on
+    # the GPU): an event between two kernels of the queue costs ~6 us of idle time there, two per bracketed launch
+    dom_stage = names.index(dominant)
     t0 = time.perf_counter()
-    marks[0].record()
     for e in range(steps):
+        _lib.check(lib.pn_profile_configure(ctx, 2 if e % DOM_EVERY == 0 else 0, dom_stage))
         sr.step(1000 + e)
-        marks[e + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     dom = read_profile(lib, names, ctx)[dominant]
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     blocks = [elapsed / steps * 1e3]
     for r in range(max(0, repeats)):
         torch.cuda.synchronize()
         tb = time.perf_counter()
         for e in range(steps):
+            _lib.check(lib.pn_profile_configure(ctx, 2 if e % DOM_EVERY == 0 else 0, dom_stage))
             sr.step(2000 + r * steps + e)
         torch.cuda.synchronize()
         blocks.append((time.perf_counter() - tb) / steps * 1e3)
+    read_profile(lib, names, ctx)
+    _lib.check(lib.pn_profile_configure(ctx, 0, -1))
+    # the steps' own durations: one more region of the same length with an event at every step boundary -- outside the timed
+    # region, because an event between two kernels of the queue costs ~6 us of idle time there (profiles/r06_glue.txt: round
+    # 5's timed region carried these marks and was the slowest of its five blocks every time)
+    marks[0].record()
+    for e in range(steps):
+        sr.step(3000 + e)
+        marks[e + 1].record()
+    torch.cuda.synchronize()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     sb = sorted(blocks)
     dispersion = {"step_ms": {"min": round(per_step[0], 4), "median": round(per_step[len(per_step) // 2], 4),
                               "max": round(per_step[-1], 4)},
                   "block_ms_per_step": {"min": round(sb[0], 4), "median": round(sb[len(sb) // 2], 4), "max": round(sb[-1], 4),
                                         "blocks": [round(b, 4) for b in blocks], "steps_per_block": steps},
-                  "note": "step_ms: GPU time between consecutive step boundaries inside the timed region (events); "
+                  "note": "step_ms: GPU time between consecutive step boundaries (events) of one more region run after the timed one; "
                           "block_ms_per_step: wall time per step of the timed region (first entry) and of %d more regions of the "
                           "same length run right after it -- a change smaller than max - min of these is not a result" % max(0, repeats)}
     _lib.check(lib.pn_profile_configure(ctx, 1, -1))

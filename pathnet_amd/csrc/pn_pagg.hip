@@ -2833,10 +2833,6 @@ WsLayout ws_layout(const Dims &d) {
         const size_t rows = Pb * L, tiles = std::max<size_t>(1, ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN));
         const double wg_flops = 2.0 * (double)rows * (double)(G * H) * (double)(2 * H);
         size_t cus = wg_flops <= 1.2e11 ? WGRAD_CUS_SHARED : 256;
-        // (tuning / A-B runs, tools/ab_wgrad_cus.sh; read ONCE per process: the split sizes the workspace, and the size query,
-        //  the forward and the backward of a call must agree on it)
-        static const int env_cus = [] { const char *e = getenv("PN_WGRAD_CUS"); return e ? std::max(8, atoi(e)) : 0; }();
-        if (env_cus) cus = (size_t)env_cus;
         size_t nz = (cus + tiles - 1) / tiles;
         const size_t max_nz = (rows + 4 * WG_KT - 1) / (4 * WG_KT);
         if (nz > max_nz) nz = max_nz;

@@ -616,7 +616,10 @@ def test_training_mode_matches_reference_golden(name):
     X = torch.as_tensor(g["X"]).cuda().requires_grad_(True)
     out = run_module(m, X, g["ids"], g["codes"], g["mask"], W, L)
     err = np.abs(out.detach().cpu().numpy() - g["out"]).max()
-    assert err < TOL_OUT * max(1.0, np.abs(g["out"]).max()), err
+    # north_star: 1e-5 on the fp32 outputs, ABSOLUTE (the bound used to scale with |out|_inf, which the x10 masks of
+    # PAGG's p = 0.9 push to 4): measured worst 8e-7 (profiles/r06_pytest_gpu_final.txt prints it)
+    print("training-mode golden %s: max |out - reference| = %.2e (|out|_inf %.2f)" % (name, err, np.abs(g["out"]).max()))
+    assert err < TOL_OUT, err
     (out * torch.as_tensor(g["G"]).cuda()).sum().backward()
     ref = {k: g["grad/" + k] for k, _ in m.named_parameters()}
     ref["X"] = g["grad_X"]
