@@ -55,8 +55,7 @@ struct Knobs {
     int pool_step = 1;          // PN_POOL_STEP: pn_pagg_train_step runs pooling forward, loss and pooling backward of a node in one launch
     int node_rgrad = 1;         // PN_NODE_RGRAD: row-reduction kernel for the node-level weight gradients of large graphs
     int sampler_stage = -1;     // PN_SAMPLER_STAGE: first-hop tables in LDS (-1: by launch size)
-    int seq4 = 4;               // PN_SEQ4: which 128-path kernels of pn_seq4.hip serve the bf16 mode (bit 2: weight gradient)
-    int b4_wide = 0;            // PN_B4_WIDE (experimental builds)
+    int seq4 = 4;               // PN_SEQ4: bit 2 = the two-stage weight-gradient GEMM of pn_seq4.hip serves the bf16 mode at hid 128
     int seqh_tail = PN_SEQH_TAIL_DEFAULT;   // PN_SEQH_TAIL: 0 = 32-path tiles only (default); 1 = the remainder round of the fp16
                                 //                recurrent launches in smaller tiles, one per CU; 8 / 16 / 24 = that size, always
 };

@@ -1,6 +1,6 @@
 // pn_seq.h -- launch parameters of the three recurrent kernels (forward recurrence, BPTT, weight gradient), shared by
-// pn_pagg.hip (the fused kernels for every hidden size up to 256) and pn_seq4.hip (the 128-row-tile kernels for the
-// headline shape, hidden size 128 with four gate slots).  Not part of the ABI.
+// pn_pagg.hip (the bf16 x 3 kernels for every hidden size up to 256), pn_seqh.hip (the fp16 x 2 kernels, the default) and
+// pn_seq4.hip (the bf16 x 3 weight-gradient GEMM of the headline shape).  Not part of the ABI.
 #pragma once
 #include <cstdint>
 
@@ -36,8 +36,6 @@ struct SeqFwdParams {
     float *saved;           // [P, L, SV, H]  SV = 5 (i,f,g,o,c) for LSTM, 1 (h_t) for RNN; may be null
     float *xh;              // [P, L, 2H]     the recurrent GEMM's input rows [x_t (after dropout) | h_{t-1}]:
                             //                the weight-gradient GEMM of the backward reads them back; may be null
-                            //                (seq_fwd4_kernel: never null -- h_t travels to the next step through it;
-                            //                 store_x tells whether the x halves are kept as well)
     uint8_t *keep;          // [P, L, H/4]    built-in dropout: keep bits of columns 4c .. 4c+3 in bits 0-3 (the backward
                             //                reads them instead of re-drawing the Philox stream); may be null
     int P, L;               // slots of this launch (one micro-batch), path length
@@ -46,7 +44,6 @@ struct SeqFwdParams {
     uint64_t seed;
     const pn_step_state *dyn;   // seed in device memory when set (hipGraph replay)
     const float *mask;      // [L, Pmask, H] explicit mask (reference order: original slot q) or null
-    int store_x;            // seq_fwd4_kernel: keep x_t (after dropout) in xh for the weight-gradient GEMM
     const SeqRange *range;  // fp16 kernels: operand ranges (device)
     float xmul;             // fp16 kernels: bound of the factor dropout applies to a gathered row (1 / (1 - p), or 16 for explicit masks)
     const float *ZW;        // seq_fwdzw_kernel: [rows of Z, G*H] = Z . W_ih^T + b (inference without dropout)
@@ -100,18 +97,26 @@ struct RgradParams {
 bool rgrad_pays(const pn_context *ctx, int64_t R, int M, int N);       // the kernel's 128 x 128 tiles and K tiles of 32 rows want >= ~50 000 rows
 int launch_rgrad(pn_context *ctx, void *stream, const RgradParams &p);
 
-// ---- pn_seq4.hip: the recurrent kernels with 128 paths per workgroup -------------------------------------------------
-// which of the three kernels take the 128-row path for this shape (bit 0: forward, bit 1: BPTT, bit 2: weight gradient);
-// 0 when the shape is outside what they are built for.  PN_SEQ4 in the environment (a bit mask) narrows it.
-enum { SEQ4_FWD = 1, SEQ4_BWD = 2, SEQ4_WGRAD = 4 };
+// ---- pn_seq3.hip: the recurrent kernels on the bf16 matrix pipe (six MFMAs per fp32 product, three planes) -----------------------
+// every multiple of 32 up to 256 as hidden size; gc: 4 = LSTM, 1 = tanh RNN, 3 = GRU on the LSTM's four gate slots
+// GRU rows of the caller's [3H, H] weights behind the four gate slots r, z, nx, nh
+__host__ __device__ __forceinline__ int gru_weight_row(int slot, int j, int H) { return (slot < 2 ? slot : 2) * H + j; }
+int launch_pack_fwd3(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G, int gru,
+                     void *Wp, float *biasc);
+int launch_pack_bwd3(void *stream, const float *w_ih, const float *w_hh, int H, int G, int gru, void *WpT);
+int launch_seq_fwd3(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
+int launch_seq_bwd3(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp);
+// the weight-gradient GEMM's output tile and K tile (the caller lays out the K splits); nsplit partials to part_w / part_b
+constexpr int WG_BM = 256, WG_BN = 256, WG_KT = 32;
+int launch_wgrad3(pn_context *ctx, void *stream, const WgradParams &wp, int nsplit);
+// g_W_ih / g_W_hh / g_b_* (+)= the nsplit partials of any of the weight-gradient GEMMs, added in split order
+int launch_wgrad_reduce(void *stream, const float *part_w, const float *part_b, int nsplit, int GH, int H, int accumulate, int gru,
+                        float *g_w_ih, float *g_w_hh, float *g_b_ih, float *g_b_hh);
+
+// ---- pn_seq4.hip: the bf16 x 3 weight-gradient GEMM with two LDS stages (hidden size 128, four gate slots) ----------------
+// SEQ4_WGRAD when the shape is the one it is built for and the context knob PN_SEQ4 has bit 2 set (default), else 0
+enum { SEQ4_WGRAD = 4 };
 int seq4_select(const pn_context *ctx, int H, int G, int L);
-// weight packing for seq_fwd4_kernel / seq_bwd4_kernel (same workspace slots and sizes as pack_fwd3 / pack_bwd3)
-int launch_pack_fwd4(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
-                     int gru, void *Wp, float *biasc);
-int launch_pack_bwd4(void *stream, const float *w_ih, const float *w_hh, int H, int G, int gru, void *WpT);
-// gc: 4 = LSTM, 3 = GRU on the LSTM's four gate slots
-int launch_seq_fwd4(pn_context *ctx, void *stream, int gc, const SeqFwdParams &sp);
-int launch_seq_bwd4(pn_context *ctx, void *stream, int gc, const SeqBwdParams &sp);
 // the weight-gradient GEMM; nsplit row splits as laid out by the caller (part_w / part_b hold nsplit partials)
 int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nsplit);
 
@@ -130,6 +135,5 @@ int launch_seq_fwdh(pn_context *ctx, void *stream, int H, int gc, const SeqFwdPa
 int launch_seq_fwdzw(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
 int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp);
 int launch_wgradh(pn_context *ctx, void *stream, const WgradParams &wp, int H, int nsplit);
-int seqh_dg_quad();     // 1: seq_bwdh_kernel writes dG as [R][H][4 gate slots] (G = 4): wgrad_reduce_kernel un-permutes the rows
 
 }  // namespace pn

@@ -27,59 +27,15 @@ using namespace pn;
 #ifndef PN_FWDH_WAVES
 #define PN_FWDH_WAVES 3     // waves per SIMD the forward is compiled for at H <= 128 (= workgroups per CU at H = 128)
 #endif
-#ifndef PN_FWDH_RB
-#define PN_FWDH_RB 1        // row blocks of 32 paths per wave of the forward at H = 64 / 128 (see seq_fwdh_kernel)
-#endif
-#ifndef PN_FWDH_RB2_PP
-#define PN_FWDH_RB2_PP 0    // RB = 2: a second register set for the hi-plane fragments (ping-pong)
-#endif
 #ifndef PN_BWDH_WAVES
 #define PN_BWDH_WAVES 2
 #endif
-#ifndef PN_WGRADH_PAIR
-#define PN_WGRADH_PAIR 0    // 1: the two gate-column blocks of a K split on one XCD (see wgradh_kernel; measured neutral, 0.183 = 0.183 ms)
-#endif
-#ifndef PN_BWDH_TOUCH
-#define PN_BWDH_TOUCH 0     // > 0: the BPTT pulls the saved rows of its NEXT step into L2 while the current step runs (LDS-DMA touches)
-#endif
-#ifndef PN_FWDH_EARLYX
-#define PN_FWDH_EARLYX 0    // 1: see seq_fwdh_kernel, EARLY_X (measured slower: 0.249 vs 0.242 ms -- the 16 registers cost a spill at 168)
-#endif
-#ifndef PN_BWDH_PIPE
-#define PN_BWDH_PIPE 1      // the BPTT requests step t-1's saved values before step t's scatter (see load_saved)
-#endif
-#ifndef PN_SEQH_PACK
-#define PN_SEQH_PACK 1      // the LSTM's saved gates as 3 dwords per element (pn_kernels.h: pack_gates) instead of 4
-#endif
-#ifndef PN_BWDH_CARRY
-#define PN_BWDH_CARRY 1     // 1: c_{t-1}, loaded for step t, stays in registers as step t-1's c_t
-#endif
-#ifndef PN_SEQH_DGQUAD
-#define PN_SEQH_DGQUAD 0    // 1: the gate gradients of a (path step, unit) as one 16-byte quad, dG [R][H][4] instead of [R][4][H]: 16 stores per
-#endif                      // BPTT step instead of 64; the weight-gradient GEMM sees a column permutation that wgrad_reduce_kernel undoes
-                            // Measured neutral (wall 0.927 vs 0.931 ms over three passes, one spilled register at 256): off
-#ifndef PN_SEQH_QUAD
-#define PN_SEQH_QUAD 1      // what the BPTT needs of a path step and unit as ONE 16-byte quad {packed gates (3 dwords), c_{t-1}}: the
-#endif                      // forward writes it with one store, the BPTT reads it with one dwordx4 load per accumulator register -- 16 saved-value
-                            // loads per step instead of 64 (with the 16 scatter atomics: below the 63 a wave can have outstanding).
-                            // Two sessions of three passes each (profiles/r05_tune_quad.txt): wall fwd+bwd 0.932 -> 0.919 ms in the first,
-                            // 0.931 = 0.931 in the second -- a quarter of the memory instructions for at best 1.4 %; kept because it is
-                            // also less code on both sides.  0 keeps round 4's [H][3] + [H] layout
-#ifndef PN_ABL
-#define PN_ABL 0            // tuning builds only (wrong results, times are the point): bit 0 the forward does not store x_t, bit 1
-#endif                      // forward and BPTT skip the o gate's saved value, bit 2 the BPTT does not store dG
-#ifndef PN_BWD_REVERSE
-#define PN_BWD_REVERSE 1
-#endif
-#ifndef PN_BWDH_SKIPZ
-#define PN_BWDH_SKIPZ 1     // the scatter issues no atomic for an element dropout zeroed (dx == 0: adding it changes nothing; 70 % of
-#endif                      // the elements at p = 0.7).  BPTT 0.375 -> 0.361, 0.364 -> 0.356 ms; with NO atomics at all (PN_ABL bit 3,
-                            // wrong results) 0.340 / 0.334: the whole scatter is 9 % of the kernel (profiles/r05_tune_scatter_tiling.txt)
-#ifndef PN_SEQH_PLANAR
-#define PN_SEQH_PLANAR 0    // 1: the three dwords of the packed gates as three [H] planes per path step instead of [H][3]: every
-#endif                      // load of the BPTT is then one full line per half-wave (the [H][3] form touches each line three times).
-                            // Measured neutral (BPTT 0.374 = 0.375 ms, forward 0.236 = 0.236): the repeats hit L1, not counted lines
-
+// Settled by measurement in rounds 4-5 and no longer build options (the alternatives and their numbers: profiles/HISTORY_r1_r4.md,
+// profiles/r05_tune_*.txt): one row block of 32 paths per wave in the forward (two: 0.253 vs 0.240 ms); the LSTM's saved values as
+// ONE 16-byte quad {packed gates (3 dwords), c_{t-1}} per path step and unit; c carried in registers across the BPTT's steps; the next
+// step's saved values requested ahead of the scatter; descending tile order in the BPTT; no atomic for elements dropout zeroed;
+// gate gradients as [R][4][H] planes; no LDS-DMA "touch" prefetch, no early x gather, no XCD pairing of the weight gradient's
+// column blocks (each measured neutral or slower).
 #ifndef PN_TRACE_H
 #define PN_TRACE_H 0        // 1: tuning builds only -- wave 0 of every workgroup stamps the cycle counter at phase boundaries
 #endif
@@ -105,15 +61,6 @@ __device__ long long *g_trace_h = nullptr;      // [blocks][64] stamps, set with
 namespace {
 
 __device__ __forceinline__ uint32_t fbits_abs(float v) { return __float_as_uint(v) & 0x7fffffffu; }
-
-// the scatter's add (PN_ABL bit 3: none at all, timing only)
-__device__ __forceinline__ void scatter_add(float *dst, float v) {
-#if PN_ABL & 8
-    (void)dst; (void)v;
-#else
-    atomicAdd(dst, v);
-#endif
-}
 
 // ---- tile geometry ------------------------------------------------------------------------------------------------
 // A launch of T = ceil(P / 32) tiles on S resident workgroup slots runs as ceil(T / S) synchronised rounds (every tile costs
@@ -250,16 +197,6 @@ __device__ __forceinline__ FwdScales fwd_scales(const SeqRange *rg, float xmul) 
     return FwdScales{exp2i(ES - e_ih), exp2i(ES - e_hh), exp2i(ES), exp2i(-ES)};
 }
 
-// One 4-byte LDS-DMA per lane: lane l's dword at g goes to LDS byte (lds_wave_base + 4 l).  No register destination -- used to
-// pull cache lines towards the CU ahead of time, the LDS target being a scratch nobody reads (pn cdna_hip_programming.md 5.7:
-// M0 is written in the statement that reads it and restored).
-__device__ __forceinline__ void touch_dma4(const void *g, uint32_t lds_wave_base) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(g), "s"(lds_wave_base)
-                 : "memory");
-}
 
 __device__ __forceinline__ int gru_weight_row(int slot, int j, int H) { return (slot < 2 ? slot : 2) * H + j; }
 
@@ -320,14 +257,14 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
     constexpr int G = GC == 3 ? 4 : GC;
     constexpr bool GRU = GC == 3;
     constexpr int MT = 32 * RB;
-    constexpr bool PACKED = GC == 4 && PN_SEQH_PACK;      // LSTM: gates as 3 dwords + c (pack_gates): 4 H dwords per path step
+    constexpr bool PACKED = GC == 4;          // LSTM: {gates as 3 dwords (pack_gates), c_{t-1}}: 4 H dwords per path step
     constexpr int NW = H / 32, NT = NW * 64, SV = PACKED ? 4 : (G == 4 ? 5 : 1);
     constexpr int KS = H / 8, KX = KS / 2;    // k-steps of 16 over [x | h]; the first KX walk x
     constexpr int PB = 4 * H + 16;            // row pitch of a plane of the tile [x | h], bytes: conflict-free ds_read_b128
     constexpr int PLANE = MT * PB;
     // three workgroups per CU: no register room for the x_{t+1} rows or a second hi-plane fragment set, the third
     // workgroup covers those latencies instead (as in seq_fwd3_kernel)
-    constexpr bool PREFETCH_X = RB == 1 && fwdh_waves<H, RB>() < 3, PING_PONG = fwdh_waves<H, RB>() < 3 && (RB == 1 || PN_FWDH_RB2_PP);
+    constexpr bool PREFETCH_X = RB == 1 && fwdh_waves<H, RB>() < 3, PING_PONG = fwdh_waves<H, RB>() < 3 && RB == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int *s_rowidx = reinterpret_cast<int *>(ldsb + 2 * PLANE);  // [MT][L] gather rows of this tile
     int *s_slotof = s_rowidx + MT * p.L;                        // [MT]
@@ -386,35 +323,8 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         asm volatile("" : "+v"(bits));      // drawn here, not sunk to the commit
         keepbits = bits;
     };
-    // EARLY_X (three workgroups per CU, where nothing is prefetched across the k loop): the rows of x_{t+1} are requested with
-    // ORDINARY loads right behind the barrier that ends the k loop, ahead of the cell update -- whose stores the compiler cannot
-    // prove distinct from the table, so the loads stay where they are written -- and committed after it: their latency runs
-    // under the cell math and its stores instead of behind them.
-    constexpr bool EARLY_X = !PREFETCH_X && RB == 1 && PN_FWDH_EARLYX;
-    [[maybe_unused]] float4 xe[NLD];
-    auto gather_early = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-            const int idx = tid_g + NT * i;
-            const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-            xe[i] = *reinterpret_cast<const float4 *>(p.Z + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (H / 4) + c4) * 4);
-        }
-        uint32_t bits = 0;
-        if (builtin_drop) {
-#pragma unroll
-            for (int i = 0; i < NLD; i++) {
-                const int idx = tid_g + NT * i;
-                const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-                const float4 m = dropout4(seed, ((uint64_t)t * p.Pmask + s_slotof[row]) * (H / 4) + c4, 1u, p.p_drop);
-                bits |= ((m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 2u : 0u) | (m.z != 0.f ? 4u : 0u) |
-                         (m.w != 0.f ? 8u : 0u)) << (4 * i);
-            }
-        }
-        keepbits = bits;
-    };
     auto gather_commit = [&](int t) {
-        if constexpr (EARLY_X) {
-        } else if constexpr (RB == 1)
+        if constexpr (RB == 1)
             wait_vm<0>(xr[0], xr[1], xr[2], xr[3]);
         else
             wait_vm<0>(xr[0], xr[1], xr[2], xr[3], xr[4 % NLD], xr[5 % NLD], xr[6 % NLD], xr[7 % NLD]);
@@ -423,7 +333,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             const int idx = tid_g + NT * i;
             const int row = idx / (H / 4), c4 = idx - row * (H / 4);
             const bool live = row < rows_here;
-            float4 v = EARLY_X ? xe[i] : make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
+            float4 v = make_float4(xr[i][0], xr[i][1], xr[i][2], xr[i][3]);
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.mask) {
                 if (live) {
@@ -447,15 +357,12 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
             if (xh4_t && live) {
                 float4 *xo = &at_bytes(xh4_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4) * 16u);
-                if (!(PN_ABL & 1)) xo[0] = v;
+                xo[0] = v;
                 if (t == 0) xo[H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
-    if (EARLY_X)
-        gather_early(0);
-    else
-        gather_issue(0);
+    gather_issue(0);
     gather_commit(0);
     __syncthreads();
 
@@ -536,10 +443,6 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         HSTAMP(4 * t + 1);
         __syncthreads();  // every wave is done reading x_t / h_{t-1}
         HSTAMP(4 * t + 2);
-        if (EARLY_X && t + 1 < p.L) {
-            tid_g = wave_u * 64 + fresh_lane();
-            gather_early(t + 1);
-        }
 
         // ---- cell update in registers; h_t goes back to LDS (scaled, split) for the next step ----------------------
         const int lane_o = fresh_lane();    // row offsets are re-derived in every step: hoisted out of the t loop they spill
@@ -575,23 +478,10 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
                 h = og * tanhf_(c);
                 if (saved_t && live) {
                     const uint32_t base = ((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(SV * H);
-                    if constexpr (PACKED && PN_SEQH_QUAD) {
-                        const uint3 pk = pack_gates(ig, fg, gg, og);
-                        *reinterpret_cast<uint4 *>(&at_bytes(saved_t, (base + 4u * col) * 4u)) =
-                            make_uint4(pk.x, pk.y, pk.z, __float_as_uint(cprev));
-                    } else if constexpr (PACKED) {
-                        if (PN_SEQH_PLANAR) {
-                            const uint3 pk = pack_gates(ig, fg, gg, og);
-                            uint32_t *sq = reinterpret_cast<uint32_t *>(&at_bytes(saved_t, (base + col) * 4u));
-                            sq[0] = pk.x; sq[H] = pk.y; sq[2 * H] = pk.z;
-                        } else {
-                            *reinterpret_cast<uint3 *>(&at_bytes(saved_t, (base + 3u * col) * 4u)) = pack_gates(ig, fg, gg, og);
-                        }
-                        at_bytes(saved_t, (base + 3u * H + col) * 4u) = c;
-                    } else {
-                        float *sv = &at_bytes(saved_t, (base + col) * 4u);
-                        sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; if (!(PN_ABL & 2)) sv[3 * H] = og; sv[4 * H] = c;
-                    }
+                    // what the BPTT needs of this path step and unit as ONE 16-byte quad: {packed gates (3 dwords), c_{t-1}}
+                    const uint3 pk = pack_gates(ig, fg, gg, og);
+                    *reinterpret_cast<uint4 *>(&at_bytes(saved_t, (base + 4u * col) * 4u)) =
+                        make_uint4(pk.x, pk.y, pk.z, __float_as_uint(cprev));
                 }
             } else {
                 h = tanhf_(acc[rb][0][r] * sc.inv_S);
@@ -619,8 +509,8 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
         }
         }
         if (t + 1 < p.L) {
-            if (!EARLY_X) tid_g = wave_u * 64 + fresh_lane();
-            if (!PREFETCH_X && !EARLY_X) gather_issue(t + 1);
+            tid_g = wave_u * 64 + fresh_lane();
+            if (!PREFETCH_X) gather_issue(t + 1);
             gather_commit(t + 1);     // (every wave is past its reads of x_t)
             __syncthreads();
         }
@@ -811,7 +701,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     constexpr int G = GC == 3 ? 4 : GC;         // GC: 4 = LSTM, 1 = tanh RNN, 3 = GRU on the LSTM's four gate slots
     constexpr bool GRU = GC == 3;
     constexpr int MT = 32, NW = H / 32;
-    constexpr bool PACKED = GC == 4 && PN_SEQH_PACK;            // (the forward's layout: pack_gates)
+    constexpr bool PACKED = GC == 4;                            // (the forward's layout: pack_gates quads)
     constexpr int NT = NW * 64, GH = G * H, SV = PACKED ? 4 : (G == 4 ? 5 : 1);
     constexpr int PB = 2 * GH + 16, PLANE = MT * PB;            // plane row pitch / plane size, bytes
     constexpr int NU = GH / 32;                                 // units of two k-steps
@@ -820,13 +710,10 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     int *s_slotof = s_rowidx + MT * p.L;                         // [MT]
     float *s_max = reinterpret_cast<float *>(s_slotof + MT);     // [8] wave maxima of |dG_t|
     uint8_t *s_keep = reinterpret_cast<uint8_t *>(s_max + 8);    // [2][MT][H/4] dropout keep bits of step t (t & 1)
-    [[maybe_unused]] const uint32_t touch_lds =                  // [NW][256 B] landing area of the touches (never read)
-        __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(s_keep + 2 * MT * (H / 4)) +
-                                       256u * (uint32_t)(threadIdx.x >> 6));
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31;
     // (descending path order: the BPTT starts on the tiles the forward wrote last; its small tiles -- SeqTiling, the
     //  remainder round -- are therefore the ones at the START of the path range, dispatched last)
-    const SeqTile tl = seq_tile_of(p.tiling, PN_BWD_REVERSE ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, MT, p.P);
+    const SeqTile tl = seq_tile_of(p.tiling, (int)(gridDim.x - 1 - blockIdx.x), MT, p.P);
     const int q0 = tl.q0, rows_here = tl.rows;          // rows_here >= 1
     const int col = 32 * wave + li;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -842,7 +729,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
     const uint8_t *keep_t = p.keep ? p.keep + tile_row * (H / 4) : nullptr;
     const float *dhn_t = p.dhn + (size_t)q0 * H;
     f32x16 dh, dc;
-    [[maybe_unused]] f32x16 cnext;      // PN_BWDH_CARRY: c_t of the step processed next (= c_{t-1} now)
+    [[maybe_unused]] f32x16 cnext;      // LSTM: c_t of the step processed next (= c_{t-1} now): loaded once, carried in registers
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = acc_row(r, lane);
@@ -850,55 +737,35 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         const float dh0 = at_bytes(dhn_t, ((uint32_t)rc * (uint32_t)H + col) * 4u);     // unconditional load, select afterwards
         dh[r] = row < rows_here ? dh0 : 0.0f;
         dc[r] = 0.0f;
-        if (PN_BWDH_CARRY && G == 4 && !GRU && !(PACKED && PN_SEQH_QUAD))      // (the quad layout: c_{L-1} = f c_{L-2} + i g, below)
-            cnext[r] = at_bytes(saved_t, ((((uint32_t)rc * (uint32_t)p.L + (p.L - 1)) * SV + (PACKED ? 3 : 4)) * (uint32_t)H + col) * 4u);
     }
     float launch_max = 0.0f;        // largest |dG| this workgroup has seen (wave-uniform after each step)
 
-    // ---- the saved values of one step, as loaded (PN_BWDH_PIPE: those of step t - 1 are requested right after step t's k
+    // ---- the saved values of one step, as loaded (those of step t - 1 are requested right after step t's k
     //      loop, ahead of its scatter -- ordinary loads, which the compiler cannot sink below the scatter's atomics -- so their
     //      latency runs under the atomics instead of in front of the next cell backward).  All loads of a step are issued
     //      together, unconditionally (padded rows read a clamped row and are zeroed afterwards).
-    constexpr int NRAW = PACKED ? 4 : (G == 4 || GRU) ? 5 : 1;
-    uint32_t raw[NRAW][16];                 // (the packed gates as three dword loads: a dwordx3 load wants three CONSECUTIVE
-                                            //  registers, and the allocator spilled half of the sixteen triples)
-    [[maybe_unused]] float raw_cn[16];      // c_t when it is not carried in registers
+    constexpr int NRAW = PACKED ? 4 : GRU ? 5 : 1;
+    uint32_t raw[NRAW][16];
     auto load_saved = [&](int t, int lane_x) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rc = min(acc_row(r, lane_x), rows_here - 1);
             const uint32_t base = ((uint32_t)rc * (uint32_t)p.L + t) * (uint32_t)(SV * H);
-            if constexpr (PACKED && PN_SEQH_QUAD) {
+            if constexpr (PACKED) {       // one 16-byte quad per (path step, unit): {packed gates (3 dwords), c_{t-1}}
                 const uint4 qd = *reinterpret_cast<const uint4 *>(&at_bytes(saved_t, (base + 4u * col) * 4u));
                 raw[0][r] = qd.x; raw[1][r] = qd.y; raw[2][r] = qd.z; raw[NRAW > 3 ? 3 : 0][r] = qd.w;
-            } else if constexpr (PACKED) {
-                if (PN_SEQH_PLANAR) {
-                    const uint32_t *gq = reinterpret_cast<const uint32_t *>(&at_bytes(saved_t, (base + col) * 4u));
-                    raw[0][r] = gq[0]; raw[1][r] = gq[H]; raw[2][r] = gq[2 * H];
-                } else {
-                    const uint32_t *gq = reinterpret_cast<const uint32_t *>(&at_bytes(saved_t, (base + 3u * col) * 4u));
-                    raw[0][r] = gq[0]; raw[1][r] = gq[1]; raw[2][r] = gq[2];
-                }
-                const float *cp = &at_bytes(saved_t, (base + 3u * H + col) * 4u);
-                raw[3][r] = __float_as_uint(cp[t > 0 ? -(SV * H) : 0]);       // c_{t-1}: the c slot of step t-1 (t = 0: unused)
-                if (!PN_BWDH_CARRY) raw_cn[r] = cp[0];
             } else {
                 const float *sv = &at_bytes(saved_t, (base + col) * 4u);
                 if constexpr (GRU) {
 #pragma unroll
                     for (int k = 0; k < 5; k++) raw[k][r] = __float_as_uint(sv[k * H]);    // r, z, n, W_hn h + b_hn, h_{t-1}
-                } else if constexpr (G == 4) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) raw[k][r] = __float_as_uint(sv[k * H]);
-                    raw[NRAW - 1][r] = __float_as_uint(sv[t > 0 ? -H : 4 * H]);            // c_{t-1} = slot 4 of step t-1
-                    if (!PN_BWDH_CARRY) raw_cn[r] = sv[4 * H];
                 } else {
                     raw[0][r] = __float_as_uint(sv[0]);                                    // h_t
                 }
             }
         }
     };
-    if (PN_BWDH_PIPE) load_saved(p.L - 1, lane);
+    load_saved(p.L - 1, lane);
 
     for (int t = p.L - 1; t >= 0; t--) {
         // (row numbers are re-derived from an opaque copy of the lane id in every step: as loop invariants the
@@ -918,7 +785,6 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         // ---- cell backward into registers
         float dgv[G][16];
         float vmax = 0.0f;
-        if (!PN_BWDH_PIPE) load_saved(t, lane_t);
         {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -927,27 +793,20 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                 if constexpr (PACKED) {
                     unpack_gates(make_uint3(raw[0][r], raw[NRAW > 1 ? 1 : 0][r], raw[NRAW > 2 ? 2 : 0][r]), vi_, vf_, vg_, vo_);
                     vc_ = t > 0 ? __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]) : 0.0f;
-                    vn_ = PN_BWDH_CARRY ? cnext[r] : raw_cn[r];
-                    // (quad layout: the last step's c is not stored -- it is f c_{t-1} + i g of the values just unpacked, which
-                    //  differs from the forward's by the gates' 24-bit rounding, 2^-24 of a value that enters through tanh)
-                    if (PN_SEQH_QUAD && t == p.L - 1) vn_ = vf_ * vc_ + vi_ * vg_;
+                    vn_ = cnext[r];
+                    // (the last step's c is not stored -- it is f c_{t-1} + i g of the values just unpacked, which differs from
+                    //  the forward's by the gates' 24-bit rounding, 2^-24 of a value that enters through tanh)
+                    if (t == p.L - 1) vn_ = vf_ * vc_ + vi_ * vg_;
                 } else if (GRU) {
                     vi_ = __uint_as_float(raw[0][r]); vf_ = __uint_as_float(raw[NRAW > 1 ? 1 : 0][r]); vg_ = __uint_as_float(raw[NRAW > 2 ? 2 : 0][r]);
                     vo_ = __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]);
                     vc_ = __uint_as_float(raw[NRAW > 4 ? 4 : 0][r]);
-                } else if (G == 4) {
-                    vi_ = __uint_as_float(raw[0][r]); vf_ = __uint_as_float(raw[NRAW > 1 ? 1 : 0][r]);
-                    vg_ = __uint_as_float(raw[NRAW > 2 ? 2 : 0][r]);
-                    vo_ = (PN_ABL & 2) ? 0.5f : __uint_as_float(raw[NRAW > 3 ? 3 : 0][r]);
-                    vc_ = t > 0 ? __uint_as_float(raw[NRAW - 1][r]) : 0.0f;
-                    vn_ = PN_BWDH_CARRY ? cnext[r] : raw_cn[r];
                 } else {
                     vi_ = __uint_as_float(raw[0][r]);
                 }
                 const int row = acc_row(r, lane_t);
                 const bool ok = row < rows_here;
                 float *d = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)p.L + t) * (uint32_t)GH + col) * 4u);
-                [[maybe_unused]] float *dq = &at_bytes(dG_t, (((uint32_t)min(row, rows_here - 1) * (uint32_t)p.L + t) * (uint32_t)GH + 4u * col) * 4u);
                 if (GRU) {
                     // h = (1 - z) n + z h_prev,  n = tanh(nx + r nh):  gradients of the four slots r, z, nx, nh; the direct
                     // path d h_t / d h_{t-1} = z is carried in dc[] across the GEMM and added to its dh output
@@ -961,12 +820,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     if (!ok) a_r = a_z = a_nx = a_nh = 0.0f;
                     dc[r] = ok ? dhv * zg : 0.0f;
                     dgv[0][r] = a_r; dgv[G > 1 ? 1 : 0][r] = a_z; dgv[G > 2 ? 2 : 0][r] = a_nx; dgv[G > 3 ? 3 : 0][r] = a_nh;
-                    if (ok) {
-                        if (PN_SEQH_DGQUAD && G == 4)
-                            *reinterpret_cast<float4 *>(dq) = make_float4(a_r, a_z, a_nx, a_nh);
-                        else
-                            d[0] = a_r, d[H] = a_z, d[2 * (G > 1 ? H : 0)] = a_nx, d[3 * (G > 1 ? H : 0)] = a_nh;
-                    }
+                    if (ok) d[0] = a_r, d[H] = a_z, d[2 * (G > 1 ? H : 0)] = a_nx, d[3 * (G > 1 ? H : 0)] = a_nh;
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a_r), fabsf(a_z))), fmaxf(fabsf(a_nx), fabsf(a_nh)));
                 } else if (G == 4) {
                     const float ig = vi_, fg = vf_, gg = vg_, og = vo_, cprev = vc_;
@@ -980,14 +834,9 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     float a_o = d_o * og * (1.0f - og);
                     if (!ok) a_i = a_f = a_g = a_o = 0.0f;
                     dc[r] = dct * fg;
-                    if (PN_BWDH_CARRY) cnext[r] = cprev;
+                    cnext[r] = cprev;
                     dgv[0][r] = a_i; dgv[G > 1 ? 1 : 0][r] = a_f; dgv[G > 2 ? 2 : 0][r] = a_g; dgv[G > 3 ? 3 : 0][r] = a_o;
-                    if (ok && !(PN_ABL & 4)) {
-                        if (PN_SEQH_DGQUAD && G == 4)
-                            *reinterpret_cast<float4 *>(dq) = make_float4(a_i, a_f, a_g, a_o);
-                        else
-                            d[0] = a_i, d[H] = a_f, d[2 * (G > 1 ? H : 0)] = a_g, d[3 * (G > 1 ? H : 0)] = a_o;
-                    }
+                    if (ok) d[0] = a_i, d[H] = a_f, d[2 * (G > 1 ? H : 0)] = a_g, d[3 * (G > 1 ? H : 0)] = a_o;
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(a_i), fabsf(a_f))), fmaxf(fabsf(a_g), fabsf(a_o)));
                 } else {
                     const float h = vi_;
@@ -1003,21 +852,6 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
         HSTAMP(6 * (p.L - 1 - t) + 1);
         __syncthreads();        // the wave maxima are in place; every wave is past the previous step's k loop
         HSTAMP(6 * (p.L - 1 - t) + 2);
-        if (PN_BWDH_TOUCH && !PACKED && t > 0) {
-            // the next step's saved rows, one lane per 128-byte line: row (0..31) x array (i f g o [c]) x segment (H/32)
-            constexpr int NARR = G == 4 ? (PN_BWDH_TOUCH < 5 ? PN_BWDH_TOUCH : 5) : 1, LINES = MT * NARR * NW;
-            const int tid_x = wave_u * 64 + lane_t;
-#pragma unroll
-            for (int e0 = 0; e0 < LINES; e0 += NT) {
-                const int e = e0 + tid_x;
-                if (e < LINES) {
-                    const int row = e / (NARR * NW), rem = e - row * (NARR * NW), k = rem / NW, j = rem - k * NW;
-                    const uint32_t rc = (uint32_t)min(row, rows_here - 1);
-                    touch_dma4(&at_bytes(saved_t, ((rc * (uint32_t)p.L + (uint32_t)(t - 1)) * (uint32_t)(SV * H) + (uint32_t)(k * H + 32 * j)) * 4u),
-                               touch_lds);
-                }
-            }
-        }
         float tmax = 0.0f;
 #pragma unroll
         for (int w = 0; w < NW; w++) tmax = fmaxf(tmax, s_max[w]);
@@ -1103,7 +937,7 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
             mfma_phase(std::integral_constant<int, 1>{});
         HSTAMP(6 * (p.L - 1 - t) + 4);
         const float inv_x = exp2i(-(e_g + e_ih)), inv_h = exp2i(-(e_g + e_hh));
-        if (PN_BWDH_PIPE) load_saved(max(t - 1, 0), lane_t);        // (dgv is dead: these take its registers; t = 0: a harmless re-load)
+        load_saved(max(t - 1, 0), lane_t);        // (dgv is dead: these take its registers; t = 0: a harmless re-load)
 
         // ---- gather backward: dZ[row(q, t)] += mask * dx.  Step 0 is the last one of the kernel and its rows are the
         //      paths' own start nodes: the wave parks its 32 x 32 block in the (then dead) plane region and each half-wave
@@ -1137,13 +971,13 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                 const int rl = 16 * hk + i, row = rl;
                 const int rid = row < rows_here ? s_rowidx[row * p.L] : -1;       // (uniform over a half-wave)
                 if (rid != cur) {
-                    if (cur >= 0) scatter_add(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
+                    if (cur >= 0) atomicAdd(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
                     cur = rid;
                     run = 0.0f;
                 }
                 run += scr[rl * 33 + li_s];
             }
-            if (cur >= 0) scatter_add(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
+            if (cur >= 0) atomicAdd(p.dZ + ((size_t)(uint32_t)cur * (uint32_t)H + col), run);
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -1157,8 +991,8 @@ __global__ __launch_bounds__(H / 32 * 64, H == 32 ? 1 : PN_BWDH_WAVES) void seq_
                     float *dst = p.dZ + ((size_t)(uint32_t)s_rowidx[row * p.L + t] * (uint32_t)H + col);
                     if (p.store_dx)
                         *dst = dx;          // deterministic mode: a row of its own per path step (det_scatter_kernel adds them up)
-                    else if (!PN_BWDH_SKIPZ || dx != 0.0f)
-                        scatter_add(dst, dx);
+                    else if (dx != 0.0f)    // (no atomic for an element dropout zeroed: 70 % of them at p = 0.7; BPTT 0.375 -> 0.361 ms)
+                        atomicAdd(dst, dx);
                 }
                 dh[r] = GRU ? acc[1][r] * inv_h + dc[r] : acc[1][r] * inv_h;
             }
@@ -1188,16 +1022,7 @@ __global__ __launch_bounds__(WH_THREADS, 2) void wgradh_kernel(WgradParams p, in
     extern __shared__ __attribute__((aligned(16))) u32x4 ldsw[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, li = lane & 31, hk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    // The two 256-row blocks of gate columns (blockIdx.y) of one K split read the SAME [x | h] rows.  Workgroups are dealt to
-    // the eight XCDs round robin by their linear id, so neighbours (y, z), (y + 1, z) sit on different L2s and both fetch the
-    // rows from memory (PMC: 8.6 row-widths per path step where 6 are needed).  With two column blocks and a multiple of
-    // eight splits the pair is re-mapped eight ids apart -- same XCD, the second read is an L2 hit.
-    unsigned by = blockIdx.y, bz = blockIdx.z;
-    if (PN_WGRADH_PAIR && gridDim.x == 1 && gridDim.y == 2 && gridDim.z % 8 == 0) {
-        const unsigned id = blockIdx.y + 2u * blockIdx.z, blk = id >> 4, r = id & 15u;
-        by = r >> 3;
-        bz = blk * 8u + (r & 7u);
-    }
+    const unsigned by = blockIdx.y, bz = blockIdx.z;
     const int m0 = by * WH_BM, n0 = blockIdx.x * WH_BN;
     const int64_t ntiles = (p.R + WH_KT - 1) / WH_KT;
     const int64_t nz = gridDim.z;
@@ -1340,7 +1165,7 @@ __global__ __launch_bounds__(WH_THREADS, 2) void wgradh_kernel(WgradParams p, in
 
 template <int H, int GC>
 int launch_fwdh_t(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
-    constexpr int RB = (H == 64 || H == 128) ? PN_FWDH_RB : 1;     // (two workgroups of 68 KB tiles per CU at H = 128)
+    constexpr int RB = 1;       // row blocks of 32 paths per wave (the kernel keeps the parameter; 2 measured slower)
     constexpr int MT = 32 * RB;
     const size_t lds_bytes = (size_t)2 * MT * (4 * H + 16) + (size_t)(MT * sp.L + MT) * 4;
     auto kern = seq_fwdh_kernel<H, GC, RB>;
@@ -1357,8 +1182,7 @@ int launch_fwdh_t(pn_context *ctx, hipStream_t stream, const SeqFwdParams &sp) {
 template <int H, int GC>
 constexpr size_t bwdh_lds_bytes(int L) {
     constexpr int MT = 32, G = GC == 3 ? 4 : GC;
-    return (size_t)2 * MT * (2 * G * H + 16) + (size_t)(MT * L + MT) * 4 + 32 + (size_t)2 * MT * (H / 4) +
-           (PN_BWDH_TOUCH ? (size_t)(H / 32) * 256 : 0);
+    return (size_t)2 * MT * (2 * G * H + 16) + (size_t)(MT * L + MT) * 4 + 32 + (size_t)2 * MT * (H / 4);
 }
 template <int H, int GC>
 int launch_bwdh_t(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
@@ -1369,7 +1193,7 @@ int launch_bwdh_t(pn_context *ctx, hipStream_t stream, const SeqBwdParams &sp) {
     SeqBwdParams lp = sp;
     int blocks = 0;
     if (int rc = plan_tiling(ctx, reinterpret_cast<const void *>(kern), H / 32 * 64, lds_bytes, sp.P, MT,
-                             /*small_first=*/PN_BWD_REVERSE != 0, &lp.tiling, &blocks))
+                             /*small_first=*/true, &lp.tiling, &blocks))
         return rc;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(H / 32 * 64), lds_bytes, stream, lp);
     PN_CHECK_HIP(hipGetLastError());
@@ -1446,10 +1270,6 @@ extern "C" int pn_debug_seq_tiling(int64_t P, int slots, int cus, int mode, int 
 }
 
 namespace pn {
-
-// dG of the fp16 BPTT with four gate slots is [R][H][4] (PN_SEQH_DGQUAD): the weight-gradient GEMM's rows come out in that
-// order and wgrad_reduce_kernel maps them back (asked at run time: tuning builds recompile this file alone)
-int seqh_dg_quad() { return PN_SEQH_DGQUAD; }
 
 int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, int clear_x, SeqRange *range) {
     hipLaunchKernelGGL(range_w_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_ih, w_hh, n_each / 4, clear_x, range);
