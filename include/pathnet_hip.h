@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 7 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
+#define PN_ABI_VERSION 8 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
                           * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
                           *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
                           *    offsets throughout; pn_clock_probe
@@ -46,7 +46,9 @@ extern "C" {
                           *    shape, not with the environment); pn_pagg_args.reuse_tables = 2; pn_pagg_shape_info; pn_pagg_args gained
                           *    Xh_ready / g_Xh_ready (events that let the node-sharded path overlap its collectives)
                           * 7: pn_context_set_knob / pn_context_get_knob: the kernel-selection knobs are part of the context (read
-                          *    from the environment once, when it is created); no call reads the environment any more */
+                          *    from the environment once, when it is created); no call reads the environment any more
+                          * 8: pn_seq_range / pn_pagg_range_offset (the fp16 recurrence's operand range and the spread of the gathered
+                          *    rows' magnitudes, for callers that want to fall back to bf16x3 on pathological inputs) */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -78,7 +80,7 @@ typedef struct pn_context pn_context;
 int pn_context_create(pn_context **out);
 int pn_context_destroy(pn_context *ctx);
 /* Kernel-selection knobs for A/B measurements and tests (none changes a result beyond rounding): PN_NODE_GEMM3, PN_EVAL_ZW,
- * PN_POOL_BWD_WG, PN_NODE_RGRAD, PN_SAMPLER_STAGE, PN_SEQ4, PN_B4_WIDE, PN_SEQH_TAIL (pn_internal.h: struct Knobs).  A context
+ * PN_POOL_BWD_WG, PN_POOL_STEP, PN_ZERO_EARLY, PN_NODE_RGRAD, PN_SAMPLER_STAGE, PN_SEQ4, PN_SEQH_TAIL (pn_internal.h: struct Knobs).  A context
  * takes its values from the environment variables of the same names ONCE, in pn_context_create; afterwards only these two
  * calls read or change them -- device entry points never call getenv, so a captured step keeps its selection and a setenv
  * on another thread cannot race a launch.  get accepts ctx = NULL (the defaults a NULL context runs with). */
@@ -366,6 +368,22 @@ int pn_pagg_workspace_bytes(const pn_pagg_shape *shape, int64_t *bytes);
 /* What the library decides from a shape: out[0] = 1 when the call runs over compact rows of the distance bank, out[1] =
  * rows of Z / dZ, out[2] = micro-batches, out[3] = PN_SEQ_MATH_* the recurrent GEMMs will use (0: the shape has none). */
 int pn_pagg_shape_info(const pn_pagg_shape *shape, int64_t out[4]);
+/* The operand ranges of the fp16 x 2 recurrent kernels (seq_math = PN_SEQ_MATH_F16X2) live in the workspace, in device memory,
+ * written by the forward's kernels.  x_bits: bit pattern of max |Z| over the distance-bank rows the call gathers from (the
+ * power-of-two scale of the gathered rows is taken from it).  x_esum / x_cnt: sum and count of the biased fp32 exponents of the
+ * non-zero maxima of a sample of tiles of Z, so that  ((x_bits >> 23) & 255) - x_esum / x_cnt  is how far, in bits, the largest
+ * value sits above the typical tile.  The two-plane fp16 split keeps 22 bits of a row within ~2^18 of the maximum and loses one
+ * bit per factor of two below that: a caller that sees a spread beyond ~18 bits (a single spike row 2^20 times the typical one)
+ * should run the call with seq_math = PN_SEQ_MATH_BF16X3, whose planes carry fp32's own exponent range.  The library itself never
+ * reads x_esum / x_cnt (no host round trip in a call); pathnet_amd/modules.py reads them back asynchronously. */
+typedef struct pn_seq_range {
+    uint32_t x_bits;
+    int32_t x_esum;
+    uint32_t x_cnt;
+    uint32_t w_ih_bits, w_hh_bits, dg_bits;     /* max |W_ih|, max |W_hh|, max |dG| of the last BPTT */
+} pn_seq_range;
+/* *offset = byte offset of the call's pn_seq_range in its workspace, or -1 when the shape runs no fp16 recurrent kernel */
+int pn_pagg_range_offset(const pn_pagg_shape *shape, int64_t *offset);
 /* out = forward(...).  Leaves what backward needs in the workspace. */
 int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 /* Gradients of sum(out * g_out) w.r.t. every parameter (overwritten, not accumulated) and X.

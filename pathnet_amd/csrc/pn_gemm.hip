@@ -43,9 +43,11 @@ struct GemmParams {
     // on the host is their upper bound (it sizes the grid), workgroups past the real count leave at once.
     const int32_t *seg, *list;
     int ind;
-    // operand range of the fp16 recurrence taken where the values are produced (run_tables): `absmax` = atomicMax of the bit
-    // patterns of |C| over what this launch stores (after bias / ReLU); `clear_word` is set to 0 by one thread of the launch --
-    // the GEMM in front of the one that takes the maximum, on the same stream
+    // operand range of the fp16 recurrence taken where the values are produced (run_tables; SeqRange of pn_seq.h, whose first
+    // three words these point to): absmax[0] = atomicMax of the bit patterns of |C| over what this launch stores (after bias /
+    // ReLU); absmax[1] += the biased exponents, absmax[2] += the count of the non-zero 32 x 32 sub-tile maxima of every eighth
+    // workgroup (the spread statistic); clear_word[0..2] are set to 0 by one thread of the launch -- the GEMM in front of the
+    // one that takes the maximum, on the same stream
     uint32_t *absmax, *clear_word;
 };
 // (IND is a template parameter: as run-time branches in front of the 24 loads of a K tile the row indirection halved the
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         //  it stores zeros)
         if (m0 >= pM || ((int)blockIdx.z * p.kchunk >= pK && p.mode != GEMM_PARTIAL)) return;
     }
-    if (p.clear_word && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) *p.clear_word = 0u;
+    if (p.clear_word && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) p.clear_word[0] = p.clear_word[1] = p.clear_word[2] = 0u;
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = max(kbeg, min(pK, kbeg + p.kchunk));
     f32x16 acc;
@@ -147,6 +149,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         // one atomic per wave at most, and none once a larger value is in (a plain read first: stale is fine, it only grows)
         if (lane == 0 && vmax > 0.0f && __float_as_uint(vmax) > *reinterpret_cast<volatile uint32_t *>(p.absmax))
             atomicMax(p.absmax, __float_as_uint(vmax));
+        if (lane == 0 && wave == 0 && vmax > 0.0f && ((blockIdx.x + blockIdx.y) & 7u) == 0u) {
+            atomicAdd(reinterpret_cast<int *>(p.absmax + 1), (int)((__float_as_uint(vmax) >> 23) & 0xffu));
+            atomicAdd(p.absmax + 2, 1u);
+        }
     }
     if (col >= p.N) return;
     const float bias = (p.bias && blockIdx.z == 0 && p.mode != GEMM_PARTIAL) ? p.bias[col] : 0.0f;
@@ -206,9 +212,9 @@ int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, co
     if (kchunk < GEMM_KT) kchunk = GEMM_KT;
     p.kchunk = kchunk;
     const int nz = K > 0 ? (K + kchunk - 1) / kchunk : 1;
-    dim3 grid((N + GEMM_BN - 1) / GEMM_BN, (M + GEMM_BM - 1) / GEMM_BM, nz);
     if (K <= 0 || M <= 0 || N <= 0) PN_FAIL(PN_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     const bool ak = (sAk == 1), bk = (sBk == 1);
+    dim3 grid((N + GEMM_BN - 1) / GEMM_BN, (M + GEMM_BM - 1) / GEMM_BM, nz);
     if (gateA)
         launch_gemm_variant<true>(stream, grid, ak, bk, p);
     else

@@ -1954,6 +1954,15 @@ int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, cons
 }
 
 
+int pn_pagg_range_offset(const pn_pagg_shape *shape, int64_t *offset) {
+    if (!shape || !offset) PN_FAIL(PN_ERR_ARG, "pn_pagg_range_offset: null");
+    Dims d;
+    if (int rc = make_dims(*shape, d)) return rc;
+    static_assert(sizeof(SeqRange) == sizeof(pn_seq_range), "pn_seq_range is the public face of SeqRange");
+    *offset = (d.math == PN_SEQ_MATH_F16X2 && d.G > 0 && !d.generic) ? (int64_t)ws_layout(d).range : -1;
+    return PN_OK;
+}
+
 int pn_pagg_debug_offsets(const pn_pagg_shape *shape, int64_t out[4]) {
     if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_debug_offsets: null");
     Dims d;

@@ -11,8 +11,15 @@ namespace pn {
 // ---- operand ranges of the fp16 two-plane kernels (pn_seqh.hip) --------------------------------------------------------
 // Largest magnitudes, kept in DEVICE memory as the bit patterns of non-negative floats (atomicMax on uint32 orders them);
 // every kernel derives its power-of-two operand scales from them when it runs -- no host round trip, capturable.
-struct SeqRange {
-    uint32_t x;             // max |Z| over the bank rows a call gathers from (range_rows_kernel, after the bank)
+struct SeqRange {           // (= struct pn_seq_range of include/pathnet_hip.h: pn_pagg_range_offset hands its place to the caller)
+    uint32_t x;             // max |Z| over the bank rows a call gathers from (the bank GEMM's epilogue, or range_rows_kernel)
+    // how wide the rows' magnitudes are spread, from a SAMPLE of tiles of Z (32 x 32 or 256 consecutive values): sum and count
+    // of the biased fp32 exponents of the sampled tiles' non-zero maxima.  exponent(x) - x_esum / x_cnt is how far the largest
+    // value sits above the typical tile, in bits; the fp16 two-plane split keeps 22 bits for rows within ~2^18 of x and loses one
+    // per factor of two below that.  Nothing in the library reads the two: the caller decides (pathnet_amd/modules.py falls back
+    // to seq_math = bf16x3, whose three bf16 planes carry fp32's own exponent range, when the spread exceeds its window)
+    int32_t x_esum;
+    uint32_t x_cnt;
     uint32_t w_ih, w_hh;    // max |W_ih|, max |W_hh|                          (range_w_kernel, before the weight packing)
     uint32_t dg;            // max |dG| of the BPTT launch the weight-gradient GEMM follows (seq_bwdh_kernel)
 };

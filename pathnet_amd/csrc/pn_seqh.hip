@@ -160,26 +160,56 @@ __global__ __launch_bounds__(1024) void range_w_kernel(const float *__restrict__
         range->w_ih = __float_as_uint(m0);
         range->w_hh = __float_as_uint(m1);
         range->dg = 0u;
-        if (clear_x) range->x = 0u;
+        if (clear_x) {
+            range->x = 0u;
+            range->x_esum = 0;
+            range->x_cnt = 0u;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void range_rows_kernel(const float *__restrict__ rows, int64_t nrows, int H4,
                                                          const int32_t *__restrict__ count, SeqRange *__restrict__ range) {
     const int64_t n = (count ? min((int64_t)*count, nrows) : nrows) * H4;
+    const int lane = threadIdx.x & 63;
+    const bool sampled = (blockIdx.x & 7u) == 0u;       // every eighth workgroup contributes to the spread statistic
     float m = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float4 a = reinterpret_cast<const float4 *>(rows)[i];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    int esum = 0, ecnt = 0;
+    // a wave covers 256 consecutive values per trip (a tile of the statistic); the loop bound is wave-uniform
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + lane;
+        float t = 0.0f;
+        if (i < n) {
+            const float4 a = reinterpret_cast<const float4 *>(rows)[i];
+            t = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+        }
+        m = fmaxf(m, t);
+        if (sampled) {
+            const float tm = wave_max(t);
+            if (tm > 0.0f) {
+                esum += (int)((__float_as_uint(tm) >> 23) & 0xffu);
+                ecnt += 1;
+            }
+        }
     }
     // one atomic per WORKGROUP: thousands of atomicMax on one address serialise (2704 of them took 33 us, 676 took 11)
     __shared__ float red[4];
+    __shared__ int reds[8];
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if (lane == 0) {
+        red[threadIdx.x >> 6] = m;
+        reds[threadIdx.x >> 6] = esum;
+        reds[4 + (threadIdx.x >> 6)] = ecnt;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (m > 0.0f) atomicMax(&range->x, __float_as_uint(m));
+        const int c = reds[4] + reds[5] + reds[6] + reds[7];
+        if (sampled && c > 0) {
+            atomicAdd(&range->x_esum, reds[0] + reds[1] + reds[2] + reds[3]);
+            atomicAdd(&range->x_cnt, (uint32_t)c);
+        }
     }
 }
 

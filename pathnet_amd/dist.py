@@ -522,10 +522,13 @@ class ShardedAggregator:
         Valid for the next call with the same X_loc and unchanged fc0 parameters (the optimizers -- torch's and
         pathnet_amd.Adam -- bump the parameters' version counters, which is what the check reads); no-grad bookkeeping only:
         the autograd graph is that of the call (fc0's backward runs on X_loc as always).  The step then uses the DENSE
-        exchange (the sparse one needs the step's paths before it can ask for rows)."""
+        exchange (the sparse one needs the step's paths before it can ask for rows): with exchange="auto" a begin_step therefore
+        MEANS dense for that step, with exchange="sparse" begin_step does nothing."""
         m = self.module
         if m.hidden_size % 32:
             return          # (the padded parameters are functions of the real ones, rebuilt per call: nothing to key on)
+        if self.exchange == "sparse":
+            return          # (the sparse exchange asks for rows by the step's paths: nothing can start before they exist)
         Xn = X_loc.contiguous().float()         # normalised ONCE: the call compares against this very tensor
         with torch.no_grad():
             pre = self._project_and_gather(m.variant, Xn, m.fc0.weight, m.fc0.bias)
@@ -540,6 +543,12 @@ class ShardedAggregator:
         key = (self._norm_key(X_loc), m.fc0.weight.data_ptr(), m.fc0.weight._version, m.fc0.bias._version)
         if pre[0] != key:
             self._prefetched = None
+            if self.exchange == "auto" and self.comm.active():
+                # With "auto" a matching prefetch means the dense collectives, none means the (collective) sparse plan: a rank
+                # that silently dropped a stale prefetch would enter other collectives than its peers and hang the group
+                # until the process-group timeout.  Stale = begin_step saw another X, or fc0 changed since.
+                raise RuntimeError("ShardedAggregator(exchange='auto'): begin_step() was called for another X_loc or the fc0 "
+                                   "parameters changed since; call begin_step right before the step it belongs to")
             return None
         return pre[1]
 

@@ -61,6 +61,10 @@ def compact_default():
     return _lib.COMPACT_ON if int(e) != 0 else _lib.COMPACT_OFF
 
 
+RANGE_WINDOW_BITS = 18      # spread (bits) of the gathered rows' magnitudes the fp16 x 2 kernels carry at full precision
+RANGE_POLL_EVERY = 16       # calls between two asynchronous read-backs of the range record
+
+
 def seq_math_default():
     """pn_pagg_shape.seq_math when a module does not say: PN_SEQ_MATH=bf16x3 selects rounds 1-3's six-MFMA bf16 products
     for the recurrent GEMMs, the default (f16x2) is three fp16 MFMAs over scaled two-plane splits (include/pathnet_hip.h)."""
@@ -197,6 +201,7 @@ class _PaggFunction(torch.autograd.Function):
             if cfg["S"] > 0:
                 _lib.check(lib.pn_pagg_forward(_lib.context(dev), ctypes.byref(a), _lib.stream_ptr(dev)))
         ctx.cfg, ctx.ws = cfg, ws
+        cfg["ws_used"] = ws         # (the module's range guard reads the call's pn_seq_range back from it)
         ctx.present = [t is not None for t in params]
         ctx.save_for_backward(X, ids, codes, sel, *[t for t in params if t is not None])
         return out
@@ -287,6 +292,7 @@ class _PaggLossFunction(torch.autograd.Function):
         head = tuple(grads.get(k) for k in ("fc0_w", "fc0_b", "w_ih", "w_hh", "b_ih", "b_hh", "att_w", "att_b", "fc2_w", "fc2_b"))
         ctx.grads = (gX,) + head + tuple(g_bank_w[d] for d in range(L)) + tuple(g_bank_b[d] for d in range(L))
         ctx.flat = flat
+        cfg["ws_used"] = ws
         ctx.mark_non_differentiable(out)
         # (without this autograd materialises a zero gradient for `out` -- an [S, C] fill launch in front of the optimizer,
         #  on the step's critical path: profiles/r06_glue.txt)
@@ -372,6 +378,17 @@ class _Aggregator(nn.Module):
         self.workspace_budget = None      # bytes; None = modules.WORKSPACE_BUDGET_BYTES (see pick_batch_groups)
         self.deterministic = None         # True / False: fixed-order backward or not; None: deterministic_default()
         self.seq_math = None              # "f16x2" / "bf16x3": arithmetic of the recurrent GEMMs; None: seq_math_default()
+        # Range guard of the default arithmetic (seq_math None -> f16x2).  Its two fp16 planes keep 22 bits of a gathered row
+        # within ~2^18 of the largest one; a single spike row 2^20 times the typical row -- bag-of-words features after fc0
+        # can do that -- costs the typical rows bits (include/pathnet_hip.h: pn_seq_range).  The forward's kernels leave the
+        # maximum and the spread of the rows' magnitudes in device memory; the module reads them back -- synchronously after
+        # its FIRST call (which is run again in bf16x3 when the spread is beyond the window), asynchronously every
+        # RANGE_POLL_EVERY-th call afterwards -- and switches itself to bf16x3 for good once it has seen such an input.
+        self.range_guard = True
+        self._range_wide = False          # sticky: an input beyond the window was seen
+        self._range_calls = 0
+        self._range_pending = None        # (pinned int32[6], event) of a read-back in flight
+        self.range_spread_bits = None     # last evaluated spread: exponent(max |Z|) - mean exponent of the sampled tiles
         self._mask_seq = None     # test hook: explicit dropout masks (reference order)
         self._mask_cls = None
         self._bank_flat = (None, None)
@@ -487,8 +504,42 @@ class _Aggregator(nn.Module):
     def forward(self, X, neis, num_w, walk_len, indices, layer_type, indxx=None, reuse_tables=False, group_slice=None):
         return self._run(X, neis, num_w, walk_len, indices, layer_type, reuse_tables=reuse_tables, group_slice=group_slice)
 
+    # ---- range guard (see _common_init) ---------------------------------------------------------------------------------
+    def _range_eval(self, rec):
+        x_bits, esum, cnt = int(rec[0]) & 0xFFFFFFFF, int(rec[1]), int(rec[2]) & 0xFFFFFFFF
+        if cnt > 0 and x_bits:
+            self.range_spread_bits = ((x_bits >> 23) & 255) - esum / cnt
+            if self.range_spread_bits > RANGE_WINDOW_BITS and not self._range_wide:
+                self._range_wide = True
+                import warnings
+                warnings.warn("pathnet_amd: the distance-bank rows span %.1f bits between their largest value and the typical row "
+                              "(window of the fp16 x 2 recurrent kernels: %d); this module now runs seq_math='bf16x3'"
+                              % (self.range_spread_bits, RANGE_WINDOW_BITS))
+
+    def _range_poll(self):
+        if self._range_pending is not None and self._range_pending[1].query():
+            rec, _ = self._range_pending
+            self._range_pending = None
+            self._range_eval(rec)
+
+    def _range_read(self, cfg, sync):
+        ws = cfg.get("ws_used")
+        off = ctypes.c_int64(-1)
+        _lib.check(_lib.load().pn_pagg_range_offset(ctypes.byref(_cfg_shape(cfg)), ctypes.byref(off)))
+        if ws is None or off.value < 0:
+            return
+        rec = torch.empty(6, dtype=torch.int32, pin_memory=True)
+        rec.copy_(ws[off.value:off.value + 24].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if sync:
+            ev.synchronize()
+            self._range_eval(rec)
+        else:
+            self._range_pending = (rec, ev)
+
     def _run(self, X, neis, num_w, walk_len, indices, layer_type, reuse_tables=False, group_slice=None, target=None,
-             grad_scale=None, fused=None, batch_position=None, seed=None):
+             grad_scale=None, fused=None, batch_position=None, seed=None, _math=None):
         """reuse_tables (extension, inference only): X and the weights are those of the previous no-grad forward of this
         module -- the validation and the test forward of an epoch (PathNet_run.py:362, :378) -- so the projected
         feature matrix and the distance bank still sitting in the module's workspace are used again.
@@ -505,12 +556,19 @@ class _Aggregator(nn.Module):
         fw, fb, params = self._param_inputs() if Hk == H else self._padded_param_inputs(Hk)
         training = self.training
         p = self.dropout_p() if training else 0.0
+        math = _math if _math is not None else (seq_math_default() if self.seq_math is None else _SEQ_MATH[self.seq_math])
+        guard = (_math is None and self.seq_math is None and self.range_guard and math != _lib.SEQ_MATH_BF16X3 and
+                 self.step_state is None)
+        if guard:
+            self._range_poll()
+            if self._range_wide:
+                math, guard = _lib.SEQ_MATH_BF16X3, False
         cfg = dict(variant=self.variant, N=X.shape[0], F=X.shape[1], H=Hk, C=self.out_size, S=S,
                    W=int(num_w), L=int(walk_len), p_seq=p, p_cls=p, mask_seq=None, mask_cls=None, bank_w=fw, bank_b=fb,
                    step_state=self.step_state, cell=self._cell_kind,
                    deterministic=deterministic_default() if self.deterministic is None else bool(self.deterministic),
                    # decisions that shape the workspace are taken once per call and travel with its shape
-                   compact=compact_default(), seq_math=seq_math_default() if self.seq_math is None else _SEQ_MATH[self.seq_math],
+                   compact=compact_default(), seq_math=math,
                    seed=(int(seed) if seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
                    if (p > 0 and self.step_state is None) else 0)
         if batch_position is not None:
@@ -584,14 +642,27 @@ class _Aggregator(nn.Module):
             if fused is None:
                 fused = cfg["batch_groups"] > 0
             if fused:
-                return _PaggLossFunction.apply(cfg, X, ids, codes, sel, target, *params)
-            from . import optim
-            out = _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
-            loss = optim.CrossEntropyLoss()(out, target.to(device=dev, dtype=torch.int64))        # the mean over the S rows
-            if grad_scale is not None:
-                loss = loss * (float(grad_scale) * max(S, 1))
-            return loss, out
-        return _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
+                res = _PaggLossFunction.apply(cfg, X, ids, codes, sel, target, *params)
+            else:
+                from . import optim
+                out = _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
+                loss = optim.CrossEntropyLoss()(out, target.to(device=dev, dtype=torch.int64))        # the mean over the S rows
+                if grad_scale is not None:
+                    loss = loss * (float(grad_scale) * max(S, 1))
+                res = (loss, out)
+        else:
+            res = _PaggFunction.apply(cfg, X, ids, codes, sel, *params)
+        if guard and S > 0:
+            first = self._range_calls == 0
+            self._range_calls += 1
+            if first or (self._range_calls % RANGE_POLL_EVERY == 0 and self._range_pending is None):
+                self._range_read(cfg, sync=first)
+                if first and self._range_wide:      # the very first result is not handed out on a range it cannot carry
+                    return self._run(X, neis, num_w, walk_len, indices, layer_type, reuse_tables=False, group_slice=group_slice,
+                                     target=target, grad_scale=grad_scale, fused=fused, batch_position=batch_position,
+                                     seed=cfg["seed"] if (p > 0 and self.step_state is None) else seed,
+                                     _math=_lib.SEQ_MATH_BF16X3)
+        return res
 
 
 class PathNet(_Aggregator):

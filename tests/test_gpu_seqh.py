@@ -278,3 +278,86 @@ def test_remainder_round_tiles_match_the_default_tiling(variant, H, S, W, L, cel
         _lib.set_knob("PN_SEQH_TAIL", old)
     assert torch.equal(out, ref_out)
     assert_grads_close(g, ref_g, rel=1e-5, zero_ok=ZERO_OK_HETERO if variant == "hetero" else ())
+
+
+def _cora_like(spike, seed=61, S=400):
+    """configs[1]'s shapes (N = 2708, F = 1433, hid 128, W = 40, L = 4; S masked nodes): bag-of-words-like features, and
+    with `spike` one node whose feature row is 2^spike times a typical one -- its projected / bank rows then sit that far
+    above every other row of Z"""
+    import pathnet_amd
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    N, F, H, C, W, L = 2708, 1433, 128, 7, 40, 4
+    m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.0).cuda().eval()
+    X = (torch.rand(N, F) < 0.0127).float()
+    X = X / X.sum(1, keepdim=True).clamp(min=1.0)
+    mask = np.zeros(N, bool)
+    mask[rng.permutation(N)[:S]] = True
+    sel = np.flatnonzero(mask)
+    hub = int(np.flatnonzero(~mask)[0])
+    if spike:
+        X[hub] *= float(2 ** spike)
+    ids = rng.integers(0, N, (S, W, L))
+    ids[:, :, 0] = sel[:, None]
+    ids[::7, 0, 2] = hub                     # a few paths do pass through the spike node
+    codes = np.minimum(rng.integers(0, L, (S, W, L)), np.arange(L)[None, None, :])
+    return m, X, ids, codes, mask, sel, W, L, hub
+
+
+def _fwd(m, X, ids, codes, mask, W, L):
+    S = int(mask.sum())
+    with torch.no_grad():
+        return m(X.cuda(), torch.as_tensor(ids.reshape(S, W * L).astype(np.int64)), W, L, mask,
+                 torch.as_tensor(codes.astype(np.int64)), None).cpu()
+
+
+@pytest.mark.parametrize("spike", [22, 40])
+def test_spike_row_beyond_the_fp16_window_falls_back_to_bf16x3(spike):
+    """the fp16 x 2 split carries a 2^18 window below the launch-wide maximum of the gathered rows.  One
+    node whose bank rows are 2^spike times the typical row (configuration size) takes the typical rows out of it.  The
+    forward's kernels leave max |Z| and the spread of the rows' magnitudes in device memory (pn_seq_range); the module reads
+    them after its first call, re-runs that call in bf16x3 and stays there.  Checked: the guard fires, the result it returns
+    is within 1e-5 of the float64 oracle.  Measured with the same input forced through the fp16 kernels: at 2^22 the typical
+    rows still carry ~17 bits and the logits stay within 1e-7 (the guard is conservative there); at 2^40 their planes are
+    zero and the forced result is wrong -- the guard is what keeps the contract."""
+    import warnings
+    m, X, ids, codes, mask, sel, W, L, hub = _cora_like(spike=spike)
+    params64 = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    want = po.forward("homo", params64, X.double(), ids, codes, sel, W, L, dtype=torch.float64).float()
+    through_hub = np.zeros(len(sel), bool)
+    through_hub[::7] = True                  # rows whose paths touch the spike node: huge pre-activations, saturated gates
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = _fwd(m, X, ids, codes, mask, W, L)
+    assert m._range_wide and m.range_spread_bits > 18 and any("bf16x3" in str(x.message) for x in w)
+    err_guarded = (out - want).abs().max().item()
+    assert err_guarded < 1e-5, err_guarded
+    # the same call forced through the fp16 kernels: the rows that never see the spike lose bits to its scale
+    m2 = _cora_like(spike=spike)[0]
+    m2.load_state_dict(m.state_dict())
+    m2.seq_math = "f16x2"
+    out16 = _fwd(m2, X, ids, codes, mask, W, L)
+    err16 = (out16 - want).abs()[~through_hub].max().item()
+    print("spike 2^%d: guarded (bf16x3) error %.2e, forced f16x2 error on rows away from the spike %.2e, spread %.1f bits"
+          % (spike, err_guarded, err16, m.range_spread_bits))
+    if spike >= 40:
+        assert err16 > 1e-5 > err_guarded
+    # and a second call of the guarded module goes straight to bf16x3 (no read-back, same values)
+    assert torch.equal(_fwd(m, X, ids, codes, mask, W, L), out)
+
+
+def test_ordinary_features_stay_on_the_fp16_kernels():
+    import warnings
+    m, X, ids, codes, mask, sel, W, L, _ = _cora_like(spike=0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = _fwd(m, X, ids, codes, mask, W, L)
+    assert not m._range_wide and m.range_spread_bits is not None and m.range_spread_bits < 12 and not w
+    params64 = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    want = po.forward("homo", params64, X.double(), ids, codes, sel, W, L, dtype=torch.float64).float()
+    assert (out - want).abs().max().item() < 1e-5
+    for _ in range(20):         # past the next ASYNCHRONOUS read-back of the record (every 16th call)
+        _fwd(m, X, ids, codes, mask, W, L)
+    torch.cuda.synchronize()
+    m._range_poll()
+    assert not m._range_wide and m.range_spread_bits < 12
