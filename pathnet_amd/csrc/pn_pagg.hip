@@ -1572,14 +1572,6 @@ inline bool use_zw(const Call &c) {
     return need <= have && need <= ((size_t)2 << 30);
 }
 
-// The fp16 weight-gradient GEMM gathers the x half of [x | h] from the bank again (WgradParams.Z) and the forward does not
-// write it: built-in dropout or none (an explicit mask -- the tests' hook -- keeps the forward's copy), context knob
-// PN_WGRAD_REGATHER (change it between steps, not between a forward and its backward)
-inline bool regather_x(const Call &c) {
-    const Dims &d = c.d;
-    return d.math == PN_SEQ_MATH_F16X2 && d.G > 0 && !d.generic && !c.a->mask_seq && knobs_of(c.ctx).wgrad_regather != 0;
-}
-
 // bound of the factor the sequence dropout applies to a gathered row: 1 / (1 - p), or 16 for explicit masks (the contract
 // of pn_pagg_shape.seq_math)
 inline float seq_xmul(const pn_pagg_args *a) {
@@ -1617,7 +1609,6 @@ int run_seq_fwd(const Call &c, int b, bool save) {
     if (d.math == PN_SEQ_MATH_F16X2) {
         sp.range = c.at<SeqRange>(c.w.range);
         sp.xmul = seq_xmul(a);
-        sp.skip_x = regather_x(c) ? 1 : 0;
         return launch_seq_fwdh(c.ctx, c.stream, d.H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp);
     }
     return launch_seq_fwd3(c.ctx, c.stream, d.H, d.cell == CELL_GRU ? 3 : d.cell == CELL_LSTM ? 4 : 1, sp);

@@ -54,7 +54,6 @@ struct SeqFwdParams {
     const SeqRange *range;  // fp16 kernels: operand ranges (device)
     float xmul;             // fp16 kernels: bound of the factor dropout applies to a gathered row (1 / (1 - p), or 16 for explicit masks)
     const float *ZW;        // seq_fwdzw_kernel: [rows of Z, G*H] = Z . W_ih^T + b (inference without dropout)
-    int skip_x;             // fp16 kernel: the x half of xh is NOT written -- the weight-gradient GEMM gathers it again (WgradParams.Z)
     SeqTiling tiling;       // fp16 kernels: filled in by the launcher
 };
 

@@ -385,9 +385,9 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, RB>())) void seq_fwdh_k
             unsigned char *d = ldsb + row * PB + 8 * c4;
             *reinterpret_cast<uint2 *>(d) = make_uint2(a0, b0);
             *reinterpret_cast<uint2 *>(d + PLANE) = make_uint2(a1, b1);
-            if (xh4_t && live) {        // (skip_x: regather_x_kernel writes these rows beside the BPTT -- pn_pagg.hip)
+            if (xh4_t && live) {
                 float4 *xo = &at_bytes(xh4_t, (((uint32_t)row * (uint32_t)p.L + t) * (uint32_t)(2 * H / 4) + c4) * 16u);
-                if (!p.skip_x) xo[0] = v;
+                xo[0] = v;
                 if (t == 0) xo[H / 4] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
