@@ -176,8 +176,12 @@ class Comm:
         return out
 
     def count_matrix(self, row, device):
-        """every rank's list of world ints -> [world][world] (row r = rank r's list)"""
-        mine = torch.tensor([[int(v) for v in row]], dtype=torch.int64, device=device)
+        """every rank's world counts -> [world][world] (row r = rank r's list).  `row` may be a device tensor: the counts then
+        travel without visiting the host first, and the ONE read-back is that of the gathered matrix"""
+        if torch.is_tensor(row):
+            mine = row.to(device=device, dtype=torch.int64).reshape(1, -1)
+        else:
+            mine = torch.tensor([[int(v) for v in row]], dtype=torch.int64, device=device)
         return self.all_gather_rows(mine, kind="all_gather_index").tolist()
 
     def counts(self, n, device):
@@ -459,8 +463,9 @@ class ShardedAggregator:
     # ---- sparse exchange: the rows the step's paths touch, and nothing else ---------------------------------------------
     def _plan_sparse(self, ids, sel):
         """Collective.  Decides the step's exchange mode and, for the sparse one, builds its plan and the compact indices.
-        -> (plan or None, ids', sel').  Three small host round trips (the touched count, the per-owner counts, the ranks'
-        count matrix): the price of moving a quarter of the rows."""
+        -> (plan or None, ids', sel').  ONE host round trip since round 6 -- the ranks' count matrix, gathered from device
+        tensors (the per-owner counts no longer visit the host on their own, the touched count is the matrix row's sum) --
+        and the exchange of the row ids rides on the communication stream, under fc0's projection of the rank's rows."""
         comm = self.comm
         if self.exchange == "dense" or not comm.active():
             return None, ids, sel
@@ -468,17 +473,24 @@ class ShardedAggregator:
         flags = torch.zeros(self.n_pad, dtype=torch.bool, device=dev)
         flags[ids.reshape(-1).long().clamp_(0, N - 1)] = True        # (the kernels clamp ids and sel the same way)
         flags[sel.long().clamp_(0, N - 1)] = True
-        touched = torch.nonzero(flags).flatten()
-        need = torch.bincount(torch.div(touched, B, rounding_mode="floor"), minlength=R).tolist()
-        matrix = comm.count_matrix(need, dev)               # matrix[r][o]: rows rank r needs from owner o
+        # owners' counts straight from the flags (a block's touched rows = the sum of its flags): no nonzero() -- whose size is a
+        # host read-back of its own -- in front of the collective
+        need_dev = flags.view(R, B).sum(1)
+        matrix = comm.count_matrix(need_dev, dev)           # matrix[r][o]: rows rank r needs from owner o  (the host round trip)
         if self.exchange == "auto" and max(sum(row) for row in matrix) * 2 >= N:
             return None, ids, sel                           # some rank touches half of the graph: the dense collectives
         me = comm.rank()
+        touched = torch.nonzero(flags).flatten()            # (its size is known by now: no further wait)
         plan = _SparsePlan()
-        plan.touched, plan.need, plan.T = touched, [int(v) for v in need], int(touched.numel())
+        plan.touched, plan.need, plan.T = touched, [int(v) for v in matrix[me]], int(sum(matrix[me]))
         plan.serve = [int(matrix[q][me]) for q in range(R)]
-        asked = comm.all_to_all_rows(touched.to(torch.int32), plan.need, plan.serve, "sparse_index")
-        plan.serve_local = asked.long() - self.row_begin
+        ask = touched.to(torch.int32)
+
+        def exchange_ids():
+            asked = comm.all_to_all_rows(ask, plan.need, plan.serve, "sparse_index")
+            return asked.long() - self.row_begin
+        # on the communication stream: fc0's projection (current stream) runs beside it, the fetch of the rows follows it there
+        plan.serve_local, _ = self._on_comm_stream(ids, ask, exchange_ids)
         rank_map = torch.cumsum(flags, 0, dtype=torch.int32) - 1
         ids_c = rank_map[ids.long().clamp_(0, N - 1)]
         sel_c = rank_map[sel.long().clamp_(0, N - 1)]

@@ -70,9 +70,11 @@ def collectives_ms(R, n_total, H, grad_bytes, link_GBs, lat_us, idx_bytes=0, row
     rs = ag
     ar = lat_us * 1e-3 + 2 * (R - 1) / R * grad_bytes / (min(R - 1, 7) * link_GBs * 1e9) * 1e3
     ix = (lat_us * 1e-3 + idx_bytes / R / (link_GBs * 1e9) * 1e3) if idx_bytes else 0.0
+    sx = 0.0
     if row_frac < 1.0:      # the row ids of the sparse exchange: one more small all-to-all
-        ix += lat_us * 1e-3 + n_total / R * row_frac * 4 / (link_GBs * 1e9) * 1e3
-    return ag + rs + ar + ix, {"all_gather_Xh": ag, "reduce_scatter_dXh": rs, "all_reduce_grads": ar, "all_gather_indices": ix}
+        sx = lat_us * 1e-3 + n_total / R * row_frac * 4 / (link_GBs * 1e9) * 1e3
+    return ag + rs + ar + ix + sx, {"all_gather_Xh": ag, "reduce_scatter_dXh": rs, "all_reduce_grads": ar, "all_gather_indices": ix,
+                                    "sparse_row_ids": sx}
 
 
 BANK_MS_PER_NODE = 6.2e-6    # measured slope of bank + bank backward over the node count at L = 4, hid = 128: 0.058 ms at 2708
@@ -110,7 +112,7 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
                 own *= min(1.0, touched_nodes(R)) / min(1.0, touched_nodes(1))
             if R > 1:
                 coll = parts["all_reduce_grads"] + parts["all_gather_indices"]
-                parts = dict(parts, all_gather_Xh=0.0, reduce_scatter_dXh=0.0)
+                parts = dict(parts, all_gather_Xh=0.0, reduce_scatter_dXh=0.0, sparse_row_ids=0.0)
         elif overlap and R > 1:
             hide_ag = (stages.get("sampler_walk", 0.0) + stages.get("sampler_fill", 0.0) + stages.get("plan_pack", 0.0)) * scale
             if sparse:      # the rows can only be asked for once the step's paths exist
@@ -120,8 +122,11 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
             ag = max(0.0, parts["all_gather_Xh"] - hide_ag)
             rs = max(0.0, parts["reduce_scatter_dXh"] + own_bwd - hide_rs)
             own = own - own_bwd
-            coll = ag + rs + parts["all_reduce_grads"] + parts["all_gather_indices"]
-            parts = dict(parts, all_gather_Xh=ag, reduce_scatter_dXh=rs)
+            # (round 6, dist.py _plan_sparse) the row ids of the sparse exchange travel on the communication stream under
+            # fc0's projection of the rank's own rows
+            sx = max(0.0, parts["sparse_row_ids"] - stages.get("fc0", 0.0) * (scale if not weak else 1.0))
+            coll = ag + rs + parts["all_reduce_grads"] + parts["all_gather_indices"] + sx
+            parts = dict(parts, all_gather_Xh=ag, reduce_scatter_dXh=rs, sparse_row_ids=sx)
         # zero fill of d Z (with the bank's rows) and d Xh (with the nodes)
         grow = R if weak else 1
         z_dz = z * zero_dz * grow * (min(1.0, touched_frac(R)) if touched_frac is not None else 1.0)
@@ -138,7 +143,7 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
 
 def newest_bench_json():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    names = ("r05_bench_final.json", "r04_bench_final.json", "r04_bench_f16_v1.json", "r03_bench_final.json")
+    names = ("r06_bench_final.json", "r05_bench_final.json", "r04_bench_final.json", "r04_bench_f16_v1.json", "r03_bench_final.json")
     return next(p for p in (os.path.join(root, "profiles", n) for n in names) if os.path.exists(p))
 
 
