@@ -77,7 +77,7 @@ struct KnobName {
     int pn::Knobs::*field;
 };
 const KnobName kKnobs[] = {{"PN_NODE_GEMM3", &pn::Knobs::node_gemm3}, {"PN_EVAL_ZW", &pn::Knobs::eval_zw},
-                           {"PN_POOL_BWD_WG", &pn::Knobs::pool_bwd_wg}, {"PN_POOL_STEP", &pn::Knobs::pool_step}, {"PN_ZERO_EARLY", &pn::Knobs::zero_early}, {"PN_NODE_RGRAD", &pn::Knobs::node_rgrad},
+                           {"PN_POOL_BWD_WG", &pn::Knobs::pool_bwd_wg}, {"PN_POOL_STEP", &pn::Knobs::pool_step}, {"PN_ZERO_EARLY", &pn::Knobs::zero_early}, {"PN_SMALL_SIDE", &pn::Knobs::small_side}, {"PN_NODE_RGRAD", &pn::Knobs::node_rgrad},
                            {"PN_SAMPLER_STAGE", &pn::Knobs::sampler_stage}, {"PN_SEQ4", &pn::Knobs::seq4},
                            {"PN_SEQH_TAIL", &pn::Knobs::seqh_tail}};
 

@@ -51,6 +51,7 @@ struct Knobs {
                                 //                tiles fill the GPU; 8: the compact bank dX as well (measured slower)
     int eval_zw = 1;            // PN_EVAL_ZW: inference forwards apply W_ih to the bank rows before the gather
     int pool_bwd_wg = 1;        // PN_POOL_BWD_WG: pooling backward as a workgroup per node
+    int small_side = 1;         // PN_SMALL_SIDE: loss sum / classifier gradient / attention reduce on the second stream under the BPTT
     int zero_early = 1;         // PN_ZERO_EARLY: pn_pagg_train_step zero-fills the backward's accumulators on the second stream, under fc0 / bank
     int pool_step = 1;          // PN_POOL_STEP: pn_pagg_train_step runs pooling forward, loss and pooling backward of a node in one launch
     int node_rgrad = 1;         // PN_NODE_RGRAD: row-reduction kernel for the node-level weight gradients of large graphs

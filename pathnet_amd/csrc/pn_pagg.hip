@@ -1095,28 +1095,34 @@ __global__ __launch_bounds__(256) void det_iota_kernel(int32_t *__restrict__ iot
 }
 
 // the pooling backward's per-workgroup attention terms ([nblk][2H + 4]: g_att_w partials, then one g_att_b term per
-// wave) added up in workgroup order: workgroup j of this kernel owns output j (j = 2H: the bias)
-__global__ __launch_bounds__(256) void det_att_reduce_kernel(const float *__restrict__ part, int nblk, int H,
-                                                             float *__restrict__ g_att_w, float *__restrict__ g_att_b) {
-    __shared__ float red[256];
-    const int j = blockIdx.x, stride = 2 * H + 4;
+// wave) added up in a fixed order.  A workgroup owns 64 consecutive outputs: sixteen row groups of 64 lanes walk the
+// partials' rows 16 apart -- every load a 256-byte run of one row -- and meet in LDS (round 6; a workgroup per output read
+// the [nblk][260] array column-wise, one cache line per element: 19 us for 1.3 MB at the headline shape)
+__global__ __launch_bounds__(1024) void det_att_reduce_kernel(const float *__restrict__ part, int nblk, int H,
+                                                              float *__restrict__ g_att_w, float *__restrict__ g_att_b) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6, stride = 2 * H + 4;
+    const int col = blockIdx.x * 64 + lane;
     float v = 0.0f;
-    if (j < 2 * H) {
-        for (int b = threadIdx.x; b < nblk; b += 256) v += part[(int64_t)b * stride + j];
-    } else {
-        for (int b = threadIdx.x; b < 4 * nblk; b += 256) v += part[(int64_t)(b >> 2) * stride + 2 * H + (b & 3)];
+    if (col < stride) {
+        const float *src = part + col;
+#pragma unroll 8
+        for (int b = rg; b < nblk; b += 16) v += src[(int64_t)b * stride];
     }
-    red[threadIdx.x] = v;
+    red[rg][lane] = v;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (j < 2 * H)
-            g_att_w[j] += red[0];
-        else
-            *g_att_b += red[0];
+    if (rg != 0) return;
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) t += red[r][lane];
+    if (col < 2 * H) {
+        g_att_w[col] += t;
+    } else if (col < stride) {      // the four per-wave bias terms sit in one workgroup (4 | 2H): lanes c .. c + 3
+        red[0][lane] = t;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (col == 2 * H) *g_att_b += (red[0][lane] + red[0][lane + 1]) + (red[0][lane + 2] + red[0][lane + 3]);
     }
 }
 
@@ -2175,10 +2181,15 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
         // fork / join is an event between two kernels of the queue and costs ~6 us of idle time there, and the BPTT waits
         // for none of the three (profiles/r06_glue.txt).
         const bool wgrad_wanted = G > 0 && (a->g_w_ih || a->g_w_hh || a->g_b_ih || a->g_b_hh);
-        const bool defer_small = side_ok && wgrad_wanted && ctx != nullptr;
+        // (small_side, round 6: ONE fork behind the pooling backward instead -- the three small launches then run on the second
+        //  stream while the BPTT runs, where defer_small put them in front of the node-level GEMMs, the longer of the two chains
+        //  behind the BPTT.  Context knob PN_SMALL_SIDE, profiles/r06_glue.txt section 7)
+        const bool small_side = side_ok && wgrad_wanted && ctx != nullptr && knobs_of(ctx).small_side != 0;
+        const bool defer_small = side_ok && wgrad_wanted && ctx != nullptr && !small_side;
+        hipStream_t small_stream = nullptr;     // set: where run_fc2_grad / att_reduce go (small_side)
         auto run_fc2_grad = [&]() -> int {
-        hipStream_t cstream = stream;
-        if (side_ok && !defer_small)
+        hipStream_t cstream = small_stream ? small_stream : stream;
+        if (side_ok && !defer_small && !small_stream)
             if (void *side = context_fork(ctx, stream)) cstream = (hipStream_t)side;
         if (pool_step) {
             hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, cstream, c.at<const float>(c.w.outb), Sb, grad_scale, loss,
@@ -2203,7 +2214,7 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             if (int rc = joiner.mark()) return rc;
         return PN_OK;
         };
-        if (!pool_step && !defer_small)
+        if (!pool_step && !defer_small && !small_side)
             if (int rc = run_fc2_grad()) return rc;
 
         // pooling / attention backward -> dhn, dXh (ego rows), dZ or dXh (attention ego), g_att_*
@@ -2269,9 +2280,10 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                     }
                     PN_CHECK_HIP(hipGetLastError());
                 }
-                if (!defer_small)
+                if (!defer_small && !small_side)
                     if (int rc = run_fc2_grad()) return rc;
             }
+            {
             StageTimer tm(ctx, ST_POOL_BWD, stream);
             if (pool_step) {
             } else if (wg) {
@@ -2289,15 +2301,23 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 hipLaunchKernelGGL(pool_bwd_kernel<16>, dim3((Sb + 3) / 4), dim3(256), lds_bytes, stream, pp);
             }
             PN_CHECK_HIP(hipGetLastError());
-            att_reduce = [=]() -> int {        // the attention weights' terms in workgroup order
+            }
+            att_reduce = [=, &small_stream]() -> int {        // the attention weights' terms in workgroup order
                 if (has_att && pp.det_att) {
-                    hipLaunchKernelGGL(det_att_reduce_kernel, dim3(2 * H + 1), dim3(256), 0, stream, pp.det_att, att_blocks, H,
-                                       pp.g_att_w, pp.g_att_b);
+                    hipLaunchKernelGGL(det_att_reduce_kernel, dim3((2 * H + 4 + 63) / 64), dim3(1024), 0,
+                                       small_stream ? small_stream : stream, pp.det_att, att_blocks, H, pp.g_att_w, pp.g_att_b);
                     PN_CHECK_HIP(hipGetLastError());
                 }
                 return PN_OK;
             };
-            if (!defer_small)
+            if (small_side) {       // behind the pooling backward: loss sum, classifier gradient, attention reduce -> second stream
+                if (void *side = context_fork(ctx, stream)) small_stream = (hipStream_t)side;
+                if (int rc = run_fc2_grad()) return rc;
+                if (int rc = att_reduce()) return rc;
+                if (small_stream)
+                    if (int rc = joiner.mark()) return rc;
+                small_stream = nullptr;
+            } else if (!defer_small)
                 if (int rc = att_reduce()) return rc;
             if (d.det) {
                 // (this micro-batch's orders were sorted on the second stream under its forward, when the backward re-ran it)

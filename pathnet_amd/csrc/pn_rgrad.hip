@@ -219,7 +219,12 @@ namespace pn {
 
 bool rgrad_pays(const pn_context *ctx, int64_t R, int M, int N) {
     if (knobs_of(ctx).node_rgrad == 0) return false;    // 0: never (A/B runs, tests)
-    return R >= 49152 && M % 4 == 0 && N % 4 == 0;
+    if (M % 4 != 0 || N % 4 != 0) return false;
+    // Round 3 chose it from ~49 000 rows up, stand-alone.  In a training step these GEMMs run on the eighth of the CUs the
+    // recurrent weight-gradient GEMM leaves free, where the fp32-input MFMA's rate (1 / 16 of the bf16 pipe's) is what
+    // bounds them: from a few thousand rows on the bf16 x 3 kernel is the shorter one there (round 6, PN_NODE_RGRAD 3 / 1:
+    // Pubmed step 5.610 -> 5.566 ms, Cora 0.9252 -> 0.9221; profiles/r06_glue.txt section 8).  3: the round-3 threshold.
+    return R >= (knobs_of(ctx).node_rgrad >= 3 ? 49152 : 2048) || knobs_of(ctx).node_rgrad == 2;
 }
 
 int launch_rgrad(pn_context *ctx, void *stream_, const RgradParams &p) {

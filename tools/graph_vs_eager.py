@@ -142,8 +142,30 @@ def analyse(dirs):
             print("     %8.2f  x%.1f  %s" % (us, cnt, k))
 
 
+def timeline(d):
+    """one step (the one of median length) kernel by kernel: start offset, duration, queue"""
+    rows = load(d)
+    marks = [i for i, r in enumerate(rows) if "step_state_advance_kernel" in r["name"]]
+    steps = [rows[a:b] for a, b in zip(marks, marks[1:])][-(STEPS - 5):]
+    if not steps:
+        raise SystemExit("no steps in %s" % d)
+    steps.sort(key=lambda st: max(r["end"] for r in st) - st[0]["start"])
+    st = steps[len(steps) // 2]
+    s0 = st[0]["start"]
+    queues = {}
+    print("== %s: the step of median span, %d kernels" % (d, len(st)))
+    print("   start us |  dur us | end us  | queue | kernel")
+    for r in st:
+        q = queues.setdefault(r["where"], len(queues))
+        print("   %8.1f | %7.1f | %7.1f | %5d | %s" % ((r["start"] - s0) / 1e3, (r["end"] - r["start"]) / 1e3, (r["end"] - s0) / 1e3, q,
+                                                    short(r["name"])))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 3 and sys.argv[1] == "run":
+    if len(sys.argv) >= 3 and sys.argv[1] == "timeline":
+        for d in sys.argv[2:]:
+            timeline(d)
+    elif len(sys.argv) >= 3 and sys.argv[1] == "run":
         run(sys.argv[2])
     elif len(sys.argv) >= 3 and sys.argv[1] == "analyse":
         analyse(sys.argv[2:])
