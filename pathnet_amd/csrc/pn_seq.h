@@ -101,7 +101,7 @@ struct RgradParams {
     float *rowsum;          // [M] += column sums of the gated A (the bias gradient), or null
     const int32_t *seg, *list;      // compact rows: A row = seg[0] + k, B row = list[seg[0] + k], k < seg[1] - seg[0]; or both null
 };
-bool rgrad_pays(const pn_context *ctx, int64_t R, int M, int N);       // the kernel's 128 x 128 tiles and K tiles of 32 rows want >= ~50 000 rows
+bool rgrad_pays(const pn_context *ctx, int64_t R, int M, int N);       // from 2 048 reduction rows on (pn_rgrad.hip)
 int launch_rgrad(pn_context *ctx, void *stream, const RgradParams &p);
 
 // ---- pn_seq3.hip: the recurrent kernels on the bf16 matrix pipe (six MFMAs per fp32 product, three planes) -----------------------
