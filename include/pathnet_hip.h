@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 8 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
+#define PN_ABI_VERSION 9 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
                           * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
                           *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
                           *    offsets throughout; pn_clock_probe
@@ -48,7 +48,8 @@ extern "C" {
                           * 7: pn_context_set_knob / pn_context_get_knob: the kernel-selection knobs are part of the context (read
                           *    from the environment once, when it is created); no call reads the environment any more
                           * 8: pn_seq_range / pn_pagg_range_offset (the fp16 recurrence's operand range and the spread of the gathered
-                          *    rows' magnitudes, for callers that want to fall back to bf16x3 on pathological inputs) */
+                          *    rows' magnitudes, for callers that want to fall back to bf16x3 on pathological inputs)
+                          * 9: pn_adam_step_advance (the optimizer's last launch moves the step state on) */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -470,6 +471,12 @@ typedef struct pn_adam_tensor {
 int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int64_t step, const pn_step_state *step_state /* dev or NULL: replaces step */,
                  void *stream);
+/* The same update with step_state's step count, after which the state is moved to the NEXT step by the update's own last
+ * launch (the workgroup that finishes last does what pn_step_state_advance does): a training loop whose steps end in this call
+ * needs no pn_step_state_advance launch in front of the next one -- ~7 us of a 0.93 ms step at the headline shape.  Uses the
+ * low 32 bits of step_state->reserved as a ticket counter (zero between calls). */
+int pn_adam_step_advance(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, pn_step_state *step_state /* dev */, void *stream);
 
 /* Byte offsets inside the aggregator workspace of the intermediates tests look at:
  * out[0] Xh [N,H], out[1] Z [N,L,H], out[2] hn [P,H] (pooling-group order), out[3] layer1 [S,2H]. */

@@ -58,7 +58,21 @@ struct AdamList {
     float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay;
     float lr;
     const pn_step_state *dyn;     // step count in device memory (hipGraph replay): the bias corrections are formed here
+    int advance;                  // pn_adam_step_advance, last launch: the workgroup that finishes last moves *dyn to the next step
 };
+
+// epoch += 1, adam_step += 1, seed = splitmix64(seed)   (= step_state_advance_kernel, pn_context.hip)
+__device__ __forceinline__ void advance_step_state(pn_step_state *s) {
+    s->epoch += 1;
+    s->adam_step += 1;
+    uint64_t z = (s->seed += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    s->seed = z ^ (z >> 31);
+}
+__global__ void adam_advance_only_kernel(pn_step_state *s) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) advance_step_state(s);
+}
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamList a) {
     float lr_over_bc1 = a.lr_over_bc1, inv_sqrt_bc2 = a.inv_sqrt_bc2;
@@ -94,6 +108,17 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamList a) {
         t.exp_avg_sq[e] = v;
         t.param[e] = p - lr_over_bc1 * (m / (sqrtf(v) * inv_sqrt_bc2 + a.eps));
     }
+    if (a.dyn && a.advance) {       // (block-uniform) every workgroup has read adam_step by the time it takes its ticket
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pn_step_state *s = const_cast<pn_step_state *>(a.dyn);
+            unsigned int *ticket = reinterpret_cast<unsigned int *>(&s->reserved);
+            if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+                atomicExch(ticket, 0u);
+                advance_step_state(s);
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -128,9 +153,11 @@ int pn_cross_entropy(const float *logits, const int64_t *target, int32_t rows, i
     return pn::launch_cross_entropy(logits, target, rows, classes, 1.0f / (float)rows, loss, g_logits, stream, true);
 }
 
-int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int64_t step, const pn_step_state *step_state, void *stream_) {
+static int adam_step_impl(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int64_t step, const pn_step_state *step_state, bool advance, void *stream_) {
     if (n_tensors < 0 || (n_tensors > 0 && !tensors)) PN_FAIL(PN_ERR_ARG, "pn_adam_step: bad tensor list");
+    if (advance && !step_state) PN_FAIL(PN_ERR_ARG, "pn_adam_step_advance: no step state to advance");
+    bool advanced = false;
     if (step_state) step = 1;       // (ignored: the kernel reads step_state->adam_step)
     if (step < 1) PN_FAIL(PN_ERR_ARG, "pn_adam_step: step counts from 1 (got %lld)", (long long)step);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -156,11 +183,27 @@ int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, flo
         a.weight_decay = weight_decay;
         a.lr = lr;
         a.dyn = step_state;
+        a.advance = (advance && at + PN_ADAM_MAX_TENSORS >= n_tensors) ? 1 : 0;      // the step's last launch
         if (blocks == 0) continue;
         hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, a);
         PN_CHECK_HIP(hipGetLastError());
+        advanced = advanced || a.advance != 0;
+    }
+    if (advance && !advanced) {     // nothing to update in the last launch: the state still moves on
+        hipLaunchKernelGGL(adam_advance_only_kernel, dim3(1), dim3(64), 0, stream, const_cast<pn_step_state *>(step_state));
+        PN_CHECK_HIP(hipGetLastError());
     }
     return PN_OK;
+}
+
+int pn_adam_step(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int64_t step, const pn_step_state *step_state, void *stream_) {
+    return adam_step_impl(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, step, step_state, false, stream_);
+}
+
+int pn_adam_step_advance(const pn_adam_tensor *tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, pn_step_state *step_state, void *stream_) {
+    return adam_step_impl(tensors, n_tensors, lr, beta1, beta2, eps, weight_decay, 1, step_state, true, stream_);
 }
 
 }  // extern "C"

@@ -112,16 +112,24 @@ class Adam(torch.optim.Optimizer):
             by_step = {}
             for item in todo:
                 by_step.setdefault(item[2]["step"], []).append(item)
+            groups_left = len(by_step)
             for step, items in by_step.items():
+                groups_left -= 1
                 arr = (_lib.AdamTensor * len(items))()
                 for i, (p, g, st) in enumerate(items):
                     arr[i] = _lib.AdamTensor(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
                                              st["exp_avg_sq"].data_ptr(), p.numel())
+                ss = self.step_state
                 with torch.cuda.device(items[0][0].device):
-                    _lib.check(lib.pn_adam_step(arr, len(items), group["lr"], group["betas"][0], group["betas"][1],
-                                                group["eps"], group["weight_decay"], step,
-                                                self.step_state.ptr() if self.step_state is not None else None,
-                                                _stream()))
+                    if ss is not None and ss.advance_in_adam and groups_left == 0 and group is self.param_groups[-1]:
+                        # the optimizer's last launch of the step moves the step state on: the next StepState.advance() is free
+                        _lib.check(lib.pn_adam_step_advance(arr, len(items), group["lr"], group["betas"][0], group["betas"][1],
+                                                            group["eps"], group["weight_decay"], ss.ptr(), _stream()))
+                        ss._advanced_by_adam = True
+                    else:
+                        _lib.check(lib.pn_adam_step(arr, len(items), group["lr"], group["betas"][0], group["betas"][1],
+                                                    group["eps"], group["weight_decay"], step,
+                                                    ss.ptr() if ss is not None else None, _stream()))
                 # the kernel wrote through raw pointers: tell autograd's version counters, which is what everything that
                 # caches a function of the parameters keys on (the modules' reuse_tables, dist.ShardedAggregator.begin_step) --
                 # torch.optim.Adam's in-place ops bump them as a matter of course.  No launch.
@@ -134,16 +142,24 @@ class StepState:
     """struct pn_step_state in device memory: {epoch, seed, adam_step} of the current training step, read by the sampler,
     the aggregator's dropout and Adam WHEN THEIR KERNELS RUN -- so a whole step (sample -> forward -> loss -> backward ->
     Adam) captured into a hipGraph (torch.cuda.CUDAGraph) replays with a new epoch / seed / step count each time.
-    ``advance()`` is the first launch of a step: epoch += 1, adam_step += 1, seed = splitmix64(seed)."""
+    ``advance()`` is the first launch of a step: epoch += 1, adam_step += 1, seed = splitmix64(seed).
+    advance_in_adam (round 6): pathnet_amd.Adam's last launch of a step performs the advance for the NEXT step
+    (pn_adam_step_advance), and the ``advance()`` that follows it launches nothing -- one launch less on the step's critical
+    path; every ``advance()`` still stands for exactly one advance of the state."""
 
-    def __init__(self, device="cuda", seed=0, first_epoch=0):
+    def __init__(self, device="cuda", seed=0, first_epoch=0, advance_in_adam=False):
         dev = torch.device(device)
         self.t = torch.tensor([int(first_epoch) - 1, int(seed) & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=dev)
+        self.advance_in_adam = bool(advance_in_adam)
+        self._advanced_by_adam = False
 
     def ptr(self):
         return ctypes.c_void_p(self.t.data_ptr())
 
     def advance(self):
+        if self._advanced_by_adam:      # the optimizer step before this one has already moved the state
+            self._advanced_by_adam = False
+            return
         with torch.cuda.device(self.t.device):
             _lib.check(_lib.load().pn_step_state_advance(self.ptr(), _lib.stream_ptr(self.t.device)))
 

@@ -83,3 +83,33 @@ def test_seeded_backward_equals_loss_backward():
             got.append({k: v.grad.clone() for k, v in m.named_parameters()})
         for k in got[0]:
             assert torch.equal(got[0][k], got[1][k]), (fused, k)
+
+
+def test_adam_that_advances_the_step_state_equals_the_explicit_advance():
+    """StepState(advance_in_adam=True): the optimizer's last launch of a step moves {epoch, seed, adam_step} on
+    (pn_adam_step_advance: the workgroup that finishes last, after every workgroup has read the step count) and the next
+    advance() launches nothing.  Same states after every step and bit-equal parameters as with the explicit launch, with
+    more tensors than one launch takes and with a step in which no parameter has a gradient."""
+    import pathnet_amd
+    torch.manual_seed(11)
+    shapes = [(300, 129), (64,), (5000,)] + [(33,)] * 45        # > PN_ADAM_MAX_TENSORS: two launches per step
+    runs = []
+    for auto in (False, True):
+        torch.manual_seed(12)
+        ps = [torch.nn.Parameter(torch.randn(*s).cuda()) for s in shapes]
+        st = pathnet_amd.StepState("cuda", seed=77, first_epoch=3, advance_in_adam=auto)
+        opt = pathnet_amd.Adam(ps, lr=0.01, weight_decay=0.001, step_state=st)
+        states = []
+        for it in range(6):
+            st.advance()
+            states.append(st.values())
+            for p in ps:
+                p.grad = None if it == 4 else torch.randn(*p.shape, device="cuda")
+            opt.step()
+        torch.cuda.synchronize()
+        assert int(st.t[3].item()) & 0xFFFFFFFF == 0            # the ticket counter is back at zero
+        runs.append((states, [p.detach().clone() for p in ps]))
+    assert runs[0][0] == runs[1][0]
+    assert runs[0][0][0] == {"epoch": 3, "seed": runs[0][0][0]["seed"], "adam_step": 1} and runs[0][0][5]["adam_step"] == 6
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
