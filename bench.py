@@ -235,7 +235,7 @@ def slim_line(full):
     """The ONE stdout line: numbers only, every key the bench contract names, nothing else.  Everything bench.py measures
     beyond it (other configurations, stage tables, notes) is in `full`, which goes to bench_extras.json and to stderr."""
     out = _pick(full, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "seq_math", "data")
+                "vs_baseline", "dtype", "seq_math", "step_api", "data")
     cfg = full.get("config", {})
     out["config"] = _pick(cfg, "workload", "nodes", "paths_per_step", "parallelism")
     r = full.get("roofline") or {}
@@ -531,9 +531,12 @@ class StepRunner:
         self.opt = pathnet_amd.Adam(self.model.parameters(), lr=0.005, weight_decay=0.0005,   # torch.optim.Adam's update, one launch
                                     **({"step_state": self.state} if self.state is not None else {}))
         self.lossf = pathnet_amd.CrossEntropyLoss()                                          # torch.nn.CrossEntropyLoss(), one launch
-        # forward / loss / backward as three library calls: what a batch that fits the workspace is quicker with (A/B in
-        # profiles/README.md); PN_BENCH_FUSED=1 runs the step through pn_pagg_train_step instead
-        self.fused = os.environ.get("PN_BENCH_FUSED", "0") not in ("", "0")
+        # one GPU: forward, loss and backward of the step in ONE library call (pn_pagg_train_step: module.forward_loss(fused=True)),
+        # since round 6 the quicker form at every size (pooling forward + loss + pooling backward in one launch, the small
+        # launches under the BPTT: profiles/r06_glue.txt; same kernels and values as the three calls, tests/test_gpu_fused_step.py);
+        # PN_BENCH_FUSED=0 runs forward / loss / backward as the reference's loop does, three calls.  Several ranks: the
+        # node-sharded runner (three calls with the collectives between them)
+        self.fused = os.environ.get("PN_BENCH_FUSED", "1") not in ("", "0")
         Y = torch.from_numpy(wl["Y"]).to(dev)
         self.runner = None
         self.overlap = os.environ.get("PN_BENCH_OVERLAP", "1") not in ("", "0")    # collectives on their own stream (dist.py)
@@ -1248,6 +1251,7 @@ def main():
                       % ("scaled 2-plane fp16 splits (3 fp16 MFMAs per fp32 product)" if seq_math_name() == "f16x2" else
                          "3-plane bf16 splits (6 bf16 MFMAs per fp32 product)"),
         "seq_math": seq_math_name(),
+        "step_api": "pn_pagg_train_step" if (sr.runner is None and sr.fused) else "forward + loss + backward (three calls)",
         "config": {"workload": {"cora": "Cora-shaped synthetic (configs[1])", "pubmed": "Pubmed-shaped synthetic (configs[2])",
                                 "bgp": "BGP-sized synthetic, hetero class (configs[3])"}[args.workload] + ": N=%d F=%d C=%d hid=%d path_num=%d path_len=%d, "
                                "%d masked nodes = %d paths/step, %s, dropout 0.7, Adam" %

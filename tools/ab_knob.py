@@ -28,8 +28,7 @@ def main():
             opts[k] = v
         else:
             values.append(int(a))
-    if opts["fused"] != "0":
-        os.environ["PN_BENCH_FUSED"] = "1"
+    os.environ["PN_BENCH_FUSED"] = "0" if opts["fused"] == "0" else "1"
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     wl = {"cora": lambda: bench.workload(0, 1), "pubmed": bench.pubmed_workload, "bgp": bench.bgp_workload}[opts["workload"]]()
