@@ -537,6 +537,7 @@ class StepRunner:
         # PN_BENCH_FUSED=0 runs forward / loss / backward as the reference's loop does, three calls.  Several ranks: the
         # node-sharded runner (three calls with the collectives between them)
         self.fused = os.environ.get("PN_BENCH_FUSED", "1") not in ("", "0")
+        self.sample_beside = os.environ.get("PN_BENCH_SAMPLE_BESIDE", "1") not in ("", "0")      # (module.paths_stream)
         Y = torch.from_numpy(wl["Y"]).to(dev)
         self.runner = None
         self.overlap = os.environ.get("PN_BENCH_OVERLAP", "1") not in ("", "0")    # collectives on their own stream (dist.py)
@@ -585,6 +586,12 @@ class StepRunner:
             self.state.advance()        # (one tiny launch: epoch + 1, Adam step + 1, the step's dropout seed)
             self.smp.sample(W, 0, nodes=self.sel32, draw_source=pathnet_amd.DRAW_PHILOX, check=False,
                             out=(self.ids_buf, self.codes_buf), step_state=self.state)
+        elif self.runner is None and self.sample_beside:
+            # this epoch's walk on the stream where the aggregator reads the paths (the library's second stream: behind the
+            # previous step's recurrent weight gradient, in front of this step's index plan -- no event, nothing on the main stream)
+            with torch.cuda.stream(self.model.paths_stream()):
+                self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, nodes=self.sel32,
+                                draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(self.ids_buf, self.codes_buf))
         else:
             self.smp.sample(W, 1234, epoch_begin=epoch, epoch_count=1, nodes=self.sel32,
                             draw_source=pathnet_amd.DRAW_PHILOX, check=False, out=(self.ids_buf, self.codes_buf))

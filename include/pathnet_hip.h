@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 9 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
+#define PN_ABI_VERSION 10 /* 2: pn_sampler_tables gained draws_per_step; pn_pairs_*, pn_uniform_*, pn_merw_*, pn_cross_entropy, pn_adam_step
                           * 4: pn_context (no process-global state); pn_pagg_shape gained S_total / group_begin / batch_groups
                           *    (micro-batches, exact sharding of the hetero class); pn_pagg_args gained reuse_tables; 64-bit
                           *    offsets throughout; pn_clock_probe
@@ -49,7 +49,8 @@ extern "C" {
                           *    from the environment once, when it is created); no call reads the environment any more
                           * 8: pn_seq_range / pn_pagg_range_offset (the fp16 recurrence's operand range and the spread of the gathered
                           *    rows' magnitudes, for callers that want to fall back to bf16x3 on pathological inputs)
-                          * 9: pn_adam_step_advance (the optimizer's last launch moves the step state on) */
+                          * 9: pn_adam_step_advance (the optimizer's last launch moves the step state on)
+                          * 10: pn_pagg_paths_stream (where a call reads its path arrays: a sampler enqueued there needs no event) */
 
 #define PN_OK 0
 #define PN_ERR_ARG (-1)          /* bad argument / unsupported shape */
@@ -385,6 +386,13 @@ typedef struct pn_seq_range {
 } pn_seq_range;
 /* *offset = byte offset of the call's pn_seq_range in its workspace, or -1 when the shape runs no fp16 recurrent kernel */
 int pn_pagg_range_offset(const pn_pagg_shape *shape, int64_t *offset);
+/* The stream on which a call with this shape, made on `stream`, READS its path arrays (ids / codes: the index plan and the
+ * touched-row marks): the context's second stream when the call forks them off (a context, one micro-batch, stages not timed one
+ * by one), else `stream` itself.  A producer of the paths enqueued THERE -- the sampler of a training loop: pn_sample_paths with
+ * *out as its stream, right before the call -- is ordered before its readers and behind those of the previous call without an
+ * event on `stream`, and runs under whatever that stream still holds of the previous step (the recurrent weight gradient):
+ * the walk leaves the step's critical path.  Ask before every call (the answer follows pn_profile_configure). */
+int pn_pagg_paths_stream(pn_context *ctx, const pn_pagg_shape *shape, void *stream, void **out);
 /* out = forward(...).  Leaves what backward needs in the workspace. */
 int pn_pagg_forward(pn_context *ctx, const pn_pagg_args *args, void *stream);
 /* Gradients of sum(out * g_out) w.r.t. every parameter (overwritten, not accumulated) and X.

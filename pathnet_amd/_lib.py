@@ -13,7 +13,7 @@ PN_OK = 0
 PN_ERR_ARG, PN_ERR_IO, PN_ERR_FORMAT, PN_ERR_HIP, PN_ERR_EMPTY_TABLE, PN_ERR_NOMEM, PN_ERR_CAPACITY = (
     -1, -2, -3, -4, -5, -6, -7)
 DRAW_GLIBC_REPLAY, DRAW_PHILOX = 0, 1
-ABI_VERSION = 9               # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
+ABI_VERSION = 10              # PN_ABI_VERSION of include/pathnet_hip.h this binding was written against
 VARIANT_HETERO, VARIANT_HOMO, VARIANT_PAGG = 0, 1, 2
 CELL_DEFAULT, CELL_LSTM, CELL_RNN, CELL_GRU, CELL_MEAN, CELL_SUM = 0, 1, 2, 3, 4, 5
 SEQ_MATH_DEFAULT, SEQ_MATH_BF16X3, SEQ_MATH_F16X2 = 0, 1, 2     # pn_pagg_shape.seq_math
@@ -128,6 +128,7 @@ SIGNATURES = {
     "pn_pagg_train_step": (ctypes.c_int, [vp, ctypes.POINTER(PaggArgs), vp, ctypes.c_float, vp, vp]),
     "pn_pagg_debug_offsets": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
     "pn_pagg_range_offset": (ctypes.c_int, [ctypes.POINTER(PaggShape), c_i64p]),
+    "pn_pagg_paths_stream": (ctypes.c_int, [vp, ctypes.POINTER(PaggShape), vp, ctypes.POINTER(ctypes.c_void_p)]),
     "pn_merw_workspace_bytes": (ctypes.c_int, [ctypes.c_int32, c_i64p]),
     "pn_merw_probabilities": (ctypes.c_int, [ctypes.c_int32, ctypes.c_int64, vp, vp, vp, vp, vp, c_f64p, ctypes.c_int32,
                                              ctypes.c_double, c_i32p, vp, ctypes.c_int64, vp]),

@@ -133,6 +133,7 @@ int ensure_dynamic_lds(pn_context *ctx, const void *kernel, int bytes) {
     return PN_OK;
 }
 
+void *context_side_stream(pn_context *ctx) { return ctx ? (void *)ctx->side : nullptr; }
 void *context_fork(pn_context *ctx, void *stream) {
     if (!ctx || !ctx->side) return nullptr;
     if (hipEventRecord(ctx->fork, (hipStream_t)stream) != hipSuccess) return nullptr;

@@ -73,6 +73,7 @@ bool profiling_every_stage(const pn_context *ctx);
 int context_check_device(const pn_context *ctx);
 // the context's second stream, forked from `stream` (event) -- nullptr when there is no context
 void *context_fork(pn_context *ctx, void *stream);
+void *context_side_stream(pn_context *ctx);      // the second stream itself (or null)
 // records the join event on the second stream; context_join makes `stream` wait for it
 int context_record_join(pn_context *ctx);
 int context_join(pn_context *ctx, void *stream);

@@ -1960,6 +1960,17 @@ int pn_linear_backward(pn_context *ctx, const float *dY, const float *gate, cons
 }
 
 
+int pn_pagg_paths_stream(pn_context *ctx, const pn_pagg_shape *shape, void *stream, void **out) {
+    if (!shape || !out) PN_FAIL(PN_ERR_ARG, "pn_pagg_paths_stream: null");
+    Dims d;
+    if (int rc = make_dims(*shape, d)) return rc;
+    // (run_tables: the plan of micro-batch 0 goes to the second stream unless every stage is timed; later micro-batches
+    //  are planned on the caller's stream)
+    void *side = (ctx && d.nb == 1 && !profiling_every_stage(ctx)) ? context_side_stream(ctx) : nullptr;
+    *out = side ? side : stream;
+    return PN_OK;
+}
+
 int pn_pagg_range_offset(const pn_pagg_shape *shape, int64_t *offset) {
     if (!shape || !offset) PN_FAIL(PN_ERR_ARG, "pn_pagg_range_offset: null");
     Dims d;

@@ -504,6 +504,33 @@ class _Aggregator(nn.Module):
     def forward(self, X, neis, num_w, walk_len, indices, layer_type, indxx=None, reuse_tables=False, group_slice=None):
         return self._run(X, neis, num_w, walk_len, indices, layer_type, reuse_tables=reuse_tables, group_slice=group_slice)
 
+    def paths_stream(self):
+        """The torch stream on which this module's NEXT call will read its path arrays (neis / layer_type), judged by the
+        shape of its last call on the current stream (pn_pagg_paths_stream): the library's second stream when the call forks
+        the index plan off, else the current stream.  A training loop that enqueues its sampler there
+        (``with torch.cuda.stream(model.paths_stream()): sampler.sample(..., out=bufs)``) takes the walk off the step's
+        critical path -- it runs under the tail of the previous step -- without an event on the main stream.  The path
+        buffers must then be written by that stream only."""
+        cur = torch.cuda.current_stream()
+        last = getattr(self, "_last_shape", None)
+        if last is None:
+            self._paths_stream_prev = cur
+            return cur
+        shape, dev = last
+        out = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            _lib.check(_lib.load().pn_pagg_paths_stream(_lib.context(dev), ctypes.byref(shape), _lib.stream_ptr(dev), ctypes.byref(out)))
+        new = cur if (not out.value or out.value == cur.cuda_stream) else torch.cuda.ExternalStream(out.value, device=dev)
+        # the readers of the previous batch's paths ran on the stream handed out last time: when the answer changes (first
+        # steps, pn_profile_configure, another batch shape) the new producer is ordered behind them once, with an event
+        prev = getattr(self, "_paths_stream_prev", None)
+        if prev is not None and prev.cuda_stream != new.cuda_stream:
+            new.wait_stream(prev)
+            new.wait_stream(cur)
+        self._paths_stream_prev = new
+        return new
+
     # ---- range guard (see _common_init) ---------------------------------------------------------------------------------
     def _range_eval(self, rec):
         x_bits, esum, cnt = int(rec[0]) & 0xFFFFFFFF, int(rec[1]), int(rec[2]) & 0xFFFFFFFF
@@ -608,6 +635,7 @@ class _Aggregator(nn.Module):
                                                 deterministic=cfg["deterministic"], S_total=cfg.get("S_total", 0),
                                                 group_begin=cfg.get("group_begin", 0), compact=cfg["compact"],
                                                 seq_math=cfg["seq_math"])
+        self._last_shape = (_cfg_shape(cfg), dev)       # (paths_stream: where the NEXT call of this shape reads its paths)
         if not cfg["grad"]:
             need = _cfg_workspace_bytes(cfg)
             fits = self._ws_eval is not None and self._ws_eval.numel() >= need and self._ws_eval.device == dev

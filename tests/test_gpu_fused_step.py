@@ -176,3 +176,50 @@ def test_pooling_step_in_one_launch_is_the_three_launches(variant, S, W, L, H, c
     #  a different order every run -- two runs of the SAME configuration differ by as much)
     for g in (g1, g2):
         assert_grads_close(g, g0, rel=1e-5, noise=3e-8, zero_ok=zero_ok)
+
+
+def test_sampler_on_the_stream_that_reads_the_paths_gives_the_same_steps():
+    """module.paths_stream() (pn_pagg_paths_stream): the training loop enqueues each step's walk on the stream where the
+    aggregator reads the path arrays -- the library's second stream -- instead of the main one: no event on the main stream, the
+    walk runs under the tail of the previous step.  Twelve steps of sample -> fused step -> Adam, host racing ahead of the GPU:
+    the same losses and parameters, bit for bit (deterministic backward), as with the sampler on the main stream."""
+    import numpy as np
+    import pathnet_amd
+    rng = np.random.default_rng(3)
+    n, F, H, C, W, L, S = 600, 40, 128, 5, 8, 4, 200
+    u = rng.integers(0, n, 3000)
+    v = rng.integers(0, n, 3000)
+    keep = u != v
+    u, v = np.concatenate([u[keep], np.arange(n)]), np.concatenate([v[keep], (np.arange(n) + 1) % n])
+    p = rng.random(len(u))
+    smp = pathnet_amd.MerwSampler(n, u.astype(np.int32), v.astype(np.int32), p, L, device="cuda")
+    X = torch.rand(n, F, device="cuda")
+    sel = torch.arange(0, n, 3, dtype=torch.int32, device="cuda")[:S]
+    y = torch.randint(0, C, (S,), device="cuda")
+    runs = []
+    for beside in (False, True):
+        torch.manual_seed(1)
+        m = pathnet_amd.PathNet_homo(F, H, C, L, dropout=0.5).cuda().train()
+        m.deterministic = True
+        opt = pathnet_amd.Adam(m.parameters(), lr=0.01)
+        ids = torch.empty((1, S, W, L), dtype=torch.int32, device="cuda")
+        codes = torch.empty((1, S, W, L), dtype=torch.uint8, device="cuda")
+        losses, streams = [], set()
+        for e in range(12):
+            st = m.paths_stream() if beside else torch.cuda.current_stream()
+            streams.add(st.cuda_stream)
+            with torch.cuda.stream(st):
+                smp.sample(W, 77, epoch_begin=e, epoch_count=1, nodes=sel, draw_source=pathnet_amd.DRAW_PHILOX, check=False,
+                           out=(ids, codes))
+            opt.zero_grad(set_to_none=True)
+            torch.manual_seed(100 + e)          # (the dropout seed of the step)
+            loss, _ = m.forward_loss(X, ids[0], W, L, sel, codes[0], y, fused=True)
+            pathnet_amd.backward(loss)
+            opt.step()
+            losses.append(loss.detach())
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), [q.detach().clone() for q in m.parameters()], streams))
+    assert len(runs[1][2]) == 2         # the first step's walk on the main stream, every later one on the library's second stream
+    assert torch.equal(runs[0][0], runs[1][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
