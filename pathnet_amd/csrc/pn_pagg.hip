@@ -1218,7 +1218,10 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
     return PN_OK;
 }
 
-constexpr int WGRAD_CUS_SHARED = 224;   // CUs of the weight-gradient launch when something is meant to run beside it (of 256)
+#ifndef PN_WGRAD_CUS_SHARED
+#define PN_WGRAD_CUS_SHARED 208    // (round 6: 224 until the node-level weight gradients moved to rgrad_kernel; tuning builds
+#endif                             //  176 .. 240: profiles/r06_glue.txt section 11)
+constexpr int WGRAD_CUS_SHARED = PN_WGRAD_CUS_SHARED;   // CUs of the weight-gradient launch when something is meant to run beside it (of 256)
 struct WsLayout {
     size_t Xh, Z, range;                                                 // node tables (first: reuse_tables relies on it)
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
@@ -1255,7 +1258,7 @@ WsLayout ws_layout(const Dims &d) {
         // whole register file: with one on every CU the node-level GEMMs of the main stream (bank / fc0 backward) cannot
         // start until the launch is over, whatever stream they are on.  A short launch (a Cora-sized batch: 0.17 ms against
         // ~0.07 ms of launch-bound GEMMs) therefore leaves an eighth of the CUs free -- the kernel is HBM-bound enough to
-        // lose 3 % on 224 CUs, the step wins 2.8 % (0.988 -> 0.959 ms); where the weight gradient is 6-12x the GEMM chain
+        // lose 3 % on 224 CUs, the step wins 2.8 % (0.988 -> 0.959 ms; round 6: 208 CUs, another -1.7 %); where the weight gradient is 6-12x the GEMM chain
         // (Pubmed, BGP size: +10 % on the kernel for nothing hidden) it keeps every CU.  profiles/r04_wgrad_cus_ab.txt
         const size_t rows = Pb * L, tiles = std::max<size_t>(1, ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN));
         const double wg_flops = 2.0 * (double)rows * (double)(G * H) * (double)(2 * H);
