@@ -1126,6 +1126,22 @@ __global__ __launch_bounds__(1024) void det_att_reduce_kernel(const float *__res
     }
 }
 
+// out [R][F4] = in [R][F] with zeros in columns F .. F4 - 1 (F4 = F rounded up to 4): 16-byte stores, dword loads
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ in, int64_t R, int F, int F4, float *__restrict__ out) {
+    const int q4 = F4 / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * q4) return;
+    const int64_t r = i / q4;
+    const int c = (int)(i - r * q4) * 4;
+    const float *src = in + r * F + c;
+    float4 v;
+    v.x = src[0];                       // (c < F always)
+    v.y = c + 1 < F ? src[1] : 0.0f;
+    v.z = c + 2 < F ? src[2] : 0.0f;
+    v.w = c + 3 < F ? src[3] : 0.0f;
+    reinterpret_cast<float4 *>(out)[i] = v;
+}
+
 // zero-fill of up to 12 buffers in one launch (the accumulated gradients of a backward)
 struct ZeroList {
     float *ptr[12];
@@ -1219,14 +1235,24 @@ int make_dims(const pn_pagg_shape &s, Dims &d) {
 }
 
 #ifndef PN_WGRAD_CUS_SHARED
-#define PN_WGRAD_CUS_SHARED 208    // (round 6: 224 until the node-level weight gradients moved to rgrad_kernel; tuning builds
-#endif                             //  176 .. 240: profiles/r06_glue.txt section 11)
+#define PN_WGRAD_CUS_SHARED 224    // (tuning builds 176 .. 240: profiles/r06_glue.txt section 11 -- 208 won while fc0's weight
+#endif                             //  gradient was a 150 us gemm_kernel launch beside it, 224 again once that ran on rgrad_kernel)
 constexpr int WGRAD_CUS_SHARED = PN_WGRAD_CUS_SHARED;   // CUs of the weight-gradient launch when something is meant to run beside it (of 256)
+// fc0's weight gradient runs on rgrad_kernel (16-byte row loads) also when F is not a multiple of 4 -- Cora's 1433 -- from a
+// copy of X with padded rows, made per backward (pad_rows_kernel: 2 x 15 MB at the headline shape, ~5 us, for a GEMM that
+// takes 150 us on the 48 CUs the recurrent weight gradient leaves it and ~60 as a row reduction).  Graphs from 2 048 nodes
+// on whose copy stays below 256 MB; floats of the copy, 0: no copy.
+inline size_t xpad_floats(const Dims &d) {
+    if (d.F % 4 == 0 || d.N < 2048 || d.det) return 0;
+    const size_t f4 = (size_t)(d.F + 3) / 4 * 4, n = (size_t)d.N * f4;
+    return n * 4 <= ((size_t)256 << 20) ? n : 0;
+}
+
 struct WsLayout {
     size_t Xh, Z, range;                                                 // node tables (first: reuse_tables relies on it)
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
-    size_t xh, keep, dG, dhn, dl1, gx, gout, bankT;                      // per micro-batch, saved / backward
+    size_t xh, keep, dG, dhn, dl1, gx, gout, bankT, xpad;                // per micro-batch, saved / backward
     size_t flags, rank, list, seg, bsum;                                 // touched-row compaction (Dims.compact)
     size_t dx, keys, iota, skey, stmp, cpart, dsel, dds, datt, dgemm;  // deterministic backward (Dims.det)
     size_t okey, osrc;                  // its three destination orders, sorted once per micro-batch into one block each: segment
@@ -1258,7 +1284,7 @@ WsLayout ws_layout(const Dims &d) {
         // whole register file: with one on every CU the node-level GEMMs of the main stream (bank / fc0 backward) cannot
         // start until the launch is over, whatever stream they are on.  A short launch (a Cora-sized batch: 0.17 ms against
         // ~0.07 ms of launch-bound GEMMs) therefore leaves an eighth of the CUs free -- the kernel is HBM-bound enough to
-        // lose 3 % on 224 CUs, the step wins 2.8 % (0.988 -> 0.959 ms; round 6: 208 CUs, another -1.7 %); where the weight gradient is 6-12x the GEMM chain
+        // lose 3 % on 224 CUs, the step wins 2.8 % (0.988 -> 0.959 ms; re-measured in round 6); where the weight gradient is 6-12x the GEMM chain
         // (Pubmed, BGP size: +10 % on the kernel for nothing hidden) it keeps every CU.  profiles/r04_wgrad_cus_ab.txt
         const size_t rows = Pb * L, tiles = std::max<size_t>(1, ((G * H + WG_BM - 1) / WG_BM) * ((2 * H + WG_BN - 1) / WG_BN));
         const double wg_flops = 2.0 * (double)rows * (double)(G * H) * (double)(2 * H);
@@ -1295,6 +1321,7 @@ WsLayout ws_layout(const Dims &d) {
     w.gout = take(Sb * (size_t)d.C * 4);                // d loss / d logits of a micro-batch (pn_pagg_train_step)
     w.datt = take(Sb * (2 * H + 4) * 4);                // per-workgroup attention-weight terms of the pooling backward
     w.bankT = take(L * H * H * 4);                      // transposed bank weights (the dX GEMM on the bf16 x 3 kernel)
+    w.xpad = take(xpad_floats(d) * 4);                  // X with its rows padded to a multiple of four floats (fc0's weight gradient on rgrad_kernel)
     w.flags = take(d.compact ? N * L + 16 : 0);
     w.rank = take(d.compact ? N * L * 4 : 0);
     w.list = take(d.compact ? (size_t)d.ZR * 4 : 0);
@@ -2530,6 +2557,15 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
             return rc;
     } else if (a->g_fc0_w && d.F % 4 == 0 && rgrad_pays(ctx, d.N, H, d.F)) {
         const RgradParams rp{dXh, xgate, a->X, H, d.F, d.N, H, d.F, a->g_fc0_w, d.F, a->g_fc0_b, nullptr, nullptr};
+        if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
+    } else if (a->g_fc0_w && xpad_floats(d) > 0 && rgrad_pays(ctx, d.N, H, (d.F + 3) / 4 * 4)) {
+        // rows of X padded to 16 bytes first (see xpad_floats); the padding columns are zeros, and outputs past F are not stored
+        const int F4 = (d.F + 3) / 4 * 4;
+        float *Xp = c.at<float>(c.w.xpad);
+        const int64_t n4 = (int64_t)d.N * (F4 / 4);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, a->X, (int64_t)d.N, d.F, F4, Xp);
+        PN_CHECK_HIP(hipGetLastError());
+        const RgradParams rp{dXh, xgate, Xp, H, F4, d.N, H, d.F, a->g_fc0_w, d.F, a->g_fc0_b, nullptr, nullptr};
         if (int rc = launch_rgrad(ctx, stream, rp)) return rc;
     } else if (a->g_fc0_w) {
         if (int rc = launch_gemm(stream, dXh, 1, H, xgate, a->X, 1, d.F, a->g_fc0_w, d.F, nullptr, H, d.F, d.N, 0,

@@ -230,7 +230,10 @@ bool rgrad_pays(const pn_context *ctx, int64_t R, int M, int N) {
 int launch_rgrad(pn_context *ctx, void *stream_, const RgradParams &p) {
     hipStream_t stream = (hipStream_t)stream_;
     if (p.R <= 0 || p.M <= 0 || p.N <= 0) return PN_OK;
-    if (p.M % 4 || p.N % 4 || p.lda % 4 || p.ldb % 4) PN_FAIL(PN_ERR_ARG, "rgrad: M, N and the row pitches must be multiples of 4");
+    // (N itself may fall short of a multiple of 4 when the rows of B are padded that far: the kernel reads whole quads of
+    //  columns and stores the first N)
+    if (p.M % 4 || p.lda % 4 || p.ldb % 4 || (p.N + 3) / 4 * 4 > p.ldb || p.M > p.lda)
+        PN_FAIL(PN_ERR_ARG, "rgrad: M and the row pitches must be multiples of 4, the pitches cover M / N rounded up to 4");
     if ((p.seg == nullptr) != (p.list == nullptr)) PN_FAIL(PN_ERR_ARG, "rgrad: seg and list go together");
     const int tiles = ((p.M + R_BM - 1) / R_BM) * ((p.N + R_BN - 1) / R_BN);
     const int64_t ntiles = (p.R + R_KT - 1) / R_KT;
