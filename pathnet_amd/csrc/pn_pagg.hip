@@ -943,6 +943,294 @@ __global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
     __syncthreads();
     pool_bwd_wg_body<HI>(p.b, lds);
 }
+// ---- the same step with the node's rows held in REGISTERS (round 6).  pool_step_kernel's bodies change the thread layout from
+// phase to phase (eight lanes per member for the dot products, a lane per column for the sums) and therefore read the node's
+// W x H final hidden states four times from memory, behind one another: ~15 dependent round trips per node, 47 us for 1 299
+// nodes and 0.27 / 1.3 ms at Pubmed / BGP size, where the launch is bound by that cache traffic.  Here wave w owns members
+// w, w + 4, ... (MM of them) and a lane columns lane + 64 i (HI of them) throughout: the rows are loaded ONCE, all at once
+// (MM x HI registers), dot products over H are wave sums, sums over W are lane-local plus one exchange through LDS -- five
+// round trips and eight barriers per node.  Same arithmetic, other summation orders than the three kernels (which the
+// deterministic mode keeps: pn_pagg_train_step's bitwise tests run there); W <= 4 MM, H <= 64 HI.
+template <int MM, int HI>
+__global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) {      // (six workgroups per CU: 1 536 slots)
+    extern __shared__ float lds[];
+    const PoolParams &f = p.f;
+    const PoolBwdParams &b = p.b;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int g = blockIdx.x, H = f.H, W = f.W, C = f.C;
+    const bool has_att = f.variant != PN_VARIANT_PAGG;
+    // per-member scalars (wave-uniform) live in LDS, [wave][MM] each: as register arrays they cost 40 VGPRs and two of the six
+    // workgroups a CU can hold
+    float *cf = lds + wave * MM;        // [4][MM] pooling coefficients
+    float *dsl = lds + 4 * MM + wave * MM;      // [4][MM] d score
+    float *sc = lds + 8 * MM;           // [4 MM] activated scores in member order (HETERO softmax)
+    float *part4 = sc + 4 * MM;         // [4][H]  waves' partial pooled sums; later [4][2H] attention-weight partials
+    float *l1s = part4 + 8 * H;         // [2H] classifier input
+    float *dp = l1s + 2 * H;            // [H]  d pooled / W
+    float *lg = dp + H;                 // [C] logits, then [C] their gradient
+    float *s_tot = lg + 2 * C;          // [4]
+    const float inv_w = 1.0f / (float)W;
+    const int64_t s0 = (int64_t)g * W;
+
+    // ---- everything the node needs from memory, requested at once
+    float hn[MM][HI], e_r[HI], aw_h[HI], aw_e[HI];
+    const int e0 = has_att ? f.egoidx[s0] : 0;
+    int same = 1;
+#pragma unroll
+    for (int k = 0; k < MM; k++) {
+        const int mem = wave + 4 * k, memc = min(mem, W - 1);
+        if (has_att) same &= f.egoidx[s0 + memc] == e0;
+#pragma unroll
+        for (int i = 0; i < HI; i++) {
+            const int j = lane + 64 * i;
+            hn[k][i] = (mem < W && j < H) ? f.hn[(s0 + memc) * H + j] : 0.0f;
+        }
+    }
+    const bool one_row = __syncthreads_and(same) != 0;
+#pragma unroll
+    for (int i = 0; i < HI; i++) {
+        const int j = lane + 64 * i, jc = min(j, H - 1);
+        aw_h[i] = (has_att && j < H) ? f.att_w[jc] : 0.0f;
+        aw_e[i] = (has_att && j < H) ? f.att_w[H + jc] : 0.0f;
+        e_r[i] = (has_att && j < H) ? f.ego_tab[(int64_t)e0 * H + jc] : 0.0f;
+    }
+    // ---- scores and pooling coefficients of this wave's members (raw scores -> cf[], LeakyReLU slopes -> bits of `neg`)
+    uint32_t neg = 0;       // bit k: member k's raw score <= 0
+    if (has_att) {
+        const float ab = f.att_b[0];
+        float edot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < HI; i++) edot += e_r[i] * aw_e[i];
+        edot = wave_sum(edot);
+#pragma unroll
+        for (int k = 0; k < MM; k++) {
+            const int mem = wave + 4 * k;
+            float part = 0.0f;
+#pragma unroll
+            for (int i = 0; i < HI; i++) part += hn[k][i] * aw_h[i];
+            float ed = edot;
+            if (!one_row) {         // (rare: a member whose path starts elsewhere)
+                const int64_t er = (int64_t)f.egoidx[s0 + min(mem, W - 1)] * H;
+                float pe = 0.0f;
+#pragma unroll
+                for (int i = 0; i < HI; i++) {
+                    const int j = lane + 64 * i;
+                    if (j < H) pe += f.ego_tab[er + j] * aw_e[i];
+                }
+                ed = wave_sum(pe);
+            }
+            const float raw = wave_sum(part) + ed + ab;
+            if (!(raw > 0.0f)) neg |= 1u << k;
+            if (lane == 0) {
+                cf[k] = raw;
+                if (mem < W) f.rawsc[s0 + mem] = raw;
+            }
+        }
+    } else if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MM; k++) {
+            cf[k] = 0.0f;
+            if (wave + 4 * k < W) f.rawsc[s0 + wave + 4 * k] = 0.0f;
+        }
+    }
+    if (f.variant == PN_VARIANT_HETERO) {       // softmax over the W members of LeakyReLU(score)
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < MM; k++) {
+                const int mem = wave + 4 * k;
+                const float r = cf[k];
+                if (mem < W) sc[mem] = r > 0.0f ? r : 0.01f * r;
+            }
+        }
+        __syncthreads();
+        const float v = lane < W ? sc[lane] : -3.4e38f;       // (W <= 4 MM <= 64)
+        const float mx = wave_max(v);
+        const float sum = wave_sum(lane < W ? expf(v - mx) : 0.0f);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < MM; k++) {
+                const float r = cf[k];
+                cf[k] = expf((r > 0.0f ? r : 0.01f * r) - mx) / sum;
+            }
+        }
+    } else if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MM; k++) cf[k] = f.variant == PN_VARIANT_HOMO ? 1.0f + cf[k] : 1.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (cf[] of this wave: written by lane 0, read by the wave)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MM; k++)
+            if (wave + 4 * k < W) f.coef[s0 + wave + 4 * k] = cf[k];
+    }
+    // ---- pooled = mean_w coef_w h_w
+#pragma unroll
+    for (int i = 0; i < HI; i++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MM; k++) acc += cf[k] * hn[k][i];       // (members past W hold zeros)
+        const int j = lane + 64 * i;
+        if (j < H) part4[wave * H + j] = acc;
+    }
+    __syncthreads();
+    // ---- layer1 = dropout([Xh[sel[g]] ; pooled]); the masks stay in registers for the backward
+    const int64_t selrow = (int64_t)min(max(f.sel[g], 0), f.N - 1) * H;
+    const uint64_t gg = (uint64_t)(f.goff + g);
+    float m_a = 1.0f, m_b = 1.0f;       // this thread's column tid (< H)
+    if (tid < H) {
+        const int j = tid;
+        float a = f.Xh[selrow + j], bq = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
+        if (f.mask) {
+            m_a = f.mask[gg * 2 * H + j];
+            m_b = f.mask[gg * 2 * H + H + j];
+        } else if (f.p_drop > 0.0f) {
+            const uint64_t seed = f.dyn ? f.dyn->seed : f.seed;
+            m_a = dropout1(seed, gg * 2 * H + j, 2u, f.p_drop);
+            m_b = dropout1(seed, gg * 2 * H + H + j, 2u, f.p_drop);
+        }
+        a *= m_a;
+        bq *= m_b;
+        float *l1 = f.layer1 + (int64_t)g * 2 * H;
+        l1[j] = a;
+        l1[H + j] = bq;
+        l1s[j] = a;
+        l1s[H + j] = bq;
+    }
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {
+        float part = 0.0f;
+        for (int j = lane; j < 2 * H; j += 64) part += l1s[j] * f.fc2_w[(int64_t)c * 2 * H + j];
+        part = wave_sum(part);
+        if (lane == 0) {
+            const float v = part + f.fc2_b[c];
+            f.out[(int64_t)g * C + c] = v;
+            lg[c] = v;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {         // the row's cross entropy exactly as cross_entropy_kernel computes it
+        float m = lg[0];
+        for (int c = 1; c < C; c++) m = fmaxf(m, lg[c]);
+        float sum = 0.0f;
+        for (int c = 0; c < C; c++) sum += expf(lg[c] - m);
+        const float lse = m + logf(sum);
+        const int t = (int)p.target[g];
+        p.lossg[g] = lse - lg[t];
+        float *go = p.gout + (int64_t)g * C;
+        for (int c = 0; c < C; c++) {
+            const float gv = (expf(lg[c] - lse) - (c == t ? 1.0f : 0.0f)) * p.scale;
+            go[c] = gv;
+            lg[C + c] = gv;
+        }
+    }
+    __syncthreads();
+    // ---- backward: d layer1 = g_out . fc2_w (masked): its ego half onto the node's row of d Xh, its pooled half / W = dp
+    if (tid < H) {
+        const int j = tid;
+        float a = 0.0f, bq = 0.0f;
+        for (int c = 0; c < C; c++) {
+            const float go = lg[C + c];
+            a += go * f.fc2_w[(int64_t)c * 2 * H + j];
+            bq += go * f.fc2_w[(int64_t)c * 2 * H + H + j];
+        }
+        atomicAdd(&b.dXh[selrow + j], a * m_a);
+        dp[j] = bq * m_b * inv_w;
+    }
+    __syncthreads();
+    float dpr[HI];
+#pragma unroll
+    for (int i = 0; i < HI; i++) {
+        const int j = lane + 64 * i;
+        dpr[i] = j < H ? dp[j] : 0.0f;
+    }
+    {       // d coef of this wave's members -> dsl[]; HETERO: through the softmax
+        float tpart = 0.0f;
+#pragma unroll
+        for (int k = 0; k < MM; k++) {
+            float part = 0.0f;
+#pragma unroll
+            for (int i = 0; i < HI; i++) part += hn[k][i] * dpr[i];
+            const float dco = wave_sum(part);
+            if (wave + 4 * k < W) tpart += cf[k] * dco;
+            if (lane == 0) dsl[k] = dco;
+        }
+        if (f.variant == PN_VARIANT_HETERO) {
+            if (lane == 0) s_tot[wave] = tpart;
+            __syncthreads();
+            const float tot = (s_tot[0] + s_tot[1]) + (s_tot[2] + s_tot[3]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < MM; k++) dsl[k] = cf[k] * (dsl[k] - tot) * ((neg >> k) & 1u ? 0.01f : 1.0f);
+            }
+        } else if (f.variant != PN_VARIANT_HOMO && lane == 0) {
+#pragma unroll
+            for (int k = 0; k < MM; k++) dsl[k] = 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- per member: d h_n; the attention-weight and attention-ego terms accumulate in registers
+    float gaw_h[HI], gaw_e[HI], ego_acc[HI], gab = 0.0f;
+#pragma unroll
+    for (int i = 0; i < HI; i++) gaw_h[i] = gaw_e[i] = ego_acc[i] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MM; k++) {
+        const int mem = wave + 4 * k;
+        if (mem >= W) break;            // (wave-uniform)
+        const float ds = dsl[k], ck = cf[k];
+        const int64_t er = (has_att && !one_row) ? (int64_t)f.egoidx[s0 + mem] * H : 0;
+#pragma unroll
+        for (int i = 0; i < HI; i++) {
+            const int j = lane + 64 * i;
+            if (j < H) {
+                float dh = ck * dpr[i];
+                if (has_att) {
+                    dh += ds * aw_h[i];
+                    gaw_h[i] += ds * hn[k][i];
+                    const float eg = ds * aw_e[i];
+                    if (one_row) {
+                        gaw_e[i] += ds * e_r[i];
+                        ego_acc[i] += eg;
+                    } else {
+                        gaw_e[i] += ds * f.ego_tab[er + j];
+                        atomicAdd(&b.dego[er + j], eg);
+                    }
+                }
+                b.dhn[(s0 + mem) * H + j] = dh;
+            }
+        }
+        gab += ds;
+    }
+    if (!has_att) return;       // block-uniform
+    float *red = part4;         // [4][2H]
+    if (one_row) {
+#pragma unroll
+        for (int i = 0; i < HI; i++) {
+            const int j = lane + 64 * i;
+            if (j < H) red[wave * H + j] = ego_acc[i];
+        }
+        __syncthreads();
+        if (tid < H) atomicAdd(&b.dego[(int64_t)e0 * H + tid], (red[tid] + red[H + tid]) + (red[2 * H + tid] + red[3 * H + tid]));
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < HI; i++) {
+        const int j = lane + 64 * i;
+        if (j < H) {
+            red[wave * 2 * H + j] = gaw_h[i];
+            red[wave * 2 * H + H + j] = gaw_e[i];
+        }
+    }
+    __syncthreads();
+    float *out = b.det_att + (int64_t)g * (2 * H + 4);
+    for (int j = tid; j < 2 * H; j += 256) out[j] = red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j];
+    if (lane == 0) out[2 * H + wave] = gab;
+}
+inline size_t pool_step2_lds_bytes(int MM, int H, int C) { return (size_t)(12 * MM + 8 * H + 2 * H + H + 2 * C + 8) * sizeof(float); }
+
 // loss[0] (+)= scale * sum of the rows' terms, in cross_entropy_kernel's order (one workgroup of 1024 threads)
 __global__ __launch_bounds__(1024) void loss_sum_kernel(const float *__restrict__ lossg, int rows, float scale,
                                                         float *__restrict__ loss, int store) {
@@ -2313,7 +2601,10 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                 const size_t lds_step = std::max(lds_bytes, pool_fwd_lds_bytes(d));
                 {
                     StageTimer tm(ctx, ST_POOL_FWD, stream);
-                    if (H <= 256) {
+                    if (d.W <= 40 && H <= 128 && H >= 32 && knobs_of(ctx).pool_step >= 1 && knobs_of(ctx).pool_step != 2) {
+                        // the node's rows in registers (pool_step2_kernel); PN_POOL_STEP=2: the three bodies back to back
+                        hipLaunchKernelGGL((pool_step2_kernel<10, 2>), dim3(Sb), dim3(256), pool_step2_lds_bytes(10, H, d.C), stream, ps);
+                    } else if (H <= 256) {
                         hipLaunchKernelGGL(pool_step_kernel<4>, dim3(Sb), dim3(256), lds_step, stream, ps);
                     } else {
                         if (int rc = ensure_dynamic_lds(ctx, reinterpret_cast<const void *>(pool_step_kernel<16>), (int)lds_step)) return rc;
