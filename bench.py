@@ -952,9 +952,10 @@ def extras_single_gpu(lib, ctx, names, dev, sr, args):
     out["fused_gather_hbm_table"] = {"paths": Sg * W, "table_MB": Nf * L * H * 4 >> 20, "seq_fwd_ms": ms,
                                      "gather_read_GBs": read_b / (ms * 1e-3) / 1e9,
                                      "gather_read_frac_of_hbm_peak": read_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "note": "inference forward of PathNet_homo on 2^20 nodes: seq_fwd3_kernel gathers the "
-                                             "same rows straight into its LDS tile; the kernel is bound by its MFMA / "
-                                             "weight-fragment stream, not by this read"}
+                                     "note": "inference forward of PathNet_homo on 2^20 nodes (nothing saved for a backward): the "
+                                             "recurrent forward gathers the same rows straight into its LDS tile; the launch is "
+                                             "bound by its weight-fragment stream and MFMAs, not by this read (the training "
+                                             "forward, which also writes six times what it gathers: profiles/r06_gather.md)"}
     return out
 
 
