@@ -143,7 +143,7 @@ def model(stages, total_ms, n_total_1, H, grad_bytes, weak, link_GBs, lat_us, id
 
 def newest_bench_json():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    names = ("r06_bench_final.json", "r05_bench_final.json", "r04_bench_final.json", "r04_bench_f16_v1.json", "r03_bench_final.json")
+    names = ("r06_bench_final_extras.json", "r05_bench_final.json", "r04_bench_final.json", "r04_bench_f16_v1.json", "r03_bench_final.json")
     return next(p for p in (os.path.join(root, "profiles", n) for n in names) if os.path.exists(p))
 
 
