@@ -1,7 +1,8 @@
 """Stand-alone times of the node-level GEMMs of a training step (fc0, the distance bank, their backward) through the C ABI:
 pn_linear_forward / pn_gemm_f32 / pn_linear_backward at the headline (Cora) and Pubmed shapes, HIP events around blocks of
-launches.  Used for the A/B of the 32 x 32-tile bf16 x 3 kernel against the 64 x 64 fp32-input one (build with -DPN_GEMMS=0):
-profiles/r06_node_gemm.txt.   python tools/bench_node_gemm.py [reps]"""
+launches.  Used for the A/Bs of gemm_kernel variants in round 6 (the 32 x 32-tile bf16 x 3 kernel, the split-K target, two K
+tiles in flight: profiles/r06_node_gemm.txt, r06_glue.txt sections 16-17), run against two builds of the library
+(PN_LIB_PATH).   python tools/bench_node_gemm.py [reps]"""
 import json
 import os
 import sys
