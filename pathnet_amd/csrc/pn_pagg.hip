@@ -976,14 +976,18 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
     float hn[MM][HI], e_r[HI], aw_h[HI], aw_e[HI];
     const int e0 = has_att ? f.egoidx[s0] : 0;
     int same = 1;
+    const float *hn_g = f.hn + s0 * H;          // (a scalar base + one 32-bit offset per load: twenty 64-bit addresses would not fit)
+    const int32_t *ego_g = f.egoidx + s0;
 #pragma unroll
     for (int k = 0; k < MM; k++) {
-        const int mem = wave + 4 * k, memc = min(mem, W - 1);
-        if (has_att) same &= f.egoidx[s0 + memc] == e0;
+        const int mem = wave + 4 * k;
+        const uint32_t memc = (uint32_t)min(mem, W - 1);
+        if (has_att) same &= ego_g[memc] == e0;
 #pragma unroll
         for (int i = 0; i < HI; i++) {
             const int j = lane + 64 * i;
-            hn[k][i] = (mem < W && j < H) ? f.hn[(s0 + memc) * H + j] : 0.0f;
+            const float v = hn_g[memc * (uint32_t)H + (uint32_t)min(j, H - 1)];
+            hn[k][i] = (mem < W && j < H) ? v : 0.0f;
         }
     }
     const bool one_row = __syncthreads_and(same) != 0;
@@ -1076,11 +1080,11 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
     }
     __syncthreads();
     // ---- layer1 = dropout([Xh[sel[g]] ; pooled]); the masks stay in registers for the backward
-    const int64_t selrow = (int64_t)min(max(f.sel[g], 0), f.N - 1) * H;
-    const uint64_t gg = (uint64_t)(f.goff + g);
     float m_a = 1.0f, m_b = 1.0f;       // this thread's column tid (< H)
     if (tid < H) {
         const int j = tid;
+        const int64_t selrow = (int64_t)min(max(f.sel[g], 0), f.N - 1) * H;
+        const uint64_t gg = (uint64_t)(f.goff + g);
         float a = f.Xh[selrow + j], bq = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
         if (f.mask) {
             m_a = f.mask[gg * 2 * H + j];
@@ -1135,7 +1139,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
             a += go * f.fc2_w[(int64_t)c * 2 * H + j];
             bq += go * f.fc2_w[(int64_t)c * 2 * H + H + j];
         }
-        atomicAdd(&b.dXh[selrow + j], a * m_a);
+        atomicAdd(&b.dXh[(int64_t)min(max(f.sel[g], 0), f.N - 1) * H + j], a * m_a);      // (re-derived: not kept live across the phases)
         dp[j] = bq * m_b * inv_w;
     }
     __syncthreads();
