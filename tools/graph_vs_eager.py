@@ -29,7 +29,9 @@ def run(mode):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     wl = bench.workload(0, 1)
-    sr = bench.StepRunner(wl, dev, 0, 1, sharded=False, device_state=True)
+    # "headline": the step exactly as bench.py times it (host-side seeds, the sampler walk on the stream that reads the paths);
+    # the other modes keep the step state in device memory, whose advance kernel marks the step boundaries
+    sr = bench.StepRunner(wl, dev, 0, 1, sharded=False, device_state=(mode != "headline"))
     if mode == "det":           # the eager step with the fixed-order backward (pn_pagg_shape.deterministic)
         sr.model.deterministic = True
     side = torch.cuda.Stream()
@@ -74,14 +76,28 @@ def load(d):
     return [dict(name=r[0], start=r[1], end=r[2], where=tuple(r[3:])) for r in cur.execute(q)]
 
 
+def cut_steps(rows):
+    """the timed steps of a trace, minus their first few: a step begins at its step_state_advance_kernel, or -- the headline
+    mode has none -- at the first kernel that STARTS after the previous step's adam_kernel has ended (its own sampler walk
+    runs earlier, under the previous step: it is listed with the step it belongs to by start time, i.e. with the previous one)"""
+    marks = [i for i, r in enumerate(rows) if "step_state_advance_kernel" in r["name"]]
+    if len(marks) < 3:
+        ends = [r["end"] for r in rows if "adam_kernel" in r["name"]]
+        marks, k = [], 0
+        for i, r in enumerate(rows):
+            if k < len(ends) and r["start"] >= ends[k]:
+                marks.append(i)
+                k += 1
+    return [rows[a:b] for a, b in zip(marks, marks[1:])][-(STEPS - 5):]
+
+
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     return n.split("(")[0][:48]
 
 
 def analyse_one(rows):
-    marks = [i for i, r in enumerate(rows) if "step_state_advance_kernel" in r["name"]]
-    steps = [rows[a:b] for a, b in zip(marks, marks[1:])][-(STEPS - 5):]      # the timed steps, minus their first few
+    steps = cut_steps(rows)
     out = dict(steps=len(steps))
     if not steps:
         return out
@@ -145,8 +161,7 @@ def analyse(dirs):
 def timeline(d):
     """one step (the one of median length) kernel by kernel: start offset, duration, queue"""
     rows = load(d)
-    marks = [i for i, r in enumerate(rows) if "step_state_advance_kernel" in r["name"]]
-    steps = [rows[a:b] for a, b in zip(marks, marks[1:])][-(STEPS - 5):]
+    steps = cut_steps(rows)
     if not steps:
         raise SystemExit("no steps in %s" % d)
     steps.sort(key=lambda st: max(r["end"] for r in st) - st[0]["start"])
