@@ -82,7 +82,7 @@ typedef struct pn_context pn_context;
 int pn_context_create(pn_context **out);
 int pn_context_destroy(pn_context *ctx);
 /* Kernel-selection knobs for A/B measurements and tests (none changes a result beyond rounding): PN_NODE_GEMM3, PN_EVAL_ZW,
- * PN_POOL_BWD_WG, PN_POOL_STEP, PN_ZERO_EARLY, PN_SMALL_SIDE, PN_NODE_RGRAD, PN_SAMPLER_STAGE, PN_SEQ4, PN_SEQH_TAIL (pn_internal.h: struct
+ * PN_POOL_BWD_WG, PN_POOL_STEP, PN_ZERO_EARLY, PN_SMALL_SIDE, PN_EVENT_DEVICE_SCOPE, PN_NODE_RGRAD, PN_SAMPLER_STAGE, PN_SEQ4, PN_SEQH_TAIL (pn_internal.h: struct
  * Knobs).  A context
  * takes its values from the environment variables of the same names ONCE, in pn_context_create; afterwards only these two
  * calls read or change them -- device entry points never call getenv, so a captured step keeps its selection and a setenv

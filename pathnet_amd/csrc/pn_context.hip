@@ -64,7 +64,8 @@ hipEvent_t take_event(pn_context *ctx) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    // (timing brackets: the device-scope form is the one meant for timing the commands between two events)
+    (void)hipEventCreateWithFlags(&e, ctx->knobs.event_dev ? hipEventDisableSystemFence : hipEventDefault);
     return e;
 }
 
@@ -77,7 +78,7 @@ struct KnobName {
     int pn::Knobs::*field;
 };
 const KnobName kKnobs[] = {{"PN_NODE_GEMM3", &pn::Knobs::node_gemm3}, {"PN_EVAL_ZW", &pn::Knobs::eval_zw},
-                           {"PN_POOL_BWD_WG", &pn::Knobs::pool_bwd_wg}, {"PN_POOL_STEP", &pn::Knobs::pool_step}, {"PN_ZERO_EARLY", &pn::Knobs::zero_early}, {"PN_SMALL_SIDE", &pn::Knobs::small_side}, {"PN_NODE_RGRAD", &pn::Knobs::node_rgrad},
+                           {"PN_POOL_BWD_WG", &pn::Knobs::pool_bwd_wg}, {"PN_POOL_STEP", &pn::Knobs::pool_step}, {"PN_ZERO_EARLY", &pn::Knobs::zero_early}, {"PN_SMALL_SIDE", &pn::Knobs::small_side}, {"PN_EVENT_DEVICE_SCOPE", &pn::Knobs::event_dev}, {"PN_NODE_RGRAD", &pn::Knobs::node_rgrad},
                            {"PN_SAMPLER_STAGE", &pn::Knobs::sampler_stage}, {"PN_SEQ4", &pn::Knobs::seq4},
                            {"PN_SEQH_TAIL", &pn::Knobs::seqh_tail}};
 
@@ -179,8 +180,11 @@ int pn_context_create(pn_context **out) try {
     hipError_t e = hipGetDevice(&c->device);
     if (e != hipSuccess) return fail(e, "hipGetDevice");
     if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    if ((e = hipEventCreateWithFlags(&c->fork, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-    if ((e = hipEventCreateWithFlags(&c->join, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+    // (both events order kernels of this device only: no host ever inspects them, so the system-scope release a recorded event
+    //  performs by default buys nothing -- the kernels' own agent-scope release at their end is what the other queue needs)
+    const unsigned ev_flags = hipEventDisableTiming | (c->knobs.event_dev ? hipEventDisableSystemFence : 0u);
+    if ((e = hipEventCreateWithFlags(&c->fork, ev_flags)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->join, ev_flags)) != hipSuccess) return fail(e, "hipEventCreate");
     // the runtime builds a stream's hardware queue at its first launch (milliseconds): pay that here
     hipLaunchKernelGGL(warm_kernel, dim3(1), dim3(64), 0, c->side);
     if ((e = hipGetLastError()) != hipSuccess) return fail(e, "first launch on the context's stream");
