@@ -217,7 +217,21 @@ int pn_context_set_knob(pn_context *ctx, const char *name, int32_t value) {
     if (!ctx || !name) PN_FAIL(PN_ERR_ARG, "pn_context_set_knob: null");
     for (const KnobName &k : kKnobs)
         if (std::strcmp(k.name, name) == 0) {
+            const bool events_change = k.field == &pn::Knobs::event_dev && (ctx->knobs.event_dev != 0) != (value != 0);
             ctx->knobs.*(k.field) = value;
+            if (events_change) {        // the fork / join pair and the pooled timing events carry the flag: made again (idle device first)
+                PN_CHECK_HIP(hipDeviceSynchronize());
+                const unsigned ev_flags = hipEventDisableTiming | (value ? hipEventDisableSystemFence : 0u);
+                hipEvent_t fork = nullptr, join = nullptr;
+                PN_CHECK_HIP(hipEventCreateWithFlags(&fork, ev_flags));
+                PN_CHECK_HIP(hipEventCreateWithFlags(&join, ev_flags));
+                (void)hipEventDestroy(ctx->fork);
+                (void)hipEventDestroy(ctx->join);
+                ctx->fork = fork;
+                ctx->join = join;
+                for (hipEvent_t e : ctx->free_events) (void)hipEventDestroy(e);
+                ctx->free_events.clear();
+            }
             return PN_OK;
         }
     PN_FAIL(PN_ERR_ARG, "pn_context_set_knob: no knob named %s", name);

@@ -52,7 +52,7 @@ struct Knobs {
     int eval_zw = 1;            // PN_EVAL_ZW: inference forwards apply W_ih to the bank rows before the gather
     int pool_bwd_wg = 1;        // PN_POOL_BWD_WG: pooling backward as a workgroup per node
     int small_side = 1;         // PN_SMALL_SIDE: loss sum / classifier gradient / attention reduce on the second stream under the BPTT
-    int event_dev = 1;          // PN_EVENT_DEVICE_SCOPE: fork / join / timing events without the system-scope release of a recorded event (read when the event is created)
+    int event_dev = 1;          // PN_EVENT_DEVICE_SCOPE: fork / join / timing events without the system-scope release of a recorded event (a change makes the events again)
     int zero_early = 1;         // PN_ZERO_EARLY: pn_pagg_train_step zero-fills the backward's accumulators on the second stream, under fc0 / bank
     int pool_step = 1;          // PN_POOL_STEP: pn_pagg_train_step runs pooling forward, loss and pooling backward of a node in one launch
     int node_rgrad = 1;         // PN_NODE_RGRAD: row-reduction kernel for the node-level weight gradients of large graphs

@@ -229,3 +229,39 @@ def test_sampler_on_the_stream_that_reads_the_paths_gives_the_same_steps():
     assert torch.equal(runs[0][0], runs[1][0])
     for a, b in zip(runs[0][1], runs[1][1]):
         assert torch.equal(a, b)
+
+
+def test_steps_are_the_same_with_either_kind_of_fork_and_join_event():
+    """The context's fork / join events order kernels of one device and are created without the system-scope release of a
+    recorded event (hipEventDisableSystemFence; knob PN_EVENT_DEVICE_SCOPE, default 1, profiles/r06_glue.txt section 22).
+    Eight training steps with the host racing ahead -- fused step, both streams at work, Adam -- give the same losses and
+    parameters bit for bit (deterministic backward) with either kind of event; changing the knob makes the events again."""
+    import pathnet_amd
+    from pathnet_amd import _lib
+    case = _case("homo", 300, 12, 4)
+    _, X, ids, codes, sel, y = case
+    old = _lib.set_knob("PN_EVENT_DEVICE_SCOPE", 1)
+    runs = []
+    try:
+        for dev_scope in (1, 0, 1):
+            _lib.set_knob("PN_EVENT_DEVICE_SCOPE", dev_scope)
+            torch.manual_seed(5)
+            m = pathnet_amd.PathNet_homo(X.shape[1], 128, 5, ids.shape[2], dropout=0.5).cuda().train()
+            m.deterministic = True
+            opt = pathnet_amd.Adam(m.parameters(), lr=0.01)
+            losses = []
+            for e in range(8):
+                opt.zero_grad(set_to_none=True)
+                torch.manual_seed(200 + e)
+                loss, _ = m.forward_loss(X, ids, ids.shape[1], ids.shape[2], sel, codes, y, fused=True)
+                pathnet_amd.backward(loss)
+                opt.step()
+                losses.append(loss.detach())
+            torch.cuda.synchronize()
+            runs.append((torch.stack(losses).cpu(), [q.detach().clone() for q in m.parameters()]))
+    finally:
+        _lib.set_knob("PN_EVENT_DEVICE_SCOPE", old)
+    for other in runs[1:]:
+        assert torch.equal(runs[0][0], other[0])
+        for a, b in zip(runs[0][1], other[1]):
+            assert torch.equal(a, b)
