@@ -225,6 +225,21 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The wave's total as a wave-uniform value, on the DPP path: four row rotations leave every lane its row's sum, the four rows'
+// sums are read with v_readlane -- ~12 VALU instead of six ds_bpermute round trips (~100 cycles each) of the butterfly above.
+// Another order of additions than wave_sum (and one that differs from lane to lane before the read-out: only the returned
+// value is meant to be used).
+__device__ __forceinline__ float wave_sum_u(float v) {
+#define PN_ROW_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+    v += PN_ROW_ROR(8);
+    v += PN_ROW_ROR(4);
+    v += PN_ROW_ROR(2);
+    v += PN_ROW_ROR(1);
+#undef PN_ROW_ROR
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

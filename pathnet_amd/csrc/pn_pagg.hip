@@ -951,6 +951,12 @@ __global__ __launch_bounds__(256) void pool_step_kernel(PoolStepParams p) {
 // (MM x HI registers), dot products over H are wave sums, sums over W are lane-local plus one exchange through LDS -- five
 // round trips and eight barriers per node.  Same arithmetic, other summation orders than the three kernels (which the
 // deterministic mode keeps: pn_pagg_train_step's bitwise tests run there); W <= 4 MM, H <= 64 HI.
+#ifdef PN_POOL_TRACE
+__device__ long long g_pool_trace[2048 * 12];
+#define PTRACE(n) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_pool_trace[blockIdx.x * 12 + (n)] = wall_clock64(); } while (0)
+#else
+#define PTRACE(n) do { } while (0)
+#endif
 template <int MM, int HI>
 __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) {      // (six workgroups per CU: 1 536 slots)
     extern __shared__ float lds[];
@@ -971,26 +977,35 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
     float *s_tot = lg + 2 * C;          // [4]
     const float inv_w = 1.0f / (float)W;
     const int64_t s0 = (int64_t)g * W;
+    PTRACE(0);
 
     // ---- everything the node needs from memory, requested at once
     float hn[MM][HI], e_r[HI], aw_h[HI], aw_e[HI];
     const int e0 = has_att ? f.egoidx[s0] : 0;
+    // (the node's own row of Xh, its target and the attention weights are asked for here as well, with the rows: loaded where they
+    //  are used they were two more dependent round trips behind barriers)
+    const int sel_g = min(max(f.sel[g], 0), f.N - 1);
+    const int tgt = (int)p.target[g];
     int same = 1;
     const float *hn_g = f.hn + s0 * H;          // (a scalar base + one 32-bit offset per load: twenty 64-bit addresses would not fit)
-    const int32_t *ego_g = f.egoidx + s0;
+    // Every load below is unconditional (clamped addresses) and its value always used -- rows past W / columns past H are zeroed by a
+    // MULTIPLICATION, the members' start rows compared whatever the variant (PAGG: a valid dummy).  As selects, hipcc moved each load
+    // into a branch of its own with a wait behind it: thirty dependent round trips, 18 of the kernel's 40 us (r06_glue.txt section 23).
+    const int32_t *ego_g = has_att ? f.egoidx + s0 : reinterpret_cast<const int32_t *>(hn_g);
+    int egv[MM];
 #pragma unroll
     for (int k = 0; k < MM; k++) {
-        const int mem = wave + 4 * k;
-        const uint32_t memc = (uint32_t)min(mem, W - 1);
-        if (has_att) same &= ego_g[memc] == e0;
+        const uint32_t memc = (uint32_t)min(wave + 4 * k, W - 1);
+        egv[k] = ego_g[memc];
 #pragma unroll
-        for (int i = 0; i < HI; i++) {
-            const int j = lane + 64 * i;
-            const float v = hn_g[memc * (uint32_t)H + (uint32_t)min(j, H - 1)];
-            hn[k][i] = (mem < W && j < H) ? v : 0.0f;
-        }
+        for (int i = 0; i < HI; i++) hn[k][i] = hn_g[memc * (uint32_t)H + (uint32_t)min(lane + 64 * i, H - 1)];
     }
-    const bool one_row = __syncthreads_and(same) != 0;
+#pragma unroll
+    for (int k = 0; k < MM; k++) {
+        same &= (int)(egv[k] == e0) | (int)!has_att;
+#pragma unroll
+        for (int i = 0; i < HI; i++) hn[k][i] *= (wave + 4 * k < W && lane + 64 * i < H) ? 1.0f : 0.0f;
+    }
 #pragma unroll
     for (int i = 0; i < HI; i++) {
         const int j = lane + 64 * i, jc = min(j, H - 1);
@@ -998,6 +1013,9 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         aw_e[i] = (has_att && j < H) ? f.att_w[H + jc] : 0.0f;
         e_r[i] = (has_att && j < H) ? f.ego_tab[(int64_t)e0 * H + jc] : 0.0f;
     }
+    const float xh_own = f.Xh[(int64_t)sel_g * H + min(tid, H - 1)];
+    const bool one_row = __syncthreads_and(same) != 0;
+    PTRACE(1);
     // ---- scores and pooling coefficients of this wave's members (raw scores -> cf[], LeakyReLU slopes -> bits of `neg`)
     uint32_t neg = 0;       // bit k: member k's raw score <= 0
     if (has_att) {
@@ -1005,7 +1023,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         float edot = 0.0f;
 #pragma unroll
         for (int i = 0; i < HI; i++) edot += e_r[i] * aw_e[i];
-        edot = wave_sum(edot);
+        edot = wave_sum_u(edot);
 #pragma unroll
         for (int k = 0; k < MM; k++) {
             const int mem = wave + 4 * k;
@@ -1021,9 +1039,9 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
                     const int j = lane + 64 * i;
                     if (j < H) pe += f.ego_tab[er + j] * aw_e[i];
                 }
-                ed = wave_sum(pe);
+                ed = wave_sum_u(pe);
             }
-            const float raw = wave_sum(part) + ed + ab;
+            const float raw = wave_sum_u(part) + ed + ab;
             if (!(raw > 0.0f)) neg |= 1u << k;
             if (lane == 0) {
                 cf[k] = raw;
@@ -1049,7 +1067,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         __syncthreads();
         const float v = lane < W ? sc[lane] : -3.4e38f;       // (W <= 4 MM <= 64)
         const float mx = wave_max(v);
-        const float sum = wave_sum(lane < W ? expf(v - mx) : 0.0f);
+        const float sum = wave_sum_u(lane < W ? expf(v - mx) : 0.0f);
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < MM; k++) {
@@ -1070,6 +1088,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
             if (wave + 4 * k < W) f.coef[s0 + wave + 4 * k] = cf[k];
     }
     // ---- pooled = mean_w coef_w h_w
+    PTRACE(2);
 #pragma unroll
     for (int i = 0; i < HI; i++) {
         float acc = 0.0f;
@@ -1079,13 +1098,13 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         if (j < H) part4[wave * H + j] = acc;
     }
     __syncthreads();
+    PTRACE(3);
     // ---- layer1 = dropout([Xh[sel[g]] ; pooled]); the masks stay in registers for the backward
     float m_a = 1.0f, m_b = 1.0f;       // this thread's column tid (< H)
     if (tid < H) {
         const int j = tid;
-        const int64_t selrow = (int64_t)min(max(f.sel[g], 0), f.N - 1) * H;
         const uint64_t gg = (uint64_t)(f.goff + g);
-        float a = f.Xh[selrow + j], bq = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
+        float a = xh_own, bq = (part4[j] + part4[H + j] + part4[2 * H + j] + part4[3 * H + j]) * inv_w;
         if (f.mask) {
             m_a = f.mask[gg * 2 * H + j];
             m_b = f.mask[gg * 2 * H + H + j];
@@ -1103,10 +1122,20 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         l1s[H + j] = bq;
     }
     __syncthreads();
+    PTRACE(4);
     for (int c = wave; c < C; c += 4) {
+        // (a fixed trip count with clamped addresses: the row's loads leave together instead of one round trip per 64 columns)
+        const float *wrow = f.fc2_w + (int64_t)c * 2 * H;
+        float wv[2 * HI];
+#pragma unroll
+        for (int q = 0; q < 2 * HI; q++) wv[q] = wrow[min(lane + 64 * q, 2 * H - 1)];
         float part = 0.0f;
-        for (int j = lane; j < 2 * H; j += 64) part += l1s[j] * f.fc2_w[(int64_t)c * 2 * H + j];
-        part = wave_sum(part);
+#pragma unroll
+        for (int q = 0; q < 2 * HI; q++) {
+            const int j = lane + 64 * q;
+            if (j < 2 * H) part += l1s[j] * wv[q];
+        }
+        part = wave_sum_u(part);
         if (lane == 0) {
             const float v = part + f.fc2_b[c];
             f.out[(int64_t)g * C + c] = v;
@@ -1114,35 +1143,49 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         }
     }
     __syncthreads();
-    if (tid == 0) {         // the row's cross entropy exactly as cross_entropy_kernel computes it
-        float m = lg[0];
-        for (int c = 1; c < C; c++) m = fmaxf(m, lg[c]);
+    PTRACE(5);
+    if (wave == 0) {        // the row's cross entropy as cross_entropy_kernel computes it, a lane per class (the sum in another order)
+        float m = -3.4e38f;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, lg[c]);
+        m = wave_max(m);
         float sum = 0.0f;
-        for (int c = 0; c < C; c++) sum += expf(lg[c] - m);
-        const float lse = m + logf(sum);
-        const int t = (int)p.target[g];
-        p.lossg[g] = lse - lg[t];
+        for (int c = lane; c < C; c += 64) sum += expf(lg[c] - m);
+        const float lse = m + logf(wave_sum_u(sum));
+        const int t = tgt;
+        if (lane == 0) p.lossg[g] = lse - lg[t];
         float *go = p.gout + (int64_t)g * C;
-        for (int c = 0; c < C; c++) {
+        for (int c = lane; c < C; c += 64) {
             const float gv = (expf(lg[c] - lse) - (c == t ? 1.0f : 0.0f)) * p.scale;
             go[c] = gv;
             lg[C + c] = gv;
         }
     }
     __syncthreads();
+    PTRACE(6);
     // ---- backward: d layer1 = g_out . fc2_w (masked): its ego half onto the node's row of d Xh, its pooled half / W = dp
     if (tid < H) {
         const int j = tid;
         float a = 0.0f, bq = 0.0f;
-        for (int c = 0; c < C; c++) {
-            const float go = lg[C + c];
-            a += go * f.fc2_w[(int64_t)c * 2 * H + j];
-            bq += go * f.fc2_w[(int64_t)c * 2 * H + H + j];
+        for (int c0 = 0; c0 < C; c0 += 4) {     // four classes' loads in flight (clamped rows, masked sums)
+            float wa[4], wb[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float *wrow = f.fc2_w + (int64_t)min(c0 + q, C - 1) * 2 * H;
+                wa[q] = wrow[j];
+                wb[q] = wrow[H + j];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float go = c0 + q < C ? lg[C + c0 + q] : 0.0f;
+                a += go * wa[q];
+                bq += go * wb[q];
+            }
         }
-        atomicAdd(&b.dXh[(int64_t)min(max(f.sel[g], 0), f.N - 1) * H + j], a * m_a);      // (re-derived: not kept live across the phases)
+        atomicAdd(&b.dXh[(int64_t)sel_g * H + j], a * m_a);
         dp[j] = bq * m_b * inv_w;
     }
     __syncthreads();
+    PTRACE(7);
     float dpr[HI];
 #pragma unroll
     for (int i = 0; i < HI; i++) {
@@ -1156,7 +1199,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
             float part = 0.0f;
 #pragma unroll
             for (int i = 0; i < HI; i++) part += hn[k][i] * dpr[i];
-            const float dco = wave_sum(part);
+            const float dco = wave_sum_u(part);
             if (wave + 4 * k < W) tpart += cf[k] * dco;
             if (lane == 0) dsl[k] = dco;
         }
@@ -1176,6 +1219,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    PTRACE(8);
     // ---- per member: d h_n; the attention-weight and attention-ego terms accumulate in registers
     float gaw_h[HI], gaw_e[HI], ego_acc[HI], gab = 0.0f;
 #pragma unroll
@@ -1208,6 +1252,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
         }
         gab += ds;
     }
+    PTRACE(9);
     if (!has_att) return;       // block-uniform
     float *red = part4;         // [4][2H]
     if (one_row) {
@@ -1232,6 +1277,7 @@ __global__ __launch_bounds__(256, 6) void pool_step2_kernel(PoolStepParams p) { 
     float *out = b.det_att + (int64_t)g * (2 * H + 4);
     for (int j = tid; j < 2 * H; j += 256) out[j] = red[j] + red[2 * H + j] + red[4 * H + j] + red[6 * H + j];
     if (lane == 0) out[2 * H + wave] = gab;
+    PTRACE(10);
 }
 inline size_t pool_step2_lds_bytes(int MM, int H, int C) { return (size_t)(12 * MM + 8 * H + 2 * H + H + 2 * C + 8) * sizeof(float); }
 
@@ -2608,6 +2654,9 @@ static int pagg_backward_impl(pn_context *ctx, const pn_pagg_args *a, void *stre
                     if (d.W <= 40 && H <= 128 && H >= 32 && knobs_of(ctx).pool_step >= 1 && knobs_of(ctx).pool_step != 2) {
                         // the node's rows in registers (pool_step2_kernel); PN_POOL_STEP=2: the three bodies back to back
                         hipLaunchKernelGGL((pool_step2_kernel<10, 2>), dim3(Sb), dim3(256), pool_step2_lds_bytes(10, H, d.C), stream, ps);
+#ifdef PN_POOL_TRACE_TWICE      // (timing experiment only: the launch again, its rows now read a second time -- results are wrong)
+                        hipLaunchKernelGGL((pool_step2_kernel<10, 2>), dim3(Sb), dim3(256), pool_step2_lds_bytes(10, H, d.C), stream, ps);
+#endif
                     } else if (H <= 256) {
                         hipLaunchKernelGGL(pool_step_kernel<4>, dim3(Sb), dim3(256), lds_step, stream, ps);
                     } else {
@@ -2892,3 +2941,9 @@ int pn_pagg_train_step(pn_context *ctx, const pn_pagg_args *a, const int64_t *ta
 }
 
 }  // extern "C"
+
+#ifdef PN_POOL_TRACE
+extern "C" int pn_debug_pool_trace(long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pool_trace), sizeof(long long) * 2048 * 12) == hipSuccess ? 0 : -1;
+}
+#endif
