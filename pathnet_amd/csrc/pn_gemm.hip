@@ -177,6 +177,93 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
+// ---- the same GEMM for a reduction of at most 128 (four K tiles), both operands K-contiguous, no gate, no row list, one
+// K chunk, stored: the distance bank (K = hid), every forward.  gemm_kernel keeps ONE K tile of loads in flight; with four
+// tiles in all that is four dependent round trips to operands the launch in front has just written (21 us for 0.35 GFLOP at the
+// headline shape).  Here the loads of all four tiles leave at once (64 registers) and each tile is consumed under a counted
+// wait; the LDS layout, the MFMA sequence and the epilogue are gemm_kernel's, so the values are bit for bit the same.
+template <int N>
+__device__ __forceinline__ void wait_vm_tile(float (&a)[8], float (&b)[8]) {
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                 : "i"(N));
+}
+__global__ __launch_bounds__(256) void gemm_k128_kernel(GemmParams p) {
+    __shared__ float As[GEMM_KT * GEMM_PITCH];
+    __shared__ float Bs[GEMM_KT * GEMM_PITCH];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, hk = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GEMM_BM, n0 = blockIdx.x * GEMM_BN;
+    if (p.clear_word && (blockIdx.x | blockIdx.y) == 0 && tid == 0) p.clear_word[0] = p.clear_word[1] = p.clear_word[2] = 0u;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    float ra[4][8], rb[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; t++)        // (tiles past K: clamped re-loads, never used)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + 256 * i, r = idx >> 5, k = min(GEMM_KT * t + (idx & 31), p.K - 1);
+            async_load_b32(ra[t][i], p.A + (int64_t)min(m0 + r, p.M - 1) * p.sAm + k);
+            async_load_b32(rb[t][i], p.B + (int64_t)min(n0 + r, p.N - 1) * p.sBn + k);
+        }
+    auto tile = [&](float (&a8)[8], float (&b8)[8], int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int idx = tid + 256 * i, r = idx >> 5, k = idx & 31;
+            As[k * GEMM_PITCH + r] = (m0 + r < p.M && k0 + k < p.K) ? a8[i] : 0.0f;
+            Bs[k * GEMM_PITCH + r] = (n0 + r < p.N && k0 + k < p.K) ? b8[i] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KT / 2; kk++) {
+            const float a = As[(2 * kk + hk) * GEMM_PITCH + wm * 32 + li];
+            const float b = Bs[(2 * kk + hk) * GEMM_PITCH + wn * 32 + li];
+            acc = mfma32(a, b, acc);
+        }
+        __syncthreads();
+    };
+    wait_vm_tile<48>(ra[0], rb[0]);
+    tile(ra[0], rb[0], 0);
+    wait_vm_tile<32>(ra[1], rb[1]);
+    if (p.K > GEMM_KT) tile(ra[1], rb[1], GEMM_KT);
+    wait_vm_tile<16>(ra[2], rb[2]);
+    if (p.K > 2 * GEMM_KT) tile(ra[2], rb[2], 2 * GEMM_KT);
+    wait_vm_tile<0>(ra[3], rb[3]);
+    if (p.K > 3 * GEMM_KT) tile(ra[3], rb[3], 3 * GEMM_KT);
+    // ---- gemm_kernel's epilogue for a stored result
+    const int col = n0 + wn * 32 + li;
+    float vmax = 0.0f;
+    if (p.absmax) {
+        const float bias_m = (p.bias && col < p.N) ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + acc_row(r, lane);
+            float v = acc[r] + bias_m;
+            if (p.relu) v = fmaxf(v, 0.0f);
+            if (row < p.M && col < p.N) vmax = fmaxf(vmax, fabsf(v));
+        }
+        vmax = wave_max(vmax);
+        if (lane == 0 && vmax > 0.0f && __float_as_uint(vmax) > *reinterpret_cast<volatile uint32_t *>(p.absmax))
+            atomicMax(p.absmax, __float_as_uint(vmax));
+        if (lane == 0 && wave == 0 && vmax > 0.0f && ((blockIdx.x + blockIdx.y) & 7u) == 0u) {
+            atomicAdd(reinterpret_cast<int *>(p.absmax + 1), (int)((__float_as_uint(vmax) >> 23) & 0xffu));
+            atomicAdd(p.absmax + 2, 1u);
+        }
+    }
+    if (col >= p.N) return;
+    const float bias = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = m0 + wm * 32 + acc_row(r, lane);
+        if (row >= p.M) continue;
+        float v = acc[r] + bias;
+        if (p.relu) v = fmaxf(v, 0.0f);
+        p.C[(int64_t)row * p.ldc + col] = v;
+    }
+}
+
 template <bool GATE, int IND>
 void launch_gemm_layout(hipStream_t stream, dim3 grid, bool ak, bool bk, const GemmParams &p) {
     if (ak && bk)
@@ -215,7 +302,10 @@ int launch_gemm(hipStream_t stream, const float *A, int64_t sAm, int64_t sAk, co
     if (K <= 0 || M <= 0 || N <= 0) PN_FAIL(PN_ERR_ARG, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
     const bool ak = (sAk == 1), bk = (sBk == 1);
     dim3 grid((N + GEMM_BN - 1) / GEMM_BN, (M + GEMM_BM - 1) / GEMM_BM, nz);
-    if (gateA)
+    // a short reduction over K-contiguous operands, stored in one piece: every K tile's loads in flight at once (gemm_k128_kernel)
+    if (ak && bk && !gateA && ind == GEMM_IND_NONE && mode == GEMM_STORE && nz == 1 && K <= 4 * GEMM_KT && !rowsum)
+        hipLaunchKernelGGL(gemm_k128_kernel, grid, dim3(256), 0, stream, p);
+    else if (gateA)
         launch_gemm_variant<true>(stream, grid, ak, bk, p);
     else
         launch_gemm_variant<false>(stream, grid, ak, bk, p);

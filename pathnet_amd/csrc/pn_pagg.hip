@@ -1587,7 +1587,7 @@ inline size_t xpad_floats(const Dims &d) {
 }
 
 struct WsLayout {
-    size_t Xh, Z, range;                                                 // node tables (first: reuse_tables relies on it)
+    size_t Xh, Z, range, wmax;                                           // node tables (first: reuse_tables relies on it); partial weight maxima
     size_t Wp, biasc, WpT, wpart, gpart, dZ, dXh;                        // weights / node-level backward
     size_t rowidx, egoidx, slotof, hn, saved, coef, rawsc, layer1, outb; // per micro-batch, forward
     size_t xh, keep, dG, dhn, dl1, gx, gout, bankT, xpad;                // per micro-batch, saved / backward
@@ -1614,6 +1614,7 @@ WsLayout ws_layout(const Dims &d) {
     w.Xh = take(N * H * 4);
     w.Z = take((size_t)d.ZR * H * 4);
     w.range = take(sizeof(SeqRange));       // operand ranges of the fp16 recurrent kernels; range.x belongs to Z
+    w.wmax = take(64 * 4);                  // partial maxima of |W_ih| / |W_hh| (range_part_kernel -> pack_fb_kernel)
     w.Wp = take(G * H * 3 * H * 4);          // (G = 0, the mean / sum encoders: no recurrent weights, no saved gates)
     w.biasc = take(G * H * 4);
     w.WpT = take(G * H * 3 * H * 4);
@@ -1886,18 +1887,12 @@ int run_pack_fwd(const Call &c, hipStream_t s) {
     }
     if (d.math == PN_SEQ_MATH_F16X2) {      // two fp16 planes, scaled by the weights' own maxima (pn_seqh.hip)
         SeqRange *rg = c.at<SeqRange>(c.w.range);
-        // (it also clears the slots this call's atomicMax launches add to; a reused dense bank keeps its range.x)
-        if (int rc = launch_range_w(s, c.a->w_ih, c.a->w_hh, (int64_t)d.Gw * d.H * d.H,
-                                    (d.compact || c.a->reuse_tables != 1) && !bank_epilogue_range(c), rg))
-            return rc;
-        if (int rc = launch_pack_fwdh(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg,
-                                      c.at<void>(c.w.Wp), c.at<float>(c.w.biasc)))
-            return rc;
-        // a training forward also packs the BPTT's planes here, on the side stream under fc0 / the bank: the backward that
-        // follows on this workspace then starts on its first real kernel (an inference forward uses that slot for Wcat)
-        if (!c.a->no_save)
-            return launch_pack_bwdh(s, c.a->w_ih, c.a->w_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, rg, c.at<void>(c.w.WpT));
-        return PN_OK;
+        // (it also clears the slots this call's atomicMax launches add to; a reused dense bank keeps its range.x.)  A training
+        // forward packs the BPTT's planes in the same launch, on the side stream under fc0 / the bank: the backward that follows
+        // on this workspace then starts on its first real kernel (an inference forward uses that slot for Wcat)
+        return launch_pack_fb(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.Gw, d.cell == CELL_GRU ? 1 : 0,
+                              (d.compact || c.a->reuse_tables != 1) && !bank_epilogue_range(c), rg, c.at<void>(c.w.wmax),
+                              c.at<void>(c.w.Wp), c.at<float>(c.w.biasc), c.a->no_save ? nullptr : c.at<void>(c.w.WpT));
     }
     return launch_pack_fwd3(s, c.a->w_ih, c.a->w_hh, c.a->b_ih, c.a->b_hh, d.H, d.G, d.cell == CELL_GRU ? 1 : 0, c.at<void>(c.w.Wp),
                             c.at<float>(c.w.biasc));

@@ -130,13 +130,13 @@ int launch_wgrad4(pn_context *ctx, void *stream, const WgradParams &wp, int nspl
 
 // ---- pn_seqh.hip: the recurrent kernels on the fp16 matrix pipe (three MFMAs per fp32 product, two planes) ------------
 // every multiple of 32 up to 256 as hidden size; gc: 4 = LSTM, 1 = tanh RNN, 3 = GRU on the LSTM's four gate slots
-// range->w_ih / w_hh = the maxima (one workgroup, stores); clears range->dg and, with clear_x, range->x for the launches below
-int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, int clear_x, SeqRange *range);
-// range->x = max(range->x, |rows[r, :]|) over r < (count ? *count : rows); ordered after the launch_range_w that cleared it
+// range->x = max(range->x, |rows[r, :]|) over r < (count ? *count : rows); ordered after the launch_pack_fb that cleared it
 int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, const int32_t *count, SeqRange *range);
-int launch_pack_fwdh(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
-                     int gru, const SeqRange *range, void *Wp, float *biasc);
-int launch_pack_bwdh(void *stream, const float *w_ih, const float *w_hh, int H, int G, int gru, const SeqRange *range, void *WpT);
+// max |W_ih| / |W_hh| (RANGE_PARTS partial maxima in `part`, 256 bytes of the workspace; range->w_ih / w_hh stored for the
+// recurrent kernels; range->dg and, with clear_x, range->x cleared for the launches that add to them) and both packings: the
+// forward's fragments + summed biases (Wp, biasc) and, unless WpT is null, the BPTT's -- two launches on `stream`
+int launch_pack_fb(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G, int Gw,
+                   int gru, int clear_x, SeqRange *range, void *part, void *Wp, float *biasc, void *WpT);
 int launch_seq_fwdh(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);
 // inference forward over pre-projected rows (sp.ZW): only the W_hh half of the products remains
 int launch_seq_fwdzw(pn_context *ctx, void *stream, int H, int gc, const SeqFwdParams &sp);

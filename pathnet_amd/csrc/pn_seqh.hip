@@ -139,14 +139,19 @@ int plan_tiling(pn_context *ctx, const void *kernel, int threads, size_t lds_byt
 }
 
 // ---- operand ranges ---------------------------------------------------------------------------------------------------
-// One workgroup: max |W_ih|, max |W_hh| stored (no atomics, nothing to clear beforehand); it also clears the slots the
-// atomicMax kernels of this call add to -- x unless the call keeps the bank of an earlier one, and dg -- so that a step
-// issues no memset launch of its own.  Runs ahead of the weight packing, on the stream that packs.
-__global__ __launch_bounds__(1024) void range_w_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int64_t n4,
-                                                       int clear_x, SeqRange *__restrict__ range) {
-    __shared__ float red[2][16];
+// max |W_ih|, max |W_hh| in two steps without an atomic or a slot to clear: RANGE_PARTS workgroups leave the maxima of their
+// slices in part[0 .. PARTS) / part[PARTS .. 2 PARTS) (the workspace's `wmax`), the packing launch that follows on the same
+// stream takes the maximum of those in every workgroup (64 L2-resident words) and its first workgroup stores range->w_ih /
+// w_hh for the recurrent kernels.  (Until round 6 ONE workgroup read both tensors: 10 us of one CU's bandwidth on the
+// chain the recurrence waits for.)  The first workgroup also clears the slots the atomicMax launches of this call add to --
+// x unless the call keeps the bank of an earlier one, and dg -- so that a step issues no memset launch of its own.
+constexpr int RANGE_PARTS = 32;
+__global__ __launch_bounds__(256) void range_part_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int64_t n4,
+                                                         int clear_x, SeqRange *__restrict__ range, uint32_t *__restrict__ part) {
+    __shared__ float red[2][4];
+    const int64_t per = (n4 + RANGE_PARTS - 1) / RANGE_PARTS, lo = (int64_t)blockIdx.x * per, hi = min(n4, lo + per);
     float m0 = 0.0f, m1 = 0.0f;
-    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
         const float4 a = reinterpret_cast<const float4 *>(w_ih)[i], b = reinterpret_cast<const float4 *>(w_hh)[i];
         m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
         m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
@@ -156,17 +161,28 @@ __global__ __launch_bounds__(1024) void range_w_kernel(const float *__restrict__
     if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = m0, red[1][threadIdx.x >> 6] = m1;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++) m0 = fmaxf(m0, red[0][w]), m1 = fmaxf(m1, red[1][w]);
-        range->w_ih = __float_as_uint(m0);
-        range->w_hh = __float_as_uint(m1);
-        range->dg = 0u;
-        if (clear_x) {
-            range->x = 0u;
-            range->x_esum = 0;
-            range->x_cnt = 0u;
+        part[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
+        part[RANGE_PARTS + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+        if (blockIdx.x == 0) {
+            range->dg = 0u;
+            if (clear_x) {
+                range->x = 0u;
+                range->x_esum = 0;
+                range->x_cnt = 0u;
+            }
         }
     }
 }
+// the two maxima from the partials, wave-uniform (every wave of the packing launch)
+__device__ __forceinline__ void range_from_parts(const uint32_t *__restrict__ part, float &m_ih, float &m_hh) {
+    const int lane = threadIdx.x & 63;
+    const float v = __uint_as_float(part[lane]);        // (RANGE_PARTS = 32: lanes 0..31 hold w_ih's, 32..63 w_hh's partial maxima)
+    static_assert(2 * RANGE_PARTS == 64, "one partial per lane");
+    float a = lane < RANGE_PARTS ? v : 0.0f, b = lane < RANGE_PARTS ? 0.0f : v;
+    m_ih = wave_max(a);
+    m_hh = wave_max(b);
+}
+
 
 __global__ __launch_bounds__(256) void range_rows_kernel(const float *__restrict__ rows, int64_t nrows, int H4,
                                                          const int32_t *__restrict__ count, SeqRange *__restrict__ range) {
@@ -238,10 +254,9 @@ __device__ __forceinline__ int gru_weight_row(int slot, int j, int H) { return (
 //   A operand: LDS holds the two planes of the tile [32][x_t | h_{t-1}], row pitch 4H + 16 bytes.
 //   GRU on the LSTM's four gate slots as in pn_pagg.hip (pack_fwd3_kernel).
 // =====================================================================================================================
-__global__ void pack_fwdh_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
-                                 const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G, int gru,
-                                 const SeqRange *__restrict__ range, u32x4 *__restrict__ Wp, float *__restrict__ biasc) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_fwdh_body(int idx, const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                               const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G, int gru,
+                                               float m_ih, float m_hh, u32x4 *__restrict__ Wp, float *__restrict__ biasc) {
     if (idx < G * H) {
         if (!gru) {
             biasc[idx] = b_ih[idx] + b_hh[idx];
@@ -262,7 +277,7 @@ __global__ void pack_fwdh_kernel(const float *__restrict__ w_ih, const float *__
     const float *src = k < H ? w_ih + (int64_t)row * H + k : w_hh + (int64_t)row * H + (k - H);
     float4 v0 = reinterpret_cast<const float4 *>(src)[0], v1 = reinterpret_cast<const float4 *>(src)[1];
     if (gru && ((g == 2 && k >= H) || (g == 3 && k < H))) v0 = v1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float sc = exp2i(scale_exp(__uint_as_float(k < H ? range->w_ih : range->w_hh)));
+    const float sc = exp2i(scale_exp(k < H ? m_ih : m_hh));
     u32x4 q0, q1;
     uint32_t x0, x1;
     split2h(v0.x * sc, v0.y * sc, x0, x1); q0[0] = x0; q1[0] = x1;
@@ -691,9 +706,8 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, 1>())) void seq_fwdzw_k
 //   Per step: cell backward into registers + wave maxima to LDS | barrier | scale, split, planes to LDS | barrier | k loop |
 //   scatter -- the next step's cell backward touches no LDS the k loop reads, so there is no third barrier.
 // =====================================================================================================================
-__global__ void pack_bwdh_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh, int H, int G, int gru,
-                                 const SeqRange *__restrict__ range, u32x4 *__restrict__ WpT) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_bwdh_body(int idx, const float *__restrict__ w_ih, const float *__restrict__ w_hh, int H, int G,
+                                               int gru, float m_ih, float m_hh, u32x4 *__restrict__ WpT) {
     const int GH = G * H, NU = GH / 32, NW = H / 32;
     if (idx >= NW * NU * 4 * 64) return;
     const int lane = idx & 63, f = (idx >> 6) & 3;
@@ -713,7 +727,7 @@ __global__ void pack_bwdh_kernel(const float *__restrict__ w_ih, const float *__
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = zero ? 0.0f : src[(int64_t)e * H];
     }
-    const float sc = exp2i(scale_exp(__uint_as_float(nt == 0 ? range->w_ih : range->w_hh)));
+    const float sc = exp2i(scale_exp(nt == 0 ? m_ih : m_hh));
     u32x4 q0, q1;
 #pragma unroll
     for (int h = 0; h < 4; h++) {
@@ -724,6 +738,25 @@ __global__ void pack_bwdh_kernel(const float *__restrict__ w_ih, const float *__
     u32x4 *dst = WpT + ((int64_t)(w * NU + u) * 2 * 4 + f) * 64 + lane;
     dst[0] = q0;
     dst[4 * 64] = q1;
+}
+
+// Both packings in ONE launch (round 6; two until then): workgroups [0, nb_fwd) the forward's fragments and the summed biases,
+// the rest the BPTT's (none for an inference forward).  Every wave takes the operand maxima from range_part_kernel's partials;
+// the first thread also leaves them in range->w_ih / w_hh for the recurrent kernels.
+__global__ __launch_bounds__(256) void pack_fb_kernel(const float *__restrict__ w_ih, const float *__restrict__ w_hh,
+                                                      const float *__restrict__ b_ih, const float *__restrict__ b_hh, int H, int G, int gru,
+                                                      const uint32_t *__restrict__ part, SeqRange *__restrict__ range, int nb_fwd,
+                                                      u32x4 *__restrict__ Wp, float *__restrict__ biasc, u32x4 *__restrict__ WpT) {
+    float m_ih, m_hh;
+    range_from_parts(part, m_ih, m_hh);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        range->w_ih = __float_as_uint(m_ih);
+        range->w_hh = __float_as_uint(m_hh);
+    }
+    if ((int)blockIdx.x < nb_fwd)
+        pack_fwdh_body(blockIdx.x * 256 + threadIdx.x, w_ih, w_hh, b_ih, b_hh, H, G, gru, m_ih, m_hh, Wp, biasc);
+    else
+        pack_bwdh_body(((int)blockIdx.x - nb_fwd) * 256 + threadIdx.x, w_ih, w_hh, H, G, gru, m_ih, m_hh, WpT);
 }
 
 template <int H, int GC>
@@ -1301,11 +1334,6 @@ extern "C" int pn_debug_seq_tiling(int64_t P, int slots, int cus, int mode, int 
 
 namespace pn {
 
-int launch_range_w(void *stream, const float *w_ih, const float *w_hh, int64_t n_each, int clear_x, SeqRange *range) {
-    hipLaunchKernelGGL(range_w_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w_ih, w_hh, n_each / 4, clear_x, range);
-    PN_CHECK_HIP(hipGetLastError());
-    return PN_OK;
-}
 
 int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, const int32_t *count, SeqRange *range) {
     hipStream_t s = (hipStream_t)stream;        // (range->x was cleared by launch_range_w, ordered before this launch)
@@ -1318,17 +1346,16 @@ int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, con
     return PN_OK;
 }
 
-int launch_pack_fwdh(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G,
-                     int gru, const SeqRange *range, void *Wp, float *biasc) {
-    hipLaunchKernelGGL(pack_fwdh_kernel, dim3((unsigned)((G * H * H / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ih,
-                       w_hh, b_ih, b_hh, H, G, gru, range, reinterpret_cast<u32x4 *>(Wp), biasc);
+int launch_pack_fb(void *stream, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, int H, int G, int Gw,
+                   int gru, int clear_x, SeqRange *range, void *part, void *Wp, float *biasc, void *WpT) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(range_part_kernel, dim3(RANGE_PARTS), dim3(256), 0, s, w_ih, w_hh, (int64_t)Gw * H * H / 4, clear_x, range,
+                       reinterpret_cast<uint32_t *>(part));
     PN_CHECK_HIP(hipGetLastError());
-    return PN_OK;
-}
-
-int launch_pack_bwdh(void *stream, const float *w_ih, const float *w_hh, int H, int G, int gru, const SeqRange *range, void *WpT) {
-    hipLaunchKernelGGL(pack_bwdh_kernel, dim3((unsigned)((G * H * H / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_ih,
-                       w_hh, H, G, gru, range, reinterpret_cast<u32x4 *>(WpT));
+    const int nb = (G * H * H / 4 + 255) / 256;         // workgroups of either packing (WpT == nullptr: the forward's alone)
+    hipLaunchKernelGGL(pack_fb_kernel, dim3((unsigned)(WpT ? 2 * nb : nb)), dim3(256), 0, s, w_ih, w_hh, b_ih, b_hh, H, G, gru,
+                       reinterpret_cast<const uint32_t *>(part), range, nb, reinterpret_cast<u32x4 *>(Wp), biasc,
+                       reinterpret_cast<u32x4 *>(WpT));
     PN_CHECK_HIP(hipGetLastError());
     return PN_OK;
 }
