@@ -1866,7 +1866,7 @@ int run_seq_bwd_generic(const Call &c, int b) {
 // true when max |Z| (SeqRange.x, the fp16 recurrence's operand range) is taken in the bank GEMM's epilogue: dense bank and
 // fc0 both on gemm_kernel in this call -- fc0's launch clears the slot, the bank's adds to it, both on the caller's stream
 // (range_rows_kernel and its place on the critical path between the bank and the recurrence are then not needed, and
-// range_w_kernel on the packing stream must NOT clear the slot: it would race the bank)
+// range_part_kernel on the packing stream must NOT clear the slot: it would race the bank)
 inline bool bank_epilogue_range(const Call &c) {
     const Dims &d = c.d;
     const pn_pagg_args *a = c.a;
@@ -2108,7 +2108,7 @@ int run_tables(const Call &c, JoinGuard &joiner, const std::function<int(hipStre
     // the fp16 recurrence scales the gathered rows by a power of two taken from the largest |Z| of the rows just computed
     // (a reused dense Z keeps its record: it sits next to Z in the workspace)
     if (int rc = joiner.join()) return rc;      // the recurrence needs the plan and the packed weights
-    // (after the join: the packing stream's range_w_kernel cleared the slot this launch adds to)
+    // (after the join: the packing stream's range_part_kernel cleared the slot this launch adds to)
     if (d.math == PN_SEQ_MATH_F16X2 && (d.compact || a->reuse_tables != 1) && !epi_range) {
         StageTimer tm(ctx, ST_BANK, stream);
         if (int rc = launch_range_rows(stream, c.Z, d.ZR, H, d.compact ? c.at<const int32_t>(c.w.seg) + L : nullptr,

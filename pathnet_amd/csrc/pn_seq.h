@@ -20,7 +20,7 @@ struct SeqRange {           // (= struct pn_seq_range of include/pathnet_hip.h: 
     // to seq_math = bf16x3, whose three bf16 planes carry fp32's own exponent range, when the spread exceeds its window)
     int32_t x_esum;
     uint32_t x_cnt;
-    uint32_t w_ih, w_hh;    // max |W_ih|, max |W_hh|                          (range_w_kernel, before the weight packing)
+    uint32_t w_ih, w_hh;    // max |W_ih|, max |W_hh|                          (pack_fb_kernel, from range_part_kernel's partials)
     uint32_t dg;            // max |dG| of the BPTT launch the weight-gradient GEMM follows (seq_bwdh_kernel)
 };
 

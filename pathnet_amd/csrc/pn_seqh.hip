@@ -11,7 +11,7 @@
 //            barriers per step where the bf16 kernel runs two passes over gate pairs with four barriers;
 //   wgrad    three MFMA groups per K tile instead of six, 70 KB of stages instead of 104.
 // Operand scaling (fp16 has 5 exponent bits): pn_kernels.h.  The scales are powers of two derived in the kernels from
-// maxima in device memory (SeqRange) -- weights: range_w_kernel; gathered rows: range_rows_kernel over the bank's output;
+// maxima in device memory (SeqRange) -- weights: range_part_kernel + pack_fb_kernel; gathered rows: range_rows_kernel over the bank's output;
 // the BPTT scales every tile of gate gradients by that tile's own maximum (computed in registers, exchanged through LDS
 // at the barrier the step needs anyway) and leaves the launch's maximum for the weight-gradient GEMM.
 #include <hip/hip_runtime.h>
@@ -248,7 +248,7 @@ __device__ __forceinline__ int gru_weight_row(int slot, int j, int H) { return (
 
 // =====================================================================================================================
 // forward recurrence
-//   Weights: pack_fwdh_kernel, B fragments of v_mfma_f32_32x32x16_f16,
+//   Weights: pack_fwdh_body (pack_fb_kernel), B fragments of v_mfma_f32_32x32x16_f16,
 //     Wp[(((w*KS + s)*2 + plane)*G + g)*64 + lane] (16 bytes) =
 //         plane of 2^e Wcat[g*H + 32w + (lane & 31)][16 s + 8 (lane >> 5) .. +7],   KS = 2H/16 k-steps, e = e_ih | e_hh
 //   A operand: LDS holds the two planes of the tile [32][x_t | h_{t-1}], row pitch 4H + 16 bytes.
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(H / 32 * 64, (fwdh_waves<H, 1>())) void seq_fwdzw_k
 
 // =====================================================================================================================
 // BPTT:  [dx_t | dh_{t-1}] = dG_t [32, G*H] . [W_ih | W_hh],  K = G*H gate columns in ONE pass (all gates resident)
-//   Weights: pack_bwdh_kernel, B fragments in units of two k-steps (kk) x two output halves (nt),
+//   Weights: pack_bwdh_body (pack_fb_kernel), B fragments in units of two k-steps (kk) x two output halves (nt),
 //     WpT[(((w*NU + u)*2 + plane)*4 + kk*2 + nt)*64 + lane] (16 bytes) =
 //         plane of 2^e Wcat[k = 32u + 16kk + 8(lane >> 5) .. +7][n = nt*H + 32w + (lane & 31)],   NU = G*H/32, e = e_ih | e_hh by nt
 //   A operand: the two fp16 planes of s_g dG_t, s_g = the power of two that puts THIS tile's largest |dG| into [2^14, 2^15).
@@ -1336,7 +1336,7 @@ namespace pn {
 
 
 int launch_range_rows(void *stream, const float *rows, int64_t nrows, int H, const int32_t *count, SeqRange *range) {
-    hipStream_t s = (hipStream_t)stream;        // (range->x was cleared by launch_range_w, ordered before this launch)
+    hipStream_t s = (hipStream_t)stream;        // (range->x was cleared by launch_pack_fb, ordered before this launch)
     const int64_t n4 = nrows * (H / 4);
     // (on the step's critical path between the bank and the recurrence: one or two 16-byte loads per thread, 11 -> ~4 us at
     //  the headline shape's 5.5 MB)
@@ -1374,7 +1374,7 @@ int launch_seq_fwdzw(pn_context *ctx, void *stream, int H, int gc, const SeqFwdP
 
 int launch_seq_bwdh(pn_context *ctx, void *stream, int H, int gc, const SeqBwdParams &sp) {
     if (!sp.range) PN_FAIL(PN_ERR_ARG, "seq_bwdh: operand ranges missing");
-    hipStream_t s = (hipStream_t)stream;        // (range->dg was cleared by the forward's launch_range_w)
+    hipStream_t s = (hipStream_t)stream;        // (range->dg was cleared by the forward's launch_pack_fb)
     return gc == 3 ? dispatch_bwdh<3>(ctx, s, H, sp) : gc == 4 ? dispatch_bwdh<4>(ctx, s, H, sp) : dispatch_bwdh<1>(ctx, s, H, sp);
 }
 
