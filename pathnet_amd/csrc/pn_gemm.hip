@@ -245,11 +245,18 @@ __global__ __launch_bounds__(256) void gemm_k128_kernel(GemmParams p) {
             if (row < p.M && col < p.N) vmax = fmaxf(vmax, fabsf(v));
         }
         vmax = wave_max(vmax);
-        if (lane == 0 && vmax > 0.0f && __float_as_uint(vmax) > *reinterpret_cast<volatile uint32_t *>(p.absmax))
-            atomicMax(p.absmax, __float_as_uint(vmax));
-        if (lane == 0 && wave == 0 && vmax > 0.0f && ((blockIdx.x + blockIdx.y) & 7u) == 0u) {
+        // ONE atomic per workgroup (the tile buffer is free: every wave is past the last barrier): all workgroups of this launch
+        // are resident at once and reach this point together -- with an atomic per wave ~1 400 of them queued up on one address
+        if (lane == 0 && wave == 0 && vmax > 0.0f && ((blockIdx.x + blockIdx.y) & 7u) == 0u) {        // (the spread statistic: as gemm_kernel)
             atomicAdd(reinterpret_cast<int *>(p.absmax + 1), (int)((__float_as_uint(vmax) >> 23) & 0xffu));
             atomicAdd(p.absmax + 2, 1u);
+        }
+        if (lane == 0) As[wave] = vmax;
+        __syncthreads();
+        if (tid == 0) {
+            const float wmax = fmaxf(fmaxf(As[0], As[1]), fmaxf(As[2], As[3]));
+            if (wmax > 0.0f && __float_as_uint(wmax) > *reinterpret_cast<volatile uint32_t *>(p.absmax))
+                atomicMax(p.absmax, __float_as_uint(wmax));
         }
     }
     if (col >= p.N) return;
