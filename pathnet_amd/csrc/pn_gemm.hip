@@ -522,7 +522,20 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(const float *__restric
     if (i >= (int64_t)M * N) return;
     const int row = (int)(i / N), col = (int)(i - (int64_t)row * N);
     float v = bias ? bias[col] : 0.0f;
-    for (int z = 0; z < nz; z++) v += part[(int64_t)z * M * N + i];
+    // the chunk sums eight at a time, all eight loads in flight (asm loads: as a plain loop hipcc waits for each partial before
+    // it asks for the next -- nz dependent round trips, the whole 6 us of this kernel at the headline shape); added in chunk order
+    const float *pz = part + i;
+    const int64_t mn = (int64_t)M * N;
+    for (int z0 = 0; z0 < nz; z0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) async_load_b32(t[u], pz + (int64_t)min(z0 + u, nz - 1) * mn);
+        wait_vm<0>(t[0], t[1], t[2], t[3]);
+        wait_vm<0>(t[4], t[5], t[6], t[7]);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (z0 + u < nz) v += t[u];
+    }
     if (relu) v = fmaxf(v, 0.0f);
     float *dst = C + (int64_t)row * ldc + col;
     if (mode == GEMM_ADD)
